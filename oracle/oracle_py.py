@@ -1,0 +1,292 @@
+"""ctypes binding of the CPU ORACLE (oracle/libps_oracle.so) and, where it was
+built, of the reference L4 library (oracle/_ref/libref_l4.so).
+
+TEST INFRASTRUCTURE ONLY.  May be imported by tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg -- never by particlesystem_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "libps_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libref_l4.so")
+
+# numpy images of the reference structs (common.h:94-145); itemsize 72 / 24 / 24 / 8
+P_DTYPE = np.dtype({
+    "names": ["id", "cell", "chunk", "seg_type", "seg_tid", "seg_fault", "is_parent",
+              "w", "age", "fertility_age", "x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az"],
+    "formats": ["<i4"] * 5 + ["u1", "u1"] + ["<f4"] * 12,
+    "offsets": [0, 4, 8, 12, 16, 20, 21] + list(range(24, 72, 4)),
+    "itemsize": 72,
+})
+T_DTYPE = np.dtype([("id", "<i4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w", "<f4"), ("age", "<f4")])
+Q_DTYPE = np.dtype([("front", "<i4"), ("rear", "<i4"), ("count", "<i4"), ("lock", "<i4"),
+                    ("rloc", "<i4"), ("seg_size", "<i4")])
+PAIR_DTYPE = np.dtype([("c", "<i4"), ("p", "<i4")])
+
+
+class Config(C.Structure):
+    _fields_ = [("max_particles_num", C.c_int), ("x_factor", C.c_int),
+                ("chunk_factor", C.c_int), ("chunk_dim", C.c_int),
+                ("cell_size", C.c_double), ("eps2", C.c_double),
+                ("collision_radius", C.c_double), ("particle_weight", C.c_double),
+                ("dt", C.c_double), ("max_v", C.c_double),
+                ("explosion_speed", C.c_double), ("life_steps", C.c_double)]
+
+
+class Derived(C.Structure):
+    _fields_ = [("grid_dim", C.c_int), ("num_cells", C.c_int), ("num_chunks", C.c_int),
+                ("cells_per_chunk", C.c_int), ("max_per_cell", C.c_int),
+                ("max_per_chunk", C.c_int), ("max_neib_particles", C.c_int),
+                ("seg_cells", C.c_int * 4), ("seg_count", C.c_int * 4),
+                ("seg_size_t", C.c_int * 4), ("seg_size", C.c_int * 4),
+                ("container_size", C.c_int), ("queue_info_size", C.c_int),
+                ("particle_life", C.c_double), ("kid_age", C.c_double),
+                ("min_fertility_age", C.c_double), ("max_fertility_age", C.c_double),
+                ("min_adult_age", C.c_double), ("max_adult_age", C.c_double),
+                ("max_dx", C.c_double)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_longlong) for n in
+                ("deaths_age", "deaths_collision", "survives", "integrated", "relocations",
+                 "relocations_lost", "births", "births_failed", "cell_overflow_kills",
+                 "explosions_skipped")]
+
+
+RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double))
+
+
+def build(force=False):
+    """Compile the oracle (and _ref when /root/reference exists)."""
+    if force or not os.path.exists(ORACLE_SO) or \
+            os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(HERE, "ps_oracle.c")):
+        subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+    if os.path.isdir("/root/reference/source/code/inc"):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(ORACLE_SO)
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        L.pso_default_config.argtypes = [C.POINTER(Config)]
+        L.pso_derive.argtypes = [C.POINTER(Config), C.POINTER(Derived)]
+        L.pso_derive.restype = ci
+        L.pso_create.argtypes = [C.POINTER(Config)]
+        L.pso_create.restype = vp
+        L.pso_destroy.argtypes = [vp]
+        L.pso_get_derived.argtypes = [vp]
+        L.pso_get_derived.restype = C.POINTER(Derived)
+        L.pso_fill_particle.argtypes = [vp] + [cf] * 6
+        L.pso_fill_particle.restype = ci
+        for n in ("pso_init_iframe", "pso_build_grid", "pso_calc_forces"):
+            getattr(L, n).argtypes = [vp]
+        L.pso_calc_forces_chunk.argtypes = [vp, ci, ci]
+        L.pso_step.argtypes = [vp, ci]
+        L.pso_set_rng.argtypes = [vp, RNG_FN, vp]
+        L.pso_set_explosions.argtypes = [vp, ci]
+        for n in ("pso_particles", "pso_tdata_buf", "pso_queue", "pso_queue_info_buf",
+                  "pso_chunkgrid", "pso_cellgrid", "pso_gridmax", "pso_pkgdistrib"):
+            getattr(L, n).argtypes = [vp]
+            getattr(L, n).restype = vp
+        L.pso_get_counters.argtypes = [vp]
+        L.pso_get_counters.restype = C.POINTER(Counters)
+        L.pso_step_index.argtypes = [vp]
+        L.pso_live_count.argtypes = [vp]
+        # L4 helpers
+        L.pso_get_cell_info.argtypes = [C.POINTER(Derived), C.POINTER(Config), ci, C.POINTER(ci)]
+        L.pso_get_cont_rloc.argtypes = [C.POINTER(Derived), ci, ci]
+        L.pso_get_info_rloc.argtypes = [C.POINTER(Derived), ci, ci]
+        L.pso_get_id_info.argtypes = [C.POINTER(Derived), ci, C.POINTER(ci)]
+        L.pso_set_pkg_segments.argtypes = [C.POINTER(Config), ci, vp]
+        L.pso_fill_cells.argtypes = [C.POINTER(Derived), ci, C.POINTER(ci)]
+        for n in ("pso_set_pos_t", "pso_set_pos_i", "pso_set_pos_x"):
+            getattr(L, n).argtypes = [C.POINTER(Config), C.POINTER(Derived), vp, cf, cf, cf]
+        L.pso_body_body_interaction.argtypes = [C.POINTER(Config), C.POINTER(Derived), vp, vp, vp]
+        L.pso_body_body_collision.argtypes = [C.POINTER(Config), C.POINTER(Derived), vp, vp]
+        L.pso_body_body_collision.restype = ci
+        L.pso_integrate.argtypes = [C.POINTER(Config), C.POINTER(Derived), vp]
+        L.pso_reset_particle.argtypes = [vp]
+        L.pso_survive_particle.argtypes = [vp]
+        L.pso_q_remove.argtypes = [vp, vp, C.POINTER(Derived), ci, ci]
+        L.pso_q_remove.restype = ci
+        L.pso_q_insert.argtypes = [vp, vp, C.POINTER(Derived), ci, ci, ci]
+        _lib = L
+    return _lib
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+_ref = None
+
+
+def ref():
+    """The reference's own L4 helpers (container only). Raises if not built."""
+    global _ref
+    if _ref is None:
+        if not have_ref():
+            raise RuntimeError("oracle/_ref/libref_l4.so not built (needs /root/reference)")
+        R = C.CDLL(REF_SO)
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        R.ref_get_cell_info.argtypes = [ci, C.POINTER(ci)]
+        R.ref_get_cont_rloc.argtypes = [ci, ci]
+        R.ref_get_info_rloc.argtypes = [ci, ci]
+        R.ref_get_id_info.argtypes = [ci, C.POINTER(ci)]
+        R.ref_set_pkg_segments.argtypes = [ci, C.POINTER(ci)]
+        R.ref_fill_cells.argtypes = [ci, C.POINTER(ci)]
+        R.ref_fill_particles.argtypes = [ci, vp, vp, ci]
+        R.ref_set_pos_x.argtypes = [vp, cf, cf, cf]
+        R.ref_set_pos_i.argtypes = [vp, cf, cf, cf]
+        R.ref_create_particle_s.argtypes = [vp, ci] + [cf] * 9
+        R.ref_reset_particle.argtypes = [vp]
+        R.ref_survive_particle.argtypes = [vp]
+        R.ref_copy_particle.argtypes = [vp, vp]
+        R.ref_body_body_interaction.argtypes = [ci, vp, vp, vp]
+        R.ref_accumulate.argtypes = [vp, ci, vp, vp]
+        R.ref_body_body_collision.argtypes = [ci, vp, vp, vp]
+        R.ref_q_remove.argtypes = [vp, vp, ci, ci]
+        R.ref_q_insert.argtypes = [vp, vp, ci, ci, ci]
+        _ref = R
+    return _ref
+
+
+def default_config(**over):
+    cfg = Config()
+    lib().pso_default_config(C.byref(cfg))
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def derive(cfg):
+    d = Derived()
+    if lib().pso_derive(C.byref(cfg), C.byref(d)) != 0:
+        raise ValueError("bad config")
+    return d
+
+
+def _view(ptr, dtype, n):
+    buf = (C.c_char * (dtype.itemsize * n)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+class System:
+    """One oracle system = the nine reference buffers + the stage functions."""
+
+    def __init__(self, cfg=None, **over):
+        self.cfg = cfg if cfg is not None else default_config(**over)
+        self.L = lib()
+        self.h = self.L.pso_create(C.byref(self.cfg))
+        if not self.h:
+            raise ValueError("pso_create failed")
+        self.d = self.L.pso_get_derived(self.h).contents
+        self._rng_cb = None
+
+    def close(self):
+        if self.h:
+            self.L.pso_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # buffers (zero-copy views)
+    @property
+    def particles(self):
+        return _view(self.L.pso_particles(self.h), P_DTYPE, self.d.container_size)
+
+    @property
+    def tdata(self):
+        return _view(self.L.pso_tdata_buf(self.h), T_DTYPE, self.d.container_size)
+
+    @property
+    def queue(self):
+        return _view(self.L.pso_queue(self.h), np.dtype("<i4"), self.d.container_size)
+
+    @property
+    def queue_info(self):
+        return _view(self.L.pso_queue_info_buf(self.h), Q_DTYPE, self.d.queue_info_size)
+
+    @property
+    def cellgrid(self):
+        n = self.d.num_cells * (1 + self.d.max_per_cell)
+        return _view(self.L.pso_cellgrid(self.h), np.dtype("<i4"), n).reshape(self.d.num_cells, -1)
+
+    @property
+    def chunkgrid(self):
+        n = self.d.num_chunks * (1 + self.d.max_per_chunk)
+        return _view(self.L.pso_chunkgrid(self.h), np.dtype("<i4"), n).reshape(self.d.num_chunks, -1)
+
+    @property
+    def gridmax(self):
+        return _view(self.L.pso_gridmax(self.h), np.dtype("<i4"), 2)
+
+    @property
+    def pkgdistrib(self):
+        return _view(self.L.pso_pkgdistrib(self.h), PAIR_DTYPE, self.d.num_chunks * 27)
+
+    @property
+    def counters(self):
+        c = self.L.pso_get_counters(self.h).contents
+        return {n: getattr(c, n) for n, _ in Counters._fields_}
+
+    def fill(self, xyz, age, fert_age, w=None):
+        """fill_particle for each row of xyz (in order); returns the slot ids."""
+        xyz = np.asarray(xyz, dtype=np.float32).reshape(-1, 3)
+        n = len(xyz)
+        age = np.broadcast_to(np.asarray(age, dtype=np.float32), (n,))
+        fert = np.broadcast_to(np.asarray(fert_age, dtype=np.float32), (n,))
+        wv = np.broadcast_to(np.asarray(self.cfg.particle_weight if w is None else w,
+                                        dtype=np.float32), (n,))
+        ids = np.empty(n, dtype=np.int32)
+        f = self.L.pso_fill_particle
+        for k in range(n):
+            ids[k] = f(self.h, float(xyz[k, 0]), float(xyz[k, 1]), float(xyz[k, 2]),
+                       float(wv[k]), float(age[k]), float(fert[k]))
+        if (ids < 0).any():
+            raise RuntimeError("fill_particle failed (%d)" % int(ids.min()))
+        return ids
+
+    def init_iframe(self):
+        self.L.pso_init_iframe(self.h)
+
+    def build_grid(self):
+        self.L.pso_build_grid(self.h)
+
+    def calc_forces(self):
+        self.L.pso_calc_forces(self.h)
+
+    def calc_forces_chunk(self, chunk, elems):
+        self.L.pso_calc_forces_chunk(self.h, chunk, elems)
+
+    def step(self, n=1):
+        self.L.pso_step(self.h, n)
+
+    def set_explosions(self, on):
+        self.L.pso_set_explosions(self.h, 1 if on else 0)
+
+    def set_rng(self, fn):
+        """fn(parent_id, step) -> ((i0,i1,i2), u)"""
+        def tramp(_user, pid, step, ints, u):
+            (a, b, c), uu = fn(pid, step)
+            ints[0], ints[1], ints[2] = a, b, c
+            u[0] = uu
+        self._rng_cb = RNG_FN(tramp)
+        self.L.pso_set_rng(self.h, self._rng_cb, None)
+
+    def live_count(self):
+        return self.L.pso_live_count(self.h)

@@ -1,0 +1,199 @@
+/*
+ * psamd.h -- C ABI of the MI355X-native particle-system step ("psamd").
+ *
+ * Drop-in boundary for the per-step hot path of abraj/particleSystem: the three
+ * stage bodies the reference registers with pmlib (task 3 init_iframe, task 8
+ * build_grid, task 6 calc_forces; DoParallelProcess loop, particleSystem.cpp
+ * 1843-1928) plus the one-off setup stages that create their inputs.  Plain
+ * pointers and sizes only; every function returns a psamd_status and never
+ * exits or throws across the boundary (the reference printf+exit(1)s instead,
+ * particleSystem.cpp:937-938, app.cu:429-431).
+ *
+ * Citations: "ps.cpp" = source/code/src/particleSystem.cpp, "psCUDA.cu" =
+ * source/code/src/particleSystemCUDA.cu, the rest under source/code/inc/.
+ *
+ * Ownership: the library owns all device memory and its HIP streams.  Host
+ * buffers passed in or out belong to the caller and are only touched during
+ * the call.  One context is used by one host thread at a time (the reference's
+ * driver thread blocks in pmWaitForTaskCompletion the same way, ps.cpp:1716).
+ */
+#ifndef PSAMD_H
+#define PSAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSAMD_ABI_VERSION 1
+
+typedef enum psamd_status {
+    PSAMD_OK = 0,
+    PSAMD_ERR_INVALID_ARG   = 1,  /* null pointer, out-of-range index, bad config          */
+    PSAMD_ERR_NO_DEVICE     = 2,  /* no usable HIP device: the product has no CPU fallback */
+    PSAMD_ERR_HIP           = 3,  /* a HIP runtime call failed (see psamd_last_error)      */
+    PSAMD_ERR_OUT_OF_MEMORY = 4,
+    PSAMD_ERR_OUTSIDE_BOX   = 5,  /* fill: "Particle location OUTSIDE box", ps.cpp:954-957 */
+    PSAMD_ERR_QUEUE_EMPTY   = 6,  /* fill: "Overflow (Reserved space full)", ps.cpp:936-939*/
+    PSAMD_ERR_CELL_OVERFLOW = 7,  /* a cell holds more than MAX_PARTICLES_PER_CELL and the
+                                     overflow policy is PSAMD_OVERFLOW_ERROR               */
+    PSAMD_ERR_STATE         = 8,  /* stage called out of order (e.g. calc before build)    */
+    PSAMD_ERR_UNSUPPORTED   = 9
+} psamd_status;
+
+/* config.flags */
+#define PSAMD_FLAG_EXPLOSIONS   0x1u  /* births enabled (ps.cpp:1306-1333) with the counter-based RNG below */
+#define PSAMD_FLAG_FAST_MATH    0x2u  /* FMA/rsq pair arithmetic: NOT bit-identical to the reference, see DESIGN.md */
+#define PSAMD_FLAG_NO_LIFECYCLE 0x4u  /* benchmark mode: no kill/survive/relocation, N stays constant */
+
+/* Runtime form of the reference's compile-time configuration, common.h:12-70.
+ * psamd_default_config() fills in the shipped values. */
+typedef struct psamd_config {
+    int32_t  max_particles_num;  /* MAX_PARTICLES_NUM        common.h:12 */
+    int32_t  x_factor;           /* X_FACTOR                 common.h:13 */
+    int32_t  chunk_factor;       /* CHUNK_FACTOR             common.h:29 */
+    int32_t  chunk_dim;          /* CHUNK_DIM                common.h:30 */
+    double   cell_size;          /* CELL_SIZE                common.h:52 */
+    double   eps2;               /* EPS2                     common.h:53 */
+    double   collision_radius;   /* COLLISION_RADIUS         common.h:54 */
+    double   particle_weight;    /* PARTICLE_WEIGHT_DEFAULT  common.h:55 */
+    double   dt;                 /* DT                       common.h:69 */
+    double   max_v;              /* MAX_V                    common.h:66 */
+    double   explosion_speed;    /* EXPLOSION_SPEED          common.h:67 */
+    double   life_steps;         /* the 300 in PARTICLE_LIFE common.h:58 */
+    int32_t  device;             /* HIP device ordinal                    */
+    uint32_t flags;              /* PSAMD_FLAG_*                          */
+    uint64_t seed;               /* explosion RNG seed (RAND_SEED, common.h:56) */
+    /* multi-GPU sharding of the pair loop: this context evaluates forces only
+     * for sorted particles [rank*ceil(n/world), ...); see psamd_calc_forces_* */
+    int32_t  rank;
+    int32_t  world;
+} psamd_config;
+
+/* Sizes DoInit derives (ps.cpp:2204-2222), in elements. */
+typedef struct psamd_sizes {
+    int32_t grid_dim, num_cells, num_chunks, cells_per_chunk;
+    int32_t max_per_cell, max_per_chunk;
+    int32_t container_size;      /* nParticles = nTdata = nQueue        */
+    int32_t queue_info_size;     /* nQueueInfo                           */
+    int64_t n_chunkgrid;         /* NUM_CHUNKS*(1+MAX_PARTICLES_PER_CHUNK) */
+    int64_t n_cellgrid;          /* NUM_CELLS*(1+MAX_PARTICLES_PER_CELL)   */
+    int32_t n_pkgdistrib;        /* NUM_CHUNKS*27 PAIRs                  */
+    int32_t seg_count[4], seg_size_t[4], seg_size[4]; /* types 1,2,4,8  */
+} psamd_sizes;
+
+/* Event counts of the last psamd_calc_forces / psamd_step call(s), cumulative. */
+typedef struct psamd_counters {
+    int64_t deaths_age, deaths_collision, survives, integrated;
+    int64_t relocations, relocations_lost, births, births_failed, cell_overflow_kills;
+    int64_t steps;
+} psamd_counters;
+
+/* Raw device pointers of the SoA state, for plumbing (collectives, interop).
+ * Valid until psamd_destroy.  Layouts are described in DESIGN.md section 3. */
+typedef struct psamd_device_view {
+    void    *pos4;        /* float4[container]  x,y,z,w                         */
+    void    *vel4;        /* float4[container]  vx,vy,vz,age                    */
+    void    *acc4;        /* float4[container]  ax,ay,az,fertility_age          */
+    void    *cell;        /* int[container]     cell index, -1 = free slot      */
+    void    *pflags;      /* uint8[container]   bit0 = is_parent                */
+    void    *sorted_id;   /* int[container]     slot ids, cell-major, id-ascending in a cell */
+    void    *snap4;       /* float4[container]  snapshot x,y,z,w_eff in sorted order */
+    void    *force4;      /* float4[container]  ax,ay,az,collision flag in sorted order */
+    void    *cell_start;  /* int[num_cells+1]   exclusive prefix of cell counts */
+    int64_t  container_size;
+    int32_t  num_cells;
+    int32_t  live;        /* live particles at the last build_grid             */
+    void    *stream;      /* hipStream_t the stages are enqueued on            */
+} psamd_device_view;
+
+typedef struct psamd_ctx psamd_ctx;
+
+/* ---- lifetime ------------------------------------------------------------ */
+int         psamd_abi_version(void);
+const char *psamd_status_string(int status);
+int         psamd_default_config(psamd_config *cfg);
+/* DoInit + init_particles + q_start_fast + pkg_distrib (ps.cpp:2200-2235,
+ * 722-753, 814-871, 893-911): allocates the container, marks every slot free. */
+int         psamd_create(const psamd_config *cfg, psamd_ctx **out);
+int         psamd_destroy(psamd_ctx *ctx);
+const char *psamd_last_error(const psamd_ctx *ctx);
+int         psamd_get_sizes(const psamd_ctx *ctx, psamd_sizes *out);
+int         psamd_get_config(const psamd_ctx *ctx, psamd_config *out);
+
+/* ---- setup stage: fill_particles, task 5 (ps.cpp:915-1048) --------------- */
+/* Places n particles in order; each takes the next free slot of its segment
+ * (q_remove) and is initialised as create_particle_s does (app.cu:189-208).
+ * w / age / fert_age may be NULL => particle_weight / 0 / 0.  ids_out (may be
+ * NULL) receives the slot ids.  On error nothing after the failing particle is
+ * placed and *n_done (may be NULL) says how many were. */
+int psamd_fill_particles(psamd_ctx *ctx, int64_t n, const float *xyz, const float *vxyz,
+                         const float *w, const float *age, const float *fert_age,
+                         int32_t *ids_out, int64_t *n_done);
+/* The reference's own initial distribution (ps.cpp:974-1028) with a fixed seed in
+ * place of std::random_device: n points uniform in the box, written to xyz_out. */
+int psamd_uniform_cloud(const psamd_ctx *ctx, int64_t n, uint32_t seed, float *xyz_out);
+
+/* ---- the reference's buffers, in the reference's own layouts -------------- */
+/* P_DATA_TYPE[count] (72-byte records, common.h:94-120) for slots first..first+count-1 */
+int psamd_upload_particles(psamd_ctx *ctx, const void *p72, int64_t first, int64_t count);
+int psamd_download_particles(psamd_ctx *ctx, void *p72, int64_t first, int64_t count);
+/* T_DATA_TYPE[count] (24-byte records, common.h:122-132): the build_grid snapshot */
+int psamd_download_tdata(psamd_ctx *ctx, void *t24, int64_t first, int64_t count);
+/* QUEUE_INFO[queue_info_size] + int[container_size] (common.h:134-139, ps.cpp:72-73) */
+int psamd_upload_queues(psamd_ctx *ctx, const void *queue_info24, const int32_t *queue);
+int psamd_download_queues(psamd_ctx *ctx, void *queue_info24, int32_t *queue);
+/* int[n_cellgrid] / int[n_chunkgrid], element 0 of each row = count (ps.cpp:1502-1516) */
+int psamd_download_cellgrid(psamd_ctx *ctx, int32_t *out);
+int psamd_download_chunkgrid(psamd_ctx *ctx, int32_t *out);
+/* PAIR[num_chunks*27] (app_common.cu:150-232) and the cell -> (chunk, seg_type,
+ * seg_tid) table (get_cell_info, app_common.cu:50-148), 3 ints per cell */
+int psamd_get_pkgdistrib(const psamd_ctx *ctx, int32_t *pairs_out);
+int psamd_get_cell_table(const psamd_ctx *ctx, int32_t *out3_per_cell);
+/* hostGridMax: [0] biggest chunk, [1] biggest cell (ps.cpp:76, read at ps.cpp:1900) */
+int psamd_get_gridmax(psamd_ctx *ctx, int32_t out2[2]);
+
+/* ---- the three per-step stages ------------------------------------------ */
+int psamd_init_iframe(psamd_ctx *ctx);  /* task 3, ps.cpp:1574-1606 / psCUDA.cu:104-150 */
+int psamd_build_grid(psamd_ctx *ctx);   /* task 8, ps.cpp:1468-1537 / psCUDA.cu:442-499 */
+int psamd_calc_forces(psamd_ctx *ctx);  /* task 6, ps.cpp:1120-1383 / psCUDA.cu:152-423 */
+/* calc_forces split at the point where ranks exchange results (multi-GPU):
+ * _pairs fills force4 for this rank's share of the sorted particles,
+ * _apply integrates every particle from a complete force4 and runs the
+ * lifecycle.  psamd_calc_forces == _pairs then _apply when world == 1. */
+int psamd_calc_forces_pairs(psamd_ctx *ctx);
+int psamd_calc_forces_apply(psamd_ctx *ctx);
+/* Sorted-index range [begin,end) whose force4 entries this rank produces, and the
+ * padded per-rank share (same on every rank) for an equal-sized all-gather. */
+int psamd_force_shard(psamd_ctx *ctx, int64_t *begin, int64_t *end, int64_t *share);
+/* nsteps x {init_iframe, build_grid, calc_forces}; asynchronous on the context's
+ * stream unless lifecycle bookkeeping forces a sync. */
+int psamd_step(psamd_ctx *ctx, int32_t nsteps);
+int psamd_synchronize(psamd_ctx *ctx);
+
+/* ---- plumbing for collectives (multi-GPU) -------------------------------------- */
+/* Enqueue all further work on the caller's HIP stream (e.g. the one RCCL orders
+ * against) instead of the context's own.  NULL restores the context's stream. */
+int psamd_set_stream(psamd_ctx *ctx, void *hip_stream);
+/* Use caller-owned device memory (>= n_float4 float4 elements, n_float4 >=
+ * container_size) as the force4 array, so a collective can fill it in place. NULL
+ * restores the context's own buffer. */
+int psamd_bind_force4(psamd_ctx *ctx, void *device_ptr, int64_t n_float4);
+
+/* ---- introspection -------------------------------------------------------- */
+int psamd_get_counters(psamd_ctx *ctx, psamd_counters *out);
+int psamd_live_count(psamd_ctx *ctx, int64_t *out);
+int psamd_device_view_get(psamd_ctx *ctx, psamd_device_view *out);
+/* Per-kernel device time of the most recent step in microseconds, measured with
+ * HIP events on the context's stream: hist, scan, scatter, sort, pairs, apply,
+ * lifecycle.  Enabled by psamd_set_timing(ctx, 1). */
+#define PSAMD_NUM_TIMERS 8
+int psamd_set_timing(psamd_ctx *ctx, int enabled);
+int psamd_get_timing(psamd_ctx *ctx, double us_out[PSAMD_NUM_TIMERS], int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSAMD_H */

@@ -88,6 +88,8 @@ def lib():
         L.pso_get_derived.restype = C.POINTER(Derived)
         L.pso_fill_particle.argtypes = [vp] + [cf] * 6
         L.pso_fill_particle.restype = ci
+        L.pso_fill_particles.argtypes = [vp, ci, vp, vp, vp, vp, vp]
+        L.pso_fill_particles.restype = ci
         for n in ("pso_init_iframe", "pso_build_grid", "pso_calc_forces"):
             getattr(L, n).argtypes = [vp]
         L.pso_calc_forces_chunk.argtypes = [vp, ci, ci]
@@ -246,19 +248,17 @@ class System:
 
     def fill(self, xyz, age, fert_age, w=None):
         """fill_particle for each row of xyz (in order); returns the slot ids."""
-        xyz = np.asarray(xyz, dtype=np.float32).reshape(-1, 3)
+        xyz = np.ascontiguousarray(np.asarray(xyz, dtype=np.float32).reshape(-1, 3))
         n = len(xyz)
-        age = np.broadcast_to(np.asarray(age, dtype=np.float32), (n,))
-        fert = np.broadcast_to(np.asarray(fert_age, dtype=np.float32), (n,))
-        wv = np.broadcast_to(np.asarray(self.cfg.particle_weight if w is None else w,
-                                        dtype=np.float32), (n,))
+        age = np.ascontiguousarray(np.broadcast_to(np.asarray(age, dtype=np.float32), (n,)))
+        fert = np.ascontiguousarray(np.broadcast_to(np.asarray(fert_age, dtype=np.float32), (n,)))
+        wv = np.ascontiguousarray(np.broadcast_to(
+            np.asarray(self.cfg.particle_weight if w is None else w, dtype=np.float32), (n,)))
         ids = np.empty(n, dtype=np.int32)
-        f = self.L.pso_fill_particle
-        for k in range(n):
-            ids[k] = f(self.h, float(xyz[k, 0]), float(xyz[k, 1]), float(xyz[k, 2]),
-                       float(wv[k]), float(age[k]), float(fert[k]))
-        if (ids < 0).any():
-            raise RuntimeError("fill_particle failed (%d)" % int(ids.min()))
+        done = self.L.pso_fill_particles(self.h, n, xyz.ctypes.data, wv.ctypes.data, age.ctypes.data,
+                                         fert.ctypes.data, ids.ctypes.data)
+        if done != n:
+            raise RuntimeError("fill_particle failed at particle %d" % done)
         return ids
 
     def init_iframe(self):

@@ -516,6 +516,20 @@ int pso_fill_particle(pso_system *s, float x, float y, float z, float w, float a
     return nid;
 }
 
+int pso_fill_particles(pso_system *s, int n, const float *xyz, const float *w,
+                       const float *age, const float *fert_age, int *ids_out)
+{
+    int k;
+    for (k = 0; k < n; k++) {
+        int id = pso_fill_particle(s, xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2],
+                                   w ? w[k] : (float)s->cfg.particle_weight,
+                                   age ? age[k] : 0.0f, fert_age ? fert_age[k] : 0.0f);
+        if (id < 0) return k;
+        if (ids_out) ids_out[k] = id;
+    }
+    return n;
+}
+
 /* ----------------------------------------------------------- the stages */
 
 /* init_iframe_host, ps.cpp:1574-1606 */

@@ -99,6 +99,10 @@ const pso_derived *pso_get_derived(const pso_system *s);
 int pso_fill_particle(pso_system *s, float x, float y, float z,
                       float w, float age, float fert_age);
 
+/* n calls of pso_fill_particle in array order; returns how many were placed */
+int pso_fill_particles(pso_system *s, int n, const float *xyz, const float *w,
+                       const float *age, const float *fert_age, int *ids_out);
+
 /* The three per-step stages, ps.cpp:1574-1606, 1468-1537, 1120-1383 (driven as
  * DoParallelProcess does, ps.cpp:1843-1928: chunks 0..NUM_CHUNKS-1 in order). */
 void pso_init_iframe(pso_system *s);

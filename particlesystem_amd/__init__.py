@@ -1,0 +1,324 @@
+"""particlesystem_amd -- MI355X-native step of abraj/particleSystem behind a C ABI.
+
+This package is a thin ctypes mirror of ``include/psamd.h`` (the drop-in boundary):
+the product is ``libpsamd.so`` (hand-written HIP kernels for gfx950 + a C++ host
+context).  The Python layer exists for tests, the benchmark and torch.distributed
+plumbing; it never computes anything itself and there is no CPU fallback: if the
+library is not built, or no HIP device is visible, calls fail loudly.
+
+Stage names follow the reference's task list (particleSystem.cpp:2269-2282):
+``init_iframe`` (task 3), ``build_grid`` (task 8), ``calc_forces`` (task 6),
+``fill_particles`` (task 5).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpsamd.so")
+
+FLAG_EXPLOSIONS = 0x1
+FLAG_FAST_MATH = 0x2
+FLAG_NO_LIFECYCLE = 0x4
+NUM_TIMERS = 8
+TIMER_NAMES = ("hist", "scan", "scatter", "sort_cells", "pairs", "apply", "lifecycle", "init_iframe")
+
+# numpy images of the reference's records (common.h:94-145)
+P_DTYPE = np.dtype({
+    "names": ["id", "cell", "chunk", "seg_type", "seg_tid", "seg_fault", "is_parent",
+              "w", "age", "fertility_age", "x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az"],
+    "formats": ["<i4"] * 5 + ["u1", "u1"] + ["<f4"] * 12,
+    "offsets": [0, 4, 8, 12, 16, 20, 21] + list(range(24, 72, 4)),
+    "itemsize": 72,
+})
+T_DTYPE = np.dtype([("id", "<i4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w", "<f4"), ("age", "<f4")])
+Q_DTYPE = np.dtype([("front", "<i4"), ("rear", "<i4"), ("count", "<i4"), ("lock", "<i4"),
+                    ("rloc", "<i4"), ("seg_size", "<i4")])
+
+
+class Config(C.Structure):
+    _fields_ = [("max_particles_num", C.c_int32), ("x_factor", C.c_int32),
+                ("chunk_factor", C.c_int32), ("chunk_dim", C.c_int32),
+                ("cell_size", C.c_double), ("eps2", C.c_double), ("collision_radius", C.c_double),
+                ("particle_weight", C.c_double), ("dt", C.c_double), ("max_v", C.c_double),
+                ("explosion_speed", C.c_double), ("life_steps", C.c_double),
+                ("device", C.c_int32), ("flags", C.c_uint32), ("seed", C.c_uint64),
+                ("rank", C.c_int32), ("world", C.c_int32)]
+
+
+class Sizes(C.Structure):
+    _fields_ = [("grid_dim", C.c_int32), ("num_cells", C.c_int32), ("num_chunks", C.c_int32),
+                ("cells_per_chunk", C.c_int32), ("max_per_cell", C.c_int32), ("max_per_chunk", C.c_int32),
+                ("container_size", C.c_int32), ("queue_info_size", C.c_int32),
+                ("n_chunkgrid", C.c_int64), ("n_cellgrid", C.c_int64), ("n_pkgdistrib", C.c_int32),
+                ("seg_count", C.c_int32 * 4), ("seg_size_t", C.c_int32 * 4), ("seg_size", C.c_int32 * 4)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in
+                ("deaths_age", "deaths_collision", "survives", "integrated", "relocations",
+                 "relocations_lost", "births", "births_failed", "cell_overflow_kills", "steps")]
+
+
+class DeviceView(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("pos4", "vel4", "acc4", "cell", "pflags", "sorted_id", "snap4", "force4", "cell_start")] + \
+               [("container_size", C.c_int64), ("num_cells", C.c_int32), ("live", C.c_int32),
+                ("stream", C.c_void_p)]
+
+
+class PsamdError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("psamd status %d: %s" % (status, message))
+        self.status = status
+
+
+# every entry point include/psamd.h declares: (name, restype, argtypes)
+_vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+ABI = [
+    ("psamd_abi_version", C.c_int, []),
+    ("psamd_status_string", C.c_char_p, [C.c_int]),
+    ("psamd_default_config", C.c_int, [C.POINTER(Config)]),
+    ("psamd_create", C.c_int, [C.POINTER(Config), C.POINTER(_vp)]),
+    ("psamd_destroy", C.c_int, [_vp]),
+    ("psamd_last_error", C.c_char_p, [_vp]),
+    ("psamd_get_sizes", C.c_int, [_vp, C.POINTER(Sizes)]),
+    ("psamd_get_config", C.c_int, [_vp, C.POINTER(Config)]),
+    ("psamd_fill_particles", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
+    ("psamd_uniform_cloud", C.c_int, [_vp, _i64, C.c_uint32, _vp]),
+    ("psamd_upload_particles", C.c_int, [_vp, _vp, _i64, _i64]),
+    ("psamd_download_particles", C.c_int, [_vp, _vp, _i64, _i64]),
+    ("psamd_download_tdata", C.c_int, [_vp, _vp, _i64, _i64]),
+    ("psamd_upload_queues", C.c_int, [_vp, _vp, _vp]),
+    ("psamd_download_queues", C.c_int, [_vp, _vp, _vp]),
+    ("psamd_download_cellgrid", C.c_int, [_vp, _vp]),
+    ("psamd_download_chunkgrid", C.c_int, [_vp, _vp]),
+    ("psamd_get_pkgdistrib", C.c_int, [_vp, _vp]),
+    ("psamd_get_cell_table", C.c_int, [_vp, _vp]),
+    ("psamd_get_gridmax", C.c_int, [_vp, _ip]),
+    ("psamd_init_iframe", C.c_int, [_vp]),
+    ("psamd_build_grid", C.c_int, [_vp]),
+    ("psamd_calc_forces", C.c_int, [_vp]),
+    ("psamd_calc_forces_pairs", C.c_int, [_vp]),
+    ("psamd_calc_forces_apply", C.c_int, [_vp]),
+    ("psamd_force_shard", C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    ("psamd_step", C.c_int, [_vp, _i32]),
+    ("psamd_synchronize", C.c_int, [_vp]),
+    ("psamd_set_stream", C.c_int, [_vp, _vp]),
+    ("psamd_bind_force4", C.c_int, [_vp, _vp, _i64]),
+    ("psamd_get_counters", C.c_int, [_vp, C.POINTER(Counters)]),
+    ("psamd_live_count", C.c_int, [_vp, C.POINTER(_i64)]),
+    ("psamd_device_view_get", C.c_int, [_vp, C.POINTER(DeviceView)]),
+    ("psamd_set_timing", C.c_int, [_vp, C.c_int]),
+    ("psamd_get_timing", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
+]
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libpsamd.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    return _build.build(force=force)
+
+
+def load():
+    """Load libpsamd.so and bind every ABI symbol. Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libpsamd.so is not built (run particlesystem_amd.build()); "
+                               "the HIP library is the only implementation, there is no fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in ABI:
+            fn = getattr(lib, name)  # AttributeError here = a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def default_config(**over):
+    cfg = Config()
+    load().psamd_default_config(C.byref(cfg))
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class ParticleSystem:
+    """One psamd context: the reference's nine buffers, resident on one MI355X."""
+
+    def __init__(self, cfg=None, **over):
+        self.lib = load()
+        self.cfg = cfg if cfg is not None else default_config(**over)
+        h = C.c_void_p()
+        st = self.lib.psamd_create(C.byref(self.cfg), C.byref(h))
+        self.h = h
+        if st != 0:
+            msg = self.lib.psamd_last_error(h).decode() if h else self.lib.psamd_status_string(st).decode()
+            if h:
+                self.lib.psamd_destroy(h)
+            self.h = None
+            raise PsamdError(st, msg)
+        self.sizes = Sizes()
+        self._ck(self.lib.psamd_get_sizes(self.h, C.byref(self.sizes)))
+
+    def _ck(self, st):
+        if st != 0:
+            raise PsamdError(st, self.lib.psamd_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.psamd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- setup ------------------------------------------------------------
+    def uniform_cloud(self, n, seed):
+        xyz = np.empty((n, 3), np.float32)
+        self._ck(self.lib.psamd_uniform_cloud(self.h, n, seed, _ptr(xyz)))
+        return xyz
+
+    def fill_particles(self, xyz, age=None, fert_age=None, w=None, vxyz=None):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        n = len(xyz)
+
+        def arr(v):
+            if v is None:
+                return None
+            return np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float32), (n,)))
+        age, fert_age, w = arr(age), arr(fert_age), arr(w)
+        vxyz = None if vxyz is None else np.ascontiguousarray(vxyz, np.float32).reshape(-1, 3)
+        ids = np.empty(n, np.int32)
+        done = C.c_int64()
+        self._ck(self.lib.psamd_fill_particles(self.h, n, _ptr(xyz), _ptr(vxyz), _ptr(w), _ptr(age),
+                                               _ptr(fert_age), _ptr(ids), C.byref(done)))
+        return ids
+
+    # ---- reference-layout buffers ------------------------------------------
+    def upload_particles(self, p, first=0):
+        p = np.ascontiguousarray(p)
+        assert p.dtype == P_DTYPE
+        self._ck(self.lib.psamd_upload_particles(self.h, _ptr(p), first, len(p)))
+
+    def download_particles(self, first=0, count=None):
+        count = self.sizes.container_size - first if count is None else count
+        p = np.zeros(count, P_DTYPE)
+        self._ck(self.lib.psamd_download_particles(self.h, _ptr(p), first, count))
+        return p
+
+    def download_tdata(self, first=0, count=None):
+        count = self.sizes.container_size - first if count is None else count
+        t = np.zeros(count, T_DTYPE)
+        self._ck(self.lib.psamd_download_tdata(self.h, _ptr(t), first, count))
+        return t
+
+    def upload_queues(self, queue_info, queue):
+        qi = np.ascontiguousarray(queue_info)
+        q = np.ascontiguousarray(queue, np.int32)
+        assert qi.dtype == Q_DTYPE and len(qi) == self.sizes.queue_info_size and len(q) == self.sizes.container_size
+        self._ck(self.lib.psamd_upload_queues(self.h, _ptr(qi), _ptr(q)))
+
+    def download_queues(self):
+        qi = np.zeros(self.sizes.queue_info_size, Q_DTYPE)
+        q = np.zeros(self.sizes.container_size, np.int32)
+        self._ck(self.lib.psamd_download_queues(self.h, _ptr(qi), _ptr(q)))
+        return qi, q
+
+    def download_cellgrid(self):
+        out = np.zeros(self.sizes.n_cellgrid, np.int32)
+        self._ck(self.lib.psamd_download_cellgrid(self.h, _ptr(out)))
+        return out.reshape(self.sizes.num_cells, -1)
+
+    def download_chunkgrid(self):
+        out = np.zeros(self.sizes.n_chunkgrid, np.int32)
+        self._ck(self.lib.psamd_download_chunkgrid(self.h, _ptr(out)))
+        return out.reshape(self.sizes.num_chunks, -1)
+
+    def pkgdistrib(self):
+        out = np.zeros(self.sizes.n_pkgdistrib * 2, np.int32)
+        self._ck(self.lib.psamd_get_pkgdistrib(self.h, _ptr(out)))
+        return out.reshape(self.sizes.num_chunks, 54)
+
+    def cell_table(self):
+        out = np.zeros(self.sizes.num_cells * 3, np.int32)
+        self._ck(self.lib.psamd_get_cell_table(self.h, _ptr(out)))
+        return out.reshape(-1, 3)
+
+    def gridmax(self):
+        out = np.zeros(2, np.int32)
+        self._ck(self.lib.psamd_get_gridmax(self.h, out.ctypes.data_as(_ip)))
+        return out
+
+    # ---- stages -------------------------------------------------------------
+    def init_iframe(self):
+        self._ck(self.lib.psamd_init_iframe(self.h))
+
+    def build_grid(self):
+        self._ck(self.lib.psamd_build_grid(self.h))
+
+    def calc_forces(self):
+        self._ck(self.lib.psamd_calc_forces(self.h))
+
+    def calc_forces_pairs(self):
+        self._ck(self.lib.psamd_calc_forces_pairs(self.h))
+
+    def calc_forces_apply(self):
+        self._ck(self.lib.psamd_calc_forces_apply(self.h))
+
+    def force_shard(self):
+        b, e, s = C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(self.lib.psamd_force_shard(self.h, C.byref(b), C.byref(e), C.byref(s)))
+        return b.value, e.value, s.value
+
+    def step(self, n=1):
+        self._ck(self.lib.psamd_step(self.h, n))
+
+    def synchronize(self):
+        self._ck(self.lib.psamd_synchronize(self.h))
+
+    def set_stream(self, hip_stream):
+        self._ck(self.lib.psamd_set_stream(self.h, hip_stream))
+
+    def bind_force4(self, device_ptr, n_float4):
+        self._ck(self.lib.psamd_bind_force4(self.h, device_ptr, n_float4))
+
+    # ---- introspection ------------------------------------------------------
+    @property
+    def counters(self):
+        c = Counters()
+        self._ck(self.lib.psamd_get_counters(self.h, C.byref(c)))
+        return {n: getattr(c, n) for n, _ in Counters._fields_}
+
+    def live_count(self):
+        n = C.c_int64()
+        self._ck(self.lib.psamd_live_count(self.h, C.byref(n)))
+        return n.value
+
+    def device_view(self):
+        v = DeviceView()
+        self._ck(self.lib.psamd_device_view_get(self.h, C.byref(v)))
+        return v
+
+    def set_timing(self, on=True):
+        self._ck(self.lib.psamd_set_timing(self.h, 1 if on else 0))
+
+    def timing(self):
+        us = (C.c_double * NUM_TIMERS)()
+        n = C.c_int64()
+        self._ck(self.lib.psamd_get_timing(self.h, us, C.byref(n)))
+        return dict(zip(TIMER_NAMES, list(us))), n.value

@@ -1,0 +1,729 @@
+// capi.hip -- the psamd context and its C ABI (include/psamd.h).
+//
+// Host side of the drop-in boundary, C++ like the reference's host code.  It mirrors
+// the reference driver's view of the path: nine buffers (ps.cpp:70-78), one-off setup
+// stages, then per step init_iframe -> build_grid -> calc_forces (ps.cpp:1843-1928).
+// All arithmetic of the step runs in the HIP kernels of kernels.hip; there is no CPU
+// fallback: without a HIP device psamd_create fails with PSAMD_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/psamd.h"
+#include "device_types.h"
+#include "geometry.hpp"
+#include "kernels.h"
+
+using namespace psamd;
+
+struct psamd_ctx {
+    Geometry geo;
+    DevParams P{};
+    SegLayout S{};
+    DeviceState d;
+    hipStream_t stream = nullptr;       // stream in use
+    hipStream_t own_stream = nullptr;   // the one this context created
+    float4 *own_force4 = nullptr;
+    std::vector<void *> allocs;
+    std::string err;
+    // host mirrors
+    std::vector<CellInfo> celltab;
+    std::vector<QueueInfo> h_qinfo;   // valid while !queues_on_device_newer
+    std::vector<int32_t> h_queue;
+    bool host_queues_valid = true;    // host mirror == device copy
+    void *staging = nullptr;          // device staging for AoS transfers
+    size_t staging_bytes = 0;
+    // stage state machine
+    bool frame_reset = false, grid_built = false, pairs_done = false;
+    int step = 0;
+    int64_t steps_total = 0;
+    int live_at_build = -1;           // host copy of fs->live (valid after a sync)
+    // timing
+    bool timing = false;
+    hipEvent_t ev[11]{};
+    bool ev_made = false;
+    double t_us[PSAMD_NUM_TIMERS]{};
+    int64_t t_launches = 0;
+};
+
+namespace {
+
+const char *status_text(int s)
+{
+    switch (s) {
+    case PSAMD_OK: return "ok";
+    case PSAMD_ERR_INVALID_ARG: return "invalid argument";
+    case PSAMD_ERR_NO_DEVICE: return "no usable HIP device (the HIP path is the only path)";
+    case PSAMD_ERR_HIP: return "HIP runtime error";
+    case PSAMD_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case PSAMD_ERR_OUTSIDE_BOX: return "particle location outside box";
+    case PSAMD_ERR_QUEUE_EMPTY: return "overflow: reserved space of the segment is full";
+    case PSAMD_ERR_CELL_OVERFLOW: return "cell or queue-op capacity exceeded on device";
+    case PSAMD_ERR_STATE: return "stage called out of order";
+    case PSAMD_ERR_UNSUPPORTED: return "unsupported";
+    }
+    return "unknown status";
+}
+
+int fail(psamd_ctx *c, int status, const std::string &what)
+{
+    if (c) c->err = std::string(status_text(status)) + ": " + what;
+    return status;
+}
+
+int hip_fail(psamd_ctx *c, hipError_t e, const char *what)
+{
+    return fail(c, e == hipErrorOutOfMemory ? PSAMD_ERR_OUT_OF_MEMORY : PSAMD_ERR_HIP,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define PS_HIP(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail((c), e_, #call); } while (0)
+
+template <typename T>
+hipError_t dev_alloc(psamd_ctx *c, T **out, size_t n)
+{
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    c->allocs.push_back(p);
+    *out = (T *)p;
+    return hipSuccess;
+}
+
+int ensure_staging(psamd_ctx *c, size_t bytes)
+{
+    if (bytes <= c->staging_bytes) return PSAMD_OK;
+    if (c->staging) (void)hipFree(c->staging);
+    c->staging = nullptr; c->staging_bytes = 0;
+    PS_HIP(c, hipMalloc(&c->staging, bytes));
+    c->staging_bytes = bytes;
+    return PSAMD_OK;
+}
+
+int pull_queues(psamd_ctx *c)   // device -> host mirror
+{
+    if (c->host_queues_valid) return PSAMD_OK;
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    PS_HIP(c, hipMemcpy(c->h_qinfo.data(), c->d.qinfo, c->h_qinfo.size() * sizeof(QueueInfo), hipMemcpyDeviceToHost));
+    PS_HIP(c, hipMemcpy(c->h_queue.data(), c->d.queue, c->h_queue.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    c->host_queues_valid = true;
+    return PSAMD_OK;
+}
+
+int push_queues(psamd_ctx *c)   // host mirror -> device
+{
+    PS_HIP(c, hipMemcpyAsync(c->d.qinfo, c->h_qinfo.data(), c->h_qinfo.size() * sizeof(QueueInfo), hipMemcpyHostToDevice, c->stream));
+    PS_HIP(c, hipMemcpyAsync(c->d.queue, c->h_queue.data(), c->h_queue.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    return PSAMD_OK;
+}
+
+// q_remove on the host mirror (app_common.cu:305-339), used by the fill stage only
+int host_q_remove(psamd_ctx *c, int seg_type, int seg_tid)
+{
+    QueueInfo &q = c->h_qinfo[(size_t)c->geo.segment_record(seg_type, seg_tid)];
+    if (q.count <= 0) return -1;
+    const int pos = q.front;
+    if (q.count == 1) { q.front = -1; q.rear = -1; }
+    else if (q.front == q.rloc + q.seg_size - 1) q.front = q.rloc;
+    else q.front++;
+    q.count--;
+    const int item = c->h_queue[(size_t)pos];
+    c->h_queue[(size_t)pos] = -1;
+    return item;
+}
+
+int check_device_errors(psamd_ctx *c)   // after a sync: sticky error bits raised by kernels
+{
+    FrameScalars fs{};
+    PS_HIP(c, hipMemcpy(&fs, c->d.fs, sizeof fs, hipMemcpyDeviceToHost));
+    c->live_at_build = fs.live;
+    if (fs.error & ERR_BAD_ID) return fail(c, PSAMD_ERR_INVALID_ARG, "uploaded particle with id != slot index");
+    if (fs.error & ERR_CELL_TOO_BIG) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "a cell holds more particles than the sort kernel ranks");
+    if (fs.error & ERR_OPS_OVERFLOW) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "lifecycle op buffer overflow");
+    if (fs.error & ERR_BUCKET_TOO_BIG) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "too many queue operations on one segment in one step");
+    return PSAMD_OK;
+}
+
+void shard_range(const psamd_ctx *c, int64_t total, int64_t &lo, int64_t &hi, int64_t &share)
+{
+    const int world = std::max(1, c->geo.cfg.world), rank = c->geo.cfg.rank;
+    share = (total + world - 1) / world;
+    lo = std::min<int64_t>(total, share * rank);
+    hi = std::min<int64_t>(total, lo + share);
+}
+
+void make_events(psamd_ctx *c)
+{
+    if (c->ev_made) return;
+    for (auto &e : c->ev) (void)hipEventCreate(&e);
+    c->ev_made = true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int psamd_abi_version(void) { return PSAMD_ABI_VERSION; }
+const char *psamd_status_string(int status) { return status_text(status); }
+
+int psamd_default_config(psamd_config *cfg)
+{
+    if (!cfg) return PSAMD_ERR_INVALID_ARG;
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->max_particles_num = 1024 * 1024;  // common.h:12
+    cfg->x_factor = 2;                     // common.h:13
+    cfg->chunk_factor = 4;                 // common.h:29
+    cfg->chunk_dim = 4;                    // common.h:30
+    cfg->cell_size = 5.0;                  // common.h:52
+    cfg->eps2 = 0.2;                       // common.h:53
+    cfg->collision_radius = 0.4;           // common.h:54
+    cfg->particle_weight = 60.0;           // common.h:55
+    cfg->dt = 0.05;                        // common.h:69
+    cfg->max_v = 10.0;                     // common.h:66
+    cfg->explosion_speed = 3.0;            // common.h:67
+    cfg->life_steps = 300.0;               // common.h:58
+    cfg->device = 0;
+    cfg->flags = 0;
+    cfg->seed = 1;                         // RAND_SEED, common.h:56
+    cfg->rank = 0;
+    cfg->world = 1;
+    return PSAMD_OK;
+}
+
+int psamd_create(const psamd_config *cfg, psamd_ctx **out)
+{
+    if (!cfg || !out) return PSAMD_ERR_INVALID_ARG;
+    *out = nullptr;
+    psamd_ctx *c = new (std::nothrow) psamd_ctx();
+    if (!c) return PSAMD_ERR_OUT_OF_MEMORY;
+    *out = c;  // returned even on failure so psamd_last_error can explain; caller destroys it
+    if (!c->geo.init(*cfg)) return fail(c, PSAMD_ERR_INVALID_ARG, "bad configuration (chunk_dim >= 3, sizes > 0, container < 2^31)");
+    if (cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world) return fail(c, PSAMD_ERR_INVALID_ARG, "rank/world");
+    const Geometry &g = c->geo;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(c, PSAMD_ERR_NO_DEVICE, "hipGetDeviceCount found none");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(c, PSAMD_ERR_NO_DEVICE, "device ordinal out of range");
+    PS_HIP(c, hipSetDevice(cfg->device));
+    PS_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+
+    DevParams &P = c->P;
+    P.G = g.G; P.num_cells = g.num_cells; P.num_chunks = g.num_chunks; P.container = g.container;
+    P.max_per_cell = g.max_per_cell; P.max_per_chunk = g.max_per_chunk;
+    P.slices = (g.max_per_cell + 63) / 64;
+    P.flags = cfg->flags;
+    P.t = (float)cfg->dt;
+    P.kid_thr = float_ceil(g.kid_age);
+    P.life_thr = float_floor(g.particle_life);
+    // every pair whose fp32 squared distance is at or below this gets the exact
+    // collision test; the margin only has to cover the rounding of sqrtf
+    P.coll_d2_gate = (float)(cfg->collision_radius * cfg->collision_radius * 1.001 + 1e-30);
+    P.dmax = (float)cfg->cell_size;   // MAX_DX = CELL_SIZE, common.h:65
+    P.vmax = (float)cfg->max_v;
+    P.w_default = (float)cfg->particle_weight;
+    P.fert_lo = (float)g.min_fert; P.fert_hi = (float)g.max_fert;
+    P.cell_size = cfg->cell_size; P.eps2 = cfg->eps2; P.coll_radius = cfg->collision_radius;
+    P.kid_age = g.kid_age; P.life = g.particle_life; P.expl_speed = cfg->explosion_speed;
+    P.seed = cfg->seed;
+    for (int k = 0; k < 5; k++) { c->S.seg_base[k] = g.seg_base[k]; c->S.info_base[k] = g.info_base[k]; }
+    for (int k = 0; k < 4; k++) c->S.seg_size_t[k] = g.seg_size_t[k];
+
+    DeviceState &d = c->d;
+    const size_t C = (size_t)g.container;
+    d.ops_cap = (int)std::min<size_t>(3 * C, (size_t)INT32_MAX / 2);
+    d.moves_cap = (int)std::min<size_t>(2 * C, (size_t)INT32_MAX / 2);
+    int *frame = nullptr;
+    const size_t frame_ints = (size_t)g.num_cells + g.num_chunks + g.queue_infos;
+    PS_HIP(c, dev_alloc(c, &d.pos4, C));
+    PS_HIP(c, dev_alloc(c, &d.vel4, C));
+    PS_HIP(c, dev_alloc(c, &d.acc4, C));
+    PS_HIP(c, dev_alloc(c, &d.cell, C));
+    PS_HIP(c, dev_alloc(c, &d.pflags, C));
+    PS_HIP(c, dev_alloc(c, &d.tdata, 6 * C));
+    PS_HIP(c, dev_alloc(c, &d.qinfo, (size_t)g.queue_infos));
+    PS_HIP(c, dev_alloc(c, &d.queue, C));
+    PS_HIP(c, dev_alloc(c, &frame, frame_ints));
+    d.cell_count = frame; d.chunk_count = frame + g.num_cells; d.rec_count = d.chunk_count + g.num_chunks;
+    PS_HIP(c, dev_alloc(c, &d.fs, 1));
+    PS_HIP(c, dev_alloc(c, &d.cell_start, (size_t)g.num_cells + 1));
+    PS_HIP(c, dev_alloc(c, &d.cursor, (size_t)g.num_cells));
+    PS_HIP(c, dev_alloc(c, &d.sorted_id, C));
+    PS_HIP(c, dev_alloc(c, &d.snap4, C));
+    PS_HIP(c, dev_alloc(c, &d.snap_age, C));
+    PS_HIP(c, dev_alloc(c, &d.force4, C));
+    c->own_force4 = d.force4;
+    PS_HIP(c, dev_alloc(c, &d.celltab, (size_t)g.num_cells));
+    PS_HIP(c, dev_alloc(c, &d.ops, (size_t)d.ops_cap));
+    PS_HIP(c, dev_alloc(c, &d.ops_sorted, (size_t)d.ops_cap));
+    PS_HIP(c, dev_alloc(c, &d.moves, (size_t)d.moves_cap));
+    PS_HIP(c, dev_alloc(c, &d.stage, 3 * (size_t)d.moves_cap));
+    PS_HIP(c, dev_alloc(c, &d.rec_start, (size_t)g.queue_infos + 1));
+    PS_HIP(c, dev_alloc(c, &d.rec_cursor, (size_t)g.queue_infos));
+    PS_HIP(c, dev_alloc(c, &d.ctr, 1));
+
+    // init_particles (ps.cpp:722-753): every slot reset, cell = -1
+    PS_HIP(c, hipMemsetAsync(d.pos4, 0, C * sizeof(float4), c->stream));
+    PS_HIP(c, hipMemsetAsync(d.vel4, 0, C * sizeof(float4), c->stream));
+    PS_HIP(c, hipMemsetAsync(d.acc4, 0, C * sizeof(float4), c->stream));
+    PS_HIP(c, hipMemsetAsync(d.pflags, 0, C, c->stream));
+    PS_HIP(c, hipMemsetAsync(d.force4, 0, C * sizeof(float4), c->stream));
+    PS_HIP(c, hipMemsetAsync(d.fs, 0, sizeof(FrameScalars), c->stream));
+    PS_HIP(c, hipMemsetAsync(d.ctr, 0, sizeof(DevCounters), c->stream));
+    PS_HIP(c, hipMemsetAsync(frame, 0, frame_ints * sizeof(int), c->stream));
+    PS_HIP(c, launch_fill_int(c->stream, d.cell, -1, C));
+    PS_HIP(c, launch_init_tdata(c->stream, d, g.container));
+    // q_start_fast (ps.cpp:814-871) and the cell table
+    g.initial_queues(c->h_qinfo, c->h_queue);
+    c->celltab = g.cell_table();
+    PS_HIP(c, hipMemcpyAsync(d.celltab, c->celltab.data(), c->celltab.size() * sizeof(CellInfo), hipMemcpyHostToDevice, c->stream));
+    int rc = push_queues(c);
+    if (rc != PSAMD_OK) return rc;
+    c->host_queues_valid = true;
+    return PSAMD_OK;
+}
+
+int psamd_destroy(psamd_ctx *c)
+{
+    if (!c) return PSAMD_OK;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void *p : c->allocs) (void)hipFree(p);
+    if (c->staging) (void)hipFree(c->staging);
+    if (c->ev_made) for (auto &e : c->ev) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return PSAMD_OK;
+}
+
+const char *psamd_last_error(const psamd_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int psamd_get_sizes(const psamd_ctx *c, psamd_sizes *o)
+{
+    if (!c || !o) return PSAMD_ERR_INVALID_ARG;
+    const Geometry &g = c->geo;
+    std::memset(o, 0, sizeof *o);
+    o->grid_dim = g.G; o->num_cells = g.num_cells; o->num_chunks = g.num_chunks;
+    o->cells_per_chunk = g.cells_per_chunk; o->max_per_cell = g.max_per_cell; o->max_per_chunk = g.max_per_chunk;
+    o->container_size = g.container; o->queue_info_size = g.queue_infos;
+    o->n_chunkgrid = (int64_t)g.num_chunks * (1 + (int64_t)g.max_per_chunk);
+    o->n_cellgrid = (int64_t)g.num_cells * (1 + (int64_t)g.max_per_cell);
+    o->n_pkgdistrib = g.num_chunks * 27;
+    for (int k = 0; k < 4; k++) { o->seg_count[k] = g.seg_count[k]; o->seg_size_t[k] = g.seg_size_t[k]; o->seg_size[k] = g.seg_size[k]; }
+    return PSAMD_OK;
+}
+
+int psamd_get_config(const psamd_ctx *c, psamd_config *o)
+{
+    if (!c || !o) return PSAMD_ERR_INVALID_ARG;
+    *o = c->geo.cfg;
+    return PSAMD_OK;
+}
+
+int psamd_uniform_cloud(const psamd_ctx *c, int64_t n, uint32_t seed, float *xyz)
+{
+    if (!c || !xyz || n < 0) return PSAMD_ERR_INVALID_ARG;
+    // ps.cpp:974-1028 draws r*sign*range per axis from a random_device-seeded mt19937;
+    // a fixed seed and one uniform draw per axis give the same distribution reproducibly
+    const float half = (float)((c->geo.G / 2) * c->geo.cfg.cell_size);
+    std::mt19937 gen(seed);
+    std::uniform_real_distribution<float> dist(-half, half);
+    for (int64_t i = 0; i < 3 * n; i++) xyz[i] = dist(gen);
+    return PSAMD_OK;
+}
+
+int psamd_fill_particles(psamd_ctx *c, int64_t n, const float *xyz, const float *vxyz, const float *w,
+                         const float *age, const float *fert_age, int32_t *ids_out, int64_t *n_done)
+{
+    if (n_done) *n_done = 0;
+    if (!c || n < 0 || (n > 0 && !xyz)) return PSAMD_ERR_INVALID_ARG;
+    if (n == 0) return PSAMD_OK;
+    int rc = pull_queues(c);
+    if (rc != PSAMD_OK) return rc;
+    const Geometry &g = c->geo;
+    struct Rec { float4 p, v, a; int cell; };
+    std::vector<int32_t> ids((size_t)n);
+    std::vector<Rec> recs((size_t)n);
+    int64_t done = 0;
+    int status = PSAMD_OK;
+    for (; done < n; done++) {
+        const float x = xyz[3 * done], y = xyz[3 * done + 1], z = xyz[3 * done + 2];
+        int cell;
+        if (!g.locate(x, y, z, cell)) { status = fail(c, PSAMD_ERR_OUTSIDE_BOX, "fill_particles"); break; }
+        const CellInfo &ci = c->celltab[(size_t)cell];
+        const int nid = host_q_remove(c, ci.seg_type, ci.seg_tid);
+        if (nid < 0) { status = fail(c, PSAMD_ERR_QUEUE_EMPTY, "fill_particles"); break; }
+        ids[(size_t)done] = nid;
+        Rec &r = recs[(size_t)done];
+        r.cell = cell;
+        r.p = make_float4(x, y, z, w ? w[done] : (float)g.cfg.particle_weight);
+        r.v = make_float4(vxyz ? vxyz[3 * done] : 0.f, vxyz ? vxyz[3 * done + 1] : 0.f, vxyz ? vxyz[3 * done + 2] : 0.f,
+                          age ? age[done] : 0.f);
+        r.a = make_float4(0.f, 0.f, 0.f, fert_age ? fert_age[done] : 0.f);
+    }
+    // create_particle_s overwrites every field of the slot (app.cu:189-208): ship the
+    // records once and let a kernel drop them into their slots
+    if (done > 0) {
+        const size_t m = (size_t)done;
+        std::vector<float4> hp(m), hv(m), ha(m);
+        std::vector<int> hc(m);
+        for (size_t k = 0; k < m; k++) { hp[k] = recs[k].p; hv[k] = recs[k].v; ha[k] = recs[k].a; hc[k] = recs[k].cell; }
+        const size_t bytes = m * (3 * sizeof(float4) + 2 * sizeof(int));
+        rc = ensure_staging(c, bytes);
+        if (rc != PSAMD_OK) return rc;
+        char *base = (char *)c->staging;
+        float4 *dp = (float4 *)base, *dv = dp + m, *da = dv + m;
+        int *dc = (int *)(da + m), *di = dc + m;
+        PS_HIP(c, hipMemcpyAsync(dp, hp.data(), m * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        PS_HIP(c, hipMemcpyAsync(dv, hv.data(), m * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        PS_HIP(c, hipMemcpyAsync(da, ha.data(), m * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        PS_HIP(c, hipMemcpyAsync(dc, hc.data(), m * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        PS_HIP(c, hipMemcpyAsync(di, ids.data(), m * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        PS_HIP(c, launch_place(c->stream, (int)done, di, dp, dv, da, dc, c->d));
+        PS_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    rc = push_queues(c);
+    if (rc != PSAMD_OK) return rc;
+    if (ids_out) std::copy(ids.begin(), ids.begin() + done, ids_out);
+    if (n_done) *n_done = done;
+    c->grid_built = false; c->pairs_done = false;
+    return status;
+}
+
+int psamd_upload_particles(psamd_ctx *c, const void *p72, int64_t first, int64_t count)
+{
+    if (!c || !p72 || first < 0 || count < 0 || first + count > c->geo.container) return PSAMD_ERR_INVALID_ARG;
+    if (count == 0) return PSAMD_OK;
+    int rc = ensure_staging(c, (size_t)count * 72);
+    if (rc != PSAMD_OK) return rc;
+    PS_HIP(c, hipMemcpyAsync(c->staging, p72, (size_t)count * 72, hipMemcpyHostToDevice, c->stream));
+    PS_HIP(c, launch_unpack_aos(c->stream, c->staging, (int)first, (int)count, c->d));
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    c->grid_built = false; c->pairs_done = false;
+    return check_device_errors(c);
+}
+
+int psamd_download_particles(psamd_ctx *c, void *p72, int64_t first, int64_t count)
+{
+    if (!c || !p72 || first < 0 || count < 0 || first + count > c->geo.container) return PSAMD_ERR_INVALID_ARG;
+    if (count == 0) return PSAMD_OK;
+    int rc = ensure_staging(c, (size_t)count * 72);
+    if (rc != PSAMD_OK) return rc;
+    PS_HIP(c, launch_pack_aos(c->stream, c->staging, (int)first, (int)count, c->geo.num_cells, c->d));
+    PS_HIP(c, hipMemcpyAsync(p72, c->staging, (size_t)count * 72, hipMemcpyDeviceToHost, c->stream));
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    return PSAMD_OK;
+}
+
+int psamd_download_tdata(psamd_ctx *c, void *t24, int64_t first, int64_t count)
+{
+    if (!c || !t24 || first < 0 || count < 0 || first + count > c->geo.container) return PSAMD_ERR_INVALID_ARG;
+    if (count == 0) return PSAMD_OK;
+    PS_HIP(c, hipMemcpyAsync(t24, c->d.tdata + 6 * first, (size_t)count * 24, hipMemcpyDeviceToHost, c->stream));
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    return PSAMD_OK;
+}
+
+int psamd_upload_queues(psamd_ctx *c, const void *qi, const int32_t *queue)
+{
+    if (!c || !qi || !queue) return PSAMD_ERR_INVALID_ARG;
+    std::memcpy(c->h_qinfo.data(), qi, c->h_qinfo.size() * sizeof(QueueInfo));
+    std::memcpy(c->h_queue.data(), queue, c->h_queue.size() * sizeof(int32_t));
+    c->host_queues_valid = true;
+    return push_queues(c);
+}
+
+int psamd_download_queues(psamd_ctx *c, void *qi, int32_t *queue)
+{
+    if (!c || !qi || !queue) return PSAMD_ERR_INVALID_ARG;
+    int rc = pull_queues(c);
+    if (rc != PSAMD_OK) return rc;
+    std::memcpy(qi, c->h_qinfo.data(), c->h_qinfo.size() * sizeof(QueueInfo));
+    std::memcpy(queue, c->h_queue.data(), c->h_queue.size() * sizeof(int32_t));
+    return PSAMD_OK;
+}
+
+// Rebuild the reference's fixed-stride lists from the compact sorted arrays.
+static int fetch_sorted(psamd_ctx *c, std::vector<int> &start, std::vector<int> &ids)
+{
+    if (!c->grid_built) return fail(c, PSAMD_ERR_STATE, "grid lists requested before build_grid");
+    start.resize((size_t)c->geo.num_cells + 1);
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    PS_HIP(c, hipMemcpy(start.data(), c->d.cell_start, start.size() * sizeof(int), hipMemcpyDeviceToHost));
+    ids.resize((size_t)std::max(start.back(), 1));
+    PS_HIP(c, hipMemcpy(ids.data(), c->d.sorted_id, (size_t)start.back() * sizeof(int), hipMemcpyDeviceToHost));
+    return PSAMD_OK;
+}
+
+int psamd_download_cellgrid(psamd_ctx *c, int32_t *out)
+{
+    if (!c || !out) return PSAMD_ERR_INVALID_ARG;
+    std::vector<int> start, ids;
+    int rc = fetch_sorted(c, start, ids);
+    if (rc != PSAMD_OK) return rc;
+    const Geometry &g = c->geo;
+    const size_t stride = 1 + (size_t)g.max_per_cell;
+    std::memset(out, 0, sizeof(int32_t) * stride * (size_t)g.num_cells);
+    for (int cell = 0; cell < g.num_cells; cell++) {
+        const int n = std::min(start[(size_t)cell + 1] - start[(size_t)cell], g.max_per_cell);
+        int32_t *row = out + stride * (size_t)cell;
+        row[0] = n;
+        for (int k = 0; k < n; k++) row[1 + k] = ids[(size_t)start[(size_t)cell] + k];
+    }
+    return PSAMD_OK;
+}
+
+int psamd_download_chunkgrid(psamd_ctx *c, int32_t *out)
+{
+    if (!c || !out) return PSAMD_ERR_INVALID_ARG;
+    std::vector<int> start, ids;
+    int rc = fetch_sorted(c, start, ids);
+    if (rc != PSAMD_OK) return rc;
+    const Geometry &g = c->geo;
+    const size_t stride = 1 + (size_t)g.max_per_chunk;
+    std::memset(out, 0, sizeof(int32_t) * stride * (size_t)g.num_chunks);
+    // the reference appends in slot order (ps.cpp:1502-1508): per chunk, ids ascending,
+    // including the ones the cell-overflow rule then killed (stored as ~id in fetch order)
+    std::vector<std::vector<int>> per((size_t)g.num_chunks);
+    for (int cell = 0; cell < g.num_cells; cell++) {
+        auto &v = per[(size_t)c->celltab[(size_t)cell].chunk];
+        for (int k = start[(size_t)cell]; k < start[(size_t)cell + 1]; k++) v.push_back(ids[(size_t)k]);
+    }
+    for (int ch = 0; ch < g.num_chunks; ch++) {
+        auto &v = per[(size_t)ch];
+        std::sort(v.begin(), v.end());
+        int32_t *row = out + stride * (size_t)ch;
+        row[0] = (int32_t)v.size();
+        const size_t n = std::min(v.size(), (size_t)g.max_per_chunk);
+        for (size_t k = 0; k < n; k++) row[1 + k] = v[k];
+    }
+    return PSAMD_OK;
+}
+
+int psamd_get_pkgdistrib(const psamd_ctx *c, int32_t *out)
+{
+    if (!c || !out) return PSAMD_ERR_INVALID_ARG;
+    for (int ch = 0; ch < c->geo.num_chunks; ch++) c->geo.chunk_segments(ch, (Pair *)out + (size_t)ch * 27);
+    return PSAMD_OK;
+}
+
+int psamd_get_cell_table(const psamd_ctx *c, int32_t *out)
+{
+    if (!c || !out) return PSAMD_ERR_INVALID_ARG;
+    for (int i = 0; i < c->geo.num_cells; i++) {
+        out[3 * i] = c->celltab[(size_t)i].chunk;
+        out[3 * i + 1] = c->celltab[(size_t)i].seg_type;
+        out[3 * i + 2] = c->celltab[(size_t)i].seg_tid;
+    }
+    return PSAMD_OK;
+}
+
+int psamd_get_gridmax(psamd_ctx *c, int32_t out2[2])
+{
+    if (!c || !out2) return PSAMD_ERR_INVALID_ARG;
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    FrameScalars fs{};
+    PS_HIP(c, hipMemcpy(&fs, c->d.fs, sizeof fs, hipMemcpyDeviceToHost));
+    out2[0] = fs.gridmax[0]; out2[1] = fs.gridmax[1];
+    c->live_at_build = fs.live;
+    return PSAMD_OK;
+}
+
+// ---- stages ---------------------------------------------------------------------
+
+int psamd_init_iframe(psamd_ctx *c)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    const Geometry &g = c->geo;
+    const size_t frame_ints = (size_t)g.num_cells + g.num_chunks + g.queue_infos;
+    if (c->timing) { make_events(c); (void)hipEventRecord(c->ev[10], c->stream); }
+    PS_HIP(c, hipMemsetAsync(c->d.cell_count, 0, frame_ints * sizeof(int), c->stream));
+    // keep the sticky error word across frames: only the per-frame scalars are cleared
+    PS_HIP(c, hipMemsetAsync(c->d.fs, 0, offsetof(FrameScalars, error), c->stream));
+    PS_HIP(c, hipMemsetAsync(&c->d.fs->n_ops, 0, 2 * sizeof(int32_t), c->stream));
+    c->frame_reset = true; c->grid_built = false; c->pairs_done = false;
+    return PSAMD_OK;
+}
+
+int psamd_build_grid(psamd_ctx *c)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (!c->frame_reset) return fail(c, PSAMD_ERR_STATE, "build_grid needs init_iframe first");
+    if (c->timing) make_events(c);
+    PS_HIP(c, launch_build_grid(c->stream, c->P, c->d, c->timing ? c->ev : nullptr));
+    c->frame_reset = false; c->grid_built = true; c->pairs_done = false;
+    c->live_at_build = -1;
+    return PSAMD_OK;
+}
+
+int psamd_force_shard(psamd_ctx *c, int64_t *begin, int64_t *end, int64_t *share)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (!c->grid_built) return fail(c, PSAMD_ERR_STATE, "force_shard needs build_grid first");
+    if (c->live_at_build < 0) {
+        PS_HIP(c, hipStreamSynchronize(c->stream));
+        int rc = check_device_errors(c);
+        if (rc != PSAMD_OK) return rc;
+    }
+    int64_t lo, hi, sh;
+    shard_range(c, c->live_at_build, lo, hi, sh);
+    if (begin) *begin = lo;
+    if (end) *end = hi;
+    if (share) *share = sh;
+    return PSAMD_OK;
+}
+
+int psamd_calc_forces_pairs(psamd_ctx *c)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (!c->grid_built) return fail(c, PSAMD_ERR_STATE, "calc_forces needs build_grid first");
+    int lo = 0, hi = INT32_MAX;
+    if (c->geo.cfg.world > 1) {
+        int64_t b, e, s;
+        int rc = psamd_force_shard(c, &b, &e, &s);
+        if (rc != PSAMD_OK) return rc;
+        lo = (int)b; hi = (int)e;
+    }
+    if (c->timing) (void)hipEventRecord(c->ev[5], c->stream);
+    PS_HIP(c, launch_pairs(c->stream, c->P, c->d, lo, hi));
+    if (c->timing) (void)hipEventRecord(c->ev[6], c->stream);
+    c->pairs_done = true;
+    return PSAMD_OK;
+}
+
+int psamd_calc_forces_apply(psamd_ctx *c)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (!c->grid_built || !c->pairs_done) return fail(c, PSAMD_ERR_STATE, "apply needs build_grid and the pair pass first");
+    if (c->timing) (void)hipEventRecord(c->ev[7], c->stream);
+    PS_HIP(c, launch_apply(c->stream, c->P, c->S, c->d, c->step, c->geo.container));
+    if (c->timing) (void)hipEventRecord(c->ev[8], c->stream);
+    if (!(c->P.flags & PSAMD_FLAG_NO_LIFECYCLE)) {
+        PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos, c->d.moves_cap));
+        c->host_queues_valid = false;
+    }
+    if (c->timing) {
+        (void)hipEventRecord(c->ev[9], c->stream);
+        PS_HIP(c, hipEventSynchronize(c->ev[9]));
+        // ev: 10 frame reset | 0 hist 1 scan 2 scatter 3 sort 4 | 5 pairs 6 | 7 apply 8 lifecycle 9
+        const int a[PSAMD_NUM_TIMERS] = {0, 1, 2, 3, 5, 7, 8, 10}, b[PSAMD_NUM_TIMERS] = {1, 2, 3, 4, 6, 8, 9, 0};
+        for (int k = 0; k < PSAMD_NUM_TIMERS; k++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->ev[a[k]], c->ev[b[k]]) == hipSuccess) c->t_us[k] += 1000.0 * ms;
+        }
+        c->t_launches++;
+    }
+    c->grid_built = false; c->pairs_done = false;
+    c->step++; c->steps_total++;
+    return PSAMD_OK;
+}
+
+int psamd_calc_forces(psamd_ctx *c)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (c->geo.cfg.world > 1) return fail(c, PSAMD_ERR_STATE, "world > 1: call _pairs, exchange force4, then _apply");
+    int rc = psamd_calc_forces_pairs(c);
+    if (rc != PSAMD_OK) return rc;
+    return psamd_calc_forces_apply(c);
+}
+
+int psamd_step(psamd_ctx *c, int32_t nsteps)
+{
+    if (!c || nsteps < 0) return PSAMD_ERR_INVALID_ARG;
+    for (int k = 0; k < nsteps; k++) {
+        int rc = psamd_init_iframe(c);
+        if (rc == PSAMD_OK) rc = psamd_build_grid(c);
+        if (rc == PSAMD_OK) rc = psamd_calc_forces(c);
+        if (rc != PSAMD_OK) return rc;
+    }
+    return PSAMD_OK;
+}
+
+int psamd_synchronize(psamd_ctx *c)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    return check_device_errors(c);
+}
+
+int psamd_get_counters(psamd_ctx *c, psamd_counters *o)
+{
+    if (!c || !o) return PSAMD_ERR_INVALID_ARG;
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    DevCounters d{};
+    PS_HIP(c, hipMemcpy(&d, c->d.ctr, sizeof d, hipMemcpyDeviceToHost));
+    o->deaths_age = (int64_t)d.deaths_age; o->deaths_collision = (int64_t)d.deaths_collision;
+    o->survives = (int64_t)d.survives; o->integrated = (int64_t)d.integrated;
+    o->relocations = (int64_t)d.relocations; o->relocations_lost = (int64_t)d.relocations_lost;
+    o->births = (int64_t)d.births; o->births_failed = (int64_t)d.births_failed;
+    o->cell_overflow_kills = (int64_t)d.cell_overflow_kills;
+    o->steps = c->steps_total;
+    return PSAMD_OK;
+}
+
+int psamd_live_count(psamd_ctx *c, int64_t *out)
+{
+    if (!c || !out) return PSAMD_ERR_INVALID_ARG;
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<int> cells((size_t)c->geo.container);
+    PS_HIP(c, hipMemcpy(cells.data(), c->d.cell, cells.size() * sizeof(int), hipMemcpyDeviceToHost));
+    int64_t n = 0;
+    for (int v : cells) n += (v >= 0 && v < c->geo.num_cells) ? 1 : 0;
+    *out = n;
+    return PSAMD_OK;
+}
+
+int psamd_device_view_get(psamd_ctx *c, psamd_device_view *o)
+{
+    if (!c || !o) return PSAMD_ERR_INVALID_ARG;
+    o->pos4 = c->d.pos4; o->vel4 = c->d.vel4; o->acc4 = c->d.acc4; o->cell = c->d.cell; o->pflags = c->d.pflags;
+    o->sorted_id = c->d.sorted_id; o->snap4 = c->d.snap4; o->force4 = c->d.force4; o->cell_start = c->d.cell_start;
+    o->container_size = c->geo.container; o->num_cells = c->geo.num_cells;
+    o->live = c->live_at_build;
+    o->stream = (void *)c->stream;
+    return PSAMD_OK;
+}
+
+int psamd_set_stream(psamd_ctx *c, void *hip_stream)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return PSAMD_OK;
+}
+
+int psamd_bind_force4(psamd_ctx *c, void *device_ptr, int64_t n_float4)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (device_ptr && n_float4 < c->geo.container) return fail(c, PSAMD_ERR_INVALID_ARG, "force4 buffer smaller than the container");
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    c->d.force4 = device_ptr ? (float4 *)device_ptr : c->own_force4;
+    return PSAMD_OK;
+}
+
+int psamd_set_timing(psamd_ctx *c, int enabled)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    c->timing = enabled != 0;
+    if (c->timing) make_events(c);
+    for (double &v : c->t_us) v = 0.0;
+    c->t_launches = 0;
+    return PSAMD_OK;
+}
+
+int psamd_get_timing(psamd_ctx *c, double us_out[PSAMD_NUM_TIMERS], int64_t *launches)
+{
+    if (!c || !us_out) return PSAMD_ERR_INVALID_ARG;
+    for (int k = 0; k < PSAMD_NUM_TIMERS; k++) us_out[k] = c->t_us[k];
+    if (launches) *launches = c->t_launches;
+    return PSAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// device_types.h -- plain structs shared by the host context and the HIP kernels.
+#pragma once
+
+#include <cstdint>
+
+namespace psamd {
+
+// Constants every kernel needs, passed by value as a kernel argument.
+struct DevParams {
+    int32_t G;              // grid_dim
+    int32_t num_cells;
+    int32_t num_chunks;
+    int32_t container;      // slots
+    int32_t max_per_cell;   // cell list capacity (MAX_PARTICLES_PER_CELL)
+    int32_t max_per_chunk;
+    int32_t slices;         // ceil(max_per_cell / 64): wave tasks per cell
+    uint32_t flags;         // PSAMD_FLAG_*
+    float t;                // (float)DT, ps.cpp:1272
+    float kid_thr;          // (double)age <  KID_AGE       <=> age < kid_thr
+    float life_thr;         // (double)age >  PARTICLE_LIFE <=> age > life_thr
+    float coll_d2_gate;     // pairs with d2 <= gate get the exact collision test
+    float dmax;             // (float)MAX_DX, ps.cpp:1278
+    float vmax;             // (float)MAX_V,  ps.cpp:1293
+    float w_default;        // (float)PARTICLE_WEIGHT_DEFAULT
+    float fert_lo, fert_hi; // (float)MIN/MAX_FERTILITY_AGE as get_random_number_h receives them
+    double cell_size;       // CELL_SIZE
+    double eps2;            // EPS2 (double literal in the reference)
+    double coll_radius;     // COLLISION_RADIUS (double literal)
+    double kid_age;         // exact double thresholds for the rare slow path
+    double life;
+    double expl_speed;      // EXPLOSION_SPEED
+    uint64_t seed;
+};
+
+// Per-frame scalars living in device memory (zeroed by init_iframe).
+struct FrameScalars {
+    int32_t gridmax[2];     // hostGridMax: biggest chunk, biggest cell (ps.cpp:76)
+    int32_t live;           // particles with a valid cell at build_grid
+    int32_t error;          // sticky bit mask, see ERR_* below
+    int32_t n_ops;          // queue operations emitted by apply
+    int32_t n_moves;        // relocation / birth records emitted by apply
+    int32_t pad[2];
+};
+
+struct DevCounters {        // cumulative, mirrors psamd_counters
+    unsigned long long deaths_age, deaths_collision, survives, integrated;
+    unsigned long long relocations, relocations_lost, births, births_failed, cell_overflow_kills;
+};
+
+enum : int32_t {
+    ERR_CELL_TOO_BIG = 1,   // a cell holds more ids than the sort kernel can rank
+    ERR_BAD_ID = 2,         // uploaded P_DATA_TYPE with id != slot
+    ERR_OPS_OVERFLOW = 4,   // lifecycle op buffer too small
+    ERR_BUCKET_TOO_BIG = 8, // more queue ops on one segment than the replay kernel holds
+};
+
+// One free-slot-queue operation produced by calc_forces (lifecycle).
+struct QueueOp {
+    uint64_t key;           // serial order of the reference: (chunk, id, sub-step)
+    int32_t rec;            // QUEUE_INFO record index (which segment's queue)
+    int32_t arg;            // insert: slot id to free; remove: index of the move record
+};
+
+// A particle that needs a new slot (segment change) or a child to be born.
+struct MoveRec {
+    int32_t src;            // slot of the particle (parent for births)
+    int32_t dst;            // filled in by the queue replay: new slot or -1
+    int32_t kind;           // 0 relocation, 1 birth
+    int32_t new_cell;
+};
+
+constexpr int SORT_MAX = 2048;   // ids one cell may hold for the in-LDS ranking
+constexpr int REPLAY_MAX = 4096; // queue ops one segment may receive per step
+
+}  // namespace psamd

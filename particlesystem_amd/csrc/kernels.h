@@ -1,0 +1,67 @@
+// kernels.h -- host-visible launch wrappers of kernels.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+#include "geometry.hpp"
+
+namespace psamd {
+
+// Container layout by segment type (slots and QUEUE_INFO records), device copy.
+struct SegLayout {
+    int32_t seg_base[5];
+    int32_t info_base[5];
+    int32_t seg_size_t[4];
+};
+
+// Every device allocation of a context.  SoA by slot unless noted.
+struct DeviceState {
+    // particle state, by slot (id == slot)
+    float4 *pos4 = nullptr;       // x, y, z, w
+    float4 *vel4 = nullptr;       // vx, vy, vz, age
+    float4 *acc4 = nullptr;       // ax, ay, az, fertility_age
+    int *cell = nullptr;          // -1 = free slot
+    uint8_t *pflags = nullptr;    // bit0 is_parent
+    uint32_t *tdata = nullptr;    // T_DATA_TYPE[container], 6 dwords each
+    // free-slot queues (reference layout)
+    QueueInfo *qinfo = nullptr;
+    int *queue = nullptr;
+    // per-frame grid
+    int *cell_count = nullptr;    // [num_cells]      \  zeroed together
+    int *chunk_count = nullptr;   // [num_chunks]      > by init_iframe
+    int *rec_count = nullptr;     // [queue_infos]    /
+    FrameScalars *fs = nullptr;
+    int *cell_start = nullptr;    // [num_cells+1]
+    int *cursor = nullptr;        // [num_cells]
+    int *sorted_id = nullptr;     // [container] cell-major, id ascending inside a cell
+    float4 *snap4 = nullptr;      // [container] sorted order: x,y,z,w_eff
+    float *snap_age = nullptr;    // [container] sorted order
+    float4 *force4 = nullptr;     // [container] sorted order: ax,ay,az,flag
+    CellInfo *celltab = nullptr;  // [num_cells]
+    // lifecycle
+    QueueOp *ops = nullptr, *ops_sorted = nullptr;
+    int ops_cap = 0;
+    MoveRec *moves = nullptr;
+    int moves_cap = 0;
+    float4 *stage = nullptr;      // 3 float4 per move
+    int *rec_start = nullptr;     // [queue_infos+1]
+    int *rec_cursor = nullptr;    // [queue_infos]
+    DevCounters *ctr = nullptr;
+};
+
+hipError_t launch_unpack_aos(hipStream_t st, const void *aos, int first, int count, const DeviceState &d);
+hipError_t launch_pack_aos(hipStream_t st, void *aos, int first, int count, int num_cells, const DeviceState &d);
+hipError_t launch_place(hipStream_t st, int n, const int *ids, const float4 *p, const float4 *v, const float4 *a,
+                        const int *cells, const DeviceState &d);
+hipError_t launch_fill_int(hipStream_t st, int *p, int v, size_t n);
+hipError_t launch_init_tdata(hipStream_t st, const DeviceState &d, int n);
+// ev (optional) = 5 events recorded before hist, scan, scatter, sort and after sort
+hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev);
+hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi);
+hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step,
+                        int live_bound);
+hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
+                            int moves_bound);
+
+}  // namespace psamd

@@ -1,0 +1,842 @@
+// kernels.hip -- hand-written gfx950 (MI355X, CDNA4) kernels for the particle step.
+//
+// Step pipeline (one launch each, all on the context's stream):
+//   k_hist      count live particles per cell                      (streaming, HBM)
+//   k_scan      exclusive prefix over cells + hostGridMax          (tiny)
+//   k_scatter   slot ids into their cell's range                   (streaming, HBM)
+//   k_sort_cells   rank ids inside each cell (ascending = the reference's cell-list
+//               order, ps.cpp:1510-1516), gather the T_DATA snapshot in that order
+//   k_pairs     27-cell softened gravity + collision flags: one WAVE per 64
+//               particles of one cell, neighbour tiles staged through LDS and
+//               broadcast to the 64 lanes, serial fp32 accumulation in the
+//               reference's order (fp32 VALU bound; no MFMA: there is no
+//               contraction here, each pair needs its own rsqrt)
+//   k_apply     death / survive / integrate / wrap / re-hash       (streaming, HBM)
+//   k_ops_* / k_replay / k_moves_*   free-slot queues + relocation, replayed in
+//               the reference's serial order
+//
+// Reference arithmetic is reproduced operation for operation: this file is built
+// with -ffp-contract=off and correctly rounded fp32 divide/sqrt, the two places
+// where the reference evaluates in double (EPS2 add, 0.5*a*t*t) do so here too.
+// Citations: ps.cpp = source/code/src/particleSystem.cpp of the reference.
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+#include "geometry.hpp"
+#include "kernels.h"
+
+namespace psamd {
+
+// (d_i2, d_i1, d_i3): the cell itself, then the reference's 26 candidates in the
+// order fill_cells probes them (app.cu:375-408).
+__constant__ signed char c_stencil[27][3] = {
+    {0, 0, 0},
+    {-1, 0, 0}, {+1, 0, 0},
+    {-1, -1, 0}, {0, -1, 0}, {+1, -1, 0},
+    {-1, +1, 0}, {0, +1, 0}, {+1, +1, 0},
+    {-1, -1, -1}, {0, -1, -1}, {+1, -1, -1},
+    {-1, 0, -1}, {0, 0, -1}, {+1, 0, -1},
+    {-1, +1, -1}, {0, +1, -1}, {+1, +1, -1},
+    {-1, -1, +1}, {0, -1, +1}, {+1, -1, +1},
+    {-1, 0, +1}, {0, 0, +1}, {+1, 0, +1},
+    {-1, +1, +1}, {0, +1, +1}, {+1, +1, +1},
+};
+
+// Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Give each
+// XCD one contiguous run of tasks so neighbouring cells' tiles hit the same L2.
+__device__ __forceinline__ int xcd_contiguous(int b, int nb)
+{
+    const int xcd = b & 7, idx = b >> 3, q = nb >> 3, r = nb & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ------------------------------------------------------------------ AoS <-> SoA
+// P_DATA_TYPE is 18 dwords (common.h:94-120): id cell chunk seg_type seg_tid
+// {seg_fault,is_parent,pad,pad} w age fert x y z vx vy vz ax ay az.
+__global__ void k_unpack_aos(const uint32_t *__restrict__ aos, int first, int count,
+                             float4 *pos4, float4 *vel4, float4 *acc4, int *cell, uint8_t *pflags,
+                             FrameScalars *fs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t *r = aos + (size_t)18 * i;
+    const int slot = first + i;
+    if ((int)r[0] != slot) atomicOr(&fs->error, ERR_BAD_ID);
+    cell[slot] = (int)r[1];
+    pflags[slot] = ((r[5] >> 8) & 0xffu) ? 1 : 0;
+    pos4[slot] = make_float4(__uint_as_float(r[9]), __uint_as_float(r[10]), __uint_as_float(r[11]), __uint_as_float(r[6]));
+    vel4[slot] = make_float4(__uint_as_float(r[12]), __uint_as_float(r[13]), __uint_as_float(r[14]), __uint_as_float(r[7]));
+    acc4[slot] = make_float4(__uint_as_float(r[15]), __uint_as_float(r[16]), __uint_as_float(r[17]), __uint_as_float(r[8]));
+}
+
+__global__ void k_pack_aos(uint32_t *__restrict__ aos, int first, int count, int num_cells,
+                           const float4 *pos4, const float4 *vel4, const float4 *acc4, const int *cell,
+                           const uint8_t *pflags, const CellInfo *celltab)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t *r = aos + (size_t)18 * i;
+    const int slot = first + i;
+    const int c = cell[slot];
+    CellInfo ci = {-1, -1, -1, 0};
+    if (c >= 0 && c < num_cells) ci = celltab[c];
+    const float4 p = pos4[slot], v = vel4[slot], a = acc4[slot];
+    r[0] = (uint32_t)slot; r[1] = (uint32_t)c; r[2] = (uint32_t)ci.chunk;
+    r[3] = (uint32_t)ci.seg_type; r[4] = (uint32_t)ci.seg_tid;
+    r[5] = pflags[slot] ? 0x100u : 0u;  // seg_fault is never set between stages
+    r[6] = __float_as_uint(p.w); r[7] = __float_as_uint(v.w); r[8] = __float_as_uint(a.w);
+    r[9] = __float_as_uint(p.x); r[10] = __float_as_uint(p.y); r[11] = __float_as_uint(p.z);
+    r[12] = __float_as_uint(v.x); r[13] = __float_as_uint(v.y); r[14] = __float_as_uint(v.z);
+    r[15] = __float_as_uint(a.x); r[16] = __float_as_uint(a.y); r[17] = __float_as_uint(a.z);
+}
+
+// fill stage: drop freshly created particles into the slots the host dequeued
+__global__ void k_place(int n, const int *__restrict__ ids, const float4 *__restrict__ p,
+                        const float4 *__restrict__ v, const float4 *__restrict__ a,
+                        const int *__restrict__ cells, float4 *pos4, float4 *vel4, float4 *acc4,
+                        int *cell, uint8_t *pflags)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int slot = ids[i];
+    pos4[slot] = p[i]; vel4[slot] = v[i]; acc4[slot] = a[i];
+    cell[slot] = cells[i]; pflags[slot] = 0;
+}
+
+__global__ void k_fill_int(int *p, int v, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+__global__ void k_init_tdata(uint32_t *tdata, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t *r = tdata + (size_t)6 * i;  // T_DATA_TYPE: id x y z w age (ps.cpp:743-748)
+    r[0] = (uint32_t)i; r[1] = r[2] = r[3] = r[4] = r[5] = 0u;
+}
+
+// ------------------------------------------------------------------ grid build
+// ps.cpp:1491: a slot takes part when 0 <= cell < NUM_CELLS.
+__global__ void k_hist(const int *__restrict__ cell, int *__restrict__ cell_count, int container, int num_cells)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int stride = gridDim.x * blockDim.x;
+    for (; i < container; i += stride) {
+        const int c = cell[i];
+        if (c >= 0 && c < num_cells) atomicAdd(&cell_count[c], 1);
+    }
+}
+
+// One workgroup: exclusive prefix of the cell counts, the scatter cursors, the chunk
+// totals and hostGridMax (ps.cpp:1504-1516: maxima are of stored entries, so capped).
+__global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restrict__ cell_count,
+                                                int *__restrict__ cell_start, int *__restrict__ cursor,
+                                                int *__restrict__ chunk_count,
+                                                const CellInfo *__restrict__ celltab, FrameScalars *fs)
+{
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    __shared__ int maxcell_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { carry_s = 0; maxcell_s = 0; }
+    __syncthreads();
+    int mymax = 0;
+    for (int base = 0; base < P.num_cells; base += 1024) {
+        const int c = base + tid;
+        const int v = (c < P.num_cells) ? cell_count[c] : 0;
+        mymax = max(mymax, min(v, P.max_per_cell));
+        int incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wv; k++) woff += wave_tot[k];
+        const int carry = carry_s;
+        const int excl = carry + woff + incl - v;
+        if (c < P.num_cells) {
+            cell_start[c] = excl;
+            cursor[c] = excl;
+            if (v > 0) atomicAdd(&chunk_count[celltab[c].chunk], v);
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = excl + v;
+        __syncthreads();
+    }
+    atomicMax(&maxcell_s, mymax);
+    __syncthreads();
+    if (tid == 0) {
+        cell_start[P.num_cells] = carry_s;
+        fs->live = carry_s;
+        fs->gridmax[1] = maxcell_s;
+    }
+    // chunk totals are complete once every thread passed the loop's last barrier
+    __threadfence();
+    __syncthreads();
+    int cm = 0;
+    for (int ch = tid; ch < P.num_chunks; ch += 1024) cm = max(cm, min(chunk_count[ch], P.max_per_chunk));
+    if (cm > 0) atomicMax(&fs->gridmax[0], cm);
+}
+
+__global__ void k_scatter(const int *__restrict__ cell, int *__restrict__ cursor, int *__restrict__ sorted_id,
+                          int container, int num_cells)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int stride = gridDim.x * blockDim.x;
+    for (; i < container; i += stride) {
+        const int c = cell[i];
+        if (c >= 0 && c < num_cells) sorted_id[atomicAdd(&cursor[c], 1)] = i;
+    }
+}
+
+// One workgroup per cell.  The scatter left the cell's ids in arrival order; the
+// reference's list is in slot order (build_grid walks slots 0..CONTAINER_SIZE-1), so
+// rank each id among the cell's ids.  Then gather the snapshot the pair kernel reads
+// (T_DATA_TYPE role, ps.cpp:1495-1500) in that order: x,y,z and the mass, the mass
+// zeroed for "kids" because bodyBodyInteraction ignores them (app_common.cu:240-243;
+// adding r*0 = +-0 leaves an fp32 sum that started at +0 bit-identical).
+// Ids ranked at or past the list capacity are the ones the reference kills
+// (ps.cpp:1517-1526): their sorted_id entry becomes -1 and the slot is reset.
+__global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__restrict__ cell_start,
+                                                     int *__restrict__ sorted_id,
+                                                     float4 *pos4, float4 *vel4, float4 *acc4,
+                                                     int *cell_arr, uint8_t *pflags,
+                                                     float4 *__restrict__ snap4, float *__restrict__ snap_age,
+                                                     uint32_t *__restrict__ tdata,
+                                                     QueueOp *ops, int ops_cap,
+                                                     FrameScalars *fs, DevCounters *ctr)
+{
+    __shared__ int ids[SORT_MAX];
+    __shared__ int ordered[SORT_MAX];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int start = cell_start[c];
+    int n = cell_start[c + 1] - start;
+    if (n == 0) return;
+    if (n > SORT_MAX) {
+        if (tid == 0) atomicOr(&fs->error, ERR_CELL_TOO_BIG);
+        n = SORT_MAX;
+    }
+    for (int e = tid; e < n; e += 256) ids[e] = sorted_id[start + e];
+    __syncthreads();
+    for (int e = tid; e < n; e += 256) {
+        const int mine = ids[e];
+        int rank = 0;
+        for (int j = 0; j < n; j++) rank += (ids[j] < mine) ? 1 : 0;
+        ordered[rank] = mine;
+    }
+    __syncthreads();
+    for (int e = tid; e < n; e += 256) {
+        const int id = ordered[e];
+        const float4 p = pos4[id];
+        const float age = vel4[id].w;
+        // the snapshot row is written before the overflow check, as in ps.cpp:1495-1500
+        uint32_t *t = tdata + (size_t)6 * id;
+        t[0] = (uint32_t)id; t[1] = __float_as_uint(p.x); t[2] = __float_as_uint(p.y);
+        t[3] = __float_as_uint(p.z); t[4] = __float_as_uint(p.w); t[5] = __float_as_uint(age);
+        if (e < P.max_per_cell) {
+            sorted_id[start + e] = id;
+            snap4[start + e] = make_float4(p.x, p.y, p.z, (age < P.kid_thr) ? 0.0f : p.w);
+            snap_age[start + e] = age;
+        } else {
+            sorted_id[start + e] = -1;
+            cell_arr[id] = -1; pflags[id] = 0;
+            pos4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vel4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+            acc4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+            atomicAdd(&ctr->cell_overflow_kills, 1ull);
+            // freed with the already-reset segment (-1,-1): queue record 0 (ps.cpp:1523-1526)
+            const int k = atomicAdd(&fs->n_ops, 1);
+            if (k < ops_cap) ops[k] = {((uint64_t)(uint32_t)id << 2) | 2ull, 0, id};
+            else atomicOr(&fs->error, ERR_OPS_OVERFLOW);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ pair kernel
+// bodyBodyInteraction, app_common.cu:236-267, for a snapshot body q = (x,y,z,w_eff).
+__device__ __forceinline__ float pair_exact(float xi, float yi, float zi, const float4 q, double eps2,
+                                            float &ax, float &ay, float &az)
+{
+    const float rx = q.x - xi, ry = q.y - yi, rz = q.z - zi;
+    const float d2 = rx * rx + ry * ry + rz * rz;
+    const float dsq = (float)((double)d2 + eps2);      // EPS2 is a double literal
+    const float six = dsq * dsq * dsq;
+    const float inv = 1.0f / sqrtf(six);               // correctly rounded sqrt, then divide
+    const float s = q.w * inv;
+    ax += rx * s; ay += ry * s; az += rz * s;
+    return d2;
+}
+
+// Same physics with fused multiply-adds and the hardware reciprocal square root:
+// differs from the reference in the last bits (PSAMD_FLAG_FAST_MATH).
+__device__ __forceinline__ float pair_fast(float xi, float yi, float zi, const float4 q, float eps2,
+                                           float &ax, float &ay, float &az)
+{
+    const float rx = q.x - xi, ry = q.y - yi, rz = q.z - zi;
+    const float d2 = fmaf(rz, rz, fmaf(ry, ry, rx * rx));
+    const float dsq = d2 + eps2;
+    const float rinv = __builtin_amdgcn_rsqf(dsq);
+    const float s = q.w * (rinv * rinv * rinv);
+    ax = fmaf(rx, s, ax); ay = fmaf(ry, s, ay); az = fmaf(rz, s, az);
+    return d2;
+}
+
+// bodyBodyCollision, app_common.cu:269-301, evaluated exactly for the few pairs whose
+// squared distance passes the gate.  0 none, 1 survive (higher id), 2 kill (lower id).
+__device__ __forceinline__ int collide_exact(const DevParams &P, float d2, float age_i, int id_i,
+                                             float age_j, int id_j)
+{
+    const float dist = sqrtf(d2);
+    if ((double)dist > P.coll_radius || (double)age_i < P.kid_age || (double)age_j < P.kid_age) return 0;
+    if ((double)age_i > P.life || (double)age_j > P.life) return 0;
+    if (id_i > id_j) return 1;
+    if (id_i < id_j) return 2;
+    return 0;
+}
+
+// One wave (one 64-thread workgroup) = 64 consecutive particles of one cell.
+// Neighbour cells are visited in the reference's stencil order and their snapshot is
+// streamed through a 1 KiB LDS tile; every lane reads the same tile entry (broadcast)
+// and adds it to its own particle's sum, so each particle sees exactly the
+// reference's sequence of fp32 additions (ps.cpp:1247-1259).
+template <bool FAST>
+__global__ __launch_bounds__(64) void k_pairs(DevParams P, const int *__restrict__ cell_start,
+                                               const float4 *__restrict__ snap4,
+                                               const float *__restrict__ snap_age,
+                                               const int *__restrict__ sorted_id,
+                                               float4 *__restrict__ force4, int lo, int hi)
+{
+    __shared__ float4 tile[64];
+    const int task = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int c = task / P.slices, slice = task - c * P.slices;
+    const int base = cell_start[c];
+    const int cnt = min(cell_start[c + 1] - base, P.max_per_cell);
+    const int first = slice * 64;
+    if (first >= cnt) return;
+    const int nvalid = min(64, cnt - first);
+    const int gi0 = base + first;
+    if (gi0 + nvalid <= lo || gi0 >= hi) return;   // another rank's share
+
+    const int lane = threadIdx.x;
+    const bool valid = lane < nvalid;
+    const int gi = gi0 + (valid ? lane : 0);
+    const float4 me = snap4[gi];
+    const float age_i = snap_age[gi];
+    const int id_i = sorted_id[gi];
+    const bool lifecycle = !(P.flags & PSAMD_FLAG_NO_LIFECYCLE);
+    const bool dead = lifecycle && (age_i > P.life_thr);       // ps.cpp:1183
+    const bool kid = age_i < P.kid_thr;
+    const bool scan = valid && lifecycle && !dead && !kid;
+
+    const int G = P.G;
+    const int i3 = c / (G * G), rem = c - i3 * G * G, i1 = rem / G, i2 = rem - i1 * G;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    int flag = 0;
+    const float eps2f = (float)P.eps2;
+
+    for (int k = 0; k < 27; k++) {
+        const int n2 = i2 + c_stencil[k][0], n1 = i1 + c_stencil[k][1], n3 = i3 + c_stencil[k][2];
+        if (n1 < 0 || n1 >= G || n2 < 0 || n2 >= G || n3 < 0 || n3 >= G) continue;
+        const int nc = n3 * G * G + n1 * G + n2;
+        const int nb = cell_start[nc];
+        const int ncnt = min(cell_start[nc + 1] - nb, P.max_per_cell);
+        for (int t0 = 0; t0 < ncnt; t0 += 64) {
+            const int n = min(64, ncnt - t0);
+            __syncthreads();                      // previous tile fully consumed
+            if (lane < n) tile[lane] = snap4[nb + t0 + lane];
+            __syncthreads();
+            float dmin = 3.0e38f;
+#pragma unroll 4
+            for (int jj = 0; jj < n; jj++) {
+                const float4 q = tile[jj];
+                const float d2 = FAST ? pair_fast(me.x, me.y, me.z, q, eps2f, ax, ay, az)
+                                      : pair_exact(me.x, me.y, me.z, q, P.eps2, ax, ay, az);
+                dmin = fminf(dmin, d2);
+            }
+            // rare: someone in this tile is within the collision gate of one of my lanes
+            if (__any(scan && !(dmin > P.coll_d2_gate))) {
+                if (scan && !(dmin > P.coll_d2_gate)) {
+                    for (int jj = 0; jj < n; jj++) {
+                        const float4 q = tile[jj];
+                        const float rx = q.x - me.x, ry = q.y - me.y, rz = q.z - me.z;
+                        const float d2 = rx * rx + ry * ry + rz * rz;
+                        const int gj = nb + t0 + jj;
+                        if (!(d2 > P.coll_d2_gate) && gj != gi)
+                            flag = max(flag, collide_exact(P, d2, age_i, id_i, snap_age[gj], sorted_id[gj]));
+                    }
+                }
+            }
+        }
+    }
+    if (dead) flag = 2;
+    if (kid) { ax = 0.f; ay = 0.f; az = 0.f; }   // every term is skipped for a kid (app_common.cu:240)
+    if (valid && gi >= lo && gi < hi) force4[gi] = make_float4(ax, ay, az, __int_as_float(flag));
+}
+
+// ------------------------------------------------------------------ apply
+__device__ __forceinline__ float clamp_mag(float v, float lim)   // ps.cpp:1279-1281, 1294-1296
+{
+    if (fabsf(v) > lim) v = lim * (v / fabsf(v));
+    return v;
+}
+
+__device__ __forceinline__ int segment_record_of_slot(const SegLayout &S, int slot)
+{
+    int k = 0;
+    while (k < 3 && slot >= S.seg_base[k + 1]) k++;
+    return S.info_base[k] + (slot - S.seg_base[k]) / S.seg_size_t[k];
+}
+
+__device__ __forceinline__ int segment_record(const SegLayout &S, int seg_type, int seg_tid)
+{
+    const int k = seg_type == 1 ? 0 : seg_type == 2 ? 1 : seg_type == 4 ? 2 : 3;
+    return S.info_base[k] + seg_tid;
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// Death, survival, integration, wrap and re-hash for every particle of the frame
+// (ps.cpp:1182-1242, 1261-1302), one thread per sorted index.  Lifecycle side
+// effects that depend on the reference's serial order (free-slot queues) are emitted
+// as QueueOp / MoveRec records and replayed afterwards.
+__global__ __launch_bounds__(256) void k_apply(DevParams P, SegLayout S, int step,
+                                                const int *__restrict__ cell_start,
+                                                const int *__restrict__ sorted_id,
+                                                const float4 *__restrict__ force4,
+                                                float4 *pos4, float4 *vel4, float4 *acc4,
+                                                int *cell_arr, uint8_t *pflags,
+                                                const CellInfo *__restrict__ celltab,
+                                                QueueOp *ops, int ops_cap, MoveRec *moves, int moves_cap,
+                                                FrameScalars *fs, DevCounters *ctr)
+{
+    const int total = cell_start[P.num_cells];
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= total) return;
+    const int id = sorted_id[gi];
+    if (id < 0) return;                                  // killed by the cell-overflow rule
+    const float4 f = force4[gi];
+    const int flag = __float_as_int(f.w);
+    const bool lifecycle = !(P.flags & PSAMD_FLAG_NO_LIFECYCLE);
+    const int old_cell = cell_arr[id];
+    const CellInfo old_ci = celltab[old_cell];
+    const uint64_t key = ((uint64_t)(uint32_t)(old_ci.chunk + 1) << 34) | ((uint64_t)(uint32_t)id << 2);
+
+    if (flag == 2) {                                     // kill, ps.cpp:1211-1235
+        const float age = vel4[id].w;
+        if (age > P.life_thr) atomicAdd(&ctr->deaths_age, 1ull); else atomicAdd(&ctr->deaths_collision, 1ull);
+        cell_arr[id] = -1; pflags[id] = 0;
+        pos4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+        vel4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int k = atomicAdd(&fs->n_ops, 1);
+        if (k < ops_cap) ops[k] = {key | 2ull, segment_record_of_slot(S, id), id};
+        else atomicOr(&fs->error, ERR_OPS_OVERFLOW);
+        return;
+    }
+    if (flag == 1) {                                     // survive_particle, app.cu:271-283
+        atomicAdd(&ctr->survives, 1ull);
+        const float fert = acc4[id].w;
+        vel4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc4[id] = make_float4(0.f, 0.f, 0.f, fert);
+        pflags[id] = 0;
+        return;
+    }
+    atomicAdd(&ctr->integrated, 1ull);
+
+    const float4 p = pos4[id];
+    float4 v = vel4[id];
+    const float fert = acc4[id].w;
+    const float axv = f.x, ayv = f.y, azv = f.z;
+    const float t = P.t;
+    // dx = v*t (fp32) + 0.5*a*t*t (double, left to right), rounded once (ps.cpp:1274-1276)
+    float dx = (float)((double)(v.x * t) + ((0.5 * (double)axv) * (double)t) * (double)t);
+    float dy = (float)((double)(v.y * t) + ((0.5 * (double)ayv) * (double)t) * (double)t);
+    float dz = (float)((double)(v.z * t) + ((0.5 * (double)azv) * (double)t) * (double)t);
+    dx = clamp_mag(dx, P.dmax); dy = clamp_mag(dy, P.dmax); dz = clamp_mag(dz, P.dmax);
+    float rx = p.x + dx, ry = p.y + dy, rz = p.z + dz;
+
+    // set_pos_t, app.cu:117-158: double floor, periodic wrap one grid length at a time
+    const int G = P.G;
+    const double cs = P.cell_size;
+    int i1 = (int)(floor((-1.0 * (double)ry) / cs) + (double)(G / 2));
+    int i2 = (int)(floor((1.0 * (double)rx) / cs) + (double)(G / 2));
+    int i3 = (int)(floor((-1.0 * (double)rz) / cs) + (double)(G / 2));
+    for (int guard = 0; guard < 64 &&
+         !((i1 >= 0 && i1 < G) && (i2 >= 0 && i2 < G) && (i3 >= 0 && i3 < G)); guard++) {
+        if (!(i1 >= 0 && i1 < G)) { const int o = i1; i1 = (i1 + G) % G; ry = (float)((double)ry + (-1.0 * (double)(i1 - o) * cs)); }
+        if (!(i2 >= 0 && i2 < G)) { const int o = i2; i2 = (i2 + G) % G; rx = (float)((double)rx + ((double)(i2 - o) * cs)); }
+        if (!(i3 >= 0 && i3 < G)) { const int o = i3; i3 = (i3 + G) % G; rz = (float)((double)rz + (-1.0 * (double)(i3 - o) * cs)); }
+    }
+    i1 = min(max(i1, 0), G - 1); i2 = min(max(i2, 0), G - 1); i3 = min(max(i3, 0), G - 1); // non-finite input only
+    const int new_cell = i3 * G * G + i1 * G + i2;
+
+    float vx = v.x + axv * t, vy = v.y + ayv * t, vz = v.z + azv * t;   // ps.cpp:1289-1296
+    vx = clamp_mag(vx, P.vmax); vy = clamp_mag(vy, P.vmax); vz = clamp_mag(vz, P.vmax);
+    const float age = v.w + t;                                         // ps.cpp:1302
+    uint8_t pf = pflags[id];
+
+    const CellInfo new_ci = celltab[new_cell];
+    const int new_rec = segment_record(S, new_ci.seg_type, new_ci.seg_tid);
+
+    // explosion, ps.cpp:1306-1333, with a counter-based RNG keyed on (seed, step, id)
+    if ((P.flags & PSAMD_FLAG_EXPLOSIONS) && lifecycle && (age >= fert) && !(pf & 1)) {
+        const uint64_t h0 = splitmix64(P.seed ^ ((uint64_t)(uint32_t)step << 32) ^ (uint64_t)(uint32_t)id);
+        const uint64_t h1 = splitmix64(h0), h2 = splitmix64(h1);
+        const int r0 = (int)((double)(h0 >> 11) * (1.0 / 9007199254740992.0) * 100.0) - 50;
+        const int r1 = (int)((double)(h1 >> 11) * (1.0 / 9007199254740992.0) * 100.0) - 50;
+        const int r2 = (int)((double)(h2 >> 11) * (1.0 / 9007199254740992.0) * 100.0) - 50;
+        float ux = (float)r0, uy = (float)r1, uz = (float)r2;
+        const float mag = sqrtf((float)((double)(ux * ux) + (double)(uy * uy) + (double)(uz * uz)));
+        ux /= mag; uy /= mag; uz /= mag;
+        vx = (float)((double)ux * P.expl_speed);
+        vy = (float)((double)uy * P.expl_speed);
+        vz = (float)((double)uz * P.expl_speed);
+        pf |= 1;
+        const int m = atomicAdd(&fs->n_moves, 1);
+        const int k = atomicAdd(&fs->n_ops, 1);
+        if (m < moves_cap && k < ops_cap) {
+            moves[m] = {id, -1, 1, new_cell};
+            ops[k] = {key | 0ull, new_rec, m};
+        } else atomicOr(&fs->error, ERR_OPS_OVERFLOW);
+    }
+
+    pos4[id] = make_float4(rx, ry, rz, p.w);
+    vel4[id] = make_float4(vx, vy, vz, age);
+    acc4[id] = make_float4(axv, ayv, azv, fert);
+    cell_arr[id] = new_cell;
+    pflags[id] = pf;
+
+    // segment change => the particle must move to a slot of the new segment
+    // (set_pos_x raises seg_fault, app.cu:178-185; handled at ps.cpp:1335-1374)
+    if (lifecycle && (new_ci.seg_type != old_ci.seg_type || new_ci.seg_tid != old_ci.seg_tid)) {
+        const int m = atomicAdd(&fs->n_moves, 1);
+        const int k = atomicAdd(&fs->n_ops, 2);
+        if (m < moves_cap && k + 1 < ops_cap) {
+            moves[m] = {id, -1, 0, new_cell};
+            ops[k] = {key | 1ull, new_rec, m};
+            ops[k + 1] = {key | 2ull, segment_record_of_slot(S, id), id};
+        } else atomicOr(&fs->error, ERR_OPS_OVERFLOW);
+    }
+}
+
+// ------------------------------------------------------------------ lifecycle replay
+__global__ void k_ops_hist(const QueueOp *__restrict__ ops, const FrameScalars *fs, int ops_cap, int *rec_count)
+{
+    const int n = min(fs->n_ops, ops_cap);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int stride = gridDim.x * blockDim.x;
+    for (; i < n; i += stride) atomicAdd(&rec_count[ops[i].rec], 1);
+}
+
+__global__ __launch_bounds__(1024) void k_ops_scan(int nrec, const int *__restrict__ rec_count,
+                                                    int *__restrict__ rec_start, int *__restrict__ rec_cursor)
+{
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nrec; base += 1024) {
+        const int r = base + tid;
+        const int v = (r < nrec) ? rec_count[r] : 0;
+        int incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wv; k++) woff += wave_tot[k];
+        const int excl = carry_s + woff + incl - v;
+        if (r < nrec) { rec_start[r] = excl; rec_cursor[r] = excl; }
+        __syncthreads();
+        if (tid == 1023) carry_s = excl + v;
+        __syncthreads();
+    }
+    if (tid == 0) rec_start[nrec] = carry_s;
+}
+
+__global__ void k_ops_scatter(const QueueOp *__restrict__ ops, const FrameScalars *fs, int ops_cap,
+                              int *rec_cursor, QueueOp *__restrict__ ops_sorted)
+{
+    const int n = min(fs->n_ops, ops_cap);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int stride = gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const QueueOp o = ops[i];
+        ops_sorted[atomicAdd(&rec_cursor[o.rec], 1)] = o;
+    }
+}
+
+// One workgroup per free-slot queue: order this step's operations on it by the
+// reference's serial key (bitonic sort in LDS), then one lane replays them on the
+// circular FIFO exactly as q_insert / q_remove do (app_common.cu:305-376).
+__global__ __launch_bounds__(256) void k_replay(const int *__restrict__ rec_start,
+                                                 const QueueOp *__restrict__ ops_sorted,
+                                                 QueueInfo *qinfo, int *queue, MoveRec *moves,
+                                                 FrameScalars *fs, DevCounters *ctr)
+{
+    extern __shared__ unsigned char lds_raw[];
+    uint64_t *keys = (uint64_t *)lds_raw;                  // REPLAY_MAX
+    int *args = (int *)(keys + REPLAY_MAX);                // REPLAY_MAX
+    const int rec = blockIdx.x, tid = threadIdx.x;
+    const int start = rec_start[rec];
+    int n = rec_start[rec + 1] - start;
+    if (n == 0) return;
+    if (n > REPLAY_MAX) {
+        if (tid == 0) atomicOr(&fs->error, ERR_BUCKET_TOO_BIG);
+        n = REPLAY_MAX;
+    }
+    int np = 1;
+    while (np < n) np <<= 1;
+    for (int e = tid; e < np; e += 256) {
+        if (e < n) { keys[e] = ops_sorted[start + e].key; args[e] = ops_sorted[start + e].arg; }
+        else { keys[e] = ~0ull; args[e] = -1; }
+    }
+    __syncthreads();
+    for (int k = 2; k <= np; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int e = tid; e < np; e += 256) {
+                const int partner = e ^ j;
+                if (partner > e) {
+                    const bool up = ((e & k) == 0);
+                    const uint64_t a = keys[e], b = keys[partner];
+                    if ((a > b) == up) {
+                        keys[e] = b; keys[partner] = a;
+                        const int t = args[e]; args[e] = args[partner]; args[partner] = t;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid != 0) return;
+    QueueInfo q = qinfo[rec];
+    unsigned long long lost = 0, reloc = 0, births = 0, births_failed = 0;
+    for (int e = 0; e < n; e++) {
+        const int sub = (int)(keys[e] & 3ull);
+        if (sub == 2) {                                    // q_insert(args[e])
+            if (q.count == q.seg_size) continue;
+            if (q.count == 0) { q.front = q.rloc; q.rear = q.rloc; }
+            else if (q.rear == q.rloc + q.seg_size - 1) q.rear = q.rloc;
+            else q.rear++;
+            q.count++;
+            queue[q.rear] = args[e];
+        } else {                                           // q_remove -> moves[args[e]].dst
+            int item = -1;
+            if (q.count > 0) {
+                const int pos = q.front;
+                if (q.count == 1) { q.front = -1; q.rear = -1; }
+                else if (q.front == q.rloc + q.seg_size - 1) q.front = q.rloc;
+                else q.front++;
+                q.count--;
+                item = queue[pos];
+                queue[pos] = -1;
+            }
+            moves[args[e]].dst = item;
+            if (sub == 1) { if (item >= 0) reloc++; else lost++; }
+            else { if (item >= 0) births++; else births_failed++; }
+        }
+    }
+    qinfo[rec] = q;
+    if (reloc) atomicAdd(&ctr->relocations, reloc);
+    if (lost) atomicAdd(&ctr->relocations_lost, lost);
+    if (births) atomicAdd(&ctr->births, births);
+    if (births_failed) atomicAdd(&ctr->births_failed, births_failed);
+}
+
+// Relocation phase 1a: read every moving particle (copy_particle, ps.cpp:1363) and
+// every parent of a child to be born.  Read-only on the particle arrays, so a
+// parent that also relocates this step is seen intact by both of its records.
+__global__ void k_moves_stage(MoveRec *moves, const FrameScalars *fs, int moves_cap,
+                              const float4 *pos4, const float4 *vel4, const float4 *acc4,
+                              const uint8_t *pflags, float4 *stage)
+{
+    const int n = min(fs->n_moves, moves_cap);
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    const MoveRec r = moves[m];
+    float4 *s = stage + (size_t)3 * m;
+    s[0] = pos4[r.src]; s[1] = vel4[r.src]; s[2] = acc4[r.src];
+    if (r.kind == 0 && pflags[r.src]) moves[m].kind = 0x100;  // is_parent travels in bit 8
+}
+
+// Relocation phase 1b: reset_particle on the vacated slots (ps.cpp:1367).
+__global__ void k_moves_reset(const MoveRec *__restrict__ moves, const FrameScalars *fs, int moves_cap,
+                              float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr, uint8_t *pflags)
+{
+    const int n = min(fs->n_moves, moves_cap);
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    const MoveRec r = moves[m];
+    if ((r.kind & 0xff) != 0) return;
+    cell_arr[r.src] = -1; pflags[r.src] = 0;
+    pos4[r.src] = make_float4(0.f, 0.f, 0.f, 0.f);
+    vel4[r.src] = make_float4(0.f, 0.f, 0.f, 0.f);
+    acc4[r.src] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// Relocation phase 2: drop each particle into the slot the queue replay assigned.
+__global__ void k_moves_commit(DevParams P, int step, const MoveRec *__restrict__ moves, const FrameScalars *fs,
+                               int moves_cap, float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr,
+                               uint8_t *pflags, const float4 *__restrict__ stage)
+{
+    const int n = min(fs->n_moves, moves_cap);
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    const MoveRec r = moves[m];
+    if (r.dst < 0) return;
+    const float4 *s = stage + (size_t)3 * m;
+    if ((r.kind & 0xff) == 0) {
+        pos4[r.dst] = s[0]; vel4[r.dst] = s[1]; acc4[r.dst] = s[2];
+        cell_arr[r.dst] = r.new_cell;
+        pflags[r.dst] = (r.kind & 0x100) ? 1 : 0;
+    } else {
+        // create_particle_s (app.cu:189-208): child at the parent's position, opposite
+        // velocity, age 0, fresh fertility age from the counter-based RNG
+        const uint64_t h0 = splitmix64(P.seed ^ ((uint64_t)(uint32_t)step << 32) ^ (uint64_t)(uint32_t)r.src);
+        const uint64_t h3 = splitmix64(splitmix64(splitmix64(h0)));
+        const double u = (double)(h3 >> 11) * (1.0 / 9007199254740992.0);
+        const float fert = (float)((double)P.fert_lo + u * (double)(P.fert_hi - P.fert_lo));
+        const float4 pp = s[0], pv = s[1];
+        pos4[r.dst] = make_float4(pp.x, pp.y, pp.z, P.w_default);
+        vel4[r.dst] = make_float4((float)(-1.0 * (double)pv.x), (float)(-1.0 * (double)pv.y),
+                                  (float)(-1.0 * (double)pv.z), 0.0f);
+        acc4[r.dst] = make_float4(0.f, 0.f, 0.f, fert);
+        cell_arr[r.dst] = r.new_cell;
+        pflags[r.dst] = 0;
+    }
+}
+
+// ------------------------------------------------------------------ launch wrappers
+#define PS_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+static inline int blocks_for(size_t n, int threads, int cap = 4096)
+{
+    size_t b = (n + threads - 1) / threads;
+    if (b > (size_t)cap) b = cap;
+    return b < 1 ? 1 : (int)b;
+}
+
+hipError_t launch_unpack_aos(hipStream_t st, const void *aos, int first, int count, const DeviceState &d)
+{
+    if (count <= 0) return hipSuccess;
+    k_unpack_aos<<<(count + 255) / 256, 256, 0, st>>>((const uint32_t *)aos, first, count, d.pos4, d.vel4, d.acc4,
+                                                      d.cell, d.pflags, d.fs);
+    PS_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_pack_aos(hipStream_t st, void *aos, int first, int count, int num_cells, const DeviceState &d)
+{
+    if (count <= 0) return hipSuccess;
+    k_pack_aos<<<(count + 255) / 256, 256, 0, st>>>((uint32_t *)aos, first, count, num_cells, d.pos4, d.vel4,
+                                                    d.acc4, d.cell, d.pflags, d.celltab);
+    PS_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_place(hipStream_t st, int n, const int *ids, const float4 *p, const float4 *v, const float4 *a,
+                        const int *cells, const DeviceState &d)
+{
+    if (n <= 0) return hipSuccess;
+    k_place<<<(n + 255) / 256, 256, 0, st>>>(n, ids, p, v, a, cells, d.pos4, d.vel4, d.acc4, d.cell, d.pflags);
+    PS_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_fill_int(hipStream_t st, int *p, int v, size_t n)
+{
+    if (n == 0) return hipSuccess;
+    k_fill_int<<<blocks_for(n, 256), 256, 0, st>>>(p, v, n);
+    PS_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_init_tdata(hipStream_t st, const DeviceState &d, int n)
+{
+    k_init_tdata<<<(n + 255) / 256, 256, 0, st>>>(d.tdata, n);
+    PS_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev)
+{
+    const int nb = blocks_for((size_t)P.container, 256, 2048);
+    if (ev) (void)hipEventRecord(ev[0], st);
+    k_hist<<<nb, 256, 0, st>>>(d.cell, d.cell_count, P.container, P.num_cells);
+    PS_LAUNCH_CHECK();
+    if (ev) (void)hipEventRecord(ev[1], st);
+    k_scan<<<1, 1024, 0, st>>>(P, d.cell_count, d.cell_start, d.cursor, d.chunk_count, d.celltab, d.fs);
+    PS_LAUNCH_CHECK();
+    if (ev) (void)hipEventRecord(ev[2], st);
+    k_scatter<<<nb, 256, 0, st>>>(d.cell, d.cursor, d.sorted_id, P.container, P.num_cells);
+    PS_LAUNCH_CHECK();
+    if (ev) (void)hipEventRecord(ev[3], st);
+    k_sort_cells<<<P.num_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
+                                               d.pflags, d.snap4, d.snap_age, d.tdata, d.ops, d.ops_cap, d.fs, d.ctr);
+    PS_LAUNCH_CHECK();
+    if (ev) (void)hipEventRecord(ev[4], st);
+    return hipSuccess;
+}
+
+hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi)
+{
+    const int tasks = P.num_cells * P.slices;
+    if (P.flags & PSAMD_FLAG_FAST_MATH)
+        k_pairs<true><<<tasks, 64, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.force4, lo, hi);
+    else
+        k_pairs<false><<<tasks, 64, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.force4, lo, hi);
+    PS_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step,
+                        int live_bound)
+{
+    if (live_bound <= 0) return hipSuccess;
+    k_apply<<<(live_bound + 255) / 256, 256, 0, st>>>(P, S, step, d.cell_start, d.sorted_id, d.force4, d.pos4,
+                                                      d.vel4, d.acc4, d.cell, d.pflags, d.celltab, d.ops, d.ops_cap,
+                                                      d.moves, d.moves_cap, d.fs, d.ctr);
+    PS_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
+                            int moves_bound)
+{
+    k_ops_hist<<<256, 256, 0, st>>>(d.ops, d.fs, d.ops_cap, d.rec_count);
+    PS_LAUNCH_CHECK();
+    k_ops_scan<<<1, 1024, 0, st>>>(nrec, d.rec_count, d.rec_start, d.rec_cursor);
+    PS_LAUNCH_CHECK();
+    k_ops_scatter<<<256, 256, 0, st>>>(d.ops, d.fs, d.ops_cap, d.rec_cursor, d.ops_sorted);
+    PS_LAUNCH_CHECK();
+    const size_t lds = (size_t)REPLAY_MAX * (sizeof(uint64_t) + sizeof(int));
+    k_replay<<<nrec, 256, lds, st>>>(d.rec_start, d.ops_sorted, d.qinfo, d.queue, d.moves, d.fs, d.ctr);
+    PS_LAUNCH_CHECK();
+    if (moves_bound > 0) {
+        const int nb = (moves_bound + 255) / 256;
+        k_moves_stage<<<nb, 256, 0, st>>>(d.moves, d.fs, d.moves_cap, d.pos4, d.vel4, d.acc4, d.pflags, d.stage);
+        PS_LAUNCH_CHECK();
+        k_moves_reset<<<nb, 256, 0, st>>>(d.moves, d.fs, d.moves_cap, d.pos4, d.vel4, d.acc4, d.cell, d.pflags);
+        PS_LAUNCH_CHECK();
+        k_moves_commit<<<nb, 256, 0, st>>>(P, step, d.moves, d.fs, d.moves_cap, d.pos4, d.vel4, d.acc4, d.cell,
+                                           d.pflags, d.stage);
+        PS_LAUNCH_CHECK();
+    }
+    return hipSuccess;
+}
+
+}  // namespace psamd

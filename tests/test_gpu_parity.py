@@ -1,0 +1,230 @@
+"""GPU parity: the HIP path behind the C ABI against the CPU oracle, bit for bit.
+
+Everything here is integer/index work or fp32 arithmetic reproduced operation by
+operation, so the bar is exact equality of the reference-layout buffers
+(P_DATA_TYPE records, free-slot queues, cell/chunk lists, T_DATA snapshot) --
+no tolerance anywhere in this file.  The fast-math mode has its own test file.
+"""
+import numpy as np
+import pytest
+
+import oracle_py as O
+import particlesystem_amd as ps
+from util import assert_same_particles, cloud, explosion_rng, g2_cloud, oracle_cfg_from
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(xyz, age, fert, flags=0, w=None, vxyz=None, **over):
+    cfg = ps.default_config(flags=flags, **over)
+    g = ps.ParticleSystem(cfg)
+    o = O.System(oracle_cfg_from(cfg))
+    ids_g = g.fill_particles(xyz, age=age, fert_age=fert, w=w, vxyz=vxyz)
+    ids_o = o.fill(xyz, age=age, fert_age=fert, w=w)
+    if vxyz is not None:
+        p = o.particles
+        p["vx"][ids_o], p["vy"][ids_o], p["vz"][ids_o] = np.asarray(vxyz, np.float32).T
+    assert np.array_equal(ids_g, ids_o)
+    return g, o
+
+
+def compare_all(g, o, what):
+    assert_same_particles(g.download_particles(), o.particles, what)
+    qi, q = g.download_queues()
+    assert qi.tobytes() == o.queue_info.tobytes(), what + ": QUEUE_INFO differs"
+    assert np.array_equal(q, o.queue), what + ": queue array differs"
+    cg, co = g.counters, o.counters
+    for k in ("deaths_age", "deaths_collision", "survives", "integrated", "relocations",
+              "relocations_lost", "births", "births_failed", "cell_overflow_kills"):
+        assert cg[k] == co[k], (what, k, cg[k], co[k])
+
+
+def test_geometry_tables_match_oracle():
+    import ctypes as C
+    for over in ({}, {"chunk_factor": 2, "chunk_dim": 3, "max_particles_num": 1000},
+                 {"chunk_factor": 3, "chunk_dim": 5, "max_particles_num": 5000},
+                 {"chunk_factor": 1, "chunk_dim": 3, "max_particles_num": 100}):
+        g = ps.ParticleSystem(ps.default_config(**over))
+        oc = oracle_cfg_from(g.cfg)
+        od = O.derive(oc)
+        s = g.sizes
+        assert (s.grid_dim, s.num_cells, s.num_chunks, s.max_per_cell, s.max_per_chunk, s.container_size,
+                s.queue_info_size) == (od.grid_dim, od.num_cells, od.num_chunks, od.max_per_cell,
+                                       od.max_per_chunk, od.container_size, od.queue_info_size)
+        tab = g.cell_table()
+        out3 = (C.c_int * 3)()
+        for c in range(od.num_cells):
+            O.lib().pso_get_cell_info(C.byref(od), C.byref(oc), c, out3)
+            assert list(out3) == list(tab[c]), (over, c)
+        pk = np.zeros(27, dtype=O.PAIR_DTYPE)
+        mine = g.pkgdistrib()
+        for ch in range(od.num_chunks):
+            O.lib().pso_set_pkg_segments(C.byref(oc), ch, pk.ctypes.data)
+            assert np.array_equal(np.stack([pk["c"], pk["p"]], 1).ravel(), mine[ch]), (over, ch)
+        # initial queues = q_start_fast
+        so = O.System(oc)
+        qi, q = g.download_queues()
+        assert qi.tobytes() == so.queue_info.tobytes() and np.array_equal(q, so.queue)
+        assert_same_particles(g.download_particles(), so.particles, "fresh container")
+        so.close()
+        g.close()
+
+
+def test_two_body_known_answers_on_gpu():
+    """the reference's own numbers for the (-4,0,0)/(4,0,0) pair."""
+    g, o = make_pair([[-4, 0, 0], [4, 0, 0]], age=np.float32(2.0), fert=1e6)
+    g.step(1)
+    p = g.download_particles()
+    a = p[2738592]
+    assert np.float32(a["ax"]) == np.float32(0.933122575)
+    assert np.float32(a["vx"]) == np.float32(0.046656128)
+    assert np.float32(a["x"]) == np.float32(-3.99883366)
+    assert np.float32(a["age"]) == np.float32(2.04999995)
+    o.step(1)
+    compare_all(g, o, "two-body step 1")
+    g.step(1)
+    o.step(1)
+    compare_all(g, o, "two-body step 2")
+
+
+def test_stage_buffers_after_build_grid():
+    xyz = cloud(20000, 3)
+    g, o = make_pair(xyz, age=2.0, fert=1e6)
+    g.init_iframe(); g.build_grid()
+    o.init_iframe(); o.build_grid()
+    assert np.array_equal(g.gridmax(), o.gridmax)
+    assert np.array_equal(g.download_cellgrid(), o.cellgrid)
+    assert np.array_equal(g.download_chunkgrid(), o.chunkgrid)
+    assert g.download_tdata().tobytes() == o.tdata.tobytes()
+    g.calc_forces(); o.calc_forces()
+    compare_all(g, o, "stage-by-stage step")
+
+
+@pytest.mark.parametrize("dt,steps", [(0.01, (1, 10, 100)), (0.05, (1, 10, 100))])
+def test_g2_cloud_full_state(dt, steps):
+    """BASELINE config 0: N=4096, 100 steps, whole container compared after 1/10/100."""
+    xyz = g2_cloud()
+    fert = (1e6 + np.arange(len(xyz))).astype(np.float32)
+    g, o = make_pair(xyz, age=np.float32(40 * dt), fert=fert, dt=dt)
+    done = 0
+    for s in steps:
+        g.step(s - done); o.step(s - done); done = s
+        compare_all(g, o, "G2 dt=%g after %d steps" % (dt, s))
+    if dt == 0.01:
+        assert g.live_count() == 2724 and g.counters["relocations"] == 1537
+    else:
+        assert g.live_count() == 1716 and g.counters["relocations"] == 11375
+
+
+@pytest.mark.parametrize("n,seed", [(1 << 16, 5), (1 << 18, 6)])
+def test_dense_cloud_steps(n, seed):
+    """16 and 64 particles per cell: long serial fp32 sums, many collisions and moves."""
+    xyz = cloud(n, seed)
+    rng = np.random.default_rng(seed)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)   # [MIN_ADULT_AGE, MAX_ADULT_AGE)
+    g, o = make_pair(xyz, age=age, fert=1e6)
+    for k in range(2):
+        g.step(1); o.step(1)
+        compare_all(g, o, "N=%d step %d" % (n, k + 1))
+
+
+def test_ages_kids_and_elders():
+    """kids exert/feel no force and never collide; age > PARTICLE_LIFE dies."""
+    n = 30000
+    xyz = cloud(n, 9)
+    rng = np.random.default_rng(9)
+    age = rng.choice(np.array([0.0, 1.4999999, 1.5, 1.5000001, 3.0, 14.96, 15.0, 15.000001, 16.0],
+                              np.float32), n)
+    g, o = make_pair(xyz, age=age, fert=1e6)
+    for k in range(3):
+        g.step(1); o.step(1)
+        compare_all(g, o, "ages step %d" % (k + 1))
+    assert g.counters["deaths_age"] > 0
+
+
+def test_wrap_and_clamps():
+    """fast particles leave the box and re-enter on the other side; dx and v clamp."""
+    n = 5000
+    rng = np.random.default_rng(13)
+    xyz = rng.uniform(-40, 40, (n, 3)).astype(np.float32)
+    xyz[: n // 2] = np.sign(xyz[: n // 2]) * rng.uniform(39.0, 39.999, (n // 2, 3)).astype(np.float32)
+    v = rng.uniform(-300, 300, (n, 3)).astype(np.float32)
+    g, o = make_pair(xyz, age=3.0, fert=1e6, vxyz=v)
+    for k in range(4):
+        g.step(1); o.step(1)
+        compare_all(g, o, "wrap step %d" % (k + 1))
+
+
+def test_cell_overflow_rule():
+    """more than MAX_PARTICLES_PER_CELL in one cell: the highest slots are killed."""
+    rng = np.random.default_rng(21)
+    xyz = rng.uniform(0.1, 4.9, (700, 3)).astype(np.float32)   # all in one cell; cap is 514
+    more = cloud(2000, 22)
+    g, o = make_pair(np.concatenate([xyz, more]), age=3.0, fert=1e6)
+    g.step(1); o.step(1)
+    compare_all(g, o, "overflow step 1")
+    assert g.counters["cell_overflow_kills"] == o.counters["cell_overflow_kills"] > 0
+    g.step(1); o.step(1)
+    compare_all(g, o, "overflow step 2")
+
+
+def test_small_grids_and_empty():
+    for over, n in (({"chunk_factor": 1, "chunk_dim": 3, "max_particles_num": 200}, 150),
+                    ({"chunk_factor": 2, "chunk_dim": 3, "max_particles_num": 2000}, 1500),
+                    ({"chunk_factor": 2, "chunk_dim": 5, "max_particles_num": 3000, "cell_size": 2.5}, 0)):
+        cfg = ps.default_config(**over)
+        G = cfg.chunk_factor * cfg.chunk_dim
+        # odd grids are not centred: i = floor(+-c/CELL_SIZE) + G/2 with integer G/2 (app.cu:126-128)
+        lo, hi = -(G // 2) * cfg.cell_size, (G - G // 2) * cfg.cell_size
+        rng = np.random.default_rng(31)
+        xyz = np.zeros((n, 3), np.float32)
+        xyz[:, 0] = rng.uniform(lo, hi, n) * 0.999
+        xyz[:, 1] = -rng.uniform(lo, hi, n) * 0.999
+        xyz[:, 2] = -rng.uniform(lo, hi, n) * 0.999
+        g, o = make_pair(xyz, age=3.0, fert=1e6, **over)
+        for k in range(3):
+            g.step(1); o.step(1)
+            compare_all(g, o, "%r step %d" % (over, k + 1))
+
+
+def test_explosions_counter_rng():
+    """births with the counter-based RNG: exact against the oracle fed the same draws."""
+    n = 20000
+    xyz = cloud(n, 41)
+    rng = np.random.default_rng(41)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    fert = rng.uniform(2.5, 9.0, n).astype(np.float32)
+    seed = 0xC0FFEE
+    g, o = make_pair(xyz, age=age, fert=fert, flags=ps.FLAG_EXPLOSIONS, seed=seed)
+    o.set_rng(explosion_rng(seed))
+    for k in range(6):
+        g.step(1); o.step(1)
+        compare_all(g, o, "explosions step %d" % (k + 1))
+    assert g.counters["births"] > 100
+
+
+def test_upload_download_roundtrip():
+    xyz = cloud(3000, 51)
+    g, o = make_pair(xyz, age=3.0, fert=1e6)
+    o.step(3)
+    g2 = ps.ParticleSystem(ps.default_config())
+    g2.upload_particles(o.particles.copy())
+    g2.upload_queues(o.queue_info.copy(), o.queue.copy())
+    assert_same_particles(g2.download_particles(), o.particles, "roundtrip")
+    g2.step(2); o.step(2)
+    assert_same_particles(g2.download_particles(), o.particles, "continued from uploaded state")
+    qi, q = g2.download_queues()
+    assert qi.tobytes() == o.queue_info.tobytes() and np.array_equal(q, o.queue)
+
+
+def test_errors_are_statuses():
+    g = ps.ParticleSystem(ps.default_config())
+    with pytest.raises(ps.PsamdError) as e:
+        g.fill_particles([[100.0, 0, 0]])
+    assert e.value.status == 5          # PSAMD_ERR_OUTSIDE_BOX (ps.cpp:954-957)
+    with pytest.raises(ps.PsamdError) as e:
+        g.build_grid()
+    assert e.value.status == 8          # PSAMD_ERR_STATE
+    with pytest.raises(ps.PsamdError) as e:
+        ps.ParticleSystem(ps.default_config(chunk_dim=2))
+    assert e.value.status == 1

@@ -89,6 +89,7 @@ typedef struct psamd_counters {
     int64_t deaths_age, deaths_collision, survives, integrated;
     int64_t relocations, relocations_lost, births, births_failed, cell_overflow_kills;
     int64_t steps;
+    int64_t particles_processed; /* sum over steps of the live particles at build_grid */
 } psamd_counters;
 
 /* Raw device pointers of the SoA state, for plumbing (collectives, interop).
@@ -173,6 +174,13 @@ int psamd_force_shard(psamd_ctx *ctx, int64_t *begin, int64_t *end, int64_t *sha
 int psamd_step(psamd_ctx *ctx, int32_t nsteps);
 int psamd_synchronize(psamd_ctx *ctx);
 
+/* ---- checkpoint / resume --------------------------------------------------------- */
+/* The reference keeps its whole state in the nine buffers; the
+ * device-side image of them (particles + free-slot queues) can be saved once and
+ * restored any number of times without leaving HBM. */
+int psamd_snapshot_save(psamd_ctx *ctx);
+int psamd_snapshot_restore(psamd_ctx *ctx);
+
 /* ---- plumbing for collectives (multi-GPU) -------------------------------------- */
 /* Enqueue all further work on the caller's HIP stream (e.g. the one RCCL orders
  * against) instead of the context's own.  NULL restores the context's stream. */
@@ -189,6 +197,11 @@ int psamd_device_view_get(psamd_ctx *ctx, psamd_device_view *out);
 /* Per-kernel device time of the most recent step in microseconds, measured with
  * HIP events on the context's stream: hist, scan, scatter, sort, pairs, apply,
  * lifecycle.  Enabled by psamd_set_timing(ctx, 1). */
+/* Exhaustive check of the hand-written correctly rounded fp32 sqrt / reciprocal used by
+ * the pair kernel against the compiler's forms, over every float with bit pattern in
+ * [lo_bits, hi_bits].  out24[0..4] = mismatches of sqrt, rcp(1 step), rcp(2 steps),
+ * rcp(3-step form), rcp(the one in use); [8..15], [16..23] = first offending inputs. */
+int psamd_selftest_math(psamd_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t out24[24]);
 #define PSAMD_NUM_TIMERS 8
 int psamd_set_timing(psamd_ctx *ctx, int enabled);
 int psamd_get_timing(psamd_ctx *ctx, double us_out[PSAMD_NUM_TIMERS], int64_t *launches);

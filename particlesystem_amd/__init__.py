@@ -60,7 +60,8 @@ class Sizes(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in
                 ("deaths_age", "deaths_collision", "survives", "integrated", "relocations",
-                 "relocations_lost", "births", "births_failed", "cell_overflow_kills", "steps")]
+                 "relocations_lost", "births", "births_failed", "cell_overflow_kills", "steps",
+                 "particles_processed")]
 
 
 class DeviceView(C.Structure):
@@ -109,11 +110,14 @@ ABI = [
     ("psamd_force_shard", C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     ("psamd_step", C.c_int, [_vp, _i32]),
     ("psamd_synchronize", C.c_int, [_vp]),
+    ("psamd_snapshot_save", C.c_int, [_vp]),
+    ("psamd_snapshot_restore", C.c_int, [_vp]),
     ("psamd_set_stream", C.c_int, [_vp, _vp]),
     ("psamd_bind_force4", C.c_int, [_vp, _vp, _i64]),
     ("psamd_get_counters", C.c_int, [_vp, C.POINTER(Counters)]),
     ("psamd_live_count", C.c_int, [_vp, C.POINTER(_i64)]),
     ("psamd_device_view_get", C.c_int, [_vp, C.POINTER(DeviceView)]),
+    ("psamd_selftest_math", C.c_int, [_vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("psamd_set_timing", C.c_int, [_vp, C.c_int]),
     ("psamd_get_timing", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
 ]
@@ -291,6 +295,12 @@ class ParticleSystem:
     def synchronize(self):
         self._ck(self.lib.psamd_synchronize(self.h))
 
+    def snapshot_save(self):
+        self._ck(self.lib.psamd_snapshot_save(self.h))
+
+    def snapshot_restore(self):
+        self._ck(self.lib.psamd_snapshot_restore(self.h))
+
     def set_stream(self, hip_stream):
         self._ck(self.lib.psamd_set_stream(self.h, hip_stream))
 
@@ -313,6 +323,11 @@ class ParticleSystem:
         v = DeviceView()
         self._ck(self.lib.psamd_device_view_get(self.h, C.byref(v)))
         return v
+
+    def selftest_math(self, lo_bits, hi_bits):
+        out = (C.c_uint64 * 24)()
+        self._ck(self.lib.psamd_selftest_math(self.h, lo_bits, hi_bits, out))
+        return list(out)
 
     def set_timing(self, on=True):
         self._ck(self.lib.psamd_set_timing(self.h, 1 if on else 0))

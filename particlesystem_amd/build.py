@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpsamd.so")
-SOURCES = ["kernels.hip", "capi.hip"]
+SOURCES = ["kernels.hip", "capi.hip", "lifecycle_sort.hip"]
 DEPS = SOURCES + ["kernels.h", "device_types.h", "geometry.hpp", os.path.join("..", "..", "include", "psamd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 

@@ -38,6 +38,10 @@ struct psamd_ctx {
     std::vector<QueueInfo> h_qinfo;   // valid while !queues_on_device_newer
     std::vector<int32_t> h_queue;
     bool host_queues_valid = true;    // host mirror == device copy
+    FrameScalars *h_fs = nullptr;     // pinned host copy of the per-frame scalars
+    int64_t processed_total = 0;      // sum over steps of the live particles at build_grid
+    char *snapshot = nullptr;         // device image for snapshot_save / _restore
+    int snapshot_step = 0;
     void *staging = nullptr;          // device staging for AoS transfers
     size_t staging_bytes = 0;
     // stage state machine
@@ -148,7 +152,6 @@ int check_device_errors(psamd_ctx *c)   // after a sync: sticky error bits raise
     if (fs.error & ERR_BAD_ID) return fail(c, PSAMD_ERR_INVALID_ARG, "uploaded particle with id != slot index");
     if (fs.error & ERR_CELL_TOO_BIG) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "a cell holds more particles than the sort kernel ranks");
     if (fs.error & ERR_OPS_OVERFLOW) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "lifecycle op buffer overflow");
-    if (fs.error & ERR_BUCKET_TOO_BIG) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "too many queue operations on one segment in one step");
     return PSAMD_OK;
 }
 
@@ -234,6 +237,17 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     P.cell_size = cfg->cell_size; P.eps2 = cfg->eps2; P.coll_radius = cfg->collision_radius;
     P.kid_age = g.kid_age; P.life = g.particle_life; P.expl_speed = cfg->explosion_speed;
     P.seed = cfg->seed;
+    auto bits_for = [](int64_t n) { int b = 1; while (((int64_t)1 << b) < n) b++; return b; };
+    P.key_chunk_shift = 2 + bits_for(g.container);
+    P.key_rec_shift = P.key_chunk_shift + bits_for((int64_t)g.num_chunks + 1);
+    P.key_bits = P.key_rec_shift + bits_for(g.queue_infos);
+    {
+        // (r.r + eps2)^3 over every pair of in-box positions, with slack for one wrap of drift
+        const double L = (double)g.G * cfg->cell_size;
+        const double lo = cfg->eps2 * cfg->eps2 * cfg->eps2, hi = std::pow(3.0 * (2.0 * L) * (2.0 * L) + cfg->eps2, 3.0);
+        P.lean_math = (lo > std::ldexp(1.0, -60) && hi < std::ldexp(1.0, 60)) ? 1 : 0;
+    }
+    if (P.key_bits > 63) return fail(c, PSAMD_ERR_UNSUPPORTED, "queue-op key does not fit 64 bits for this configuration");
     for (int k = 0; k < 5; k++) { c->S.seg_base[k] = g.seg_base[k]; c->S.info_base[k] = g.info_base[k]; }
     for (int k = 0; k < 4; k++) c->S.seg_size_t[k] = g.seg_size_t[k];
 
@@ -242,7 +256,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     d.ops_cap = (int)std::min<size_t>(3 * C, (size_t)INT32_MAX / 2);
     d.moves_cap = (int)std::min<size_t>(2 * C, (size_t)INT32_MAX / 2);
     int *frame = nullptr;
-    const size_t frame_ints = (size_t)g.num_cells + g.num_chunks + g.queue_infos;
+    const size_t frame_ints = (size_t)g.num_cells + g.num_chunks;
     PS_HIP(c, dev_alloc(c, &d.pos4, C));
     PS_HIP(c, dev_alloc(c, &d.vel4, C));
     PS_HIP(c, dev_alloc(c, &d.acc4, C));
@@ -252,7 +266,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.qinfo, (size_t)g.queue_infos));
     PS_HIP(c, dev_alloc(c, &d.queue, C));
     PS_HIP(c, dev_alloc(c, &frame, frame_ints));
-    d.cell_count = frame; d.chunk_count = frame + g.num_cells; d.rec_count = d.chunk_count + g.num_chunks;
+    d.cell_count = frame; d.chunk_count = frame + g.num_cells;
     PS_HIP(c, dev_alloc(c, &d.fs, 1));
     PS_HIP(c, dev_alloc(c, &d.cell_start, (size_t)g.num_cells + 1));
     PS_HIP(c, dev_alloc(c, &d.cursor, (size_t)g.num_cells));
@@ -262,12 +276,15 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.force4, C));
     c->own_force4 = d.force4;
     PS_HIP(c, dev_alloc(c, &d.celltab, (size_t)g.num_cells));
-    PS_HIP(c, dev_alloc(c, &d.ops, (size_t)d.ops_cap));
-    PS_HIP(c, dev_alloc(c, &d.ops_sorted, (size_t)d.ops_cap));
+    PS_HIP(c, dev_alloc(c, &d.op_keys, (size_t)d.ops_cap));
+    PS_HIP(c, dev_alloc(c, &d.op_keys_sorted, (size_t)d.ops_cap));
+    PS_HIP(c, dev_alloc(c, &d.op_args, (size_t)d.ops_cap));
+    PS_HIP(c, dev_alloc(c, &d.op_args_sorted, (size_t)d.ops_cap));
+    PS_HIP(c, sort_ops_tmp_bytes((size_t)d.ops_cap, P.key_bits, &d.sort_tmp_bytes));
+    { char *tmp = nullptr; PS_HIP(c, dev_alloc(c, &tmp, d.sort_tmp_bytes)); d.sort_tmp = tmp; }
+    PS_HIP(c, hipHostMalloc((void **)&c->h_fs, sizeof(FrameScalars), hipHostMallocDefault));
     PS_HIP(c, dev_alloc(c, &d.moves, (size_t)d.moves_cap));
     PS_HIP(c, dev_alloc(c, &d.stage, 3 * (size_t)d.moves_cap));
-    PS_HIP(c, dev_alloc(c, &d.rec_start, (size_t)g.queue_infos + 1));
-    PS_HIP(c, dev_alloc(c, &d.rec_cursor, (size_t)g.queue_infos));
     PS_HIP(c, dev_alloc(c, &d.ctr, 1));
 
     // init_particles (ps.cpp:722-753): every slot reset, cell = -1
@@ -297,6 +314,7 @@ int psamd_destroy(psamd_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->staging) (void)hipFree(c->staging);
+    if (c->h_fs) (void)hipHostFree(c->h_fs);
     if (c->ev_made) for (auto &e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -542,7 +560,7 @@ int psamd_init_iframe(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
     const Geometry &g = c->geo;
-    const size_t frame_ints = (size_t)g.num_cells + g.num_chunks + g.queue_infos;
+    const size_t frame_ints = (size_t)g.num_cells + g.num_chunks;
     if (c->timing) { make_events(c); (void)hipEventRecord(c->ev[10], c->stream); }
     PS_HIP(c, hipMemsetAsync(c->d.cell_count, 0, frame_ints * sizeof(int), c->stream));
     // keep the sticky error word across frames: only the per-frame scalars are cleared
@@ -605,8 +623,15 @@ int psamd_calc_forces_apply(psamd_ctx *c)
     if (c->timing) (void)hipEventRecord(c->ev[7], c->stream);
     PS_HIP(c, launch_apply(c->stream, c->P, c->S, c->d, c->step, c->geo.container));
     if (c->timing) (void)hipEventRecord(c->ev[8], c->stream);
-    if (!(c->P.flags & PSAMD_FLAG_NO_LIFECYCLE)) {
-        PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos, c->d.moves_cap));
+    // one small read-back per step, as the reference's driver does for hostGridMax
+    // (ps.cpp:1878-1900): live count, sticky errors and the sizes of the op lists
+    PS_HIP(c, hipMemcpyAsync(c->h_fs, c->d.fs, sizeof(FrameScalars), hipMemcpyDeviceToHost, c->stream));
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    c->live_at_build = c->h_fs->live;
+    c->processed_total += c->h_fs->live;
+    if (c->h_fs->error) return check_device_errors(c);
+    if (c->h_fs->n_ops > 0 || c->h_fs->n_moves > 0) {
+        PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos, c->h_fs->n_ops, c->h_fs->n_moves));
         c->host_queues_valid = false;
     }
     if (c->timing) {
@@ -665,6 +690,7 @@ int psamd_get_counters(psamd_ctx *c, psamd_counters *o)
     o->births = (int64_t)d.births; o->births_failed = (int64_t)d.births_failed;
     o->cell_overflow_kills = (int64_t)d.cell_overflow_kills;
     o->steps = c->steps_total;
+    o->particles_processed = c->processed_total;
     return PSAMD_OK;
 }
 
@@ -691,6 +717,48 @@ int psamd_device_view_get(psamd_ctx *c, psamd_device_view *o)
     return PSAMD_OK;
 }
 
+// particles (pos4, vel4, acc4, cell, pflags) + QUEUE_INFO + queue, back to back
+static size_t snapshot_bytes(const psamd_ctx *c)
+{
+    const size_t C = (size_t)c->geo.container;
+    return C * (3 * sizeof(float4) + sizeof(int) + 1) + (size_t)c->geo.queue_infos * sizeof(QueueInfo) + C * sizeof(int);
+}
+
+static int snapshot_copy(psamd_ctx *c, bool save)
+{
+    const size_t C = (size_t)c->geo.container;
+    char *p = c->snapshot;
+    struct { void *dev; size_t bytes; } parts[] = {
+        {c->d.pos4, C * sizeof(float4)}, {c->d.vel4, C * sizeof(float4)}, {c->d.acc4, C * sizeof(float4)},
+        {c->d.cell, C * sizeof(int)}, {c->d.qinfo, (size_t)c->geo.queue_infos * sizeof(QueueInfo)},
+        {c->d.queue, C * sizeof(int)}, {c->d.pflags, C},
+    };
+    for (auto &part : parts) {
+        if (save) PS_HIP(c, hipMemcpyAsync(p, part.dev, part.bytes, hipMemcpyDeviceToDevice, c->stream));
+        else PS_HIP(c, hipMemcpyAsync(part.dev, p, part.bytes, hipMemcpyDeviceToDevice, c->stream));
+        p += part.bytes;
+    }
+    return PSAMD_OK;
+}
+
+int psamd_snapshot_save(psamd_ctx *c)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (!c->snapshot) PS_HIP(c, dev_alloc(c, &c->snapshot, snapshot_bytes(c)));
+    c->snapshot_step = c->step;
+    return snapshot_copy(c, true);
+}
+
+int psamd_snapshot_restore(psamd_ctx *c)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (!c->snapshot) return fail(c, PSAMD_ERR_STATE, "snapshot_restore without a saved snapshot");
+    c->step = c->snapshot_step;
+    c->host_queues_valid = false;
+    c->frame_reset = false; c->grid_built = false; c->pairs_done = false;
+    return snapshot_copy(c, false);
+}
+
 int psamd_set_stream(psamd_ctx *c, void *hip_stream)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
@@ -705,6 +773,20 @@ int psamd_bind_force4(psamd_ctx *c, void *device_ptr, int64_t n_float4)
     if (device_ptr && n_float4 < c->geo.container) return fail(c, PSAMD_ERR_INVALID_ARG, "force4 buffer smaller than the container");
     PS_HIP(c, hipStreamSynchronize(c->stream));
     c->d.force4 = device_ptr ? (float4 *)device_ptr : c->own_force4;
+    return PSAMD_OK;
+}
+
+int psamd_selftest_math(psamd_ctx *c, uint32_t lo_bits, uint32_t hi_bits, uint64_t out24[24])
+{
+    if (!c || !out24 || hi_bits < lo_bits) return PSAMD_ERR_INVALID_ARG;
+    unsigned long long *d = nullptr;
+    PS_HIP(c, hipMalloc((void **)&d, 24 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 24 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = launch_selftest_math(c->stream, lo_bits, hi_bits, d);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out24, d, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return hip_fail(c, e, "selftest_math");
     return PSAMD_OK;
 }
 

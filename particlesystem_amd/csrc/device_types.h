@@ -30,6 +30,11 @@ struct DevParams {
     double life;
     double expl_speed;      // EXPLOSION_SPEED
     uint64_t seed;
+    // layout of a queue-op sort key: | record | chunk+1 | slot id | sub-step (2 bits) |
+    int32_t key_chunk_shift; // 2 + bits(container)
+    int32_t key_rec_shift;   // key_chunk_shift + bits(num_chunks + 1)
+    int32_t key_bits;        // key_rec_shift + bits(queue records)
+    int32_t lean_math;       // 1: the lean exact sqrt/rcp are valid for this box (host-checked range)
 };
 
 // Per-frame scalars living in device memory (zeroed by init_iframe).
@@ -51,16 +56,13 @@ enum : int32_t {
     ERR_CELL_TOO_BIG = 1,   // a cell holds more ids than the sort kernel can rank
     ERR_BAD_ID = 2,         // uploaded P_DATA_TYPE with id != slot
     ERR_OPS_OVERFLOW = 4,   // lifecycle op buffer too small
-    ERR_BUCKET_TOO_BIG = 8, // more queue ops on one segment than the replay kernel holds
 };
 
-// One free-slot-queue operation produced by calc_forces (lifecycle).
-struct QueueOp {
-    uint64_t key;           // serial order of the reference: (chunk, id, sub-step)
-    int32_t rec;            // QUEUE_INFO record index (which segment's queue)
-    int32_t arg;            // insert: slot id to free; remove: index of the move record
-};
-
+// A free-slot-queue operation produced by calc_forces is a (key, arg) pair kept in
+// two parallel arrays: key = record | chunk+1 | id | sub orders the operations of
+// one queue exactly as the reference's serial loops meet them (chunk by chunk, slot
+// by slot; within a particle: birth remove (0), relocation remove (1), insert (2));
+// arg = slot id to free (insert) or index of the MoveRec waiting for a slot (remove).
 // A particle that needs a new slot (segment change) or a child to be born.
 struct MoveRec {
     int32_t src;            // slot of the particle (parent for births)
@@ -70,6 +72,7 @@ struct MoveRec {
 };
 
 constexpr int SORT_MAX = 2048;   // ids one cell may hold for the in-LDS ranking
-constexpr int REPLAY_MAX = 4096; // queue ops one segment may receive per step
+constexpr int REPLAY_CHUNK = 2048;   // queue ops staged through LDS at a time
+constexpr int QUEUE_WINDOW = 10240;  // largest segment (slots) whose queue is replayed in LDS
 
 }  // namespace psamd

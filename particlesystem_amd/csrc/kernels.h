@@ -28,9 +28,8 @@ struct DeviceState {
     QueueInfo *qinfo = nullptr;
     int *queue = nullptr;
     // per-frame grid
-    int *cell_count = nullptr;    // [num_cells]      \  zeroed together
-    int *chunk_count = nullptr;   // [num_chunks]      > by init_iframe
-    int *rec_count = nullptr;     // [queue_infos]    /
+    int *cell_count = nullptr;    // [num_cells]   \ zeroed together
+    int *chunk_count = nullptr;   // [num_chunks]  / by init_iframe
     FrameScalars *fs = nullptr;
     int *cell_start = nullptr;    // [num_cells+1]
     int *cursor = nullptr;        // [num_cells]
@@ -40,13 +39,14 @@ struct DeviceState {
     float4 *force4 = nullptr;     // [container] sorted order: ax,ay,az,flag
     CellInfo *celltab = nullptr;  // [num_cells]
     // lifecycle
-    QueueOp *ops = nullptr, *ops_sorted = nullptr;
+    uint64_t *op_keys = nullptr, *op_keys_sorted = nullptr;
+    int *op_args = nullptr, *op_args_sorted = nullptr;
     int ops_cap = 0;
+    void *sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
     MoveRec *moves = nullptr;
     int moves_cap = 0;
     float4 *stage = nullptr;      // 3 float4 per move
-    int *rec_start = nullptr;     // [queue_infos+1]
-    int *rec_cursor = nullptr;    // [queue_infos]
     DevCounters *ctr = nullptr;
 };
 
@@ -55,13 +55,18 @@ hipError_t launch_pack_aos(hipStream_t st, void *aos, int first, int count, int 
 hipError_t launch_place(hipStream_t st, int n, const int *ids, const float4 *p, const float4 *v, const float4 *a,
                         const int *cells, const DeviceState &d);
 hipError_t launch_fill_int(hipStream_t st, int *p, int v, size_t n);
+hipError_t launch_selftest_math(hipStream_t st, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out24);
 hipError_t launch_init_tdata(hipStream_t st, const DeviceState &d, int n);
 // ev (optional) = 5 events recorded before hist, scan, scatter, sort and after sort
 hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev);
 hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi);
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step,
                         int live_bound);
+// n_ops / n_moves are the exact counts read back from FrameScalars after apply
 hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
-                            int moves_bound);
+                            int n_ops, int n_moves);
+// lifecycle_sort.hip (rocPRIM radix sort of the op keys; library code, not a hot path)
+hipError_t sort_ops_tmp_bytes(size_t n, int key_bits, size_t *bytes);
+hipError_t sort_ops(hipStream_t st, const DeviceState &d, int n, int key_bits);
 
 }  // namespace psamd

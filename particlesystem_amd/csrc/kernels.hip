@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
                                                      int *cell_arr, uint8_t *pflags,
                                                      float4 *__restrict__ snap4, float *__restrict__ snap_age,
                                                      uint32_t *__restrict__ tdata,
-                                                     QueueOp *ops, int ops_cap,
+                                                     uint64_t *op_keys, int *op_args, int ops_cap,
                                                      FrameScalars *fs, DevCounters *ctr)
 {
     __shared__ int ids[SORT_MAX];
@@ -251,13 +251,81 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
             atomicAdd(&ctr->cell_overflow_kills, 1ull);
             // freed with the already-reset segment (-1,-1): queue record 0 (ps.cpp:1523-1526)
             const int k = atomicAdd(&fs->n_ops, 1);
-            if (k < ops_cap) ops[k] = {((uint64_t)(uint32_t)id << 2) | 2ull, 0, id};
+            if (k < ops_cap) { op_keys[k] = ((uint64_t)(uint32_t)id << 2) | 2ull; op_args[k] = id; }
             else atomicOr(&fs->error, ERR_OPS_OVERFLOW);
         }
     }
 }
 
 // ------------------------------------------------------------------ pair kernel
+// Correctly rounded fp32 sqrt and reciprocal without the range/denormal scaffolding
+// the compiler wraps around them: valid for normal inputs well inside the exponent
+// range (the host only selects them when eps2^3 .. (3 L^2 + eps2)^3 lies in
+// [2^-60, 2^60]).  Both are checked against the compiler's correctly rounded forms
+// over EVERY float of that range by psamd_selftest_math (tests/test_gpu_math.py).
+__device__ __forceinline__ float sqrt_rn_lean(float a)
+{
+    const float r = __builtin_amdgcn_rsqf(a);
+    float g = a * r;
+    float h = 0.5f * r;
+    const float e = __builtin_fmaf(-h, g, 0.5f);
+    h = __builtin_fmaf(h, e, h);
+    g = __builtin_fmaf(g, e, g);
+    const float d = __builtin_fmaf(-g, g, a);
+    return __builtin_fmaf(d, h, g);
+}
+
+template <int ITER>
+__device__ __forceinline__ float rcp_rn_lean(float q)
+{
+    float x = __builtin_amdgcn_rcpf(q);
+#pragma unroll
+    for (int k = 0; k < ITER; k++) {
+        const float e = __builtin_fmaf(-q, x, 1.0f);
+        x = __builtin_fmaf(e, x, x);
+    }
+    return x;
+}
+
+// the compiler's division sequence without div_scale / div_fixup (exponent handling)
+__device__ __forceinline__ float rcp_rn_markstein(float d)
+{
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float e0 = __builtin_fmaf(-d, r, 1.0f);
+    const float y1 = __builtin_fmaf(e0, r, r);
+    const float r0 = __builtin_fmaf(-d, y1, 1.0f);
+    const float q1 = __builtin_fmaf(r0, y1, y1);
+    const float r1 = __builtin_fmaf(-d, q1, 1.0f);
+    return __builtin_fmaf(r1, y1, q1);
+}
+
+#ifndef PSAMD_RCP_VARIANT
+#define PSAMD_RCP_VARIANT 1
+#endif
+__device__ __forceinline__ float rcp_rn_selected(float q)
+{
+#if PSAMD_RCP_VARIANT == 1
+    return rcp_rn_lean<1>(q);
+#elif PSAMD_RCP_VARIANT == 2
+    return rcp_rn_lean<2>(q);
+#else
+    return rcp_rn_markstein(q);
+#endif
+}
+
+__device__ __forceinline__ float pair_exact_lean(float xi, float yi, float zi, const float4 q, double eps2,
+                                                 float &ax, float &ay, float &az)
+{
+    const float rx = q.x - xi, ry = q.y - yi, rz = q.z - zi;
+    const float d2 = rx * rx + ry * ry + rz * rz;
+    const float dsq = (float)((double)d2 + eps2);
+    const float six = dsq * dsq * dsq;
+    const float inv = rcp_rn_selected(sqrt_rn_lean(six));
+    const float s = q.w * inv;
+    ax += rx * s; ay += ry * s; az += rz * s;
+    return d2;
+}
+
 // bodyBodyInteraction, app_common.cu:236-267, for a snapshot body q = (x,y,z,w_eff).
 __device__ __forceinline__ float pair_exact(float xi, float yi, float zi, const float4 q, double eps2,
                                             float &ax, float &ay, float &az)
@@ -304,7 +372,8 @@ __device__ __forceinline__ int collide_exact(const DevParams &P, float d2, float
 // streamed through a 1 KiB LDS tile; every lane reads the same tile entry (broadcast)
 // and adds it to its own particle's sum, so each particle sees exactly the
 // reference's sequence of fp32 additions (ps.cpp:1247-1259).
-template <bool FAST>
+// MODE 0: exact, compiler's sqrt/div; 1: exact, lean sqrt/rcp; 2: fast math
+template <int MODE>
 __global__ __launch_bounds__(64) void k_pairs(DevParams P, const int *__restrict__ cell_start,
                                                const float4 *__restrict__ snap4,
                                                const float *__restrict__ snap_age,
@@ -354,8 +423,9 @@ __global__ __launch_bounds__(64) void k_pairs(DevParams P, const int *__restrict
 #pragma unroll 4
             for (int jj = 0; jj < n; jj++) {
                 const float4 q = tile[jj];
-                const float d2 = FAST ? pair_fast(me.x, me.y, me.z, q, eps2f, ax, ay, az)
-                                      : pair_exact(me.x, me.y, me.z, q, P.eps2, ax, ay, az);
+                const float d2 = MODE == 2 ? pair_fast(me.x, me.y, me.z, q, eps2f, ax, ay, az)
+                               : MODE == 1 ? pair_exact_lean(me.x, me.y, me.z, q, P.eps2, ax, ay, az)
+                                           : pair_exact(me.x, me.y, me.z, q, P.eps2, ax, ay, az);
                 dmin = fminf(dmin, d2);
             }
             // rare: someone in this tile is within the collision gate of one of my lanes
@@ -406,10 +476,36 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
     return x ^ (x >> 31);
 }
 
+// Wave-aggregated bump allocation: every lane asks for `need` (0..3) consecutive
+// entries of a list whose fill count lives at *counter; one atomic per wave.
+__device__ __forceinline__ int wave_alloc(int need, int *counter)
+{
+    const int lane = (int)__lane_id();
+    int incl = need;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    const int total = __shfl(incl, 63);
+    int base = 0;
+    if (total > 0) {
+        if (lane == 63) base = atomicAdd(counter, total);
+        base = __shfl(base, 63);
+    }
+    return base + incl - need;
+}
+
+// one atomic per wave for an event counter
+__device__ __forceinline__ void wave_count(bool pred, unsigned long long *counter)
+{
+    const unsigned long long m = __ballot(pred);
+    if (m != 0ull && (int)__lane_id() == (int)__ffsll((long long)m) - 1) atomicAdd(counter, (unsigned long long)__popcll(m));
+}
+
 // Death, survival, integration, wrap and re-hash for every particle of the frame
 // (ps.cpp:1182-1242, 1261-1302), one thread per sorted index.  Lifecycle side
 // effects that depend on the reference's serial order (free-slot queues) are emitted
-// as QueueOp / MoveRec records and replayed afterwards.
+// as (key, arg) queue operations and MoveRec records and replayed afterwards.
 __global__ __launch_bounds__(256) void k_apply(DevParams P, SegLayout S, int step,
                                                 const int *__restrict__ cell_start,
                                                 const int *__restrict__ sorted_id,
@@ -417,254 +513,212 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P, SegLayout S, int ste
                                                 float4 *pos4, float4 *vel4, float4 *acc4,
                                                 int *cell_arr, uint8_t *pflags,
                                                 const CellInfo *__restrict__ celltab,
-                                                QueueOp *ops, int ops_cap, MoveRec *moves, int moves_cap,
+                                                uint64_t *op_keys, int *op_args, int ops_cap,
+                                                MoveRec *moves, int moves_cap,
                                                 FrameScalars *fs, DevCounters *ctr)
 {
     const int total = cell_start[P.num_cells];
     const int gi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi >= total) return;
-    const int id = sorted_id[gi];
-    if (id < 0) return;                                  // killed by the cell-overflow rule
-    const float4 f = force4[gi];
-    const int flag = __float_as_int(f.w);
+    // whole waves past the end leave; inside a live wave every lane reaches the
+    // wave-level allocations below
+    if ((gi & ~63) >= total) return;
+    const int id = (gi < total) ? sorted_id[gi] : -1;    // -1: killed by the cell-overflow rule
+    const bool active = id >= 0;
     const bool lifecycle = !(P.flags & PSAMD_FLAG_NO_LIFECYCLE);
-    const int old_cell = cell_arr[id];
-    const CellInfo old_ci = celltab[old_cell];
-    const uint64_t key = ((uint64_t)(uint32_t)(old_ci.chunk + 1) << 34) | ((uint64_t)(uint32_t)id << 2);
 
-    if (flag == 2) {                                     // kill, ps.cpp:1211-1235
-        const float age = vel4[id].w;
-        if (age > P.life_thr) atomicAdd(&ctr->deaths_age, 1ull); else atomicAdd(&ctr->deaths_collision, 1ull);
+    int flag = 0, old_cell = 0, new_cell = 0;
+    float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) { f = force4[gi]; flag = __float_as_int(f.w); old_cell = cell_arr[id]; }
+    const CellInfo old_ci = active ? celltab[old_cell] : CellInfo{0, 1, 0, 0};
+    const uint64_t key = ((uint64_t)(uint32_t)(old_ci.chunk + 1) << P.key_chunk_shift) | ((uint64_t)(uint32_t)id << 2);
+
+    const bool killed = active && flag == 2, survived = active && flag == 1, moved = active && flag == 0;
+    bool died_of_age = false, born = false, relocate = false;
+    int new_rec = 0;
+
+    if (killed) {                                        // kill, ps.cpp:1211-1235
+        died_of_age = vel4[id].w > P.life_thr;
         cell_arr[id] = -1; pflags[id] = 0;
         pos4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
         vel4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
         acc4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int k = atomicAdd(&fs->n_ops, 1);
-        if (k < ops_cap) ops[k] = {key | 2ull, segment_record_of_slot(S, id), id};
-        else atomicOr(&fs->error, ERR_OPS_OVERFLOW);
-        return;
-    }
-    if (flag == 1) {                                     // survive_particle, app.cu:271-283
-        atomicAdd(&ctr->survives, 1ull);
+    } else if (survived) {                               // survive_particle, app.cu:271-283
         const float fert = acc4[id].w;
         vel4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
         acc4[id] = make_float4(0.f, 0.f, 0.f, fert);
         pflags[id] = 0;
-        return;
+    } else if (moved) {
+        const float4 p = pos4[id];
+        const float4 v = vel4[id];
+        const float fert = acc4[id].w;
+        const float axv = f.x, ayv = f.y, azv = f.z;
+        const float t = P.t;
+        // dx = v*t (fp32) + 0.5*a*t*t (double, left to right), rounded once (ps.cpp:1274-1276)
+        float dx = (float)((double)(v.x * t) + ((0.5 * (double)axv) * (double)t) * (double)t);
+        float dy = (float)((double)(v.y * t) + ((0.5 * (double)ayv) * (double)t) * (double)t);
+        float dz = (float)((double)(v.z * t) + ((0.5 * (double)azv) * (double)t) * (double)t);
+        dx = clamp_mag(dx, P.dmax); dy = clamp_mag(dy, P.dmax); dz = clamp_mag(dz, P.dmax);
+        float rx = p.x + dx, ry = p.y + dy, rz = p.z + dz;
+
+        // set_pos_t, app.cu:117-158: double floor, periodic wrap one grid length at a time
+        const int G = P.G;
+        const double cs = P.cell_size;
+        int i1 = (int)(floor((-1.0 * (double)ry) / cs) + (double)(G / 2));
+        int i2 = (int)(floor((1.0 * (double)rx) / cs) + (double)(G / 2));
+        int i3 = (int)(floor((-1.0 * (double)rz) / cs) + (double)(G / 2));
+        for (int guard = 0; guard < 64 &&
+             !((i1 >= 0 && i1 < G) && (i2 >= 0 && i2 < G) && (i3 >= 0 && i3 < G)); guard++) {
+            if (!(i1 >= 0 && i1 < G)) { const int o = i1; i1 = (i1 + G) % G; ry = (float)((double)ry + (-1.0 * (double)(i1 - o) * cs)); }
+            if (!(i2 >= 0 && i2 < G)) { const int o = i2; i2 = (i2 + G) % G; rx = (float)((double)rx + ((double)(i2 - o) * cs)); }
+            if (!(i3 >= 0 && i3 < G)) { const int o = i3; i3 = (i3 + G) % G; rz = (float)((double)rz + (-1.0 * (double)(i3 - o) * cs)); }
+        }
+        i1 = min(max(i1, 0), G - 1); i2 = min(max(i2, 0), G - 1); i3 = min(max(i3, 0), G - 1); // non-finite input only
+        new_cell = i3 * G * G + i1 * G + i2;
+
+        float vx = v.x + axv * t, vy = v.y + ayv * t, vz = v.z + azv * t;   // ps.cpp:1289-1296
+        vx = clamp_mag(vx, P.vmax); vy = clamp_mag(vy, P.vmax); vz = clamp_mag(vz, P.vmax);
+        const float age = v.w + t;                                         // ps.cpp:1302
+        uint8_t pf = pflags[id];
+        const CellInfo new_ci = celltab[new_cell];
+        new_rec = segment_record(S, new_ci.seg_type, new_ci.seg_tid);
+
+        // explosion, ps.cpp:1306-1333, with a counter-based RNG keyed on (seed, step, id)
+        if ((P.flags & PSAMD_FLAG_EXPLOSIONS) && lifecycle && (age >= fert) && !(pf & 1)) {
+            const uint64_t h0 = splitmix64(P.seed ^ ((uint64_t)(uint32_t)step << 32) ^ (uint64_t)(uint32_t)id);
+            const uint64_t h1 = splitmix64(h0), h2 = splitmix64(h1);
+            const int r0 = (int)((double)(h0 >> 11) * (1.0 / 9007199254740992.0) * 100.0) - 50;
+            const int r1 = (int)((double)(h1 >> 11) * (1.0 / 9007199254740992.0) * 100.0) - 50;
+            const int r2 = (int)((double)(h2 >> 11) * (1.0 / 9007199254740992.0) * 100.0) - 50;
+            float ux = (float)r0, uy = (float)r1, uz = (float)r2;
+            const float mag = sqrtf((float)((double)(ux * ux) + (double)(uy * uy) + (double)(uz * uz)));
+            ux /= mag; uy /= mag; uz /= mag;
+            vx = (float)((double)ux * P.expl_speed);
+            vy = (float)((double)uy * P.expl_speed);
+            vz = (float)((double)uz * P.expl_speed);
+            pf |= 1;
+            born = true;
+        }
+        pos4[id] = make_float4(rx, ry, rz, p.w);
+        vel4[id] = make_float4(vx, vy, vz, age);
+        acc4[id] = make_float4(axv, ayv, azv, fert);
+        cell_arr[id] = new_cell;
+        pflags[id] = pf;
+        // segment change => the particle must move to a slot of the new segment
+        // (set_pos_x raises seg_fault, app.cu:178-185; handled at ps.cpp:1335-1374)
+        relocate = lifecycle && (new_ci.seg_type != old_ci.seg_type || new_ci.seg_tid != old_ci.seg_tid);
     }
-    atomicAdd(&ctr->integrated, 1ull);
 
-    const float4 p = pos4[id];
-    float4 v = vel4[id];
-    const float fert = acc4[id].w;
-    const float axv = f.x, ayv = f.y, azv = f.z;
-    const float t = P.t;
-    // dx = v*t (fp32) + 0.5*a*t*t (double, left to right), rounded once (ps.cpp:1274-1276)
-    float dx = (float)((double)(v.x * t) + ((0.5 * (double)axv) * (double)t) * (double)t);
-    float dy = (float)((double)(v.y * t) + ((0.5 * (double)ayv) * (double)t) * (double)t);
-    float dz = (float)((double)(v.z * t) + ((0.5 * (double)azv) * (double)t) * (double)t);
-    dx = clamp_mag(dx, P.dmax); dy = clamp_mag(dy, P.dmax); dz = clamp_mag(dz, P.dmax);
-    float rx = p.x + dx, ry = p.y + dy, rz = p.z + dz;
+    wave_count(moved, &ctr->integrated);
+    wave_count(survived, &ctr->survives);
+    wave_count(killed && died_of_age, &ctr->deaths_age);
+    wave_count(killed && !died_of_age, &ctr->deaths_collision);
 
-    // set_pos_t, app.cu:117-158: double floor, periodic wrap one grid length at a time
-    const int G = P.G;
-    const double cs = P.cell_size;
-    int i1 = (int)(floor((-1.0 * (double)ry) / cs) + (double)(G / 2));
-    int i2 = (int)(floor((1.0 * (double)rx) / cs) + (double)(G / 2));
-    int i3 = (int)(floor((-1.0 * (double)rz) / cs) + (double)(G / 2));
-    for (int guard = 0; guard < 64 &&
-         !((i1 >= 0 && i1 < G) && (i2 >= 0 && i2 < G) && (i3 >= 0 && i3 < G)); guard++) {
-        if (!(i1 >= 0 && i1 < G)) { const int o = i1; i1 = (i1 + G) % G; ry = (float)((double)ry + (-1.0 * (double)(i1 - o) * cs)); }
-        if (!(i2 >= 0 && i2 < G)) { const int o = i2; i2 = (i2 + G) % G; rx = (float)((double)rx + ((double)(i2 - o) * cs)); }
-        if (!(i3 >= 0 && i3 < G)) { const int o = i3; i3 = (i3 + G) % G; rz = (float)((double)rz + (-1.0 * (double)(i3 - o) * cs)); }
+    // queue operations: kill -> insert; birth -> remove; relocation -> remove + insert
+    const int n_op = (killed ? 1 : 0) + (born ? 1 : 0) + (relocate ? 2 : 0);
+    const int n_mv = (born ? 1 : 0) + (relocate ? 1 : 0);
+    if (!__any(n_op != 0)) return;
+    int k = wave_alloc(n_op, &fs->n_ops);
+    int m = wave_alloc(n_mv, &fs->n_moves);
+    if (n_op == 0) return;
+    if (k + n_op > ops_cap || m + n_mv > moves_cap) { atomicOr(&fs->error, ERR_OPS_OVERFLOW); return; }
+    const uint64_t own_rec = (uint64_t)(uint32_t)segment_record_of_slot(S, id) << P.key_rec_shift;
+    const uint64_t dst_rec = (uint64_t)(uint32_t)new_rec << P.key_rec_shift;
+    if (killed) { op_keys[k] = own_rec | key | 2ull; op_args[k] = id; }
+    if (born) {
+        moves[m] = {id, -1, 1, new_cell};
+        op_keys[k] = dst_rec | key | 0ull; op_args[k] = m;
+        k++; m++;
     }
-    i1 = min(max(i1, 0), G - 1); i2 = min(max(i2, 0), G - 1); i3 = min(max(i3, 0), G - 1); // non-finite input only
-    const int new_cell = i3 * G * G + i1 * G + i2;
-
-    float vx = v.x + axv * t, vy = v.y + ayv * t, vz = v.z + azv * t;   // ps.cpp:1289-1296
-    vx = clamp_mag(vx, P.vmax); vy = clamp_mag(vy, P.vmax); vz = clamp_mag(vz, P.vmax);
-    const float age = v.w + t;                                         // ps.cpp:1302
-    uint8_t pf = pflags[id];
-
-    const CellInfo new_ci = celltab[new_cell];
-    const int new_rec = segment_record(S, new_ci.seg_type, new_ci.seg_tid);
-
-    // explosion, ps.cpp:1306-1333, with a counter-based RNG keyed on (seed, step, id)
-    if ((P.flags & PSAMD_FLAG_EXPLOSIONS) && lifecycle && (age >= fert) && !(pf & 1)) {
-        const uint64_t h0 = splitmix64(P.seed ^ ((uint64_t)(uint32_t)step << 32) ^ (uint64_t)(uint32_t)id);
-        const uint64_t h1 = splitmix64(h0), h2 = splitmix64(h1);
-        const int r0 = (int)((double)(h0 >> 11) * (1.0 / 9007199254740992.0) * 100.0) - 50;
-        const int r1 = (int)((double)(h1 >> 11) * (1.0 / 9007199254740992.0) * 100.0) - 50;
-        const int r2 = (int)((double)(h2 >> 11) * (1.0 / 9007199254740992.0) * 100.0) - 50;
-        float ux = (float)r0, uy = (float)r1, uz = (float)r2;
-        const float mag = sqrtf((float)((double)(ux * ux) + (double)(uy * uy) + (double)(uz * uz)));
-        ux /= mag; uy /= mag; uz /= mag;
-        vx = (float)((double)ux * P.expl_speed);
-        vy = (float)((double)uy * P.expl_speed);
-        vz = (float)((double)uz * P.expl_speed);
-        pf |= 1;
-        const int m = atomicAdd(&fs->n_moves, 1);
-        const int k = atomicAdd(&fs->n_ops, 1);
-        if (m < moves_cap && k < ops_cap) {
-            moves[m] = {id, -1, 1, new_cell};
-            ops[k] = {key | 0ull, new_rec, m};
-        } else atomicOr(&fs->error, ERR_OPS_OVERFLOW);
-    }
-
-    pos4[id] = make_float4(rx, ry, rz, p.w);
-    vel4[id] = make_float4(vx, vy, vz, age);
-    acc4[id] = make_float4(axv, ayv, azv, fert);
-    cell_arr[id] = new_cell;
-    pflags[id] = pf;
-
-    // segment change => the particle must move to a slot of the new segment
-    // (set_pos_x raises seg_fault, app.cu:178-185; handled at ps.cpp:1335-1374)
-    if (lifecycle && (new_ci.seg_type != old_ci.seg_type || new_ci.seg_tid != old_ci.seg_tid)) {
-        const int m = atomicAdd(&fs->n_moves, 1);
-        const int k = atomicAdd(&fs->n_ops, 2);
-        if (m < moves_cap && k + 1 < ops_cap) {
-            moves[m] = {id, -1, 0, new_cell};
-            ops[k] = {key | 1ull, new_rec, m};
-            ops[k + 1] = {key | 2ull, segment_record_of_slot(S, id), id};
-        } else atomicOr(&fs->error, ERR_OPS_OVERFLOW);
+    if (relocate) {
+        moves[m] = {id, -1, 0, new_cell};
+        op_keys[k] = dst_rec | key | 1ull; op_args[k] = m;
+        op_keys[k + 1] = own_rec | key | 2ull; op_args[k + 1] = id;
     }
 }
 
 // ------------------------------------------------------------------ lifecycle replay
-__global__ void k_ops_hist(const QueueOp *__restrict__ ops, const FrameScalars *fs, int ops_cap, int *rec_count)
-{
-    const int n = min(fs->n_ops, ops_cap);
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int stride = gridDim.x * blockDim.x;
-    for (; i < n; i += stride) atomicAdd(&rec_count[ops[i].rec], 1);
-}
-
-__global__ __launch_bounds__(1024) void k_ops_scan(int nrec, const int *__restrict__ rec_count,
-                                                    int *__restrict__ rec_start, int *__restrict__ rec_cursor)
-{
-    __shared__ int wave_tot[16];
-    __shared__ int carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < nrec; base += 1024) {
-        const int r = base + tid;
-        const int v = (r < nrec) ? rec_count[r] : 0;
-        int incl = v;
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) wave_tot[wv] = incl;
-        __syncthreads();
-        int woff = 0;
-        for (int k = 0; k < wv; k++) woff += wave_tot[k];
-        const int excl = carry_s + woff + incl - v;
-        if (r < nrec) { rec_start[r] = excl; rec_cursor[r] = excl; }
-        __syncthreads();
-        if (tid == 1023) carry_s = excl + v;
-        __syncthreads();
-    }
-    if (tid == 0) rec_start[nrec] = carry_s;
-}
-
-__global__ void k_ops_scatter(const QueueOp *__restrict__ ops, const FrameScalars *fs, int ops_cap,
-                              int *rec_cursor, QueueOp *__restrict__ ops_sorted)
-{
-    const int n = min(fs->n_ops, ops_cap);
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int stride = gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        const QueueOp o = ops[i];
-        ops_sorted[atomicAdd(&rec_cursor[o.rec], 1)] = o;
-    }
-}
-
-// One workgroup per free-slot queue: order this step's operations on it by the
-// reference's serial key (bitonic sort in LDS), then one lane replays them on the
-// circular FIFO exactly as q_insert / q_remove do (app_common.cu:305-376).
-__global__ __launch_bounds__(256) void k_replay(const int *__restrict__ rec_start,
-                                                 const QueueOp *__restrict__ ops_sorted,
+// One workgroup per free-slot queue.  The step's operations arrive sorted by key
+// (record-major), so the queue's run is found by binary search; one lane then replays
+// it on the circular FIFO exactly as q_insert / q_remove do (app_common.cu:305-376).
+// The queue's slice of the queue array and the operations are staged through LDS so
+// the serial walk never waits on global memory.
+__global__ __launch_bounds__(256) void k_replay(DevParams P, int n_ops,
+                                                 const uint64_t *__restrict__ keys,
+                                                 const int *__restrict__ args,
                                                  QueueInfo *qinfo, int *queue, MoveRec *moves,
-                                                 FrameScalars *fs, DevCounters *ctr)
+                                                 DevCounters *ctr)
 {
-    extern __shared__ unsigned char lds_raw[];
-    uint64_t *keys = (uint64_t *)lds_raw;                  // REPLAY_MAX
-    int *args = (int *)(keys + REPLAY_MAX);                // REPLAY_MAX
+    __shared__ int window[QUEUE_WINDOW];
+    __shared__ int op_arg[REPLAY_CHUNK];
+    __shared__ unsigned char op_sub[REPLAY_CHUNK];
     const int rec = blockIdx.x, tid = threadIdx.x;
-    const int start = rec_start[rec];
-    int n = rec_start[rec + 1] - start;
-    if (n == 0) return;
-    if (n > REPLAY_MAX) {
-        if (tid == 0) atomicOr(&fs->error, ERR_BUCKET_TOO_BIG);
-        n = REPLAY_MAX;
-    }
-    int np = 1;
-    while (np < n) np <<= 1;
-    for (int e = tid; e < np; e += 256) {
-        if (e < n) { keys[e] = ops_sorted[start + e].key; args[e] = ops_sorted[start + e].arg; }
-        else { keys[e] = ~0ull; args[e] = -1; }
-    }
-    __syncthreads();
-    for (int k = 2; k <= np; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int e = tid; e < np; e += 256) {
-                const int partner = e ^ j;
-                if (partner > e) {
-                    const bool up = ((e & k) == 0);
-                    const uint64_t a = keys[e], b = keys[partner];
-                    if ((a > b) == up) {
-                        keys[e] = b; keys[partner] = a;
-                        const int t = args[e]; args[e] = args[partner]; args[partner] = t;
+    // [lo, hi) = operations whose key carries this record
+    const uint64_t klo = (uint64_t)(uint32_t)rec << P.key_rec_shift;
+    const uint64_t khi = (uint64_t)(uint32_t)(rec + 1) << P.key_rec_shift;
+    int lo = 0, hi = n_ops;
+    { int a = 0, b = n_ops; while (a < b) { const int m = (a + b) >> 1; if (keys[m] < klo) a = m + 1; else b = m; } lo = a; }
+    { int a = lo, b = n_ops; while (a < b) { const int m = (a + b) >> 1; if (keys[m] < khi) a = m + 1; else b = m; } hi = a; }
+    if (hi == lo) return;
+
+    QueueInfo q = qinfo[rec];
+    const bool in_lds = q.seg_size <= QUEUE_WINDOW;
+    if (in_lds) for (int e = tid; e < q.seg_size; e += 256) window[e] = queue[q.rloc + e];
+    unsigned long long lost = 0, reloc = 0, births = 0, births_failed = 0;
+
+    for (int c0 = lo; c0 < hi; c0 += REPLAY_CHUNK) {
+        const int n = min(REPLAY_CHUNK, hi - c0);
+        __syncthreads();
+        for (int e = tid; e < n; e += 256) {
+            op_arg[e] = args[c0 + e];
+            op_sub[e] = (unsigned char)(keys[c0 + e] & 3ull);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int e = 0; e < n; e++) {
+                const int sub = op_sub[e], arg = op_arg[e];
+                if (sub == 2) {                                // q_insert(arg)
+                    if (q.count == q.seg_size) continue;
+                    if (q.count == 0) { q.front = q.rloc; q.rear = q.rloc; }
+                    else if (q.rear == q.rloc + q.seg_size - 1) q.rear = q.rloc;
+                    else q.rear++;
+                    q.count++;
+                    if (in_lds) window[q.rear - q.rloc] = arg; else queue[q.rear] = arg;
+                } else {                                       // q_remove -> moves[arg].dst
+                    int item = -1;
+                    if (q.count > 0) {
+                        const int pos = q.front;
+                        if (q.count == 1) { q.front = -1; q.rear = -1; }
+                        else if (q.front == q.rloc + q.seg_size - 1) q.front = q.rloc;
+                        else q.front++;
+                        q.count--;
+                        if (in_lds) { item = window[pos - q.rloc]; window[pos - q.rloc] = -1; }
+                        else { item = queue[pos]; queue[pos] = -1; }
                     }
+                    moves[arg].dst = item;
+                    if (sub == 1) { if (item >= 0) reloc++; else lost++; }
+                    else { if (item >= 0) births++; else births_failed++; }
                 }
             }
-            __syncthreads();
         }
     }
-    if (tid != 0) return;
-    QueueInfo q = qinfo[rec];
-    unsigned long long lost = 0, reloc = 0, births = 0, births_failed = 0;
-    for (int e = 0; e < n; e++) {
-        const int sub = (int)(keys[e] & 3ull);
-        if (sub == 2) {                                    // q_insert(args[e])
-            if (q.count == q.seg_size) continue;
-            if (q.count == 0) { q.front = q.rloc; q.rear = q.rloc; }
-            else if (q.rear == q.rloc + q.seg_size - 1) q.rear = q.rloc;
-            else q.rear++;
-            q.count++;
-            queue[q.rear] = args[e];
-        } else {                                           // q_remove -> moves[args[e]].dst
-            int item = -1;
-            if (q.count > 0) {
-                const int pos = q.front;
-                if (q.count == 1) { q.front = -1; q.rear = -1; }
-                else if (q.front == q.rloc + q.seg_size - 1) q.front = q.rloc;
-                else q.front++;
-                q.count--;
-                item = queue[pos];
-                queue[pos] = -1;
-            }
-            moves[args[e]].dst = item;
-            if (sub == 1) { if (item >= 0) reloc++; else lost++; }
-            else { if (item >= 0) births++; else births_failed++; }
-        }
+    __syncthreads();
+    if (in_lds) for (int e = tid; e < q.seg_size; e += 256) queue[q.rloc + e] = window[e];
+    if (tid == 0) {
+        qinfo[rec] = q;
+        if (reloc) atomicAdd(&ctr->relocations, reloc);
+        if (lost) atomicAdd(&ctr->relocations_lost, lost);
+        if (births) atomicAdd(&ctr->births, births);
+        if (births_failed) atomicAdd(&ctr->births_failed, births_failed);
     }
-    qinfo[rec] = q;
-    if (reloc) atomicAdd(&ctr->relocations, reloc);
-    if (lost) atomicAdd(&ctr->relocations_lost, lost);
-    if (births) atomicAdd(&ctr->births, births);
-    if (births_failed) atomicAdd(&ctr->births_failed, births_failed);
 }
 
 // Relocation phase 1a: read every moving particle (copy_particle, ps.cpp:1363) and
 // every parent of a child to be born.  Read-only on the particle arrays, so a
 // parent that also relocates this step is seen intact by both of its records.
-__global__ void k_moves_stage(MoveRec *moves, const FrameScalars *fs, int moves_cap,
+__global__ void k_moves_stage(MoveRec *moves, int n,
                               const float4 *pos4, const float4 *vel4, const float4 *acc4,
                               const uint8_t *pflags, float4 *stage)
 {
-    const int n = min(fs->n_moves, moves_cap);
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n) return;
     const MoveRec r = moves[m];
@@ -674,10 +728,9 @@ __global__ void k_moves_stage(MoveRec *moves, const FrameScalars *fs, int moves_
 }
 
 // Relocation phase 1b: reset_particle on the vacated slots (ps.cpp:1367).
-__global__ void k_moves_reset(const MoveRec *__restrict__ moves, const FrameScalars *fs, int moves_cap,
+__global__ void k_moves_reset(const MoveRec *__restrict__ moves, int n,
                               float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr, uint8_t *pflags)
 {
-    const int n = min(fs->n_moves, moves_cap);
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n) return;
     const MoveRec r = moves[m];
@@ -689,11 +742,10 @@ __global__ void k_moves_reset(const MoveRec *__restrict__ moves, const FrameScal
 }
 
 // Relocation phase 2: drop each particle into the slot the queue replay assigned.
-__global__ void k_moves_commit(DevParams P, int step, const MoveRec *__restrict__ moves, const FrameScalars *fs,
-                               int moves_cap, float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr,
+__global__ void k_moves_commit(DevParams P, int step, const MoveRec *__restrict__ moves, int n,
+                               float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr,
                                uint8_t *pflags, const float4 *__restrict__ stage)
 {
-    const int n = min(fs->n_moves, moves_cap);
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n) return;
     const MoveRec r = moves[m];
@@ -718,6 +770,43 @@ __global__ void k_moves_commit(DevParams P, int step, const MoveRec *__restrict_
         cell_arr[r.dst] = r.new_cell;
         pflags[r.dst] = 0;
     }
+}
+
+// ------------------------------------------------------------------ self test
+// Compare the lean sqrt / reciprocal with the compiler's correctly rounded forms on
+// every float whose bit pattern lies in [lo_bits, hi_bits].  out[0..4] = mismatch
+// counts of sqrt, rcp<1>, rcp<2>, markstein rcp, selected rcp; out[5..] = first few
+// offending bit patterns of the selected pair.
+__global__ void k_selftest_math(uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out)
+{
+    const uint64_t span = (uint64_t)hi_bits - lo_bits + 1;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long bad[5] = {0, 0, 0, 0, 0};
+    for (; i < span; i += stride) {
+        const float a = __uint_as_float(lo_bits + (uint32_t)i);
+        const float s_ref = sqrtf(a), r_ref = 1.0f / a;
+        if (__float_as_uint(sqrt_rn_lean(a)) != __float_as_uint(s_ref)) {
+            bad[0]++;
+            const unsigned long long k = atomicAdd(&out[5], 1ull);
+            if (k < 8) out[8 + k] = __float_as_uint(a);
+        }
+        if (__float_as_uint(rcp_rn_lean<1>(a)) != __float_as_uint(r_ref)) bad[1]++;
+        if (__float_as_uint(rcp_rn_lean<2>(a)) != __float_as_uint(r_ref)) bad[2]++;
+        if (__float_as_uint(rcp_rn_markstein(a)) != __float_as_uint(r_ref)) bad[3]++;
+        if (__float_as_uint(rcp_rn_selected(a)) != __float_as_uint(r_ref)) {
+            bad[4]++;
+            const unsigned long long k = atomicAdd(&out[6], 1ull);
+            if (k < 8) out[16 + k] = __float_as_uint(a);
+        }
+    }
+    for (int k = 0; k < 5; k++) if (bad[k]) atomicAdd(&out[k], bad[k]);
+}
+
+hipError_t launch_selftest_math(hipStream_t st, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out24)
+{
+    k_selftest_math<<<4096, 256, 0, st>>>(lo_bits, hi_bits, out24);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ launch wrappers
@@ -786,7 +875,7 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[3], st);
     k_sort_cells<<<P.num_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
-                                               d.pflags, d.snap4, d.snap_age, d.tdata, d.ops, d.ops_cap, d.fs, d.ctr);
+                                               d.pflags, d.snap4, d.snap_age, d.tdata, d.op_keys, d.op_args, d.ops_cap, d.fs, d.ctr);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[4], st);
     return hipSuccess;
@@ -796,9 +885,11 @@ hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d
 {
     const int tasks = P.num_cells * P.slices;
     if (P.flags & PSAMD_FLAG_FAST_MATH)
-        k_pairs<true><<<tasks, 64, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.force4, lo, hi);
+        k_pairs<2><<<tasks, 64, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.force4, lo, hi);
+    else if (P.lean_math)
+        k_pairs<1><<<tasks, 64, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.force4, lo, hi);
     else
-        k_pairs<false><<<tasks, 64, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.force4, lo, hi);
+        k_pairs<0><<<tasks, 64, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.force4, lo, hi);
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -808,32 +899,28 @@ hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, 
 {
     if (live_bound <= 0) return hipSuccess;
     k_apply<<<(live_bound + 255) / 256, 256, 0, st>>>(P, S, step, d.cell_start, d.sorted_id, d.force4, d.pos4,
-                                                      d.vel4, d.acc4, d.cell, d.pflags, d.celltab, d.ops, d.ops_cap,
+                                                      d.vel4, d.acc4, d.cell, d.pflags, d.celltab, d.op_keys, d.op_args, d.ops_cap,
                                                       d.moves, d.moves_cap, d.fs, d.ctr);
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }
 
 hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
-                            int moves_bound)
+                            int n_ops, int n_moves)
 {
-    k_ops_hist<<<256, 256, 0, st>>>(d.ops, d.fs, d.ops_cap, d.rec_count);
-    PS_LAUNCH_CHECK();
-    k_ops_scan<<<1, 1024, 0, st>>>(nrec, d.rec_count, d.rec_start, d.rec_cursor);
-    PS_LAUNCH_CHECK();
-    k_ops_scatter<<<256, 256, 0, st>>>(d.ops, d.fs, d.ops_cap, d.rec_cursor, d.ops_sorted);
-    PS_LAUNCH_CHECK();
-    const size_t lds = (size_t)REPLAY_MAX * (sizeof(uint64_t) + sizeof(int));
-    k_replay<<<nrec, 256, lds, st>>>(d.rec_start, d.ops_sorted, d.qinfo, d.queue, d.moves, d.fs, d.ctr);
-    PS_LAUNCH_CHECK();
-    if (moves_bound > 0) {
-        const int nb = (moves_bound + 255) / 256;
-        k_moves_stage<<<nb, 256, 0, st>>>(d.moves, d.fs, d.moves_cap, d.pos4, d.vel4, d.acc4, d.pflags, d.stage);
+    if (n_ops > 0) {
+        hipError_t e = sort_ops(st, d, n_ops, P.key_bits);
+        if (e != hipSuccess) return e;
+        k_replay<<<nrec, 256, 0, st>>>(P, n_ops, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue, d.moves, d.ctr);
         PS_LAUNCH_CHECK();
-        k_moves_reset<<<nb, 256, 0, st>>>(d.moves, d.fs, d.moves_cap, d.pos4, d.vel4, d.acc4, d.cell, d.pflags);
+    }
+    if (n_moves > 0) {
+        const int nb = (n_moves + 255) / 256;
+        k_moves_stage<<<nb, 256, 0, st>>>(d.moves, n_moves, d.pos4, d.vel4, d.acc4, d.pflags, d.stage);
         PS_LAUNCH_CHECK();
-        k_moves_commit<<<nb, 256, 0, st>>>(P, step, d.moves, d.fs, d.moves_cap, d.pos4, d.vel4, d.acc4, d.cell,
-                                           d.pflags, d.stage);
+        k_moves_reset<<<nb, 256, 0, st>>>(d.moves, n_moves, d.pos4, d.vel4, d.acc4, d.cell, d.pflags);
+        PS_LAUNCH_CHECK();
+        k_moves_commit<<<nb, 256, 0, st>>>(P, step, d.moves, n_moves, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
         PS_LAUNCH_CHECK();
     }
     return hipSuccess;

@@ -165,7 +165,9 @@ def main():
     for _ in range(args.warmup):
         one_step()
     sync()
-    # pairs per launch, measured on the state the timed region starts from
+    # pairs per launch, measured on the state the timed steps start from
+    if not args.evolve:
+        g.snapshot_restore()
     g.init_iframe(); g.build_grid()
     counts0 = g.download_cellgrid()[:, 0].copy()
     g.set_timing(True)
@@ -178,10 +180,12 @@ def main():
     elapsed = time.perf_counter() - t0
     tim, launches = g.timing()
     g.set_timing(False)
+    ctr = g.counters
+    if not args.evolve:
+        g.snapshot_restore()
     g.init_iframe(); g.build_grid()
     counts1 = g.download_cellgrid()[:, 0].copy()
     live = int(counts1.sum())
-    ctr = g.counters
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")

@@ -285,7 +285,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, hipHostMalloc((void **)&c->h_fs, sizeof(FrameScalars), hipHostMallocDefault));
     PS_HIP(c, dev_alloc(c, &d.moves, (size_t)d.moves_cap));
     PS_HIP(c, dev_alloc(c, &d.stage, 3 * (size_t)d.moves_cap));
-    PS_HIP(c, dev_alloc(c, &d.ctr, 1));
+    PS_HIP(c, dev_alloc(c, &d.ctr, (size_t)COUNTER_COPIES));
 
     // init_particles (ps.cpp:722-753): every slot reset, cell = -1
     PS_HIP(c, hipMemsetAsync(d.pos4, 0, C * sizeof(float4), c->stream));
@@ -294,7 +294,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, hipMemsetAsync(d.pflags, 0, C, c->stream));
     PS_HIP(c, hipMemsetAsync(d.force4, 0, C * sizeof(float4), c->stream));
     PS_HIP(c, hipMemsetAsync(d.fs, 0, sizeof(FrameScalars), c->stream));
-    PS_HIP(c, hipMemsetAsync(d.ctr, 0, sizeof(DevCounters), c->stream));
+    PS_HIP(c, hipMemsetAsync(d.ctr, 0, sizeof(DevCounters) * COUNTER_COPIES, c->stream));
     PS_HIP(c, hipMemsetAsync(frame, 0, frame_ints * sizeof(int), c->stream));
     PS_HIP(c, launch_fill_int(c->stream, d.cell, -1, C));
     PS_HIP(c, launch_init_tdata(c->stream, d, g.container));
@@ -682,8 +682,14 @@ int psamd_get_counters(psamd_ctx *c, psamd_counters *o)
 {
     if (!c || !o) return PSAMD_ERR_INVALID_ARG;
     PS_HIP(c, hipStreamSynchronize(c->stream));
+    DevCounters copies[COUNTER_COPIES];
+    PS_HIP(c, hipMemcpy(copies, c->d.ctr, sizeof copies, hipMemcpyDeviceToHost));
     DevCounters d{};
-    PS_HIP(c, hipMemcpy(&d, c->d.ctr, sizeof d, hipMemcpyDeviceToHost));
+    for (const DevCounters &k : copies) {
+        d.deaths_age += k.deaths_age; d.deaths_collision += k.deaths_collision; d.survives += k.survives;
+        d.integrated += k.integrated; d.relocations += k.relocations; d.relocations_lost += k.relocations_lost;
+        d.births += k.births; d.births_failed += k.births_failed; d.cell_overflow_kills += k.cell_overflow_kills;
+    }
     o->deaths_age = (int64_t)d.deaths_age; o->deaths_collision = (int64_t)d.deaths_collision;
     o->survives = (int64_t)d.survives; o->integrated = (int64_t)d.integrated;
     o->relocations = (int64_t)d.relocations; o->relocations_lost = (int64_t)d.relocations_lost;
@@ -780,8 +786,8 @@ int psamd_selftest_math(psamd_ctx *c, uint32_t lo_bits, uint32_t hi_bits, uint64
 {
     if (!c || !out24 || hi_bits < lo_bits) return PSAMD_ERR_INVALID_ARG;
     unsigned long long *d = nullptr;
-    PS_HIP(c, hipMalloc((void **)&d, 24 * sizeof(unsigned long long)));
-    hipError_t e = hipMemsetAsync(d, 0, 24 * sizeof(unsigned long long), c->stream);
+    PS_HIP(c, hipMalloc((void **)&d, 26 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 26 * sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) e = launch_selftest_math(c->stream, lo_bits, hi_bits, d);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(out24, d, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost);

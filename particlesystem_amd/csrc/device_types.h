@@ -42,15 +42,19 @@ struct FrameScalars {
     int32_t gridmax[2];     // hostGridMax: biggest chunk, biggest cell (ps.cpp:76)
     int32_t live;           // particles with a valid cell at build_grid
     int32_t error;          // sticky bit mask, see ERR_* below
-    int32_t n_ops;          // queue operations emitted by apply
-    int32_t n_moves;        // relocation / birth records emitted by apply
+    int32_t n_ops;          // queue operations emitted by apply   \ allocated together as one
+    int32_t n_moves;        // relocation / birth records emitted  / 64-bit word (ops low)
     int32_t pad[2];
 };
 
-struct DevCounters {        // cumulative, mirrors psamd_counters
+// Cumulative event counters, mirrors psamd_counters.  Kept in COUNTER_COPIES copies on
+// separate 128-byte lines (workgroup b adds to copy b % COUNTER_COPIES; the host sums
+// them): same-line atomics are served one at a time by the memory side.
+struct alignas(128) DevCounters {
     unsigned long long deaths_age, deaths_collision, survives, integrated;
     unsigned long long relocations, relocations_lost, births, births_failed, cell_overflow_kills;
 };
+constexpr int COUNTER_COPIES = 64;
 
 enum : int32_t {
     ERR_CELL_TOO_BIG = 1,   // a cell holds more ids than the sort kernel can rank

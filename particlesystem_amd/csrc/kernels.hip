@@ -130,6 +130,61 @@ __global__ void k_hist(const int *__restrict__ cell, int *__restrict__ cell_coun
     }
 }
 
+// Same two kernels with a workgroup-private histogram in LDS (grids of <= LDS_CELLS
+// cells): a workgroup owns SLOTS_PER_WG consecutive slots, which by the container's
+// construction belong to one or two segments, i.e. a handful of cells, so almost all
+// atomics stay in LDS and only the touched bins go to memory.
+constexpr int LDS_CELLS = 8192;
+constexpr int SLOTS_PER_WG = 4096;
+
+__global__ __launch_bounds__(1024) void k_hist_lds(const int *__restrict__ cell, int *__restrict__ cell_count,
+                                                    int container, int num_cells)
+{
+    __shared__ int h[LDS_CELLS];
+    const int tid = threadIdx.x, base = blockIdx.x * SLOTS_PER_WG;
+    for (int c = tid; c < num_cells; c += 1024) h[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < SLOTS_PER_WG; i += 1024) {
+        const int slot = base + i;
+        if (slot < container) {
+            const int c = cell[slot];
+            if (c >= 0 && c < num_cells) atomicAdd(&h[c], 1);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < num_cells; c += 1024) {
+        const int v = h[c];
+        if (v) atomicAdd(&cell_count[c], v);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_scatter_lds(const int *__restrict__ cell, int *__restrict__ cursor,
+                                                       int *__restrict__ sorted_id, int container, int num_cells)
+{
+    __shared__ int h[LDS_CELLS];
+    const int tid = threadIdx.x, base = blockIdx.x * SLOTS_PER_WG;
+    for (int c = tid; c < num_cells; c += 1024) h[c] = 0;
+    __syncthreads();
+    int mine[SLOTS_PER_WG / 1024];
+#pragma unroll
+    for (int i = 0; i < SLOTS_PER_WG / 1024; i++) {
+        const int slot = base + i * 1024 + tid;
+        int c = -1;
+        if (slot < container) { c = cell[slot]; if (c < 0 || c >= num_cells) c = -1; }
+        mine[i] = c;
+        if (c >= 0) atomicAdd(&h[c], 1);
+    }
+    __syncthreads();
+    for (int c = tid; c < num_cells; c += 1024) {      // reserve this workgroup's run in each touched cell
+        const int v = h[c];
+        if (v) h[c] = atomicAdd(&cursor[c], v);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SLOTS_PER_WG / 1024; i++)
+        if (mine[i] >= 0) sorted_id[atomicAdd(&h[mine[i]], 1)] = base + i * 1024 + tid;
+}
+
 // One workgroup: exclusive prefix of the cell counts, the scatter cursors, the chunk
 // totals and hostGridMax (ps.cpp:1504-1516: maxima are of stored entries, so capped).
 __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restrict__ cell_count,
@@ -137,11 +192,15 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
                                                 int *__restrict__ chunk_count,
                                                 const CellInfo *__restrict__ celltab, FrameScalars *fs)
 {
+    constexpr int LDS_CHUNKS = 4096;
     __shared__ int wave_tot[16];
     __shared__ int carry_s;
     __shared__ int maxcell_s;
+    __shared__ int chunk_s[LDS_CHUNKS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool chunks_in_lds = P.num_chunks <= LDS_CHUNKS;
     if (tid == 0) { carry_s = 0; maxcell_s = 0; }
+    if (chunks_in_lds) for (int ch = tid; ch < P.num_chunks; ch += 1024) chunk_s[ch] = 0;
     __syncthreads();
     int mymax = 0;
     for (int base = 0; base < P.num_cells; base += 1024) {
@@ -162,7 +221,10 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
         if (c < P.num_cells) {
             cell_start[c] = excl;
             cursor[c] = excl;
-            if (v > 0) atomicAdd(&chunk_count[celltab[c].chunk], v);
+            if (v > 0) {
+                if (chunks_in_lds) atomicAdd(&chunk_s[celltab[c].chunk], v);
+                else atomicAdd(&chunk_count[celltab[c].chunk], v);
+            }
         }
         __syncthreads();
         if (tid == 1023) carry_s = excl + v;
@@ -176,10 +238,18 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
         fs->gridmax[1] = maxcell_s;
     }
     // chunk totals are complete once every thread passed the loop's last barrier
-    __threadfence();
-    __syncthreads();
     int cm = 0;
-    for (int ch = tid; ch < P.num_chunks; ch += 1024) cm = max(cm, min(chunk_count[ch], P.max_per_chunk));
+    if (chunks_in_lds) {
+        for (int ch = tid; ch < P.num_chunks; ch += 1024) {
+            const int v = chunk_s[ch];
+            chunk_count[ch] = v;
+            cm = max(cm, min(v, P.max_per_chunk));
+        }
+    } else {
+        __threadfence();
+        __syncthreads();
+        for (int ch = tid; ch < P.num_chunks; ch += 1024) cm = max(cm, min(chunk_count[ch], P.max_per_chunk));
+    }
     if (cm > 0) atomicMax(&fs->gridmax[0], cm);
 }
 
@@ -248,7 +318,7 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
             pos4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
             vel4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
             acc4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
-            atomicAdd(&ctr->cell_overflow_kills, 1ull);
+            atomicAdd(&(ctr + (blockIdx.x % COUNTER_COPIES))->cell_overflow_kills, 1ull);
             // freed with the already-reset segment (-1,-1): queue record 0 (ps.cpp:1523-1526)
             const int k = atomicAdd(&fs->n_ops, 1);
             if (k < ops_cap) { op_keys[k] = ((uint64_t)(uint32_t)id << 2) | 2ull; op_args[k] = id; }
@@ -299,6 +369,33 @@ __device__ __forceinline__ float rcp_rn_markstein(float d)
     return __builtin_fmaf(r1, y1, q1);
 }
 
+// RN(1 / RN(sqrt(a))) -- the reference's two roundings -- with the reciprocal's Newton
+// iteration started from the rsq estimate the square root already refined (2h ~ 1/g)
+// instead of a second transcendental.
+template <int NR>
+__device__ __forceinline__ float inv_sqrt_rn2_via_h(float a)
+{
+    const float r = __builtin_amdgcn_rsqf(a);
+    float g = a * r;
+    float h = 0.5f * r;
+    const float e = __builtin_fmaf(-h, g, 0.5f);
+    h = __builtin_fmaf(h, e, h);
+    g = __builtin_fmaf(g, e, g);
+    const float d = __builtin_fmaf(-g, g, a);
+    const float q = __builtin_fmaf(d, h, g);          // RN(sqrt(a))
+    float x = h + h;
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        const float e2 = __builtin_fmaf(-q, x, 1.0f);
+        x = __builtin_fmaf(e2, x, x);
+    }
+    return x;
+}
+
+#ifndef PSAMD_INV_VARIANT
+#define PSAMD_INV_VARIANT 0
+#endif
+
 #ifndef PSAMD_RCP_VARIANT
 #define PSAMD_RCP_VARIANT 1
 #endif
@@ -313,6 +410,17 @@ __device__ __forceinline__ float rcp_rn_selected(float q)
 #endif
 }
 
+__device__ __forceinline__ float inv_sqrt_selected(float six)
+{
+#if PSAMD_INV_VARIANT == 1
+    return inv_sqrt_rn2_via_h<1>(six);
+#elif PSAMD_INV_VARIANT == 2
+    return inv_sqrt_rn2_via_h<2>(six);
+#else
+    return rcp_rn_selected(sqrt_rn_lean(six));
+#endif
+}
+
 __device__ __forceinline__ float pair_exact_lean(float xi, float yi, float zi, const float4 q, double eps2,
                                                  float &ax, float &ay, float &az)
 {
@@ -320,7 +428,7 @@ __device__ __forceinline__ float pair_exact_lean(float xi, float yi, float zi, c
     const float d2 = rx * rx + ry * ry + rz * rz;
     const float dsq = (float)((double)d2 + eps2);
     const float six = dsq * dsq * dsq;
-    const float inv = rcp_rn_selected(sqrt_rn_lean(six));
+    const float inv = inv_sqrt_selected(six);
     const float s = q.w * inv;
     ax += rx * s; ay += ry * s; az += rz * s;
     return d2;
@@ -476,30 +584,15 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
     return x ^ (x >> 31);
 }
 
-// Wave-aggregated bump allocation: every lane asks for `need` (0..3) consecutive
-// entries of a list whose fill count lives at *counter; one atomic per wave.
-__device__ __forceinline__ int wave_alloc(int need, int *counter)
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ int wave_incl_scan(int v)
 {
     const int lane = (int)__lane_id();
-    int incl = need;
     for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
+        const int o = __shfl_up(v, d);
+        if (lane >= d) v += o;
     }
-    const int total = __shfl(incl, 63);
-    int base = 0;
-    if (total > 0) {
-        if (lane == 63) base = atomicAdd(counter, total);
-        base = __shfl(base, 63);
-    }
-    return base + incl - need;
-}
-
-// one atomic per wave for an event counter
-__device__ __forceinline__ void wave_count(bool pred, unsigned long long *counter)
-{
-    const unsigned long long m = __ballot(pred);
-    if (m != 0ull && (int)__lane_id() == (int)__ffsll((long long)m) - 1) atomicAdd(counter, (unsigned long long)__popcll(m));
+    return v;
 }
 
 // Death, survival, integration, wrap and re-hash for every particle of the frame
@@ -517,11 +610,14 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P, SegLayout S, int ste
                                                 MoveRec *moves, int moves_cap,
                                                 FrameScalars *fs, DevCounters *ctr)
 {
+    __shared__ int s_ops, s_moves, s_base_ops, s_base_moves;
+    __shared__ unsigned int s_cnt[4];
     const int total = cell_start[P.num_cells];
     const int gi = blockIdx.x * blockDim.x + threadIdx.x;
-    // whole waves past the end leave; inside a live wave every lane reaches the
-    // wave-level allocations below
-    if ((gi & ~63) >= total) return;
+    // whole workgroups past the end leave; inside a live one every thread reaches the
+    // workgroup-level allocation below
+    if ((int)(blockIdx.x * blockDim.x) >= total) return;
+    if (threadIdx.x == 0) { s_ops = 0; s_moves = 0; s_cnt[0] = s_cnt[1] = s_cnt[2] = s_cnt[3] = 0; }
     const int id = (gi < total) ? sorted_id[gi] : -1;    // -1: killed by the cell-overflow rule
     const bool active = id >= 0;
     const bool lifecycle = !(P.flags & PSAMD_FLAG_NO_LIFECYCLE);
@@ -608,18 +704,44 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P, SegLayout S, int ste
         relocate = lifecycle && (new_ci.seg_type != old_ci.seg_type || new_ci.seg_tid != old_ci.seg_tid);
     }
 
-    wave_count(moved, &ctr->integrated);
-    wave_count(survived, &ctr->survives);
-    wave_count(killed && died_of_age, &ctr->deaths_age);
-    wave_count(killed && !died_of_age, &ctr->deaths_collision);
-
-    // queue operations: kill -> insert; birth -> remove; relocation -> remove + insert
+    // Event counters and list space: wave -> workgroup (LDS) -> one global atomic per
+    // workgroup.  Queue operations: kill -> insert; birth -> remove; relocation ->
+    // remove + insert.  Moves: one record per birth / relocation.
+    const int lane = (int)__lane_id();
     const int n_op = (killed ? 1 : 0) + (born ? 1 : 0) + (relocate ? 2 : 0);
     const int n_mv = (born ? 1 : 0) + (relocate ? 1 : 0);
-    if (!__any(n_op != 0)) return;
-    int k = wave_alloc(n_op, &fs->n_ops);
-    int m = wave_alloc(n_mv, &fs->n_moves);
+    const int op_incl = wave_incl_scan(n_op), mv_incl = wave_incl_scan(n_mv);
+    const unsigned long long b0 = __ballot(moved), b1 = __ballot(survived),
+                             b2 = __ballot(killed && died_of_age), b3 = __ballot(killed && !died_of_age);
+    __syncthreads();                                     // s_* zeroed
+    int wave_ops = 0, wave_moves = 0;
+    if (lane == 63) {
+        if (op_incl) wave_ops = atomicAdd(&s_ops, op_incl);
+        if (mv_incl) wave_moves = atomicAdd(&s_moves, mv_incl);
+        if (b0) atomicAdd(&s_cnt[0], (unsigned)__popcll(b0));
+        if (b1) atomicAdd(&s_cnt[1], (unsigned)__popcll(b1));
+        if (b2) atomicAdd(&s_cnt[2], (unsigned)__popcll(b2));
+        if (b3) atomicAdd(&s_cnt[3], (unsigned)__popcll(b3));
+    }
+    wave_ops = __shfl(wave_ops, 63); wave_moves = __shfl(wave_moves, 63);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        DevCounters *mine = ctr + (blockIdx.x % COUNTER_COPIES);
+        if (s_cnt[0]) atomicAdd(&mine->integrated, (unsigned long long)s_cnt[0]);
+        if (s_cnt[1]) atomicAdd(&mine->survives, (unsigned long long)s_cnt[1]);
+        if (s_cnt[2]) atomicAdd(&mine->deaths_age, (unsigned long long)s_cnt[2]);
+        if (s_cnt[3]) atomicAdd(&mine->deaths_collision, (unsigned long long)s_cnt[3]);
+        if (s_ops | s_moves) {
+            // n_ops (low word) and n_moves (high word) grow with a single 64-bit atomic
+            const unsigned long long both = ((unsigned long long)(unsigned)s_moves << 32) | (unsigned)s_ops;
+            const unsigned long long old = atomicAdd((unsigned long long *)&fs->n_ops, both);
+            s_base_ops = (int)(old & 0xffffffffull); s_base_moves = (int)(old >> 32);
+        }
+    }
+    __syncthreads();
     if (n_op == 0) return;
+    int k = s_base_ops + wave_ops + op_incl - n_op;
+    int m = s_base_moves + wave_moves + mv_incl - n_mv;
     if (k + n_op > ops_cap || m + n_mv > moves_cap) { atomicOr(&fs->error, ERR_OPS_OVERFLOW); return; }
     const uint64_t own_rec = (uint64_t)(uint32_t)segment_record_of_slot(S, id) << P.key_rec_shift;
     const uint64_t dst_rec = (uint64_t)(uint32_t)new_rec << P.key_rec_shift;
@@ -705,10 +827,11 @@ __global__ __launch_bounds__(256) void k_replay(DevParams P, int n_ops,
     if (in_lds) for (int e = tid; e < q.seg_size; e += 256) queue[q.rloc + e] = window[e];
     if (tid == 0) {
         qinfo[rec] = q;
-        if (reloc) atomicAdd(&ctr->relocations, reloc);
-        if (lost) atomicAdd(&ctr->relocations_lost, lost);
-        if (births) atomicAdd(&ctr->births, births);
-        if (births_failed) atomicAdd(&ctr->births_failed, births_failed);
+        DevCounters *mine = ctr + (blockIdx.x % COUNTER_COPIES);
+        if (reloc) atomicAdd(&mine->relocations, reloc);
+        if (lost) atomicAdd(&mine->relocations_lost, lost);
+        if (births) atomicAdd(&mine->births, births);
+        if (births_failed) atomicAdd(&mine->births_failed, births_failed);
     }
 }
 
@@ -776,31 +899,35 @@ __global__ void k_moves_commit(DevParams P, int step, const MoveRec *__restrict_
 // Compare the lean sqrt / reciprocal with the compiler's correctly rounded forms on
 // every float whose bit pattern lies in [lo_bits, hi_bits].  out[0..4] = mismatch
 // counts of sqrt, rcp<1>, rcp<2>, markstein rcp, selected rcp; out[5..] = first few
-// offending bit patterns of the selected pair.
+// offending bit patterns of the selected pair.  (out has 26 words: 24 + 2 cursors)
 __global__ void k_selftest_math(uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out)
 {
     const uint64_t span = (uint64_t)hi_bits - lo_bits + 1;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    unsigned long long bad[5] = {0, 0, 0, 0, 0};
+    unsigned long long bad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (; i < span; i += stride) {
         const float a = __uint_as_float(lo_bits + (uint32_t)i);
         const float s_ref = sqrtf(a), r_ref = 1.0f / a;
         if (__float_as_uint(sqrt_rn_lean(a)) != __float_as_uint(s_ref)) {
             bad[0]++;
-            const unsigned long long k = atomicAdd(&out[5], 1ull);
+            const unsigned long long k = atomicAdd(&out[25], 1ull);
             if (k < 8) out[8 + k] = __float_as_uint(a);
         }
         if (__float_as_uint(rcp_rn_lean<1>(a)) != __float_as_uint(r_ref)) bad[1]++;
         if (__float_as_uint(rcp_rn_lean<2>(a)) != __float_as_uint(r_ref)) bad[2]++;
         if (__float_as_uint(rcp_rn_markstein(a)) != __float_as_uint(r_ref)) bad[3]++;
-        if (__float_as_uint(rcp_rn_selected(a)) != __float_as_uint(r_ref)) {
-            bad[4]++;
-            const unsigned long long k = atomicAdd(&out[6], 1ull);
+        if (__float_as_uint(rcp_rn_selected(a)) != __float_as_uint(r_ref)) bad[4]++;
+        const float c_ref = 1.0f / s_ref;
+        if (__float_as_uint(inv_sqrt_rn2_via_h<1>(a)) != __float_as_uint(c_ref)) bad[5]++;
+        if (__float_as_uint(inv_sqrt_rn2_via_h<2>(a)) != __float_as_uint(c_ref)) bad[6]++;
+        if (__float_as_uint(inv_sqrt_selected(a)) != __float_as_uint(c_ref)) {
+            bad[7]++;
+            const unsigned long long k = atomicAdd(&out[24], 1ull);
             if (k < 8) out[16 + k] = __float_as_uint(a);
         }
     }
-    for (int k = 0; k < 5; k++) if (bad[k]) atomicAdd(&out[k], bad[k]);
+    for (int k = 0; k < 8; k++) if (bad[k]) atomicAdd(&out[k], bad[k]);
 }
 
 hipError_t launch_selftest_math(hipStream_t st, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out24)
@@ -864,14 +991,18 @@ hipError_t launch_init_tdata(hipStream_t st, const DeviceState &d, int n)
 hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev)
 {
     const int nb = blocks_for((size_t)P.container, 256, 2048);
+    const bool lds = P.num_cells <= LDS_CELLS;
+    const int nwg = (P.container + SLOTS_PER_WG - 1) / SLOTS_PER_WG;
     if (ev) (void)hipEventRecord(ev[0], st);
-    k_hist<<<nb, 256, 0, st>>>(d.cell, d.cell_count, P.container, P.num_cells);
+    if (lds) k_hist_lds<<<nwg, 1024, 0, st>>>(d.cell, d.cell_count, P.container, P.num_cells);
+    else k_hist<<<nb, 256, 0, st>>>(d.cell, d.cell_count, P.container, P.num_cells);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[1], st);
     k_scan<<<1, 1024, 0, st>>>(P, d.cell_count, d.cell_start, d.cursor, d.chunk_count, d.celltab, d.fs);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[2], st);
-    k_scatter<<<nb, 256, 0, st>>>(d.cell, d.cursor, d.sorted_id, P.container, P.num_cells);
+    if (lds) k_scatter_lds<<<nwg, 1024, 0, st>>>(d.cell, d.cursor, d.sorted_id, P.container, P.num_cells);
+    else k_scatter<<<nb, 256, 0, st>>>(d.cell, d.cursor, d.sorted_id, P.container, P.num_cells);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[3], st);
     k_sort_cells<<<P.num_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,

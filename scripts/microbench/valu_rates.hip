@@ -1,0 +1,105 @@
+// valu_rates.hip -- per-instruction issue cost on gfx950 for the ops the pair kernel
+// uses.  Each kernel runs ITER x UNROLL independent-chain instances of one op at full
+// occupancy; output = ns per wave-instruction per SIMD and cycles at the measured clock.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+constexpr int ITER = 4096;
+
+template <int OP>
+__global__ __launch_bounds__(256) void k(float *out, float seed, unsigned long long *clk)
+{
+    float a[8];
+    double d[8];
+    for (int i = 0; i < 8; i++) { a[i] = seed + threadIdx.x * 1e-3f + i; d[i] = a[i]; }
+    const float c1 = seed * 0.999f, c2 = seed * 1e-3f;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (OP == 0) a[i] = __builtin_fmaf(a[i], c1, c2);
+            if (OP == 1) a[i] = a[i] * c1;
+            if (OP == 2) a[i] = a[i] + c2;
+            if (OP == 3) a[i] = __builtin_amdgcn_rsqf(a[i]);
+            if (OP == 4) a[i] = __builtin_amdgcn_rcpf(a[i]);
+            if (OP == 5) d[i] = d[i] + (double)c2;
+            if (OP == 6) { d[i] = (double)a[i]; asm volatile("" : "+v"(d[i])); a[i] = a[i] + c2; }       // cvt_f64_f32 (+1 add)
+            if (OP == 7) { a[i] = (float)d[i]; asm volatile("" : "+v"(a[i])); d[i] = d[i] + (double)c2; } // cvt_f32_f64 (+1 add_f64)
+            if (OP == 8) a[i] = fminf(a[i], fminf(c1, a[(i + 1) & 7]));
+            if (OP == 9) a[i] = __builtin_sqrtf(a[i]);   // v_sqrt_f32 + fixups (correctly rounded)
+            if (OP == 10) d[i] = __builtin_fma(d[i], (double)c1, (double)c2);
+        }
+        if (OP == 11) {   // packed fp32 fma: 4 x v_pk_fma_f32 on 8 floats
+            typedef float v2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                v2 x = {a[i], a[i + 1]}, y = {c1, c1}, z = {c2, c2};
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(x) : "v"(x), "v"(y), "v"(z));
+                a[i] = x.x; a[i + 1] = x.y;
+            }
+        }
+        if (OP == 12) {   // packed fp32 mul
+            typedef float v2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                v2 x = {a[i], a[i + 1]}, y = {c1, c1};
+                asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y));
+                a[i] = x.x; a[i + 1] = x.y;
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0; double sd = 0;
+    for (int i = 0; i < 8; i++) { s += a[i]; sd += d[i]; }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s + (float)sd;
+    if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
+}
+
+template <int OP>
+int run(const char *name, int per_iter, float *out, unsigned long long *clk)
+{
+    const int blocks = 256 * 8, threads = 256;   // 8 waves per SIMD
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    k<OP><<<blocks, threads>>>(out, 1.0001f, clk);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    k<OP><<<blocks, threads>>>(out, 1.0001f, clk);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long c = 0;
+    CHECK(hipMemcpy(&c, clk, sizeof c, hipMemcpyDeviceToHost));
+    const double waves = (double)blocks * threads / 64, simds = 256.0 * 4;
+    const double insts_per_simd = waves * ITER * per_iter / simds;
+    const double ns_per_inst = ms * 1e6 / insts_per_simd;
+    // s_memtime ticks at 100 MHz on gfx9: clock = cycles... report ns only plus the wave's own view
+    printf("%-28s %8.3f ms  %7.3f ns/wave-inst/SIMD  (%.2f cyc @2.4GHz, %.2f @2.1GHz) memtime=%llu\n", name, ms, ns_per_inst,
+           ns_per_inst * 2.4, ns_per_inst * 2.1, c);
+    return 0;
+}
+
+int main()
+{
+    float *out; unsigned long long *clk;
+    CHECK(hipMalloc(&out, 256 * 8 * 256 * sizeof(float)));
+    CHECK(hipMalloc(&clk, 8));
+    run<0>("v_fma_f32", 8, out, clk);
+    run<1>("v_mul_f32", 8, out, clk);
+    run<2>("v_add_f32", 8, out, clk);
+    run<3>("v_rsq_f32", 8, out, clk);
+    run<4>("v_rcp_f32", 8, out, clk);
+    run<5>("v_add_f64", 8, out, clk);
+    run<6>("v_cvt_f64_f32 + v_add_f32", 16, out, clk);
+    run<7>("v_cvt_f32_f64 + v_add_f64", 16, out, clk);
+    run<8>("v_min3_f32", 8, out, clk);
+    run<9>("sqrtf correctly rounded", 8, out, clk);
+    run<10>("v_fma_f64", 8, out, clk);
+    run<11>("v_pk_fma_f32 (2 fma)", 4, out, clk);
+    run<12>("v_pk_mul_f32 (2 mul)", 4, out, clk);
+    return 0;
+}

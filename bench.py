@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--evolve", action="store_true", help="free-running steps instead of one pass per step over the same cloud")
+    ap.add_argument("--force-dist", action="store_true", help="take the collective code path even with one rank (rehearsal)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,12 +116,29 @@ def main():
     if not os.path.exists(ps.LIB_PATH):
         if rank == 0:
             ps.build()
+    from particlesystem_amd.sharded import step_sharded
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist.barrier()
+        if world == 1 and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", RANK="0", WORLD_SIZE="1")
+        # librccl prints a version banner on stdout when the first communicator comes up;
+        # the driver wants exactly one JSON line there, so park fd 1 on stderr meanwhile
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            warm = torch.zeros(world * 4, device="cuda")
+            dist.all_gather_into_tensor(warm, warm[rank * 4:(rank + 1) * 4])
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     cfg_over = dict()
     flags = ps.FLAG_FAST_MATH if args.fast_math else 0
@@ -132,7 +150,7 @@ def main():
     G = g.sizes.grid_dim
 
     force = None
-    if world > 1:
+    if use_dist:
         torch.cuda.set_device(local_rank)
         cap = g.sizes.container_size + world
         force = torch.zeros((cap, 4), dtype=torch.float32, device="cuda")
@@ -144,20 +162,14 @@ def main():
     def one_step():
         if not args.evolve:
             g.snapshot_restore()
-        if world == 1:
+        if not use_dist:
             g.step(1)
             return
-        g.init_iframe()
-        g.build_grid()
-        _, _, share = g.force_shard()
-        g.calc_forces_pairs()
-        full = force[: world * share]
-        dist.all_gather_into_tensor(full, full[rank * share:(rank + 1) * share])
-        g.calc_forces_apply()
+        step_sharded(g, force, dist, rank, world, always_gather=True)
 
     def sync():
         g.synchronize()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -187,7 +199,7 @@ def main():
     counts1 = g.download_cellgrid()[:, 0].copy()
     live = int(counts1.sum())
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -231,7 +243,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     g.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -174,6 +174,12 @@ int psamd_force_shard(psamd_ctx *ctx, int64_t *begin, int64_t *end, int64_t *sha
 int psamd_step(psamd_ctx *ctx, int32_t nsteps);
 int psamd_synchronize(psamd_ctx *ctx);
 
+/* float4 (ax, ay, az, flag-as-int-bits) entries [first, first+count) of the sorted-order
+ * force array, to or from host memory: lets ranks exchange their shards through any
+ * transport (the benchmark uses RCCL on device memory instead, psamd_bind_force4). */
+int psamd_download_force4(psamd_ctx *ctx, void *out_float4, int64_t first, int64_t count);
+int psamd_upload_force4(psamd_ctx *ctx, const void *in_float4, int64_t first, int64_t count);
+
 /* ---- checkpoint / resume --------------------------------------------------------- */
 /* The reference keeps its whole state in the nine buffers; the
  * device-side image of them (particles + free-slot queues) can be saved once and

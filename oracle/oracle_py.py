@@ -93,6 +93,10 @@ def lib():
         for n in ("pso_init_iframe", "pso_build_grid", "pso_calc_forces"):
             getattr(L, n).argtypes = [vp]
         L.pso_calc_forces_chunk.argtypes = [vp, ci, ci]
+        L.pso_sorted_count.argtypes = [vp]
+        L.pso_sorted_count.restype = ci
+        L.pso_calc_pairs.argtypes = [vp, ci, ci, vp]
+        L.pso_apply_forces.argtypes = [vp, vp]
         L.pso_step.argtypes = [vp, ci]
         L.pso_set_rng.argtypes = [vp, RNG_FN, vp]
         L.pso_set_explosions.argtypes = [vp, ci]
@@ -272,6 +276,17 @@ class System:
 
     def calc_forces_chunk(self, chunk, elems):
         self.L.pso_calc_forces_chunk(self.h, chunk, elems)
+
+    def sorted_count(self):
+        return self.L.pso_sorted_count(self.h)
+
+    def calc_pairs(self, lo, hi, force4):
+        assert force4.dtype == np.float32 and force4.flags["C_CONTIGUOUS"]
+        self.L.pso_calc_pairs(self.h, lo, hi, force4.ctypes.data)
+
+    def apply_forces(self, force4):
+        assert force4.dtype == np.float32 and force4.flags["C_CONTIGUOUS"]
+        self.L.pso_apply_forces(self.h, force4.ctypes.data)
 
     def step(self, n=1):
         self.L.pso_step(self.h, n)

@@ -577,112 +577,204 @@ void pso_build_grid(pso_system *s)
     }
 }
 
-/* calc_forces_host for one chunk, ps.cpp:1120-1383 */
-void pso_calc_forces_chunk(pso_system *s, int chunk, int subtask_elems)
+/* neighbour id list of a cell: fill_cells + fill_particles, app.cu:370-452 */
+static int gather_neighbours(pso_system *s, int cell)
+{
+    const pso_derived *d = &s->d;
+    const int cstride = 1 + d->max_per_cell;
+    int cells[27], ncell = pso_fill_cells(d, cell, cells), nn = 0, i;
+    for (i = 0; i < ncell; i++) {
+        const int *cl = s->cellgrid + (size_t)cells[i] * cstride;
+        int t, cnt = cl[0];
+        for (t = 1; t <= cnt; t++)
+            if (nn < d->max_neib_particles) s->neib[nn++] = cl[t];
+    }
+    return nn;
+}
+
+/* death + collision scan (ps.cpp:1182-1208) and force loop (ps.cpp:1247-1259) of one
+ * particle over the gathered list; nothing is modified.  Returns the collision flag. */
+static int scan_and_accumulate(pso_system *s, const pso_particle *me, int nn, float acc[3], int *died_of_age)
 {
     const pso_config *c = &s->cfg;
     const pso_derived *d = &s->d;
-    const int *row = s->chunkgrid + (size_t)chunk * (1 + d->max_per_chunk);
-    const int cstride = 1 + d->max_per_cell;
-    int tid;
+    int collision_flag = 0, i;
+    acc[0] = acc[1] = acc[2] = 0.0f;
+    *died_of_age = 0;
+    if ((double)me->age > d->particle_life) { *died_of_age = 1; return 2; }
+    for (i = 0; i < nn; i++) {
+        const pso_tdata *nb = &s->tdata[s->neib[i]];
+        int flag = 0;
+        if (me->id != nb->id) flag = pso_body_body_collision(c, d, me, nb);
+        if (flag > collision_flag) collision_flag = flag;
+        if (collision_flag == 2) break;
+    }
+    if (collision_flag > 0) return collision_flag;
+    for (i = 0; i < nn; i++) {
+        const pso_tdata *nb = &s->tdata[s->neib[i]];
+        if (me->id != nb->id) pso_body_body_interaction(c, d, me, nb, acc);
+    }
+    return 0;
+}
 
+/* everything calc_forces does with one particle once flag and acceleration are known:
+ * kill / survive (ps.cpp:1210-1242), integrate (1261-1302), explosion (1306-1333),
+ * relocation (1335-1374) */
+static void finish_particle(pso_system *s, pso_particle *me, int collision_flag, int died_of_age, const float acc[3])
+{
+    const pso_config *c = &s->cfg;
+    const pso_derived *d = &s->d;
+    const int id = me->id;
+    int seg[2];
+
+    if (collision_flag == 2) {
+        if (died_of_age) s->ctr.deaths_age++; else s->ctr.deaths_collision++;
+        pso_get_id_info(d, id, seg);
+        pso_reset_particle(me);
+        pso_q_insert(s->queue_info, s->queue, d, seg[0], seg[1], id);
+        return;
+    }
+    if (collision_flag == 1) { pso_survive_particle(me); s->ctr.survives++; return; }
+
+    me->ax = acc[0]; me->ay = acc[1]; me->az = acc[2];
+    pso_integrate(c, d, me);
+    s->ctr.integrated++;
+
+    if (s->explosions && (me->age >= me->fertility_age) && !me->is_parent) {
+        if (!s->rng) {
+            s->ctr.explosions_skipped++;
+        } else {
+            int ri[3], nid; double u = 0.0;
+            float ux, uy, uz, mag, vx, vy, vz;
+            s->rng(s->rng_user, id, s->step, ri, &u);
+            ux = (float)(ri[0] * 1.0); uy = (float)(ri[1] * 1.0); uz = (float)(ri[2] * 1.0);
+            mag = sqrtf((float)(ux * ux * 1.0 + uy * uy * 1.0 + uz * uz * 1.0)); /* ps.cpp:50 */
+            ux /= mag; uy /= mag; uz /= mag;
+            vx = (float)(ux * c->explosion_speed);
+            vy = (float)(uy * c->explosion_speed);
+            vz = (float)(uz * c->explosion_speed);
+            me->is_parent = 1;
+            me->vx = vx; me->vy = vy; me->vz = vz;
+            nid = pso_q_remove(s->queue_info, s->queue, d, me->seg_type, me->seg_tid);
+            if (nid >= 0) {
+                float lo = (float)d->min_fertility_age, hi = (float)d->max_fertility_age;
+                float fert = (float)(lo + u * (hi - lo)); /* ps.cpp:29-36 */
+                create_particle(c, d, &s->particles[nid], (float)c->particle_weight, 0.0f, fert,
+                                me->x, me->y, me->z,
+                                (float)(-1.0 * vx), (float)(-1.0 * vy), (float)(-1.0 * vz));
+                s->ctr.births++;
+            } else s->ctr.births_failed++;
+        }
+    }
+
+    if (me->seg_fault) {
+        int nid;
+        pso_get_id_info(d, id, seg);
+        nid = pso_q_remove(s->queue_info, s->queue, d, me->seg_type, me->seg_tid);
+        if (nid >= 0) {
+            pso_particle *dst = &s->particles[nid];
+            int keep = dst->id;          /* copy_particle, app.cu:232-237 */
+            *dst = *me; dst->id = keep;
+            dst->seg_fault = 0;
+            s->ctr.relocations++;
+        } else s->ctr.relocations_lost++;
+        pso_reset_particle(me);
+        pso_q_insert(s->queue_info, s->queue, d, seg[0], seg[1], id);
+    }
+}
+
+/* calc_forces_host for one chunk, ps.cpp:1120-1383 */
+void pso_calc_forces_chunk(pso_system *s, int chunk, int subtask_elems)
+{
+    const pso_derived *d = &s->d;
+    const int *row = s->chunkgrid + (size_t)chunk * (1 + d->max_per_chunk);
+    int tid;
     for (tid = 0; tid < subtask_elems; tid++) {
-        int chunk_size = row[0], pid, id, collision_flag = 0, i, nn = 0, ncell, cells[27], seg[2];
-        float acc[3] = {0.0f, 0.0f, 0.0f};
+        int chunk_size = row[0], pid, nn, flag, aged;
+        float acc[3];
         pso_particle *me;
         if (tid > chunk_size - 1) continue;
         if (tid >= d->max_per_chunk) continue; /* beyond what build_grid stored */
         pid = row[tid + 1];
         if (pid < 0) continue;
         me = &s->particles[pid];
-        id = me->id;
         if (!(me->cell >= 0 && me->cell < d->num_cells)) continue;
+        nn = gather_neighbours(s, me->cell);
+        flag = scan_and_accumulate(s, me, nn, acc, &aged);
+        finish_particle(s, me, flag, aged, acc);
+    }
+}
 
-        /* fill_cells + fill_particles, app.cu:370-452: concatenate the id
-         * lists of the neighbour cells, stencil order then slot order */
-        ncell = pso_fill_cells(d, me->cell, cells);
-        for (i = 0; i < ncell; i++) {
-            const int *cl = s->cellgrid + (size_t)cells[i] * cstride;
-            int t, cnt = cl[0];
-            for (t = 1; t <= cnt; t++)
-                if (nn < d->max_neib_particles) s->neib[nn++] = cl[t];
-        }
+/* ---- the same stage cut in two (test support for the sharded multi-GPU path) ---- */
 
-        /* death by age, ps.cpp:1183-1185 */
-        if ((double)me->age > d->particle_life) { collision_flag = 2; s->ctr.deaths_age++; }
-        else {
-            /* collision scan, ps.cpp:1188-1208 */
-            for (i = 0; i < nn; i++) {
-                const pso_tdata *nb = &s->tdata[s->neib[i]];
-                int flag = 0;
-                if (me->id != nb->id) flag = pso_body_body_collision(c, d, me, nb);
-                if (flag > collision_flag) collision_flag = flag;
-                if (collision_flag == 2) break;
-            }
-            if (collision_flag == 2) s->ctr.deaths_collision++;
-        }
-        if (collision_flag == 2) { /* ps.cpp:1211-1235 */
-            pso_get_id_info(d, id, seg);
-            pso_reset_particle(me);
-            pso_q_insert(s->queue_info, s->queue, d, seg[0], seg[1], id);
-            continue;
-        }
-        if (collision_flag == 1) { pso_survive_particle(me); s->ctr.survives++; continue; }
+int pso_sorted_count(const pso_system *s)
+{
+    int c, n = 0;
+    for (c = 0; c < s->d.num_cells; c++) n += s->cellgrid[(size_t)c * (1 + s->d.max_per_cell)];
+    return n;
+}
 
-        /* force loop, ps.cpp:1247-1263 */
-        for (i = 0; i < nn; i++) {
-            const pso_tdata *nb = &s->tdata[s->neib[i]];
-            if (me->id != nb->id) pso_body_body_interaction(c, d, me, nb, acc);
-        }
-        me->ax = acc[0]; me->ay = acc[1]; me->az = acc[2];
-
-        pso_integrate(c, d, me); /* ps.cpp:1268-1302 */
-        s->ctr.integrated++;
-
-        /* explosion, ps.cpp:1306-1333 */
-        if (s->explosions && (me->age >= me->fertility_age) && !me->is_parent) {
-            if (!s->rng) {
-                s->ctr.explosions_skipped++;
-            } else {
-                int ri[3], nid; double u = 0.0;
-                float ux, uy, uz, mag, vx, vy, vz;
-                s->rng(s->rng_user, id, s->step, ri, &u);
-                ux = (float)(ri[0] * 1.0); uy = (float)(ri[1] * 1.0); uz = (float)(ri[2] * 1.0);
-                mag = sqrtf((float)(ux * ux * 1.0 + uy * uy * 1.0 + uz * uz * 1.0)); /* ps.cpp:50 */
-                ux /= mag; uy /= mag; uz /= mag;
-                vx = (float)(ux * c->explosion_speed);
-                vy = (float)(uy * c->explosion_speed);
-                vz = (float)(uz * c->explosion_speed);
-                me->is_parent = 1;
-                me->vx = vx; me->vy = vy; me->vz = vz;
-                nid = pso_q_remove(s->queue_info, s->queue, d, me->seg_type, me->seg_tid);
-                if (nid >= 0) {
-                    float lo = (float)d->min_fertility_age, hi = (float)d->max_fertility_age;
-                    float fert = (float)(lo + u * (hi - lo)); /* ps.cpp:29-36 */
-                    create_particle(c, d, &s->particles[nid], (float)c->particle_weight, 0.0f, fert,
-                                    me->x, me->y, me->z,
-                                    (float)(-1.0 * vx), (float)(-1.0 * vy), (float)(-1.0 * vz));
-                    s->ctr.births++;
-                } else s->ctr.births_failed++;
-            }
-        }
-
-        /* segment change => new slot, new id; ps.cpp:1335-1374 */
-        if (me->seg_fault) {
-            int nid;
-            pso_get_id_info(d, id, seg);
-            nid = pso_q_remove(s->queue_info, s->queue, d, me->seg_type, me->seg_tid);
-            if (nid >= 0) {
-                pso_particle *dst = &s->particles[nid];
-                int keep = dst->id;          /* copy_particle, app.cu:232-237 */
-                *dst = *me; dst->id = keep;
-                dst->seg_fault = 0;
-                s->ctr.relocations++;
-            } else s->ctr.relocations_lost++;
-            pso_reset_particle(me);
-            pso_q_insert(s->queue_info, s->queue, d, seg[0], seg[1], id);
+void pso_calc_pairs(pso_system *s, int lo, int hi, float *force4)
+{
+    const pso_derived *d = &s->d;
+    const int cstride = 1 + d->max_per_cell;
+    int c, gi = 0;
+    for (c = 0; c < d->num_cells; c++) {
+        const int *cl = s->cellgrid + (size_t)c * cstride;
+        int t, cnt = cl[0];
+        if (gi + cnt <= lo || gi >= hi) { gi += cnt; continue; }
+        for (t = 1; t <= cnt; t++, gi++) {
+            const pso_particle *me = &s->particles[cl[t]];
+            int nn, flag, aged;
+            float acc[3];
+            union { int i; float f; } bits;
+            if (gi < lo || gi >= hi) continue;
+            nn = gather_neighbours(s, c);
+            flag = scan_and_accumulate(s, me, nn, acc, &aged);
+            bits.i = flag;
+            force4[4 * gi] = acc[0]; force4[4 * gi + 1] = acc[1]; force4[4 * gi + 2] = acc[2];
+            force4[4 * gi + 3] = bits.f;
         }
     }
+}
+
+void pso_apply_forces(pso_system *s, const float *force4)
+{
+    const pso_derived *d = &s->d;
+    const int cstride = 1 + d->max_per_cell;
+    /* sorted index of every slot that is in a cell list */
+    int *rank = (int *)malloc(sizeof(int) * (size_t)d->container_size);
+    int c, gi = 0, ch, biggest = s->gridmax[0];
+    if (!rank) return;
+    for (c = 0; c < d->container_size; c++) rank[c] = -1;
+    for (c = 0; c < d->num_cells; c++) {
+        const int *cl = s->cellgrid + (size_t)c * cstride;
+        int t;
+        for (t = 1; t <= cl[0]; t++) rank[cl[t]] = gi++;
+    }
+    /* the reference's serial order: chunk by chunk, chunk list order (ps.cpp:1900-1912, 1140-1163) */
+    for (ch = 0; ch < d->num_chunks; ch++) {
+        const int *row = s->chunkgrid + (size_t)ch * (1 + d->max_per_chunk);
+        int tid;
+        for (tid = 0; tid < biggest; tid++) {
+            pso_particle *me;
+            union { int i; float f; } bits;
+            float acc[3];
+            int pid, k, aged;
+            if (tid > row[0] - 1 || tid >= d->max_per_chunk) continue;
+            pid = row[tid + 1];
+            if (pid < 0) continue;
+            me = &s->particles[pid];
+            if (!(me->cell >= 0 && me->cell < d->num_cells)) continue;
+            k = rank[pid];
+            if (k < 0) continue;
+            acc[0] = force4[4 * k]; acc[1] = force4[4 * k + 1]; acc[2] = force4[4 * k + 2];
+            bits.f = force4[4 * k + 3];
+            aged = (double)me->age > d->particle_life;
+            finish_particle(s, me, bits.i, aged, acc);
+        }
+    }
+    free(rank);
 }
 
 /* the batches of ps.cpp:1900-1912 visit chunks 0..NUM_CHUNKS-1 in order */

@@ -112,6 +112,18 @@ void pso_calc_forces(pso_system *s);
 void pso_calc_forces_chunk(pso_system *s, int chunk, int subtask_elems);
 void pso_step(pso_system *s, int nsteps);
 
+/* calc_forces cut where ranks exchange results (test support for the sharded path):
+ * pso_calc_pairs evaluates, WITHOUT touching any state, the collision flag and the
+ * acceleration of the particles with sorted index in [lo, hi) -- sorted = cell-major,
+ * slot-ascending inside a cell, i.e. the concatenated cell lists -- into
+ * force4[4*k] = ax, ay, az, flag (as float bits of the int).  pso_apply_forces then
+ * performs everything calc_forces does after its two neighbour loops, in the
+ * reference's serial order, taking flag and acceleration from force4.
+ * pairs(0, n) followed by apply is exactly pso_calc_forces. */
+int  pso_sorted_count(const pso_system *s);
+void pso_calc_pairs(pso_system *s, int lo, int hi, float *force4);
+void pso_apply_forces(pso_system *s, const float *force4);
+
 void pso_set_rng(pso_system *s, pso_rng_fn fn, void *user);
 void pso_set_explosions(pso_system *s, int enabled);
 

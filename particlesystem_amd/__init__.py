@@ -110,6 +110,8 @@ ABI = [
     ("psamd_force_shard", C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     ("psamd_step", C.c_int, [_vp, _i32]),
     ("psamd_synchronize", C.c_int, [_vp]),
+    ("psamd_download_force4", C.c_int, [_vp, _vp, _i64, _i64]),
+    ("psamd_upload_force4", C.c_int, [_vp, _vp, _i64, _i64]),
     ("psamd_snapshot_save", C.c_int, [_vp]),
     ("psamd_snapshot_restore", C.c_int, [_vp]),
     ("psamd_set_stream", C.c_int, [_vp, _vp]),
@@ -294,6 +296,15 @@ class ParticleSystem:
 
     def synchronize(self):
         self._ck(self.lib.psamd_synchronize(self.h))
+
+    def download_force4(self, first, count):
+        out = np.zeros((count, 4), np.float32)
+        self._ck(self.lib.psamd_download_force4(self.h, _ptr(out), first, count))
+        return out
+
+    def upload_force4(self, arr, first):
+        arr = np.ascontiguousarray(arr, np.float32).reshape(-1, 4)
+        self._ck(self.lib.psamd_upload_force4(self.h, _ptr(arr), first, len(arr)))
 
     def snapshot_save(self):
         self._ck(self.lib.psamd_snapshot_save(self.h))

@@ -287,6 +287,28 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.stage, 3 * (size_t)d.moves_cap));
     PS_HIP(c, dev_alloc(c, &d.ctr, (size_t)COUNTER_COPIES));
 
+    // From which squared distance on is the fp32 add of EPS2 bit-identical to the
+    // reference's double add?  Try a few candidates, each checked on the device for
+    // every float up to the largest squared distance two in-box particles can have.
+    P.eps2f = (float)cfg->eps2;
+    P.eps_f32_from = INFINITY;   // default: always add in double
+    if (P.lean_math && cfg->eps2 > 0) {
+        const double L = (double)g.G * cfg->cell_size;
+        const float d2_max = (float)(3.0 * (2.0 * L) * (2.0 * L));
+        unsigned long long *bad = (unsigned long long *)d.fs;   // scratch, zeroed again below
+        auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+        for (double mult : {1.5, 2.0, 4.0, 8.0, 16.0, 64.0}) {
+            const float from = (float)(mult * cfg->eps2);
+            if (!(from < d2_max)) break;
+            unsigned long long h_bad = 1;
+            PS_HIP(c, hipMemsetAsync(bad, 0, sizeof(unsigned long long), c->stream));
+            PS_HIP(c, launch_validate_eps(c->stream, fbits(from), fbits(d2_max), cfg->eps2, P.eps2f, bad));
+            PS_HIP(c, hipMemcpyAsync(&h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost, c->stream));
+            PS_HIP(c, hipStreamSynchronize(c->stream));
+            if (h_bad == 0) { P.eps_f32_from = from; break; }
+        }
+    }
+
     // init_particles (ps.cpp:722-753): every slot reset, cell = -1
     PS_HIP(c, hipMemsetAsync(d.pos4, 0, C * sizeof(float4), c->stream));
     PS_HIP(c, hipMemsetAsync(d.vel4, 0, C * sizeof(float4), c->stream));
@@ -720,6 +742,24 @@ int psamd_device_view_get(psamd_ctx *c, psamd_device_view *o)
     o->container_size = c->geo.container; o->num_cells = c->geo.num_cells;
     o->live = c->live_at_build;
     o->stream = (void *)c->stream;
+    return PSAMD_OK;
+}
+
+int psamd_download_force4(psamd_ctx *c, void *out, int64_t first, int64_t count)
+{
+    if (!c || !out || first < 0 || count < 0 || first + count > c->geo.container) return PSAMD_ERR_INVALID_ARG;
+    if (count == 0) return PSAMD_OK;
+    PS_HIP(c, hipMemcpyAsync(out, c->d.force4 + first, (size_t)count * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    return PSAMD_OK;
+}
+
+int psamd_upload_force4(psamd_ctx *c, const void *in, int64_t first, int64_t count)
+{
+    if (!c || !in || first < 0 || count < 0 || first + count > c->geo.container) return PSAMD_ERR_INVALID_ARG;
+    if (count == 0) return PSAMD_OK;
+    PS_HIP(c, hipMemcpyAsync(c->d.force4 + first, in, (size_t)count * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    PS_HIP(c, hipStreamSynchronize(c->stream));
     return PSAMD_OK;
 }
 

@@ -35,6 +35,10 @@ struct DevParams {
     int32_t key_rec_shift;   // key_chunk_shift + bits(num_chunks + 1)
     int32_t key_bits;        // key_rec_shift + bits(queue records)
     int32_t lean_math;       // 1: the lean exact sqrt/rcp are valid for this box (host-checked range)
+    // (float)((double)d2 + eps2) == d2 + eps2f for every float d2 in [eps_f32_from, d2_max]
+    // (verified exhaustively on the device at context creation); below it the add is done in double
+    float eps2f;
+    float eps_f32_from;
 };
 
 // Per-frame scalars living in device memory (zeroed by init_iframe).

@@ -55,6 +55,8 @@ hipError_t launch_pack_aos(hipStream_t st, void *aos, int first, int count, int 
 hipError_t launch_place(hipStream_t st, int n, const int *ids, const float4 *p, const float4 *v, const float4 *a,
                         const int *cells, const DeviceState &d);
 hipError_t launch_fill_int(hipStream_t st, int *p, int v, size_t n);
+hipError_t launch_validate_eps(hipStream_t st, uint32_t lo_bits, uint32_t hi_bits, double eps2, float eps2f,
+                               unsigned long long *out);
 hipError_t launch_selftest_math(hipStream_t st, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out24);
 hipError_t launch_init_tdata(hipStream_t st, const DeviceState &d, int n);
 // ev (optional) = 5 events recorded before hist, scan, scatter, sort and after sort

@@ -421,6 +421,7 @@ __device__ __forceinline__ float inv_sqrt_selected(float six)
 #endif
 }
 
+// One snapshot body onto one particle, lean exact arithmetic, EPS2 added in double.
 __device__ __forceinline__ float pair_exact_lean(float xi, float yi, float zi, const float4 q, double eps2,
                                                  float &ax, float &ay, float &az)
 {
@@ -432,6 +433,42 @@ __device__ __forceinline__ float pair_exact_lean(float xi, float yi, float zi, c
     const float s = q.w * inv;
     ax += rx * s; ay += ry * s; az += rz * s;
     return d2;
+}
+
+// Four consecutive snapshot bodies onto one particle, added in order.  The reference
+// adds the double literal EPS2 in double and rounds to float; from eps_f32_from upwards
+// a plain fp32 add gives the same bits (checked for every such float when the context
+// is created), so only a wave that holds a closer pair among these four pays for the
+// double-precision adds.  Returns the smallest of the four squared distances.
+__device__ __forceinline__ float pairs4_exact_lean(float xi, float yi, float zi, const float4 q0, const float4 q1,
+                                                   const float4 q2, const float4 q3, double eps2, float eps2f,
+                                                   float eps_f32_from, float &ax, float &ay, float &az)
+{
+    const float rx0 = q0.x - xi, ry0 = q0.y - yi, rz0 = q0.z - zi;
+    const float rx1 = q1.x - xi, ry1 = q1.y - yi, rz1 = q1.z - zi;
+    const float rx2 = q2.x - xi, ry2 = q2.y - yi, rz2 = q2.z - zi;
+    const float rx3 = q3.x - xi, ry3 = q3.y - yi, rz3 = q3.z - zi;
+    const float d0 = rx0 * rx0 + ry0 * ry0 + rz0 * rz0;
+    const float d1 = rx1 * rx1 + ry1 * ry1 + rz1 * rz1;
+    const float d2 = rx2 * rx2 + ry2 * ry2 + rz2 * rz2;
+    const float d3 = rx3 * rx3 + ry3 * ry3 + rz3 * rz3;
+    const float dm = fminf(fminf(d0, d1), fminf(d2, d3));
+    float e0, e1, e2, e3;
+    if (__any(dm < eps_f32_from)) {
+        e0 = (float)((double)d0 + eps2); e1 = (float)((double)d1 + eps2);
+        e2 = (float)((double)d2 + eps2); e3 = (float)((double)d3 + eps2);
+    } else {
+        e0 = d0 + eps2f; e1 = d1 + eps2f; e2 = d2 + eps2f; e3 = d3 + eps2f;
+    }
+    const float s0 = q0.w * inv_sqrt_selected(e0 * e0 * e0);
+    const float s1 = q1.w * inv_sqrt_selected(e1 * e1 * e1);
+    const float s2 = q2.w * inv_sqrt_selected(e2 * e2 * e2);
+    const float s3 = q3.w * inv_sqrt_selected(e3 * e3 * e3);
+    ax += rx0 * s0; ay += ry0 * s0; az += rz0 * s0;
+    ax += rx1 * s1; ay += ry1 * s1; az += rz1 * s1;
+    ax += rx2 * s2; ay += ry2 * s2; az += rz2 * s2;
+    ax += rx3 * s3; ay += ry3 * s3; az += rz3 * s3;
+    return dm;
 }
 
 // bodyBodyInteraction, app_common.cu:236-267, for a snapshot body q = (x,y,z,w_eff).
@@ -528,13 +565,21 @@ __global__ __launch_bounds__(64) void k_pairs(DevParams P, const int *__restrict
             if (lane < n) tile[lane] = snap4[nb + t0 + lane];
             __syncthreads();
             float dmin = 3.0e38f;
+            if (MODE == 1) {
+                int jj = 0;
+                for (; jj + 4 <= n; jj += 4)
+                    dmin = fminf(dmin, pairs4_exact_lean(me.x, me.y, me.z, tile[jj], tile[jj + 1], tile[jj + 2],
+                                                         tile[jj + 3], P.eps2, P.eps2f, P.eps_f32_from, ax, ay, az));
+                for (; jj < n; jj++)
+                    dmin = fminf(dmin, pair_exact_lean(me.x, me.y, me.z, tile[jj], P.eps2, ax, ay, az));
+            } else {
 #pragma unroll 4
-            for (int jj = 0; jj < n; jj++) {
-                const float4 q = tile[jj];
-                const float d2 = MODE == 2 ? pair_fast(me.x, me.y, me.z, q, eps2f, ax, ay, az)
-                               : MODE == 1 ? pair_exact_lean(me.x, me.y, me.z, q, P.eps2, ax, ay, az)
-                                           : pair_exact(me.x, me.y, me.z, q, P.eps2, ax, ay, az);
-                dmin = fminf(dmin, d2);
+                for (int jj = 0; jj < n; jj++) {
+                    const float4 q = tile[jj];
+                    const float d2 = MODE == 2 ? pair_fast(me.x, me.y, me.z, q, eps2f, ax, ay, az)
+                                               : pair_exact(me.x, me.y, me.z, q, P.eps2, ax, ay, az);
+                    dmin = fminf(dmin, d2);
+                }
             }
             // rare: someone in this tile is within the collision gate of one of my lanes
             if (__any(scan && !(dmin > P.coll_d2_gate))) {
@@ -928,6 +973,28 @@ __global__ void k_selftest_math(uint32_t lo_bits, uint32_t hi_bits, unsigned lon
         }
     }
     for (int k = 0; k < 8; k++) if (bad[k]) atomicAdd(&out[k], bad[k]);
+}
+
+// out[0] += number of floats x with bits in [lo_bits, hi_bits] for which the fp32 add of
+// eps2f differs from the reference's double add rounded to float
+__global__ void k_validate_eps(uint32_t lo_bits, uint32_t hi_bits, double eps2, float eps2f, unsigned long long *out)
+{
+    const uint64_t span = (uint64_t)hi_bits - lo_bits + 1;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (; i < span; i += stride) {
+        const float x = __uint_as_float(lo_bits + (uint32_t)i);
+        if (__float_as_uint(x + eps2f) != __float_as_uint((float)((double)x + eps2))) bad++;
+    }
+    if (bad) atomicAdd(out, bad);
+}
+
+hipError_t launch_validate_eps(hipStream_t st, uint32_t lo_bits, uint32_t hi_bits, double eps2, float eps2f,
+                               unsigned long long *out)
+{
+    k_validate_eps<<<2048, 256, 0, st>>>(lo_bits, hi_bits, eps2, eps2f, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_selftest_math(hipStream_t st, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out24)

@@ -228,3 +228,35 @@ def test_errors_are_statuses():
     with pytest.raises(ps.PsamdError) as e:
         ps.ParticleSystem(ps.default_config(chunk_dim=2))
     assert e.value.status == 1
+
+
+def test_two_rank_contexts_share_the_pair_loop():
+    """world=2 on one GPU: two contexts each evaluate half of the sorted particles,
+    swap their force4 shards through host memory, and both must stay bit-identical
+    to the single-context run and to the oracle."""
+    n = 30000
+    xyz = cloud(n, 61)
+    rng = np.random.default_rng(61)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    ranks = [ps.ParticleSystem(ps.default_config(rank=r, world=2)) for r in range(2)]
+    for g in ranks:
+        g.fill_particles(xyz, age=age, fert_age=1e6)
+    single, o = make_pair(xyz, age=age, fert=1e6)
+    for step in range(4):
+        shards = []
+        for g in ranks:
+            g.init_iframe(); g.build_grid()
+            lo, hi, share = g.force_shard()
+            g.calc_forces_pairs()
+            shards.append((lo, g.download_force4(lo, hi - lo)))
+        assert shards[0][0] == 0 and shards[1][0] == len(shards[0][1])
+        for g in ranks:
+            for lo, arr in shards:
+                g.upload_force4(arr, lo)
+            g.calc_forces_apply()
+        single.step(1); o.step(1)
+        for r, g in enumerate(ranks):
+            compare_all(g, o, "rank %d of 2, step %d" % (r, step + 1))
+        compare_all(single, o, "single context step %d" % (step + 1))
+    with pytest.raises(ps.PsamdError):
+        ranks[0].init_iframe(); ranks[0].build_grid(); ranks[0].calc_forces()   # world > 1 needs the split calls

@@ -309,6 +309,8 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
         }
     }
 
+    P.slow_below = std::max(P.eps_f32_from, std::nextafterf(P.coll_d2_gate, INFINITY));
+
     // init_particles (ps.cpp:722-753): every slot reset, cell = -1
     PS_HIP(c, hipMemsetAsync(d.pos4, 0, C * sizeof(float4), c->stream));
     PS_HIP(c, hipMemsetAsync(d.vel4, 0, C * sizeof(float4), c->stream));

@@ -39,6 +39,8 @@ struct DevParams {
     // (verified exhaustively on the device at context creation); below it the add is done in double
     float eps2f;
     float eps_f32_from;
+    float slow_below;        // max(eps_f32_from, just above coll_d2_gate): closer pairs take the slow branch
+    float pad_f;
 };
 
 // Per-frame scalars living in device memory (zeroed by init_iframe).

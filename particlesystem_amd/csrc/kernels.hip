@@ -345,6 +345,16 @@ __device__ __forceinline__ float sqrt_rn_lean(float a)
     return __builtin_fmaf(d, h, g);
 }
 
+// the same without the Goldschmidt refinement of (g, h): one residual correction only
+__device__ __forceinline__ float sqrt_rn_short(float a)
+{
+    const float r = __builtin_amdgcn_rsqf(a);
+    const float g = a * r;
+    const float h = 0.5f * r;
+    const float d = __builtin_fmaf(-g, g, a);
+    return __builtin_fmaf(d, h, g);
+}
+
 template <int ITER>
 __device__ __forceinline__ float rcp_rn_lean(float q)
 {
@@ -417,58 +427,8 @@ __device__ __forceinline__ float inv_sqrt_selected(float six)
 #elif PSAMD_INV_VARIANT == 2
     return inv_sqrt_rn2_via_h<2>(six);
 #else
-    return rcp_rn_selected(sqrt_rn_lean(six));
+    return rcp_rn_selected(sqrt_rn_short(six));
 #endif
-}
-
-// One snapshot body onto one particle, lean exact arithmetic, EPS2 added in double.
-__device__ __forceinline__ float pair_exact_lean(float xi, float yi, float zi, const float4 q, double eps2,
-                                                 float &ax, float &ay, float &az)
-{
-    const float rx = q.x - xi, ry = q.y - yi, rz = q.z - zi;
-    const float d2 = rx * rx + ry * ry + rz * rz;
-    const float dsq = (float)((double)d2 + eps2);
-    const float six = dsq * dsq * dsq;
-    const float inv = inv_sqrt_selected(six);
-    const float s = q.w * inv;
-    ax += rx * s; ay += ry * s; az += rz * s;
-    return d2;
-}
-
-// Four consecutive snapshot bodies onto one particle, added in order.  The reference
-// adds the double literal EPS2 in double and rounds to float; from eps_f32_from upwards
-// a plain fp32 add gives the same bits (checked for every such float when the context
-// is created), so only a wave that holds a closer pair among these four pays for the
-// double-precision adds.  Returns the smallest of the four squared distances.
-__device__ __forceinline__ float pairs4_exact_lean(float xi, float yi, float zi, const float4 q0, const float4 q1,
-                                                   const float4 q2, const float4 q3, double eps2, float eps2f,
-                                                   float eps_f32_from, float &ax, float &ay, float &az)
-{
-    const float rx0 = q0.x - xi, ry0 = q0.y - yi, rz0 = q0.z - zi;
-    const float rx1 = q1.x - xi, ry1 = q1.y - yi, rz1 = q1.z - zi;
-    const float rx2 = q2.x - xi, ry2 = q2.y - yi, rz2 = q2.z - zi;
-    const float rx3 = q3.x - xi, ry3 = q3.y - yi, rz3 = q3.z - zi;
-    const float d0 = rx0 * rx0 + ry0 * ry0 + rz0 * rz0;
-    const float d1 = rx1 * rx1 + ry1 * ry1 + rz1 * rz1;
-    const float d2 = rx2 * rx2 + ry2 * ry2 + rz2 * rz2;
-    const float d3 = rx3 * rx3 + ry3 * ry3 + rz3 * rz3;
-    const float dm = fminf(fminf(d0, d1), fminf(d2, d3));
-    float e0, e1, e2, e3;
-    if (__any(dm < eps_f32_from)) {
-        e0 = (float)((double)d0 + eps2); e1 = (float)((double)d1 + eps2);
-        e2 = (float)((double)d2 + eps2); e3 = (float)((double)d3 + eps2);
-    } else {
-        e0 = d0 + eps2f; e1 = d1 + eps2f; e2 = d2 + eps2f; e3 = d3 + eps2f;
-    }
-    const float s0 = q0.w * inv_sqrt_selected(e0 * e0 * e0);
-    const float s1 = q1.w * inv_sqrt_selected(e1 * e1 * e1);
-    const float s2 = q2.w * inv_sqrt_selected(e2 * e2 * e2);
-    const float s3 = q3.w * inv_sqrt_selected(e3 * e3 * e3);
-    ax += rx0 * s0; ay += ry0 * s0; az += rz0 * s0;
-    ax += rx1 * s1; ay += ry1 * s1; az += rz1 * s1;
-    ax += rx2 * s2; ay += ry2 * s2; az += rz2 * s2;
-    ax += rx3 * s3; ay += ry3 * s3; az += rz3 * s3;
-    return dm;
 }
 
 // bodyBodyInteraction, app_common.cu:236-267, for a snapshot body q = (x,y,z,w_eff).
@@ -510,6 +470,76 @@ __device__ __forceinline__ int collide_exact(const DevParams &P, float d2, float
     if (id_i > id_j) return 1;
     if (id_i < id_j) return 2;
     return 0;
+}
+
+// Lean exact pair arithmetic for k_pairs<1>.  The reference adds the double literal EPS2
+// in double and rounds to float; from eps_f32_from upwards a plain fp32 add gives the same
+// bits (checked for every such float when the context is created).  A wave takes the
+// slow branch only when one of its lanes holds a pair closer than `slow_below` =
+// max(eps_f32_from, collision gate): there EPS2 is added in double and the exact collision
+// rule is evaluated for the pairs inside the gate, so the common path carries neither.
+struct PairCtx {
+    float xi, yi, zi, age_i;
+    int id_i, gi;
+    bool scan;
+};
+
+__device__ __forceinline__ void pairs4_exact_lean(const DevParams &P, const PairCtx &c, const float4 q0,
+                                                  const float4 q1, const float4 q2, const float4 q3, int gj0,
+                                                  const float *__restrict__ snap_age,
+                                                  const int *__restrict__ sorted_id,
+                                                  float &ax, float &ay, float &az, int &flag)
+{
+    const float rx0 = q0.x - c.xi, ry0 = q0.y - c.yi, rz0 = q0.z - c.zi;
+    const float rx1 = q1.x - c.xi, ry1 = q1.y - c.yi, rz1 = q1.z - c.zi;
+    const float rx2 = q2.x - c.xi, ry2 = q2.y - c.yi, rz2 = q2.z - c.zi;
+    const float rx3 = q3.x - c.xi, ry3 = q3.y - c.yi, rz3 = q3.z - c.zi;
+    const float d0 = rx0 * rx0 + ry0 * ry0 + rz0 * rz0;
+    const float d1 = rx1 * rx1 + ry1 * ry1 + rz1 * rz1;
+    const float d2 = rx2 * rx2 + ry2 * ry2 + rz2 * rz2;
+    const float d3 = rx3 * rx3 + ry3 * ry3 + rz3 * rz3;
+    const float dm = fminf(fminf(d0, d1), fminf(d2, d3));
+    float e0, e1, e2, e3;
+    if (__any(dm < P.slow_below)) {
+        e0 = (float)((double)d0 + P.eps2); e1 = (float)((double)d1 + P.eps2);
+        e2 = (float)((double)d2 + P.eps2); e3 = (float)((double)d3 + P.eps2);
+        if (c.scan && !(dm > P.coll_d2_gate)) {
+            if (!(d0 > P.coll_d2_gate) && gj0 != c.gi)
+                flag = max(flag, collide_exact(P, d0, c.age_i, c.id_i, snap_age[gj0], sorted_id[gj0]));
+            if (!(d1 > P.coll_d2_gate) && gj0 + 1 != c.gi)
+                flag = max(flag, collide_exact(P, d1, c.age_i, c.id_i, snap_age[gj0 + 1], sorted_id[gj0 + 1]));
+            if (!(d2 > P.coll_d2_gate) && gj0 + 2 != c.gi)
+                flag = max(flag, collide_exact(P, d2, c.age_i, c.id_i, snap_age[gj0 + 2], sorted_id[gj0 + 2]));
+            if (!(d3 > P.coll_d2_gate) && gj0 + 3 != c.gi)
+                flag = max(flag, collide_exact(P, d3, c.age_i, c.id_i, snap_age[gj0 + 3], sorted_id[gj0 + 3]));
+        }
+    } else {
+        e0 = d0 + P.eps2f; e1 = d1 + P.eps2f; e2 = d2 + P.eps2f; e3 = d3 + P.eps2f;
+    }
+    const float s0 = q0.w * inv_sqrt_selected(e0 * e0 * e0);
+    const float s1 = q1.w * inv_sqrt_selected(e1 * e1 * e1);
+    const float s2 = q2.w * inv_sqrt_selected(e2 * e2 * e2);
+    const float s3 = q3.w * inv_sqrt_selected(e3 * e3 * e3);
+    ax += rx0 * s0; ay += ry0 * s0; az += rz0 * s0;
+    ax += rx1 * s1; ay += ry1 * s1; az += rz1 * s1;
+    ax += rx2 * s2; ay += ry2 * s2; az += rz2 * s2;
+    ax += rx3 * s3; ay += ry3 * s3; az += rz3 * s3;
+}
+
+__device__ __forceinline__ void pair1_exact_lean(const DevParams &P, const PairCtx &c, const float4 q, int gj,
+                                                 const float *__restrict__ snap_age,
+                                                 const int *__restrict__ sorted_id,
+                                                 float &ax, float &ay, float &az, int &flag)
+{
+    const float rx = q.x - c.xi, ry = q.y - c.yi, rz = q.z - c.zi;
+    const float d2 = rx * rx + ry * ry + rz * rz;
+    const float e = (float)((double)d2 + P.eps2);
+    if (__any(c.scan && !(d2 > P.coll_d2_gate))) {
+        if (c.scan && !(d2 > P.coll_d2_gate) && gj != c.gi)
+            flag = max(flag, collide_exact(P, d2, c.age_i, c.id_i, snap_age[gj], sorted_id[gj]));
+    }
+    const float s = q.w * inv_sqrt_selected(e * e * e);
+    ax += rx * s; ay += ry * s; az += rz * s;
 }
 
 // One wave (one 64-thread workgroup) = 64 consecutive particles of one cell.
@@ -566,12 +596,14 @@ __global__ __launch_bounds__(64) void k_pairs(DevParams P, const int *__restrict
             __syncthreads();
             float dmin = 3.0e38f;
             if (MODE == 1) {
+                const PairCtx ctx = {me.x, me.y, me.z, age_i, id_i, gi, scan};
                 int jj = 0;
                 for (; jj + 4 <= n; jj += 4)
-                    dmin = fminf(dmin, pairs4_exact_lean(me.x, me.y, me.z, tile[jj], tile[jj + 1], tile[jj + 2],
-                                                         tile[jj + 3], P.eps2, P.eps2f, P.eps_f32_from, ax, ay, az));
+                    pairs4_exact_lean(P, ctx, tile[jj], tile[jj + 1], tile[jj + 2], tile[jj + 3], nb + t0 + jj,
+                                      snap_age, sorted_id, ax, ay, az, flag);
                 for (; jj < n; jj++)
-                    dmin = fminf(dmin, pair_exact_lean(me.x, me.y, me.z, tile[jj], P.eps2, ax, ay, az));
+                    pair1_exact_lean(P, ctx, tile[jj], nb + t0 + jj, snap_age, sorted_id, ax, ay, az, flag);
+                continue;                         // collisions were handled inline
             } else {
 #pragma unroll 4
                 for (int jj = 0; jj < n; jj++) {
@@ -964,7 +996,7 @@ __global__ void k_selftest_math(uint32_t lo_bits, uint32_t hi_bits, unsigned lon
         if (__float_as_uint(rcp_rn_markstein(a)) != __float_as_uint(r_ref)) bad[3]++;
         if (__float_as_uint(rcp_rn_selected(a)) != __float_as_uint(r_ref)) bad[4]++;
         const float c_ref = 1.0f / s_ref;
-        if (__float_as_uint(inv_sqrt_rn2_via_h<1>(a)) != __float_as_uint(c_ref)) bad[5]++;
+        if (__float_as_uint(sqrt_rn_short(a)) != __float_as_uint(s_ref)) bad[5]++;
         if (__float_as_uint(inv_sqrt_rn2_via_h<2>(a)) != __float_as_uint(c_ref)) bad[6]++;
         if (__float_as_uint(inv_sqrt_selected(a)) != __float_as_uint(c_ref)) {
             bad[7]++;

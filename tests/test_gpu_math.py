@@ -20,9 +20,10 @@ def bits(x):
 def test_lean_sqrt_and_rcp_are_correctly_rounded_everywhere_in_range():
     g = ps.ParticleSystem(ps.default_config())
     out = g.selftest_math(bits(2.0 ** -62), bits(2.0 ** 62))
-    print("mismatches sqrt, rcp1, rcp2, rcp3, rcp-in-use, invsqrt_h1, invsqrt_h2, invsqrt-in-use:", out[:8],
+    print("mismatches sqrt, rcp1, rcp2, rcp3, rcp-in-use, sqrt_short, invsqrt_h2, invsqrt-in-use:", out[:8],
           [hex(v) for v in out[8:24] if v])
     assert out[0] == 0, "lean sqrt differs from the correctly rounded sqrt"
+    assert out[5] == 0, "short sqrt (the one in use) differs from the correctly rounded sqrt"
     assert out[4] == 0, "selected reciprocal differs from the correctly rounded 1/x"
     assert out[7] == 0, "the pair kernel's 1/sqrt differs from RN(1/RN(sqrt x))"
     g.close()

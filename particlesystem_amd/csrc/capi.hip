@@ -256,7 +256,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     d.ops_cap = (int)std::min<size_t>(3 * C, (size_t)INT32_MAX / 2);
     d.moves_cap = (int)std::min<size_t>(2 * C, (size_t)INT32_MAX / 2);
     int *frame = nullptr;
-    const size_t frame_ints = (size_t)g.num_cells + g.num_chunks;
+    const size_t frame_ints = (size_t)g.num_cells + g.num_chunks + g.queue_infos;
     PS_HIP(c, dev_alloc(c, &d.pos4, C));
     PS_HIP(c, dev_alloc(c, &d.vel4, C));
     PS_HIP(c, dev_alloc(c, &d.acc4, C));
@@ -266,7 +266,9 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.qinfo, (size_t)g.queue_infos));
     PS_HIP(c, dev_alloc(c, &d.queue, C));
     PS_HIP(c, dev_alloc(c, &frame, frame_ints));
-    d.cell_count = frame; d.chunk_count = frame + g.num_cells;
+    d.cell_count = frame; d.chunk_count = frame + g.num_cells; d.rec_count = d.chunk_count + g.num_chunks;
+    PS_HIP(c, dev_alloc(c, &d.rec_start, (size_t)g.queue_infos + 1));
+    PS_HIP(c, dev_alloc(c, &d.rec_cursor, (size_t)g.queue_infos));
     PS_HIP(c, dev_alloc(c, &d.fs, 1));
     PS_HIP(c, dev_alloc(c, &d.cell_start, (size_t)g.num_cells + 1));
     PS_HIP(c, dev_alloc(c, &d.cursor, (size_t)g.num_cells));
@@ -584,12 +586,12 @@ int psamd_init_iframe(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
     const Geometry &g = c->geo;
-    const size_t frame_ints = (size_t)g.num_cells + g.num_chunks;
+    const size_t frame_ints = (size_t)g.num_cells + g.num_chunks + g.queue_infos;
     if (c->timing) { make_events(c); (void)hipEventRecord(c->ev[10], c->stream); }
     PS_HIP(c, hipMemsetAsync(c->d.cell_count, 0, frame_ints * sizeof(int), c->stream));
     // keep the sticky error word across frames: only the per-frame scalars are cleared
     PS_HIP(c, hipMemsetAsync(c->d.fs, 0, offsetof(FrameScalars, error), c->stream));
-    PS_HIP(c, hipMemsetAsync(&c->d.fs->n_ops, 0, 2 * sizeof(int32_t), c->stream));
+    PS_HIP(c, hipMemsetAsync(&c->d.fs->n_ops, 0, 3 * sizeof(int32_t), c->stream));
     c->frame_reset = true; c->grid_built = false; c->pairs_done = false;
     return PSAMD_OK;
 }
@@ -647,6 +649,7 @@ int psamd_calc_forces_apply(psamd_ctx *c)
     if (c->timing) (void)hipEventRecord(c->ev[7], c->stream);
     PS_HIP(c, launch_apply(c->stream, c->P, c->S, c->d, c->step, c->geo.container));
     if (c->timing) (void)hipEventRecord(c->ev[8], c->stream);
+    if (!(c->P.flags & PSAMD_FLAG_NO_LIFECYCLE)) PS_HIP(c, launch_ops_census(c->stream, c->P, c->d, c->geo.queue_infos));
     // one small read-back per step, as the reference's driver does for hostGridMax
     // (ps.cpp:1878-1900): live count, sticky errors and the sizes of the op lists
     PS_HIP(c, hipMemcpyAsync(c->h_fs, c->d.fs, sizeof(FrameScalars), hipMemcpyDeviceToHost, c->stream));
@@ -655,7 +658,8 @@ int psamd_calc_forces_apply(psamd_ctx *c)
     c->processed_total += c->h_fs->live;
     if (c->h_fs->error) return check_device_errors(c);
     if (c->h_fs->n_ops > 0 || c->h_fs->n_moves > 0) {
-        PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos, c->h_fs->n_ops, c->h_fs->n_moves));
+        PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos, c->h_fs->n_ops, c->h_fs->n_moves,
+                                    c->h_fs->max_bucket));
         c->host_queues_valid = false;
     }
     if (c->timing) {

@@ -50,7 +50,8 @@ struct FrameScalars {
     int32_t error;          // sticky bit mask, see ERR_* below
     int32_t n_ops;          // queue operations emitted by apply   \ allocated together as one
     int32_t n_moves;        // relocation / birth records emitted  / 64-bit word (ops low)
-    int32_t pad[2];
+    int32_t max_bucket;     // most queue operations any one segment received this step
+    int32_t pad;
 };
 
 // Cumulative event counters, mirrors psamd_counters.  Kept in COUNTER_COPIES copies on
@@ -83,6 +84,7 @@ struct MoveRec {
 
 constexpr int SORT_MAX = 2048;   // ids one cell may hold for the in-LDS ranking
 constexpr int REPLAY_CHUNK = 2048;   // queue ops staged through LDS at a time
-constexpr int QUEUE_WINDOW = 10240;  // largest segment (slots) whose queue is replayed in LDS
+constexpr int QUEUE_WINDOW = 6144;   // largest segment (slots) whose queue is replayed in LDS
+constexpr int BUCKET_MAX = 2048;     // ops per segment the one-workgroup fast replay sorts in LDS
 
 }  // namespace psamd

@@ -42,6 +42,9 @@ struct DeviceState {
     uint64_t *op_keys = nullptr, *op_keys_sorted = nullptr;
     int *op_args = nullptr, *op_args_sorted = nullptr;
     int ops_cap = 0;
+    int *rec_count = nullptr;     // [queue_infos] zeroed with the frame
+    int *rec_start = nullptr;     // [queue_infos + 1]
+    int *rec_cursor = nullptr;    // [queue_infos]
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     MoveRec *moves = nullptr;
@@ -64,9 +67,11 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
 hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi);
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step,
                         int live_bound);
-// n_ops / n_moves are the exact counts read back from FrameScalars after apply
+// after apply, before the per-step read-back: ops per queue record, their prefix and maximum
+hipError_t launch_ops_census(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec);
+// n_ops / n_moves / max_bucket are the counts read back from FrameScalars
 hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
-                            int n_ops, int n_moves);
+                            int n_ops, int n_moves, int max_bucket);
 // lifecycle_sort.hip (rocPRIM radix sort of the op keys; library code, not a hot path)
 hipError_t sort_ops_tmp_bytes(size_t n, int key_bits, size_t *bytes);
 hipError_t sort_ops(hipStream_t st, const DeviceState &d, int n, int key_bits);

@@ -912,6 +912,219 @@ __global__ __launch_bounds__(256) void k_replay(DevParams P, int n_ops,
     }
 }
 
+// ---- fast path: bucket the operations by queue record, then one workgroup per record
+// sorts its (<= BUCKET_MAX) operations in LDS and replays them in parallel ----------
+
+// ops per record; n_ops is still on the device at this point
+__global__ __launch_bounds__(1024) void k_ops_hist(const uint64_t *__restrict__ keys, const FrameScalars *fs,
+                                                    int ops_cap, int rec_shift, int nrec, int *rec_count)
+{
+    __shared__ int h[LDS_CELLS];
+    const int n = min(fs->n_ops, ops_cap), tid = threadIdx.x;
+    if ((long long)blockIdx.x * SLOTS_PER_WG >= n) return;
+    const bool lds = nrec <= LDS_CELLS;
+    if (lds) { for (int r = tid; r < nrec; r += 1024) h[r] = 0; __syncthreads(); }
+    for (long long b0 = (long long)blockIdx.x * SLOTS_PER_WG; b0 < n; b0 += (long long)gridDim.x * SLOTS_PER_WG)
+        for (int i = tid; i < SLOTS_PER_WG; i += 1024) {
+            const long long e = b0 + i;
+            if (e < n) {
+                const int r = (int)(keys[e] >> rec_shift);
+                if (lds) atomicAdd(&h[r], 1); else atomicAdd(&rec_count[r], 1);
+            }
+        }
+    if (lds) {
+        __syncthreads();
+        for (int r = tid; r < nrec; r += 1024) if (h[r]) atomicAdd(&rec_count[r], h[r]);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_ops_scan(int nrec, const int *__restrict__ rec_count,
+                                                    int *__restrict__ rec_start, int *__restrict__ rec_cursor,
+                                                    FrameScalars *fs)
+{
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s, max_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { carry_s = 0; max_s = 0; }
+    __syncthreads();
+    int mymax = 0;
+    for (int base = 0; base < nrec; base += 1024) {
+        const int r = base + tid;
+        const int v = (r < nrec) ? rec_count[r] : 0;
+        mymax = max(mymax, v);
+        const int incl = wave_incl_scan(v);
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wv; k++) woff += wave_tot[k];
+        const int excl = carry_s + woff + incl - v;
+        if (r < nrec) { rec_start[r] = excl; rec_cursor[r] = excl; }
+        __syncthreads();
+        if (tid == 1023) carry_s = excl + v;
+        __syncthreads();
+    }
+    atomicMax(&max_s, mymax);
+    __syncthreads();
+    if (tid == 0) { rec_start[nrec] = carry_s; fs->max_bucket = max_s; }
+}
+
+__global__ __launch_bounds__(1024) void k_ops_scatter(const uint64_t *__restrict__ keys, const int *__restrict__ args,
+                                                       int n, int rec_shift, int nrec, int *rec_cursor,
+                                                       uint64_t *__restrict__ keys_out, int *__restrict__ args_out)
+{
+    __shared__ int h[LDS_CELLS];
+    const int tid = threadIdx.x, base = blockIdx.x * SLOTS_PER_WG;
+    const bool lds = nrec <= LDS_CELLS;
+    int mine[SLOTS_PER_WG / 1024];
+    if (lds) { for (int r = tid; r < nrec; r += 1024) h[r] = 0; __syncthreads(); }
+#pragma unroll
+    for (int i = 0; i < SLOTS_PER_WG / 1024; i++) {
+        const int e = base + i * 1024 + tid;
+        mine[i] = (e < n) ? (int)(keys[e] >> rec_shift) : -1;
+        if (lds && mine[i] >= 0) atomicAdd(&h[mine[i]], 1);
+    }
+    if (lds) {
+        __syncthreads();
+        for (int r = tid; r < nrec; r += 1024) { const int v = h[r]; if (v) h[r] = atomicAdd(&rec_cursor[r], v); }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < SLOTS_PER_WG / 1024; i++)
+        if (mine[i] >= 0) {
+            const int e = base + i * 1024 + tid;
+            const int pos = lds ? atomicAdd(&h[mine[i]], 1) : atomicAdd(&rec_cursor[mine[i]], 1);
+            keys_out[pos] = keys[e]; args_out[pos] = args[e];
+        }
+}
+
+// One workgroup per queue record with at most BUCKET_MAX operations: rank them by key in
+// LDS, then replay.  When the queue provably neither runs empty nor fills up during the
+// step (prefix sums of +1/-1 over the sorted operations), every operation's effect on
+// the circular FIFO has a closed form -- the k-th remove takes logical element k, the
+// k-th insert becomes logical element count0 + k -- and all of them are applied at once;
+// otherwise one lane walks the list exactly as q_insert / q_remove do.
+__global__ __launch_bounds__(256) void k_replay_bucket(const int *__restrict__ rec_start,
+                                                        const uint64_t *__restrict__ keys,
+                                                        const int *__restrict__ args,
+                                                        QueueInfo *qinfo, int *queue, MoveRec *moves,
+                                                        DevCounters *ctr)
+{
+    __shared__ uint64_t kbuf[BUCKET_MAX];      // keys; later reused as ins_arg
+    __shared__ int abuf[BUCKET_MAX];
+    __shared__ int s_arg[BUCKET_MAX];
+    __shared__ unsigned char s_sub[BUCKET_MAX];
+    __shared__ int window[QUEUE_WINDOW];
+    __shared__ int wave_tot[4];
+    __shared__ int s_bad;
+    const int rec = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int start = rec_start[rec];
+    const int n = min(rec_start[rec + 1] - start, BUCKET_MAX);
+    if (n == 0) return;
+    QueueInfo q = qinfo[rec];
+    const bool in_lds = q.seg_size <= QUEUE_WINDOW;
+    for (int e = tid; e < n; e += 256) { kbuf[e] = keys[start + e]; abuf[e] = args[start + e]; }
+    if (in_lds) for (int e = tid; e < q.seg_size; e += 256) window[e] = queue[q.rloc + e];
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    for (int e = tid; e < n; e += 256) {              // keys are unique: rank = #smaller
+        const uint64_t mine = kbuf[e];
+        int rank = 0;
+        for (int j = 0; j < n; j++) rank += (kbuf[j] < mine) ? 1 : 0;
+        s_arg[rank] = abuf[e];
+        s_sub[rank] = (unsigned char)(mine & 3ull);
+    }
+    __syncthreads();
+    int *ins_arg = (int *)kbuf;                        // keys no longer needed
+
+    // prefix counts of inserts / removes before each of my (up to 8 consecutive) operations
+    const int per = (n + 255) / 256, e0 = tid * per, e1 = min(n, e0 + per);
+    int my_ins = 0, my_rem = 0;
+    for (int e = e0; e < e1; e++) { if (s_sub[e] == 2) my_ins++; else my_rem++; }
+    const int packed = my_ins | (my_rem << 16);
+    const int incl = wave_incl_scan(packed);
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    int off = 0, total = 0;
+    for (int k = 0; k < 4; k++) { if (k < wv) off += wave_tot[k]; total += wave_tot[k]; }
+    const int excl = off + incl - packed;
+    int ins_b = excl & 0xffff, rem_b = excl >> 16;
+    const int I = total & 0xffff, R = total >> 16;
+    const int count0 = q.count, size = q.seg_size;
+    {   // would any operation meet an empty or a full queue?
+        int ib = ins_b, rb = rem_b;
+        bool bad = (count0 <= 0) || !in_lds;
+        for (int e = e0; e < e1; e++) {
+            const int c = count0 + ib - rb;
+            if (s_sub[e] == 2) { bad |= !(c < size); ib++; } else { bad |= !(c >= 2); rb++; }
+        }
+        if (bad) s_bad = 1;
+    }
+    __syncthreads();
+    unsigned long long lost = 0, reloc = 0, births = 0, births_failed = 0;
+    if (s_bad) {
+        if (tid == 0) {
+            for (int e = 0; e < n; e++) {
+                const int sub = s_sub[e], arg = s_arg[e];
+                if (sub == 2) {                                // q_insert(arg), app_common.cu:346-376
+                    if (q.count == q.seg_size) continue;
+                    if (q.count == 0) { q.front = q.rloc; q.rear = q.rloc; }
+                    else if (q.rear == q.rloc + q.seg_size - 1) q.rear = q.rloc;
+                    else q.rear++;
+                    q.count++;
+                    if (in_lds) window[q.rear - q.rloc] = arg; else queue[q.rear] = arg;
+                } else {                                       // q_remove, app_common.cu:305-339
+                    int item = -1;
+                    if (q.count > 0) {
+                        const int pos = q.front;
+                        if (q.count == 1) { q.front = -1; q.rear = -1; }
+                        else if (q.front == q.rloc + q.seg_size - 1) q.front = q.rloc;
+                        else q.front++;
+                        q.count--;
+                        if (in_lds) { item = window[pos - q.rloc]; window[pos - q.rloc] = -1; }
+                        else { item = queue[pos]; queue[pos] = -1; }
+                    }
+                    moves[arg].dst = item;
+                    if (sub == 1) { if (item >= 0) reloc++; else lost++; }
+                    else { if (item >= 0) births++; else births_failed++; }
+                }
+            }
+        }
+    } else {
+        const int F = q.front - q.rloc;                // offset of logical element 0
+        for (int e = e0, ib = ins_b; e < e1; e++) if (s_sub[e] == 2) ins_arg[ib++] = s_arg[e];
+        __syncthreads();
+        for (int e = e0, rb = rem_b; e < e1; e++)
+            if (s_sub[e] != 2) {
+                const int item = (rb < count0) ? window[(F + rb) % size] : ins_arg[rb - count0];
+                moves[s_arg[e]].dst = item;
+                if (s_sub[e] == 1) reloc++; else births++;
+                rb++;
+            }
+        __syncthreads();
+        for (int r = tid; r < R; r += 256) window[(F + r) % size] = -1;          // every removed element
+        __syncthreads();
+        for (int k = tid; k < I; k += 256)                                        // inserts that stayed
+            if (count0 + k >= R) window[(F + count0 + k) % size] = ins_arg[k];
+        if (tid == 0) {
+            q.count = count0 + I - R;
+            q.front = q.rloc + (F + R) % size;
+            q.rear = q.rloc + (F + count0 + I - 1) % size;
+        }
+    }
+    __syncthreads();
+    if (in_lds) for (int e = tid; e < q.seg_size; e += 256) queue[q.rloc + e] = window[e];
+    if (tid == 0) qinfo[rec] = q;
+    DevCounters *mine = ctr + (blockIdx.x % COUNTER_COPIES);
+    reloc = (unsigned long long)wave_incl_scan((int)reloc); births = (unsigned long long)wave_incl_scan((int)births);
+    lost = (unsigned long long)wave_incl_scan((int)lost); births_failed = (unsigned long long)wave_incl_scan((int)births_failed);
+    if (lane == 63) {
+        if (reloc) atomicAdd(&mine->relocations, reloc);
+        if (births) atomicAdd(&mine->births, births);
+        if (lost) atomicAdd(&mine->relocations_lost, lost);
+        if (births_failed) atomicAdd(&mine->births_failed, births_failed);
+    }
+}
+
 // Relocation phase 1a: read every moving particle (copy_particle, ps.cpp:1363) and
 // every parent of a child to be born.  Read-only on the particle arrays, so a
 // parent that also relocates this step is seen intact by both of its records.
@@ -1135,10 +1348,28 @@ hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, 
     return hipSuccess;
 }
 
-hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
-                            int n_ops, int n_moves)
+hipError_t launch_ops_census(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec)
 {
-    if (n_ops > 0) {
+    k_ops_hist<<<512, 1024, 0, st>>>(d.op_keys, d.fs, d.ops_cap, P.key_rec_shift, nrec, d.rec_count);
+    PS_LAUNCH_CHECK();
+    k_ops_scan<<<1, 1024, 0, st>>>(nrec, d.rec_count, d.rec_start, d.rec_cursor, d.fs);
+    PS_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
+                            int n_ops, int n_moves, int max_bucket)
+{
+    if (n_ops > 0 && max_bucket <= BUCKET_MAX) {
+        // usual case: every queue's operations fit one workgroup's LDS
+        k_ops_scatter<<<(n_ops + SLOTS_PER_WG - 1) / SLOTS_PER_WG, 1024, 0, st>>>(
+            d.op_keys, d.op_args, n_ops, P.key_rec_shift, nrec, d.rec_cursor, d.op_keys_sorted, d.op_args_sorted);
+        PS_LAUNCH_CHECK();
+        k_replay_bucket<<<nrec, 256, 0, st>>>(d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
+                                              d.moves, d.ctr);
+        PS_LAUNCH_CHECK();
+    } else if (n_ops > 0) {
+        // a queue with a very long list (e.g. record 0 during a collapse): global sort + serial walk
         hipError_t e = sort_ops(st, d, n_ops, P.key_bits);
         if (e != hipSuccess) return e;
         k_replay<<<nrec, 256, 0, st>>>(P, n_ops, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue, d.moves, d.ctr);

@@ -273,6 +273,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.cell_start, (size_t)g.num_cells + 1));
     PS_HIP(c, dev_alloc(c, &d.cursor, (size_t)g.num_cells));
     PS_HIP(c, dev_alloc(c, &d.sorted_id, C));
+    PS_HIP(c, dev_alloc(c, &d.rank_of_slot, C));
     PS_HIP(c, dev_alloc(c, &d.snap4, C));
     PS_HIP(c, dev_alloc(c, &d.snap_age, C));
     PS_HIP(c, dev_alloc(c, &d.force4, C));

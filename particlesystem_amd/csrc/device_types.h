@@ -82,7 +82,7 @@ struct MoveRec {
     int32_t new_cell;
 };
 
-constexpr int SORT_MAX = 2048;   // ids one cell may hold for the in-LDS ranking
+constexpr int SORT_MAX = 4096;   // ids one cell may hold for the in-LDS ranking
 constexpr int REPLAY_CHUNK = 2048;   // queue ops staged through LDS at a time
 constexpr int QUEUE_WINDOW = 6144;   // largest segment (slots) whose queue is replayed in LDS
 constexpr int BUCKET_MAX = 2048;     // ops per segment the one-workgroup fast replay sorts in LDS

@@ -34,6 +34,7 @@ struct DeviceState {
     int *cell_start = nullptr;    // [num_cells+1]
     int *cursor = nullptr;        // [num_cells]
     int *sorted_id = nullptr;     // [container] cell-major, id ascending inside a cell
+    int *rank_of_slot = nullptr;  // [container] inverse of sorted_id for the slots of this frame
     float4 *snap4 = nullptr;      // [container] sorted order: x,y,z,w_eff
     float *snap_age = nullptr;    // [container] sorted order
     float4 *force4 = nullptr;     // [container] sorted order: ax,ay,az,flag

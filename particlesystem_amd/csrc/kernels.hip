@@ -277,11 +277,11 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
                                                      float4 *pos4, float4 *vel4, float4 *acc4,
                                                      int *cell_arr, uint8_t *pflags,
                                                      float4 *__restrict__ snap4, float *__restrict__ snap_age,
-                                                     uint32_t *__restrict__ tdata,
+                                                     uint32_t *__restrict__ tdata, int *__restrict__ rank_of_slot,
                                                      uint64_t *op_keys, int *op_args, int ops_cap,
                                                      FrameScalars *fs, DevCounters *ctr)
 {
-    __shared__ int ids[SORT_MAX];
+    __shared__ __attribute__((aligned(16))) int ids[SORT_MAX + 4];
     __shared__ int ordered[SORT_MAX];
     const int c = blockIdx.x, tid = threadIdx.x;
     const int start = cell_start[c];
@@ -293,10 +293,18 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
     }
     for (int e = tid; e < n; e += 256) ids[e] = sorted_id[start + e];
     __syncthreads();
+    // pad to a multiple of 4 with INT_MAX so the ranking reads whole 16-byte LDS words
+    for (int e = n + tid; e < ((n + 3) & ~3); e += 256) ids[e] = 0x7fffffff;
+    __syncthreads();
     for (int e = tid; e < n; e += 256) {
         const int mine = ids[e];
         int rank = 0;
-        for (int j = 0; j < n; j++) rank += (ids[j] < mine) ? 1 : 0;
+        const int4 *v = reinterpret_cast<const int4 *>(ids);
+#pragma unroll 4
+        for (int j = 0; j < (n + 3) / 4; j++) {
+            const int4 q = v[j];
+            rank += (q.x < mine) + (q.y < mine) + (q.z < mine) + (q.w < mine);
+        }
         ordered[rank] = mine;
     }
     __syncthreads();
@@ -310,6 +318,7 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
         t[3] = __float_as_uint(p.z); t[4] = __float_as_uint(p.w); t[5] = __float_as_uint(age);
         if (e < P.max_per_cell) {
             sorted_id[start + e] = id;
+            rank_of_slot[id] = start + e;
             snap4[start + e] = make_float4(p.x, p.y, p.z, (age < P.kid_thr) ? 0.0f : p.w);
             snap_age[start + e] = age;
         } else {
@@ -673,12 +682,13 @@ __device__ __forceinline__ int wave_incl_scan(int v)
 }
 
 // Death, survival, integration, wrap and re-hash for every particle of the frame
-// (ps.cpp:1182-1242, 1261-1302), one thread per sorted index.  Lifecycle side
+// (ps.cpp:1182-1242, 1261-1302), one thread per SLOT so that the particle arrays stream
+// through coalesced (live slots are dense at the head of every segment); only the
+// force record is gathered through the slot's rank in the sorted order.  Lifecycle side
 // effects that depend on the reference's serial order (free-slot queues) are emitted
 // as (key, arg) queue operations and MoveRec records and replayed afterwards.
-__global__ __launch_bounds__(256) void k_apply(DevParams P, SegLayout S, int step,
-                                                const int *__restrict__ cell_start,
-                                                const int *__restrict__ sorted_id,
+__global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int step,
+                                                const int *__restrict__ rank_of_slot,
                                                 const float4 *__restrict__ force4,
                                                 float4 *pos4, float4 *vel4, float4 *acc4,
                                                 int *cell_arr, uint8_t *pflags,
@@ -689,19 +699,19 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P, SegLayout S, int ste
 {
     __shared__ int s_ops, s_moves, s_base_ops, s_base_moves;
     __shared__ unsigned int s_cnt[4];
-    const int total = cell_start[P.num_cells];
-    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
-    // whole workgroups past the end leave; inside a live one every thread reaches the
-    // workgroup-level allocation below
-    if ((int)(blockIdx.x * blockDim.x) >= total) return;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;       // slot == particle id
     if (threadIdx.x == 0) { s_ops = 0; s_moves = 0; s_cnt[0] = s_cnt[1] = s_cnt[2] = s_cnt[3] = 0; }
-    const int id = (gi < total) ? sorted_id[gi] : -1;    // -1: killed by the cell-overflow rule
-    const bool active = id >= 0;
+    int old_cell = -1;
+    if (id < P.container) old_cell = cell_arr[id];
+    // free slots (and the ones the cell-overflow rule just killed) have cell == -1
+    const bool active = old_cell >= 0 && old_cell < P.num_cells;
+    if (!__syncthreads_or(active)) return;                        // nothing alive in this workgroup
+    const int gi = active ? rank_of_slot[id] : 0;
     const bool lifecycle = !(P.flags & PSAMD_FLAG_NO_LIFECYCLE);
 
-    int flag = 0, old_cell = 0, new_cell = 0;
+    int flag = 0, new_cell = 0;
     float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (active) { f = force4[gi]; flag = __float_as_int(f.w); old_cell = cell_arr[id]; }
+    if (active) { f = force4[gi]; flag = __float_as_int(f.w); }
     const CellInfo old_ci = active ? celltab[old_cell] : CellInfo{0, 1, 0, 0};
     const uint64_t key = ((uint64_t)(uint32_t)(old_ci.chunk + 1) << P.key_chunk_shift) | ((uint64_t)(uint32_t)id << 2);
 
@@ -1009,7 +1019,7 @@ __global__ __launch_bounds__(256) void k_replay_bucket(const int *__restrict__ r
                                                         QueueInfo *qinfo, int *queue, MoveRec *moves,
                                                         DevCounters *ctr)
 {
-    __shared__ uint64_t kbuf[BUCKET_MAX];      // keys; later reused as ins_arg
+    __shared__ __attribute__((aligned(16))) uint64_t kbuf[BUCKET_MAX + 2];   // keys; later reused as ins_arg
     __shared__ int abuf[BUCKET_MAX];
     __shared__ int s_arg[BUCKET_MAX];
     __shared__ unsigned char s_sub[BUCKET_MAX];
@@ -1026,13 +1036,27 @@ __global__ __launch_bounds__(256) void k_replay_bucket(const int *__restrict__ r
     if (in_lds) for (int e = tid; e < q.seg_size; e += 256) window[e] = queue[q.rloc + e];
     if (tid == 0) s_bad = 0;
     __syncthreads();
-    for (int e = tid; e < n; e += 256) {              // keys are unique: rank = #smaller
-        const uint64_t mine = kbuf[e];
-        int rank = 0;
-        for (int j = 0; j < n; j++) rank += (kbuf[j] < mine) ? 1 : 0;
-        s_arg[rank] = abuf[e];
-        s_sub[rank] = (unsigned char)(mine & 3ull);
-    }
+    // bitonic sort of (key, arg) in LDS, padded to a power of two with +inf keys
+    int np = 2;
+    while (np < n) np <<= 1;
+    for (int e = n + tid; e < np; e += 256) { kbuf[e] = ~0ull; abuf[e] = -1; }
+    __syncthreads();
+    for (int k = 2; k <= np; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (np >> 1); t += 256) {
+                // t-th compare-exchange pair of this stage: e has bit j clear
+                const int e = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int partner = e | j;
+                const uint64_t a = kbuf[e], b = kbuf[partner];
+                const bool up = (e & k) == 0;
+                if ((a > b) == up) {
+                    kbuf[e] = b; kbuf[partner] = a;
+                    const int x = abuf[e]; abuf[e] = abuf[partner]; abuf[partner] = x;
+                }
+            }
+            __syncthreads();
+        }
+    for (int e = tid; e < n; e += 256) { s_arg[e] = abuf[e]; s_sub[e] = (unsigned char)(kbuf[e] & 3ull); }
     __syncthreads();
     int *ins_arg = (int *)kbuf;                        // keys no longer needed
 
@@ -1318,7 +1342,7 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[3], st);
     k_sort_cells<<<P.num_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
-                                               d.pflags, d.snap4, d.snap_age, d.tdata, d.op_keys, d.op_args, d.ops_cap, d.fs, d.ctr);
+                                               d.pflags, d.snap4, d.snap_age, d.tdata, d.rank_of_slot, d.op_keys, d.op_args, d.ops_cap, d.fs, d.ctr);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[4], st);
     return hipSuccess;
@@ -1341,7 +1365,7 @@ hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, 
                         int live_bound)
 {
     if (live_bound <= 0) return hipSuccess;
-    k_apply<<<(live_bound + 255) / 256, 256, 0, st>>>(P, S, step, d.cell_start, d.sorted_id, d.force4, d.pos4,
+    k_apply<<<(live_bound + 1023) / 1024, 1024, 0, st>>>(P, S, step, d.rank_of_slot, d.force4, d.pos4,
                                                       d.vel4, d.acc4, d.cell, d.pflags, d.celltab, d.op_keys, d.op_args, d.ops_cap,
                                                       d.moves, d.moves_cap, d.fs, d.ctr);
     PS_LAUNCH_CHECK();

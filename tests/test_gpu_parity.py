@@ -260,3 +260,33 @@ def test_two_rank_contexts_share_the_pair_loop():
         compare_all(single, o, "single context step %d" % (step + 1))
     with pytest.raises(ps.PsamdError):
         ranks[0].init_iframe(); ranks[0].build_grid(); ranks[0].calc_forces()   # world > 1 needs the split calls
+
+
+def test_large_grid_uses_the_global_atomic_build():
+    """BASELINE config 4's grid (40^3 = 64000 cells, more than fit an LDS histogram): the
+    fallback hist/scatter kernels and the 1000-chunk scan, against the oracle."""
+    over = {"chunk_factor": 10, "chunk_dim": 4, "max_particles_num": 200000}
+    n = 150000
+    xyz = cloud(n, 71, 100.0)
+    rng = np.random.default_rng(71)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    g, o = make_pair(xyz, age=age, fert=1e6, **over)
+    assert g.sizes.num_cells == 64000
+    for k in range(3):
+        g.step(1); o.step(1)
+        compare_all(g, o, "40^3 grid step %d" % (k + 1))
+
+
+def test_snapshot_restore_is_exact():
+    xyz = cloud(20000, 81)
+    g, o = make_pair(xyz, age=3.0, fert=1e6)
+    g.step(2); o.step(2)
+    g.snapshot_save()
+    g.step(3)
+    g.snapshot_restore()
+    compare_all_state_only = assert_same_particles
+    compare_all_state_only(g.download_particles(), o.particles, "restored")
+    qi, q = g.download_queues()
+    assert qi.tobytes() == o.queue_info.tobytes() and np.array_equal(q, o.queue)
+    g.step(1); o.step(1)
+    assert_same_particles(g.download_particles(), o.particles, "step after restore")

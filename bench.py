@@ -51,6 +51,15 @@ def make_inputs(ps, sysobj, n, seed):
     return xyz, age, fert
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC capture (profiles/), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+            return float(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch_corrected"])
+    except Exception:
+        return None
+
+
 def pair_count(cellgrid_counts, G):
     """pairs one pair-kernel launch evaluates: sum_c n_c * sum_{c' in stencil(c)} n_c'."""
     c = cellgrid_counts.astype(np.int64).reshape(G, G, G)
@@ -230,10 +239,11 @@ def main():
                        "relocations": ctr["relocations"], "relocations_lost": ctr["relocations_lost"],
                        "cell_overflow_kills": ctr["cell_overflow_kills"]},
             "roofline": {"kernel": "k_pairs", "bound": "valu", "achieved": ach_tflops, "peak": VALU_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach_tflops / VALU_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": ach_tflops / VALU_PEAK_TFLOPS,
+                         "traffic": measured_traffic("k_pairs<1>") if world == 1 and not args.fast_math else None,
                          "pairs_per_launch": pairs_rank, "flop_per_pair": FLOP_PER_PAIR, "us_per_launch": us_pairs},
             "roofline_streaming": {"kernel": "k_apply", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                                   "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS, "traffic": measured_traffic("k_apply"),
                                    "bytes_per_update": APPLY_BYTES_PER_UPDATE, "us_per_launch": us_apply},
             "kernel_us_per_step": {k: v / max(launches, 1) for k, v in tim.items()},
         }

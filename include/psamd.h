@@ -167,7 +167,9 @@ int psamd_calc_forces(psamd_ctx *ctx);  /* task 6, ps.cpp:1120-1383 / psCUDA.cu:
 int psamd_calc_forces_pairs(psamd_ctx *ctx);
 int psamd_calc_forces_apply(psamd_ctx *ctx);
 /* Sorted-index range [begin,end) whose force4 entries this rank produces, and the
- * padded per-rank share (same on every rank) for an equal-sized all-gather. */
+ * per-rank share (same on every rank) for an equal-sized all-gather.  The ranges are cut
+ * from an upper bound of the live count that the context tracks on the host (no
+ * read-back), so the last ranges may extend past the live particles. */
 int psamd_force_shard(psamd_ctx *ctx, int64_t *begin, int64_t *end, int64_t *share);
 /* nsteps x {init_iframe, build_grid, calc_forces}; asynchronous on the context's
  * stream unless lifecycle bookkeeping forces a sync. */

@@ -49,6 +49,9 @@ struct psamd_ctx {
     int step = 0;
     int64_t steps_total = 0;
     int live_at_build = -1;           // host copy of fs->live (valid after a sync)
+    // upper bound of the live count at the next build_grid, kept on the host so that the
+    // sharded path needs no read-back between build and pair pass (-1 = unknown)
+    int64_t live_bound = 0, snapshot_live_bound = 0;
     // timing
     bool timing = false;
     hipEvent_t ev[11]{};
@@ -151,16 +154,19 @@ int check_device_errors(psamd_ctx *c)   // after a sync: sticky error bits raise
     c->live_at_build = fs.live;
     if (fs.error & ERR_BAD_ID) return fail(c, PSAMD_ERR_INVALID_ARG, "uploaded particle with id != slot index");
     if (fs.error & ERR_CELL_TOO_BIG) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "a cell holds more particles than the sort kernel ranks");
+    if (fs.error & ERR_SHARD_BOUND) return fail(c, PSAMD_ERR_STATE, "more live particles than the shards cover (stale bound)");
     if (fs.error & ERR_OPS_OVERFLOW) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "lifecycle op buffer overflow");
     return PSAMD_OK;
 }
 
-void shard_range(const psamd_ctx *c, int64_t total, int64_t &lo, int64_t &hi, int64_t &share)
+// `bound` >= the number of sorted particles; entries past the real count are never
+// produced or consumed, so a loose bound only costs balance
+void shard_range(const psamd_ctx *c, int64_t bound, int64_t &lo, int64_t &hi, int64_t &share)
 {
     const int world = std::max(1, c->geo.cfg.world), rank = c->geo.cfg.rank;
-    share = (total + world - 1) / world;
-    lo = std::min<int64_t>(total, share * rank);
-    hi = std::min<int64_t>(total, lo + share);
+    share = (bound + world - 1) / world;
+    lo = share * rank;
+    hi = lo + share;
 }
 
 void make_events(psamd_ctx *c)
@@ -438,6 +444,7 @@ int psamd_fill_particles(psamd_ctx *c, int64_t n, const float *xyz, const float 
     if (rc != PSAMD_OK) return rc;
     if (ids_out) std::copy(ids.begin(), ids.begin() + done, ids_out);
     if (n_done) *n_done = done;
+    if (c->live_bound >= 0) c->live_bound += done;
     c->grid_built = false; c->pairs_done = false;
     return status;
 }
@@ -452,6 +459,7 @@ int psamd_upload_particles(psamd_ctx *c, const void *p72, int64_t first, int64_t
     PS_HIP(c, launch_unpack_aos(c->stream, c->staging, (int)first, (int)count, c->d));
     PS_HIP(c, hipStreamSynchronize(c->stream));
     c->grid_built = false; c->pairs_done = false;
+    c->live_bound = -1;
     return check_device_errors(c);
 }
 
@@ -612,13 +620,14 @@ int psamd_force_shard(psamd_ctx *c, int64_t *begin, int64_t *end, int64_t *share
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
     if (!c->grid_built) return fail(c, PSAMD_ERR_STATE, "force_shard needs build_grid first");
-    if (c->live_at_build < 0) {
+    if (c->live_bound < 0) {            // e.g. after an upload: ask the device once
         PS_HIP(c, hipStreamSynchronize(c->stream));
         int rc = check_device_errors(c);
         if (rc != PSAMD_OK) return rc;
+        c->live_bound = c->live_at_build;
     }
     int64_t lo, hi, sh;
-    shard_range(c, c->live_at_build, lo, hi, sh);
+    shard_range(c, c->live_bound, lo, hi, sh);
     if (begin) *begin = lo;
     if (end) *end = hi;
     if (share) *share = sh;
@@ -629,15 +638,15 @@ int psamd_calc_forces_pairs(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
     if (!c->grid_built) return fail(c, PSAMD_ERR_STATE, "calc_forces needs build_grid first");
-    int lo = 0, hi = INT32_MAX;
+    int lo = 0, hi = INT32_MAX, covered = INT32_MAX;
     if (c->geo.cfg.world > 1) {
         int64_t b, e, s;
         int rc = psamd_force_shard(c, &b, &e, &s);
         if (rc != PSAMD_OK) return rc;
-        lo = (int)b; hi = (int)e;
+        lo = (int)b; hi = (int)e; covered = (int)std::min<int64_t>(s * c->geo.cfg.world, INT32_MAX);
     }
     if (c->timing) (void)hipEventRecord(c->ev[5], c->stream);
-    PS_HIP(c, launch_pairs(c->stream, c->P, c->d, lo, hi));
+    PS_HIP(c, launch_pairs(c->stream, c->P, c->d, lo, hi, covered));
     if (c->timing) (void)hipEventRecord(c->ev[6], c->stream);
     c->pairs_done = true;
     return PSAMD_OK;
@@ -656,6 +665,7 @@ int psamd_calc_forces_apply(psamd_ctx *c)
     PS_HIP(c, hipMemcpyAsync(c->h_fs, c->d.fs, sizeof(FrameScalars), hipMemcpyDeviceToHost, c->stream));
     PS_HIP(c, hipStreamSynchronize(c->stream));
     c->live_at_build = c->h_fs->live;
+    c->live_bound = std::min<int64_t>(c->geo.container, (int64_t)c->h_fs->live + c->h_fs->n_moves);   // births <= moves
     c->processed_total += c->h_fs->live;
     if (c->h_fs->error) return check_device_errors(c);
     if (c->h_fs->n_ops > 0 || c->h_fs->n_moves > 0) {
@@ -799,6 +809,7 @@ int psamd_snapshot_save(psamd_ctx *c)
     if (!c) return PSAMD_ERR_INVALID_ARG;
     if (!c->snapshot) PS_HIP(c, dev_alloc(c, &c->snapshot, snapshot_bytes(c)));
     c->snapshot_step = c->step;
+    c->snapshot_live_bound = c->live_bound;
     return snapshot_copy(c, true);
 }
 
@@ -807,6 +818,7 @@ int psamd_snapshot_restore(psamd_ctx *c)
     if (!c) return PSAMD_ERR_INVALID_ARG;
     if (!c->snapshot) return fail(c, PSAMD_ERR_STATE, "snapshot_restore without a saved snapshot");
     c->step = c->snapshot_step;
+    c->live_bound = c->snapshot_live_bound;
     c->host_queues_valid = false;
     c->frame_reset = false; c->grid_built = false; c->pairs_done = false;
     return snapshot_copy(c, false);

@@ -67,6 +67,7 @@ enum : int32_t {
     ERR_CELL_TOO_BIG = 1,   // a cell holds more ids than the sort kernel can rank
     ERR_BAD_ID = 2,         // uploaded P_DATA_TYPE with id != slot
     ERR_OPS_OVERFLOW = 4,   // lifecycle op buffer too small
+    ERR_SHARD_BOUND = 8,    // more sorted particles than world * share
 };
 
 // A free-slot-queue operation produced by calc_forces is a (key, arg) pair kept in

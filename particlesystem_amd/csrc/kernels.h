@@ -65,7 +65,8 @@ hipError_t launch_selftest_math(hipStream_t st, uint32_t lo_bits, uint32_t hi_bi
 hipError_t launch_init_tdata(hipStream_t st, const DeviceState &d, int n);
 // ev (optional) = 5 events recorded before hist, scan, scatter, sort and after sort
 hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev);
-hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi);
+// lo/hi: this rank's sorted range; covered = world * share (all ranks' ranges together)
+hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi, int covered);
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step,
                         int live_bound);
 // after apply, before the per-step read-back: ops per queue record, their prefix and maximum

@@ -562,9 +562,11 @@ __global__ __launch_bounds__(64) void k_pairs(DevParams P, const int *__restrict
                                                const float4 *__restrict__ snap4,
                                                const float *__restrict__ snap_age,
                                                const int *__restrict__ sorted_id,
-                                               float4 *__restrict__ force4, int lo, int hi)
+                                               float4 *__restrict__ force4, int lo, int hi, int covered,
+                                               FrameScalars *fs)
 {
     __shared__ float4 tile[64];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && cell_start[P.num_cells] > covered) atomicOr(&fs->error, ERR_SHARD_BOUND);
     const int task = xcd_contiguous(blockIdx.x, gridDim.x);
     const int c = task / P.slices, slice = task - c * P.slices;
     const int base = cell_start[c];
@@ -1348,15 +1350,15 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     return hipSuccess;
 }
 
-hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi)
+hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi, int covered)
 {
     const int tasks = P.num_cells * P.slices;
     if (P.flags & PSAMD_FLAG_FAST_MATH)
-        k_pairs<2><<<tasks, 64, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.force4, lo, hi);
+        k_pairs<2><<<tasks, 64, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.force4, lo, hi, covered, d.fs);
     else if (P.lean_math)
-        k_pairs<1><<<tasks, 64, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.force4, lo, hi);
+        k_pairs<1><<<tasks, 64, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.force4, lo, hi, covered, d.fs);
     else
-        k_pairs<0><<<tasks, 64, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.force4, lo, hi);
+        k_pairs<0><<<tasks, 64, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.force4, lo, hi, covered, d.fs);
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -46,7 +46,6 @@ typedef enum psamd_status {
 /* config.flags */
 #define PSAMD_FLAG_EXPLOSIONS   0x1u  /* births enabled (ps.cpp:1306-1333) with the counter-based RNG below */
 #define PSAMD_FLAG_FAST_MATH    0x2u  /* FMA/rsq pair arithmetic: NOT bit-identical to the reference, see DESIGN.md */
-#define PSAMD_FLAG_NO_LIFECYCLE 0x4u  /* benchmark mode: no kill/survive/relocation, N stays constant */
 
 /* Runtime form of the reference's compile-time configuration, common.h:12-70.
  * psamd_default_config() fills in the shipped values. */

@@ -22,7 +22,6 @@ LIB_PATH = os.path.join(HERE, "libpsamd.so")
 
 FLAG_EXPLOSIONS = 0x1
 FLAG_FAST_MATH = 0x2
-FLAG_NO_LIFECYCLE = 0x4
 NUM_TIMERS = 8
 TIMER_NAMES = ("hist", "scan", "scatter", "sort_cells", "pairs", "apply", "lifecycle", "init_iframe")
 

@@ -659,7 +659,7 @@ int psamd_calc_forces_apply(psamd_ctx *c)
     if (c->timing) (void)hipEventRecord(c->ev[7], c->stream);
     PS_HIP(c, launch_apply(c->stream, c->P, c->S, c->d, c->step, c->geo.container));
     if (c->timing) (void)hipEventRecord(c->ev[8], c->stream);
-    if (!(c->P.flags & PSAMD_FLAG_NO_LIFECYCLE)) PS_HIP(c, launch_ops_census(c->stream, c->P, c->d, c->geo.queue_infos));
+    PS_HIP(c, launch_ops_census(c->stream, c->P, c->d, c->geo.queue_infos));
     // one small read-back per step, as the reference's driver does for hostGridMax
     // (ps.cpp:1878-1900): live count, sticky errors and the sizes of the op lists
     PS_HIP(c, hipMemcpyAsync(c->h_fs, c->d.fs, sizeof(FrameScalars), hipMemcpyDeviceToHost, c->stream));

@@ -583,10 +583,9 @@ __global__ __launch_bounds__(64) void k_pairs(DevParams P, const int *__restrict
     const float4 me = snap4[gi];
     const float age_i = snap_age[gi];
     const int id_i = sorted_id[gi];
-    const bool lifecycle = !(P.flags & PSAMD_FLAG_NO_LIFECYCLE);
-    const bool dead = lifecycle && (age_i > P.life_thr);       // ps.cpp:1183
+    const bool dead = age_i > P.life_thr;                      // ps.cpp:1183
     const bool kid = age_i < P.kid_thr;
-    const bool scan = valid && lifecycle && !dead && !kid;
+    const bool scan = valid && !dead && !kid;
 
     const int G = P.G;
     const int i3 = c / (G * G), rem = c - i3 * G * G, i1 = rem / G, i2 = rem - i1 * G;
@@ -709,7 +708,6 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
     const bool active = old_cell >= 0 && old_cell < P.num_cells;
     if (!__syncthreads_or(active)) return;                        // nothing alive in this workgroup
     const int gi = active ? rank_of_slot[id] : 0;
-    const bool lifecycle = !(P.flags & PSAMD_FLAG_NO_LIFECYCLE);
 
     int flag = 0, new_cell = 0;
     float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -768,7 +766,7 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
         new_rec = segment_record(S, new_ci.seg_type, new_ci.seg_tid);
 
         // explosion, ps.cpp:1306-1333, with a counter-based RNG keyed on (seed, step, id)
-        if ((P.flags & PSAMD_FLAG_EXPLOSIONS) && lifecycle && (age >= fert) && !(pf & 1)) {
+        if ((P.flags & PSAMD_FLAG_EXPLOSIONS) && (age >= fert) && !(pf & 1)) {
             const uint64_t h0 = splitmix64(P.seed ^ ((uint64_t)(uint32_t)step << 32) ^ (uint64_t)(uint32_t)id);
             const uint64_t h1 = splitmix64(h0), h2 = splitmix64(h1);
             const int r0 = (int)((double)(h0 >> 11) * (1.0 / 9007199254740992.0) * 100.0) - 50;
@@ -790,7 +788,7 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
         pflags[id] = pf;
         // segment change => the particle must move to a slot of the new segment
         // (set_pos_x raises seg_fault, app.cu:178-185; handled at ps.cpp:1335-1374)
-        relocate = lifecycle && (new_ci.seg_type != old_ci.seg_type || new_ci.seg_tid != old_ci.seg_tid);
+        relocate = (new_ci.seg_type != old_ci.seg_type || new_ci.seg_tid != old_ci.seg_tid);
     }
 
     // Event counters and list space: wave -> workgroup (LDS) -> one global atomic per

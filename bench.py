@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--chunk-factor", type=int, default=4, help="grid = (chunk_factor*chunk_dim)^3 cells (reference: 4)")
+    ap.add_argument("--chunk-dim", type=int, default=4)
     ap.add_argument("--evolve", action="store_true", help="free-running steps instead of one pass per step over the same cloud")
     ap.add_argument("--force-dist", action="store_true", help="take the collective code path even with one rank (rehearsal)")
     args = ap.parse_args()
@@ -149,10 +151,10 @@ def main():
             os.dup2(saved, 1)
             os.close(saved)
 
-    cfg_over = dict()
+    cfg_over = dict(chunk_factor=args.chunk_factor, chunk_dim=args.chunk_dim,
+                    max_particles_num=max(args.n, 1 << 20))
     flags = ps.FLAG_FAST_MATH if args.fast_math else 0
-    cfg = ps.default_config(device=local_rank, rank=rank, world=world, flags=flags,
-                            max_particles_num=max(args.n, 1 << 20) if args.n <= (1 << 20) else args.n, **cfg_over)
+    cfg = ps.default_config(device=local_rank, rank=rank, world=world, flags=flags, **cfg_over)
     g = ps.ParticleSystem(cfg)
     xyz, age, fert = make_inputs(ps, g, args.n, args.seed)
     g.fill_particles(xyz, age=age, fert_age=fert)
@@ -230,9 +232,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: N=%d uniform cloud, 16^3 cells x 5.0, 27-cell cutoff gravity "
+            "config": {"workload": "BASELINE configs[2]: N=%d uniform cloud, %d^3 cells x 5.0, 27-cell cutoff gravity "
                                    "+ reference collisions/integrate/wrap/relocation, all constants at reference defaults, "
-                                   "%s" % (args.n, "free-running" if args.evolve else "each step = one pass over the same cloud (restored in HBM)"),
+                                   "%s" % (args.n, G, "free-running" if args.evolve else "each step = one pass over the same cloud (restored in HBM)"),
                        "arithmetic": "fast-math" if args.fast_math else "reference-exact fp32 (bitwise parity mode)",
                        "parallelism": "pair loop sharded x%d + RCCL all-gather of float4 results" % world if world > 1 else "single GPU",
                        "updates_in_timed_region": updates, "live_after": live,

@@ -386,7 +386,14 @@ int psamd_uniform_cloud(const psamd_ctx *c, int64_t n, uint32_t seed, float *xyz
     const float half = (float)((c->geo.G / 2) * c->geo.cfg.cell_size);
     std::mt19937 gen(seed);
     std::uniform_real_distribution<float> dist(-half, half);
-    for (int64_t i = 0; i < 3 * n; i++) xyz[i] = dist(gen);
+    for (int64_t i = 0; i < n; i++) {
+        // a draw can land exactly on a face that belongs to the neighbouring (missing)
+        // cell: -half on the negated axes y and z, +half (float rounding) on x; draw again
+        int cell;
+        do {
+            xyz[3 * i] = dist(gen); xyz[3 * i + 1] = dist(gen); xyz[3 * i + 2] = dist(gen);
+        } while (!c->geo.locate(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], cell));
+    }
     return PSAMD_OK;
 }
 

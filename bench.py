@@ -162,11 +162,19 @@ def main():
 
     force = None
     if use_dist:
+        # One explicit (non-default) stream carries the stage kernels AND is the stream
+        # RCCL orders its collectives against, so pair pass -> all-gather -> apply are
+        # ordered by the stream alone.  (The legacy default stream has handle 0, which
+        # psamd_set_stream reads as "use the context's own stream": never pass it.)
         torch.cuda.set_device(local_rank)
+        stream = torch.cuda.Stream(device=local_rank)
+        torch.cuda.set_stream(stream)
+        assert stream.cuda_stream != 0
         cap = g.sizes.container_size + world
         force = torch.zeros((cap, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
         g.bind_force4(force.data_ptr(), cap)
-        g.set_stream(torch.cuda.current_stream().cuda_stream)
+        g.set_stream(stream.cuda_stream)
 
     g.snapshot_save()
 

@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--chunk-dim", type=int, default=4)
     ap.add_argument("--evolve", action="store_true", help="free-running steps instead of one pass per step over the same cloud")
     ap.add_argument("--force-dist", action="store_true", help="take the collective code path even with one rank (rehearsal)")
+    ap.add_argument("--sim-world", type=int, default=0, help="diagnostic: time ONE rank's work of an N-rank run on one GPU "
+                    "(its pair shard + the replicated stages; no collective, results are not valid physics)")
+    ap.add_argument("--sim-rank", type=int, default=0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,7 +157,8 @@ def main():
     cfg_over = dict(chunk_factor=args.chunk_factor, chunk_dim=args.chunk_dim,
                     max_particles_num=max(args.n, 1 << 20))
     flags = ps.FLAG_FAST_MATH if args.fast_math else 0
-    cfg = ps.default_config(device=local_rank, rank=rank, world=world, flags=flags, **cfg_over)
+    cfg = ps.default_config(device=local_rank, rank=args.sim_rank if args.sim_world else rank,
+                            world=args.sim_world if args.sim_world else world, flags=flags, **cfg_over)
     g = ps.ParticleSystem(cfg)
     xyz, age, fert = make_inputs(ps, g, args.n, args.seed)
     g.fill_particles(xyz, age=age, fert_age=fert)
@@ -181,6 +185,9 @@ def main():
     def one_step():
         if not args.evolve:
             g.snapshot_restore()
+        if args.sim_world:
+            g.init_iframe(); g.build_grid(); g.force_shard(); g.calc_forces_pairs(); g.calc_forces_apply()
+            return
         if not use_dist:
             g.step(1)
             return

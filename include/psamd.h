@@ -204,6 +204,10 @@ int psamd_device_view_get(psamd_ctx *ctx, psamd_device_view *out);
 /* Per-kernel device time of the most recent step in microseconds, measured with
  * HIP events on the context's stream: hist, scan, scatter, sort, pairs, apply,
  * lifecycle.  Enabled by psamd_set_timing(ctx, 1). */
+/* Diagnostic builds (-DPSAMD_WAVE_TRACE) record per pair-kernel wave: start, end
+ * (100 MHz real-time counter) and hardware id; 3 words per wave slot.  Zeros otherwise. */
+int psamd_debug_wave_trace(psamd_ctx *ctx, uint64_t *out, int64_t n_words);
+
 /* Exhaustive check of the hand-written correctly rounded fp32 sqrt / reciprocal used by
  * the pair kernel against the compiler's forms, over every float with bit pattern in
  * [lo_bits, hi_bits].  out24[0..4] = mismatches of sqrt, rcp(1 step), rcp(2 steps),

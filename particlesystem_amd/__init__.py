@@ -118,6 +118,7 @@ ABI = [
     ("psamd_get_counters", C.c_int, [_vp, C.POINTER(Counters)]),
     ("psamd_live_count", C.c_int, [_vp, C.POINTER(_i64)]),
     ("psamd_device_view_get", C.c_int, [_vp, C.POINTER(DeviceView)]),
+    ("psamd_debug_wave_trace", C.c_int, [_vp, _vp, _i64]),
     ("psamd_selftest_math", C.c_int, [_vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("psamd_set_timing", C.c_int, [_vp, C.c_int]),
     ("psamd_get_timing", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
@@ -333,6 +334,12 @@ class ParticleSystem:
         v = DeviceView()
         self._ck(self.lib.psamd_device_view_get(self.h, C.byref(v)))
         return v
+
+    def wave_trace(self):
+        n = 3 * (self.sizes.num_cells * ((self.sizes.max_per_cell + 63) // 64) + 4)
+        out = np.zeros(n, np.uint64)
+        self._ck(self.lib.psamd_debug_wave_trace(self.h, _ptr(out), n))
+        return out.reshape(-1, 3)
 
     def selftest_math(self, lo_bits, hi_bits):
         out = (C.c_uint64 * 24)()

@@ -25,6 +25,7 @@ def needs_build():
 
 
 def build(force=False, verbose=False, extra=()):
+    extra = list(extra) + os.environ.get("PSAMD_EXTRA_FLAGS", "").split()
     if not force and not needs_build():
         return LIB
     cmd = [HIPCC] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]

@@ -278,6 +278,8 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.fs, 1));
     PS_HIP(c, dev_alloc(c, &d.cell_start, (size_t)g.num_cells + 1));
     PS_HIP(c, dev_alloc(c, &d.cursor, (size_t)g.num_cells));
+    PS_HIP(c, dev_alloc(c, &d.task_start, (size_t)g.num_cells + 1));
+    PS_HIP(c, dev_alloc(c, &d.task_list, (size_t)g.num_cells * P.slices));
     PS_HIP(c, dev_alloc(c, &d.sorted_id, C));
     PS_HIP(c, dev_alloc(c, &d.rank_of_slot, C));
     PS_HIP(c, dev_alloc(c, &d.snap4, C));
@@ -295,6 +297,8 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.moves, (size_t)d.moves_cap));
     PS_HIP(c, dev_alloc(c, &d.stage, 3 * (size_t)d.moves_cap));
     PS_HIP(c, dev_alloc(c, &d.ctr, (size_t)COUNTER_COPIES));
+    PS_HIP(c, dev_alloc(c, &d.trace, 3 * ((size_t)g.num_cells * P.slices + 4)));
+    PS_HIP(c, hipMemsetAsync(d.trace, 0, 3 * ((size_t)g.num_cells * P.slices + 4) * sizeof(unsigned long long), c->stream));
 
     // From which squared distance on is the fp32 add of EPS2 bit-identical to the
     // reference's double add?  Try a few candidates, each checked on the device for
@@ -653,7 +657,7 @@ int psamd_calc_forces_pairs(psamd_ctx *c)
         lo = (int)b; hi = (int)e; covered = (int)std::min<int64_t>(s * c->geo.cfg.world, INT32_MAX);
     }
     if (c->timing) (void)hipEventRecord(c->ev[5], c->stream);
-    PS_HIP(c, launch_pairs(c->stream, c->P, c->d, lo, hi, covered));
+    PS_HIP(c, launch_pairs(c->stream, c->P, c->d, lo, hi, covered, c->geo.cfg.world > 1));
     if (c->timing) (void)hipEventRecord(c->ev[6], c->stream);
     c->pairs_done = true;
     return PSAMD_OK;
@@ -845,6 +849,15 @@ int psamd_bind_force4(psamd_ctx *c, void *device_ptr, int64_t n_float4)
     if (device_ptr && n_float4 < c->geo.container) return fail(c, PSAMD_ERR_INVALID_ARG, "force4 buffer smaller than the container");
     PS_HIP(c, hipStreamSynchronize(c->stream));
     c->d.force4 = device_ptr ? (float4 *)device_ptr : c->own_force4;
+    return PSAMD_OK;
+}
+
+int psamd_debug_wave_trace(psamd_ctx *c, uint64_t *out, int64_t n_words)
+{
+    if (!c || !out) return PSAMD_ERR_INVALID_ARG;
+    const int64_t have = 3 * ((int64_t)c->geo.num_cells * c->P.slices + 4);
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    PS_HIP(c, hipMemcpy(out, c->d.trace, (size_t)std::min(have, n_words) * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return PSAMD_OK;
 }
 

@@ -51,7 +51,9 @@ struct FrameScalars {
     int32_t n_ops;          // queue operations emitted by apply   \ allocated together as one
     int32_t n_moves;        // relocation / birth records emitted  / 64-bit word (ops low)
     int32_t max_bucket;     // most queue operations any one segment received this step
-    int32_t pad;
+    int32_t n_tasks;        // non-empty (cell, slice) tasks of the pair kernel this frame
+    int32_t shard_task_lo;  // first pair-kernel task (cell * slices) of this rank's share
+    int32_t shard_task_n;   // number of tasks from there that can hold a particle of the share
 };
 
 // Cumulative event counters, mirrors psamd_counters.  Kept in COUNTER_COPIES copies on

@@ -33,6 +33,8 @@ struct DeviceState {
     FrameScalars *fs = nullptr;
     int *cell_start = nullptr;    // [num_cells+1]
     int *cursor = nullptr;        // [num_cells]
+    int *task_start = nullptr;    // [num_cells+1] prefix of 64-particle slices per cell
+    int *task_list = nullptr;     // [num_cells * slices] non-empty (cell, slice) tasks, cell-major
     int *sorted_id = nullptr;     // [container] cell-major, id ascending inside a cell
     int *rank_of_slot = nullptr;  // [container] inverse of sorted_id for the slots of this frame
     float4 *snap4 = nullptr;      // [container] sorted order: x,y,z,w_eff
@@ -52,6 +54,7 @@ struct DeviceState {
     int moves_cap = 0;
     float4 *stage = nullptr;      // 3 float4 per move
     DevCounters *ctr = nullptr;
+    unsigned long long *trace = nullptr;  // 3 words per pair-kernel wave slot (diagnostic builds only)
 };
 
 hipError_t launch_unpack_aos(hipStream_t st, const void *aos, int first, int count, const DeviceState &d);
@@ -66,7 +69,8 @@ hipError_t launch_init_tdata(hipStream_t st, const DeviceState &d, int n);
 // ev (optional) = 5 events recorded before hist, scan, scatter, sort and after sort
 hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev);
 // lo/hi: this rank's sorted range; covered = world * share (all ranks' ranges together)
-hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi, int covered);
+hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi, int covered,
+                        bool sharded);
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step,
                         int live_bound);
 // after apply, before the per-step read-back: ops per queue record, their prefix and maximum

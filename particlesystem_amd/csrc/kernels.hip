@@ -21,6 +21,8 @@
 // Citations: ps.cpp = source/code/src/particleSystem.cpp of the reference.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device_types.h"
 #include "geometry.hpp"
 #include "kernels.h"
@@ -189,12 +191,14 @@ __global__ __launch_bounds__(1024) void k_scatter_lds(const int *__restrict__ ce
 // totals and hostGridMax (ps.cpp:1504-1516: maxima are of stored entries, so capped).
 __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restrict__ cell_count,
                                                 int *__restrict__ cell_start, int *__restrict__ cursor,
-                                                int *__restrict__ chunk_count,
+                                                int *__restrict__ task_start, int *__restrict__ chunk_count,
                                                 const CellInfo *__restrict__ celltab, FrameScalars *fs)
 {
+    // two prefix sums at once, packed in 64 bits: particles per cell (low word) and
+    // 64-particle pair-kernel tasks per cell (high word)
     constexpr int LDS_CHUNKS = 4096;
-    __shared__ int wave_tot[16];
-    __shared__ int carry_s;
+    __shared__ long long wave_tot[16];
+    __shared__ long long carry_s;
     __shared__ int maxcell_s;
     __shared__ int chunk_s[LDS_CHUNKS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -207,34 +211,38 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
         const int c = base + tid;
         const int v = (c < P.num_cells) ? cell_count[c] : 0;
         mymax = max(mymax, min(v, P.max_per_cell));
-        int incl = v;
+        const long long both = ((long long)((min(v, P.max_per_cell) + 63) >> 6) << 32) | (long long)v;
+        long long incl = both;
         for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d);
+            const long long o = __shfl_up(incl, d);
             if (lane >= d) incl += o;
         }
         if (lane == 63) wave_tot[wv] = incl;
         __syncthreads();
-        int woff = 0;
+        long long woff = 0;
         for (int k = 0; k < wv; k++) woff += wave_tot[k];
-        const int carry = carry_s;
-        const int excl = carry + woff + incl - v;
+        const long long excl2 = carry_s + woff + incl - both;
+        const int excl = (int)(excl2 & 0xffffffffll);
         if (c < P.num_cells) {
             cell_start[c] = excl;
             cursor[c] = excl;
+            task_start[c] = (int)(excl2 >> 32);
             if (v > 0) {
                 if (chunks_in_lds) atomicAdd(&chunk_s[celltab[c].chunk], v);
                 else atomicAdd(&chunk_count[celltab[c].chunk], v);
             }
         }
         __syncthreads();
-        if (tid == 1023) carry_s = excl + v;
+        if (tid == 1023) carry_s = excl2 + both;
         __syncthreads();
     }
     atomicMax(&maxcell_s, mymax);
     __syncthreads();
     if (tid == 0) {
-        cell_start[P.num_cells] = carry_s;
-        fs->live = carry_s;
+        cell_start[P.num_cells] = (int)(carry_s & 0xffffffffll);
+        task_start[P.num_cells] = (int)(carry_s >> 32);
+        fs->live = (int)(carry_s & 0xffffffffll);
+        fs->n_tasks = (int)(carry_s >> 32);
         fs->gridmax[1] = maxcell_s;
     }
     // chunk totals are complete once every thread passed the loop's last barrier
@@ -262,6 +270,15 @@ __global__ void k_scatter(const int *__restrict__ cell, int *__restrict__ cursor
         const int c = cell[i];
         if (c >= 0 && c < num_cells) sorted_id[atomicAdd(&cursor[c], 1)] = i;
     }
+}
+
+// the pair kernel's work list: one entry per non-empty (cell, 64-particle slice)
+__global__ void k_build_tasks(DevParams P, const int *__restrict__ task_start, int *__restrict__ task_list)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.num_cells) return;
+    const int t0 = task_start[c], n = task_start[c + 1] - t0;
+    for (int s = 0; s < n; s++) task_list[t0 + s] = c * P.slices + s;
 }
 
 // One workgroup per cell.  The scatter left the cell's ids in arrival order; the
@@ -551,23 +568,64 @@ __device__ __forceinline__ void pair1_exact_lean(const DevParams &P, const PairC
     ax += rx * s; ay += ry * s; az += rz * s;
 }
 
+// Which entries of the task list can hold a particle with sorted index in [lo, hi)?  The
+// list is cell-major, so it is the run belonging to the cells between the cell of `lo` and
+// the cell of `hi - 1`.  One tiny launch per step on a sharded rank.
+__global__ void k_shard_tasks(DevParams P, const int *__restrict__ cell_start, const int *__restrict__ task_start,
+                              int lo, int hi, FrameScalars *fs)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int total = cell_start[P.num_cells];
+    lo = min(lo, total); hi = min(hi, total);
+    if (hi <= lo) { fs->shard_task_lo = 0; fs->shard_task_n = 0; return; }
+    auto cell_of = [&](int gi) {          // largest c with cell_start[c] <= gi
+        int a = 0, b = P.num_cells - 1;
+        while (a < b) { const int m = (a + b + 1) >> 1; if (cell_start[m] <= gi) a = m; else b = m - 1; }
+        return a;
+    };
+    const int c_lo = cell_of(lo), c_hi = cell_of(hi - 1);
+    fs->shard_task_lo = task_start[c_lo];
+    fs->shard_task_n = task_start[c_hi + 1] - task_start[c_lo];
+}
+
 // One wave (one 64-thread workgroup) = 64 consecutive particles of one cell.
 // Neighbour cells are visited in the reference's stencil order and their snapshot is
 // streamed through a 1 KiB LDS tile; every lane reads the same tile entry (broadcast)
 // and adds it to its own particle's sum, so each particle sees exactly the
 // reference's sequence of fp32 additions (ps.cpp:1247-1259).
 // MODE 0: exact, compiler's sqrt/div; 1: exact, lean sqrt/rcp; 2: fast math
-template <int MODE>
-__global__ __launch_bounds__(64) void k_pairs(DevParams P, const int *__restrict__ cell_start,
+// no s_barrier: a wave only ever touches its own LDS tile, and a wave's LDS operations
+// complete in issue order, so a compiler-level fence is all the ordering it needs
+#define PS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+template <int MODE, bool SHARDED>
+__global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restrict__ cell_start,
                                                const float4 *__restrict__ snap4,
                                                const float *__restrict__ snap_age,
                                                const int *__restrict__ sorted_id,
+                                               const int *__restrict__ task_list,
                                                float4 *__restrict__ force4, int lo, int hi, int covered,
-                                               FrameScalars *fs)
+                                               FrameScalars *fs, unsigned long long *trace)
 {
-    __shared__ float4 tile[64];
+    // Workgroups of four INDEPENDENT waves (no workgroup barrier anywhere): the hardware
+    // deals a workgroup's waves over the four SIMDs of its CU and workgroups over the
+    // CUs, which keeps even a small share (a few waves per CU) evenly spread.
+    __shared__ float4 tiles[4][64];
+    const int wave = threadIdx.x >> 6;
+    float4 *tile = tiles[wave];
     if (blockIdx.x == 0 && threadIdx.x == 0 && cell_start[P.num_cells] > covered) atomicOr(&fs->error, ERR_SHARD_BOUND);
-    const int task = xcd_contiguous(blockIdx.x, gridDim.x);
+    // The work list holds only non-empty (cell, slice) tasks; the first `ntask` workgroups
+    // take one each (so the dispatcher deals the real work evenly over the CUs), spread
+    // over all eight XCDs with each XCD walking a contiguous run of cells.
+    const int ntask = SHARDED ? fs->shard_task_n : fs->n_tasks;
+    const int nwg = (ntask + 3) >> 2;
+    if ((int)blockIdx.x >= nwg) return;
+    const int slot = xcd_contiguous(blockIdx.x, nwg) * 4 + wave;
+    if (slot >= ntask) return;
+    const int task = task_list[(SHARDED ? fs->shard_task_lo : 0) + slot];
+#ifdef PSAMD_WAVE_TRACE
+    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int c = task / P.slices, slice = task - c * P.slices;
     const int base = cell_start[c];
     const int cnt = min(cell_start[c + 1] - base, P.max_per_cell);
@@ -577,7 +635,7 @@ __global__ __launch_bounds__(64) void k_pairs(DevParams P, const int *__restrict
     const int gi0 = base + first;
     if (gi0 + nvalid <= lo || gi0 >= hi) return;   // another rank's share
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const bool valid = lane < nvalid;
     const int gi = gi0 + (valid ? lane : 0);
     const float4 me = snap4[gi];
@@ -593,35 +651,54 @@ __global__ __launch_bounds__(64) void k_pairs(DevParams P, const int *__restrict
     int flag = 0;
     const float eps2f = (float)P.eps2;
 
-    for (int k = 0; k < 27; k++) {
-        const int n2 = i2 + c_stencil[k][0], n1 = i1 + c_stencil[k][1], n3 = i3 + c_stencil[k][2];
-        if (n1 < 0 || n1 >= G || n2 < 0 || n2 >= G || n3 < 0 || n3 >= G) continue;
-        const int nc = n3 * G * G + n1 * G + n2;
-        const int nb = cell_start[nc];
-        const int ncnt = min(cell_start[nc + 1] - nb, P.max_per_cell);
-        for (int t0 = 0; t0 < ncnt; t0 += 64) {
-            const int n = min(64, ncnt - t0);
-            __syncthreads();                      // previous tile fully consumed
-            if (lane < n) tile[lane] = snap4[nb + t0 + lane];
-            __syncthreads();
+    // Lane k (< 27) looks up neighbour cell k of the stencil once: its range in the
+    // sorted order, or an empty range if it lies outside the grid.
+    int my_nb = 0, my_cnt = 0;
+    if (lane < 27) {
+        const int n2 = i2 + c_stencil[lane][0], n1 = i1 + c_stencil[lane][1], n3 = i3 + c_stencil[lane][2];
+        if (n1 >= 0 && n1 < G && n2 >= 0 && n2 < G && n3 >= 0 && n3 < G) {
+            const int nc = n3 * G * G + n1 * G + n2;
+            my_nb = cell_start[nc];
+            my_cnt = min(cell_start[nc + 1] - my_nb, P.max_per_cell);
+        }
+    }
+    // Tiles of 64 snapshot entries, in stencil order then list order.  The next tile's
+    // global load is issued before the current tile is consumed, so its latency hides
+    // behind ~64 x 32 VALU instructions even when only a couple of waves share a SIMD.
+    int k = 0, t0 = 0;
+    int nb = __shfl(my_nb, 0), ncnt = __shfl(my_cnt, 0);
+    while (ncnt == 0 && ++k < 27) { nb = __shfl(my_nb, k); ncnt = __shfl(my_cnt, k); }
+    bool have = k < 27;
+    float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (have && lane < min(64, ncnt)) pre = snap4[nb + lane];
+    while (have) {
+        const int c_nb = nb, c_t0 = t0, n = min(64, ncnt - t0);
+        PS_WAVE_SYNC();                           // previous tile fully consumed
+        if (lane < n) tile[lane] = pre;
+        t0 += 64;                                 // advance to the next non-empty tile
+        if (t0 >= ncnt) {
+            t0 = 0; ncnt = 0;
+            while (ncnt == 0 && ++k < 27) { nb = __shfl(my_nb, k); ncnt = __shfl(my_cnt, k); }
+        }
+        have = k < 27;
+        if (have && lane < min(64, ncnt - t0)) pre = snap4[nb + t0 + lane];
+        PS_WAVE_SYNC();
+        if (MODE == 1) {
+            const PairCtx ctx = {me.x, me.y, me.z, age_i, id_i, gi, scan};
+            int jj = 0;
+            for (; jj + 4 <= n; jj += 4)
+                pairs4_exact_lean(P, ctx, tile[jj], tile[jj + 1], tile[jj + 2], tile[jj + 3], c_nb + c_t0 + jj,
+                                  snap_age, sorted_id, ax, ay, az, flag);
+            for (; jj < n; jj++)
+                pair1_exact_lean(P, ctx, tile[jj], c_nb + c_t0 + jj, snap_age, sorted_id, ax, ay, az, flag);
+        } else {
             float dmin = 3.0e38f;
-            if (MODE == 1) {
-                const PairCtx ctx = {me.x, me.y, me.z, age_i, id_i, gi, scan};
-                int jj = 0;
-                for (; jj + 4 <= n; jj += 4)
-                    pairs4_exact_lean(P, ctx, tile[jj], tile[jj + 1], tile[jj + 2], tile[jj + 3], nb + t0 + jj,
-                                      snap_age, sorted_id, ax, ay, az, flag);
-                for (; jj < n; jj++)
-                    pair1_exact_lean(P, ctx, tile[jj], nb + t0 + jj, snap_age, sorted_id, ax, ay, az, flag);
-                continue;                         // collisions were handled inline
-            } else {
 #pragma unroll 4
-                for (int jj = 0; jj < n; jj++) {
-                    const float4 q = tile[jj];
-                    const float d2 = MODE == 2 ? pair_fast(me.x, me.y, me.z, q, eps2f, ax, ay, az)
-                                               : pair_exact(me.x, me.y, me.z, q, P.eps2, ax, ay, az);
-                    dmin = fminf(dmin, d2);
-                }
+            for (int jj = 0; jj < n; jj++) {
+                const float4 q = tile[jj];
+                const float d2 = MODE == 2 ? pair_fast(me.x, me.y, me.z, q, eps2f, ax, ay, az)
+                                           : pair_exact(me.x, me.y, me.z, q, P.eps2, ax, ay, az);
+                dmin = fminf(dmin, d2);
             }
             // rare: someone in this tile is within the collision gate of one of my lanes
             if (__any(scan && !(dmin > P.coll_d2_gate))) {
@@ -630,7 +707,7 @@ __global__ __launch_bounds__(64) void k_pairs(DevParams P, const int *__restrict
                         const float4 q = tile[jj];
                         const float rx = q.x - me.x, ry = q.y - me.y, rz = q.z - me.z;
                         const float d2 = rx * rx + ry * ry + rz * rz;
-                        const int gj = nb + t0 + jj;
+                        const int gj = c_nb + c_t0 + jj;
                         if (!(d2 > P.coll_d2_gate) && gj != gi)
                             flag = max(flag, collide_exact(P, d2, age_i, id_i, snap_age[gj], sorted_id[gj]));
                     }
@@ -641,6 +718,14 @@ __global__ __launch_bounds__(64) void k_pairs(DevParams P, const int *__restrict
     if (dead) flag = 2;
     if (kid) { ax = 0.f; ay = 0.f; az = 0.f; }   // every term is skipped for a kid (app_common.cu:240)
     if (valid && gi >= lo && gi < hi) force4[gi] = make_float4(ax, ay, az, __int_as_float(flag));
+#ifdef PSAMD_WAVE_TRACE
+    if (lane == 0) {   // diagnostic build only: when and where did this wave run
+        unsigned long long *t = trace + (size_t)3 * (blockIdx.x * 4 + wave);
+        t[0] = trace_t0; t[1] = __builtin_amdgcn_s_memrealtime();
+        t[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32)   // XCC_ID
+               | __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);                             // HW_ID
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ apply
@@ -1334,7 +1419,9 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     else k_hist<<<nb, 256, 0, st>>>(d.cell, d.cell_count, P.container, P.num_cells);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[1], st);
-    k_scan<<<1, 1024, 0, st>>>(P, d.cell_count, d.cell_start, d.cursor, d.chunk_count, d.celltab, d.fs);
+    k_scan<<<1, 1024, 0, st>>>(P, d.cell_count, d.cell_start, d.cursor, d.task_start, d.chunk_count, d.celltab, d.fs);
+    PS_LAUNCH_CHECK();
+    k_build_tasks<<<(P.num_cells + 255) / 256, 256, 0, st>>>(P, d.task_start, d.task_list);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[2], st);
     if (lds) k_scatter_lds<<<nwg, 1024, 0, st>>>(d.cell, d.cursor, d.sorted_id, P.container, P.num_cells);
@@ -1348,17 +1435,28 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     return hipSuccess;
 }
 
-hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi, int covered)
+template <int MODE>
+static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi,
+                                    int covered, bool sharded)
 {
     const int tasks = P.num_cells * P.slices;
-    if (P.flags & PSAMD_FLAG_FAST_MATH)
-        k_pairs<2><<<tasks, 64, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.force4, lo, hi, covered, d.fs);
-    else if (P.lean_math)
-        k_pairs<1><<<tasks, 64, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.force4, lo, hi, covered, d.fs);
-    else
-        k_pairs<0><<<tasks, 64, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.force4, lo, hi, covered, d.fs);
-    PS_LAUNCH_CHECK();
-    return hipSuccess;
+    if (sharded) {
+        k_shard_tasks<<<1, 64, 0, st>>>(P, d.cell_start, d.task_start, lo, hi, d.fs);
+        k_pairs<MODE, true><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.task_list, d.force4,
+                                                   lo, hi, covered, d.fs, d.trace);
+    } else {
+        k_pairs<MODE, false><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.task_list, d.force4,
+                                                    lo, hi, covered, d.fs, d.trace);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi, int covered,
+                        bool sharded)
+{
+    if (P.flags & PSAMD_FLAG_FAST_MATH) return launch_pairs_mode<2>(st, P, d, lo, hi, covered, sharded);
+    if (P.lean_math) return launch_pairs_mode<1>(st, P, d, lo, hi, covered, sharded);
+    return launch_pairs_mode<0>(st, P, d, lo, hi, covered, sharded);
 }
 
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step,

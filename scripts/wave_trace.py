@@ -1,0 +1,33 @@
+"""Diagnostic: per-wave timeline of the pair kernel for one simulated rank.
+Build first with PSAMD_EXTRA_FLAGS=-DPSAMD_WAVE_TRACE python particlesystem_amd/build.py --force"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import particlesystem_amd as ps
+world, rank = int(sys.argv[1]), int(sys.argv[2])
+n = 1 << 20
+g = ps.ParticleSystem(ps.default_config(rank=rank, world=world))
+xyz = g.uniform_cloud(n, 2026)
+age = np.random.default_rng(2026).uniform(15 / 7, 7.5, n).astype(np.float32)
+g.fill_particles(xyz, age=age, fert_age=np.full(n, 1e6, np.float32))
+g.snapshot_save()
+for _ in range(3):
+    g.snapshot_restore(); g.init_iframe(); g.build_grid()
+    if world > 1: g.force_shard()
+    g.calc_forces_pairs(); g.calc_forces_apply()
+g.synchronize()
+t = g.wave_trace()
+t = t[t[:, 1] > 0]
+t0 = t[:, 0].min()
+start = (t[:, 0] - t0) / 100.0   # us
+dur = (t[:, 1] - t[:, 0]) / 100.0
+hw = t[:, 2] & 0xffffffff
+xcc = t[:, 2] >> 32
+cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 0x3
+where = (xcc.astype(np.int64) << 12) | (se.astype(np.int64) << 8) | (sh.astype(np.int64) << 6) | (cu.astype(np.int64) << 2) | simd.astype(np.int64)
+print("waves", len(t), "kernel span us %.1f" % ((t[:, 1].max() - t0) / 100.0))
+print("start us: min %.1f p50 %.1f p99 %.1f max %.1f" % (start.min(), np.median(start), np.percentile(start, 99), start.max()))
+print("dur us: min %.1f p50 %.1f p99 %.1f max %.1f" % (dur.min(), np.median(dur), np.percentile(dur, 99), dur.max()))
+u, cnt = np.unique(where, return_counts=True)
+print("distinct SIMDs used", len(u), "waves per SIMD: min %d p50 %d max %d" % (cnt.min(), np.median(cnt), cnt.max()))
+print("distinct CUs", len(np.unique(where >> 2)), "XCCs", np.unique(xcc))

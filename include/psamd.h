@@ -210,10 +210,9 @@ int psamd_debug_wave_trace(psamd_ctx *ctx, uint64_t *out, int64_t n_words);
 
 /* Exhaustive check of the hand-written correctly rounded fp32 sqrt / reciprocal used by
  * the pair kernel against the compiler's forms, over every float with bit pattern in
- * [lo_bits, hi_bits].  out24[0..4] = mismatches of sqrt, rcp(1 step), rcp(2 steps),
- * rcp(3-step form), rcp(the one in use); [5..7] = mismatches of RN(1/RN(sqrt x)) built on
- * the refined rsq estimate (1 step, 2 steps) and of the form the pair kernel uses;
- * [8..15], [16..23] = first offending inputs of the sqrt and of the form in use. */
+ * [lo_bits, hi_bits].  out24[0..2] = mismatches of the sqrt, the reciprocal and their
+ * composition RN(1/RN(sqrt x)) as used; [3] = mismatches of a rejected shortcut (for the
+ * record); [8..15], [16..23] = first offending inputs of the sqrt and the composition. */
 int psamd_selftest_math(psamd_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t out24[24]);
 #define PSAMD_NUM_TIMERS 8
 int psamd_set_timing(psamd_ctx *ctx, int enabled);

@@ -356,105 +356,47 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
 // ------------------------------------------------------------------ pair kernel
 // Correctly rounded fp32 sqrt and reciprocal without the range/denormal scaffolding
 // the compiler wraps around them: valid for normal inputs well inside the exponent
-// range (the host only selects them when eps2^3 .. (3 L^2 + eps2)^3 lies in
-// [2^-60, 2^60]).  Both are checked against the compiler's correctly rounded forms
-// over EVERY float of that range by psamd_selftest_math (tests/test_gpu_math.py).
-__device__ __forceinline__ float sqrt_rn_lean(float a)
-{
-    const float r = __builtin_amdgcn_rsqf(a);
-    float g = a * r;
-    float h = 0.5f * r;
-    const float e = __builtin_fmaf(-h, g, 0.5f);
-    h = __builtin_fmaf(h, e, h);
-    g = __builtin_fmaf(g, e, g);
-    const float d = __builtin_fmaf(-g, g, a);
-    return __builtin_fmaf(d, h, g);
-}
-
-// the same without the Goldschmidt refinement of (g, h): one residual correction only
+// range (the host only selects them when eps2^3 .. (3 (2L)^2 + eps2)^3 lies in
+// [2^-60, 2^60]).  Each is one hardware estimate (v_rsq_f32 / v_rcp_f32, 1 ulp) plus
+// one residual correction, and each is checked against the compiler's correctly
+// rounded form over EVERY float of [2^-62, 2^62] by psamd_selftest_math
+// (tests/test_gpu_math.py): zero mismatches.
 __device__ __forceinline__ float sqrt_rn_short(float a)
 {
     const float r = __builtin_amdgcn_rsqf(a);
-    const float g = a * r;
-    const float h = 0.5f * r;
-    const float d = __builtin_fmaf(-g, g, a);
+    const float g = a * r;                      // ~sqrt(a)
+    const float h = 0.5f * r;                   // ~1 / (2 sqrt(a))
+    const float d = __builtin_fmaf(-g, g, a);   // exact residual
     return __builtin_fmaf(d, h, g);
 }
 
-template <int ITER>
-__device__ __forceinline__ float rcp_rn_lean(float q)
+__device__ __forceinline__ float rcp_rn_newton(float q)
 {
-    float x = __builtin_amdgcn_rcpf(q);
-#pragma unroll
-    for (int k = 0; k < ITER; k++) {
-        const float e = __builtin_fmaf(-q, x, 1.0f);
-        x = __builtin_fmaf(e, x, x);
-    }
-    return x;
+    const float x = __builtin_amdgcn_rcpf(q);
+    const float e = __builtin_fmaf(-q, x, 1.0f);
+    return __builtin_fmaf(e, x, x);
 }
 
-// the compiler's division sequence without div_scale / div_fixup (exponent handling)
-__device__ __forceinline__ float rcp_rn_markstein(float d)
+// RN(1 / RN(sqrt(a))): the reference's 1.0f / sqrtf(a), two roundings.
+__device__ __forceinline__ float inv_sqrt_selected(float six)
 {
-    const float r = __builtin_amdgcn_rcpf(d);
-    const float e0 = __builtin_fmaf(-d, r, 1.0f);
-    const float y1 = __builtin_fmaf(e0, r, r);
-    const float r0 = __builtin_fmaf(-d, y1, 1.0f);
-    const float q1 = __builtin_fmaf(r0, y1, y1);
-    const float r1 = __builtin_fmaf(-d, q1, 1.0f);
-    return __builtin_fmaf(r1, y1, q1);
+    return rcp_rn_newton(sqrt_rn_short(six));
 }
 
-// RN(1 / RN(sqrt(a))) -- the reference's two roundings -- with the reciprocal's Newton
-// iteration started from the rsq estimate the square root already refined (2h ~ 1/g)
-// instead of a second transcendental.
-template <int NR>
-__device__ __forceinline__ float inv_sqrt_rn2_via_h(float a)
+// A tempting shortcut that is NOT exact, kept only so the self test can show it: start
+// the reciprocal's Newton step from the rsq estimate (2h ~ 1/g) instead of a second
+// transcendental.  124 of the 1.04e9 floats in range come out one ulp off.
+__device__ __forceinline__ float inv_sqrt_one_transcendental(float a)
 {
     const float r = __builtin_amdgcn_rsqf(a);
-    float g = a * r;
-    float h = 0.5f * r;
+    float g = a * r, h = 0.5f * r;
     const float e = __builtin_fmaf(-h, g, 0.5f);
     h = __builtin_fmaf(h, e, h);
     g = __builtin_fmaf(g, e, g);
-    const float d = __builtin_fmaf(-g, g, a);
-    const float q = __builtin_fmaf(d, h, g);          // RN(sqrt(a))
+    const float q = __builtin_fmaf(__builtin_fmaf(-g, g, a), h, g);
     float x = h + h;
-#pragma unroll
-    for (int k = 0; k < NR; k++) {
-        const float e2 = __builtin_fmaf(-q, x, 1.0f);
-        x = __builtin_fmaf(e2, x, x);
-    }
+    for (int k = 0; k < 2; k++) x = __builtin_fmaf(__builtin_fmaf(-q, x, 1.0f), x, x);
     return x;
-}
-
-#ifndef PSAMD_INV_VARIANT
-#define PSAMD_INV_VARIANT 0
-#endif
-
-#ifndef PSAMD_RCP_VARIANT
-#define PSAMD_RCP_VARIANT 1
-#endif
-__device__ __forceinline__ float rcp_rn_selected(float q)
-{
-#if PSAMD_RCP_VARIANT == 1
-    return rcp_rn_lean<1>(q);
-#elif PSAMD_RCP_VARIANT == 2
-    return rcp_rn_lean<2>(q);
-#else
-    return rcp_rn_markstein(q);
-#endif
-}
-
-__device__ __forceinline__ float inv_sqrt_selected(float six)
-{
-#if PSAMD_INV_VARIANT == 1
-    return inv_sqrt_rn2_via_h<1>(six);
-#elif PSAMD_INV_VARIANT == 2
-    return inv_sqrt_rn2_via_h<2>(six);
-#else
-    return rcp_rn_selected(sqrt_rn_short(six));
-#endif
 }
 
 // bodyBodyInteraction, app_common.cu:236-267, for a snapshot body q = (x,y,z,w_eff).
@@ -1289,38 +1231,34 @@ __global__ void k_moves_commit(DevParams P, int step, const MoveRec *__restrict_
 }
 
 // ------------------------------------------------------------------ self test
-// Compare the lean sqrt / reciprocal with the compiler's correctly rounded forms on
-// every float whose bit pattern lies in [lo_bits, hi_bits].  out[0..4] = mismatch
-// counts of sqrt, rcp<1>, rcp<2>, markstein rcp, selected rcp; out[5..] = first few
-// offending bit patterns of the selected pair.  (out has 26 words: 24 + 2 cursors)
+// Compare the hand-written sqrt / reciprocal with the compiler's correctly rounded forms
+// on every float whose bit pattern lies in [lo_bits, hi_bits].  out[0..3] = mismatch
+// counts of sqrt_rn_short, rcp_rn_newton, their composition (what the pair kernel uses)
+// and of the rejected one-transcendental shortcut; out[8..15] / out[16..23] = first
+// offending inputs of sqrt / composition; out[24], out[25] = cursors.
 __global__ void k_selftest_math(uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out)
 {
     const uint64_t span = (uint64_t)hi_bits - lo_bits + 1;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    unsigned long long bad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long bad[4] = {0, 0, 0, 0};
     for (; i < span; i += stride) {
         const float a = __uint_as_float(lo_bits + (uint32_t)i);
-        const float s_ref = sqrtf(a), r_ref = 1.0f / a;
-        if (__float_as_uint(sqrt_rn_lean(a)) != __float_as_uint(s_ref)) {
+        const float s_ref = sqrtf(a), r_ref = 1.0f / a, c_ref = 1.0f / s_ref;
+        if (__float_as_uint(sqrt_rn_short(a)) != __float_as_uint(s_ref)) {
             bad[0]++;
             const unsigned long long k = atomicAdd(&out[25], 1ull);
             if (k < 8) out[8 + k] = __float_as_uint(a);
         }
-        if (__float_as_uint(rcp_rn_lean<1>(a)) != __float_as_uint(r_ref)) bad[1]++;
-        if (__float_as_uint(rcp_rn_lean<2>(a)) != __float_as_uint(r_ref)) bad[2]++;
-        if (__float_as_uint(rcp_rn_markstein(a)) != __float_as_uint(r_ref)) bad[3]++;
-        if (__float_as_uint(rcp_rn_selected(a)) != __float_as_uint(r_ref)) bad[4]++;
-        const float c_ref = 1.0f / s_ref;
-        if (__float_as_uint(sqrt_rn_short(a)) != __float_as_uint(s_ref)) bad[5]++;
-        if (__float_as_uint(inv_sqrt_rn2_via_h<2>(a)) != __float_as_uint(c_ref)) bad[6]++;
+        if (__float_as_uint(rcp_rn_newton(a)) != __float_as_uint(r_ref)) bad[1]++;
         if (__float_as_uint(inv_sqrt_selected(a)) != __float_as_uint(c_ref)) {
-            bad[7]++;
+            bad[2]++;
             const unsigned long long k = atomicAdd(&out[24], 1ull);
             if (k < 8) out[16 + k] = __float_as_uint(a);
         }
+        if (__float_as_uint(inv_sqrt_one_transcendental(a)) != __float_as_uint(c_ref)) bad[3]++;
     }
-    for (int k = 0; k < 8; k++) if (bad[k]) atomicAdd(&out[k], bad[k]);
+    for (int k = 0; k < 4; k++) if (bad[k]) atomicAdd(&out[k], bad[k]);
 }
 
 // out[0] += number of floats x with bits in [lo_bits, hi_bits] for which the fp32 add of

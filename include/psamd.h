@@ -89,6 +89,7 @@ typedef struct psamd_counters {
     int64_t relocations, relocations_lost, births, births_failed, cell_overflow_kills;
     int64_t steps;
     int64_t particles_processed; /* sum over steps of the live particles at build_grid */
+    int64_t max_ops_one_queue;   /* most free-slot-queue operations one segment got in one step */
 } psamd_counters;
 
 /* Raw device pointers of the SoA state, for plumbing (collectives, interop).
@@ -122,6 +123,14 @@ int         psamd_destroy(psamd_ctx *ctx);
 const char *psamd_last_error(const psamd_ctx *ctx);
 int         psamd_get_sizes(const psamd_ctx *ctx, psamd_sizes *out);
 int         psamd_get_config(const psamd_ctx *ctx, psamd_config *out);
+
+/* ---- host-only geometry (no device needed) ------------------------------------------ */
+/* What DoInit and the one-off setup stages derive from a configuration, computed on the
+ * host without touching a GPU: sizes (ps.cpp:2204-2222), the cell -> (chunk, seg_type,
+ * seg_tid) table (get_cell_info), the chunk package table (set_pkg_segments) and the
+ * initial free-slot queues (q_start_fast).  Any output pointer may be NULL. */
+int psamd_describe(const psamd_config *cfg, psamd_sizes *sizes, int32_t *cell_table3,
+                   int32_t *pkgdistrib_pairs, void *queue_info24, int32_t *queue);
 
 /* ---- setup stage: fill_particles, task 5 (ps.cpp:915-1048) --------------- */
 /* Places n particles in order; each takes the next free slot of its segment

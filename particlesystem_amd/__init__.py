@@ -60,7 +60,7 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in
                 ("deaths_age", "deaths_collision", "survives", "integrated", "relocations",
                  "relocations_lost", "births", "births_failed", "cell_overflow_kills", "steps",
-                 "particles_processed")]
+                 "particles_processed", "max_ops_one_queue")]
 
 
 class DeviceView(C.Structure):
@@ -88,6 +88,7 @@ ABI = [
     ("psamd_destroy", C.c_int, [_vp]),
     ("psamd_last_error", C.c_char_p, [_vp]),
     ("psamd_get_sizes", C.c_int, [_vp, C.POINTER(Sizes)]),
+    ("psamd_describe", C.c_int, [C.POINTER(Config), C.POINTER(Sizes), _vp, _vp, _vp, _vp]),
     ("psamd_get_config", C.c_int, [_vp, C.POINTER(Config)]),
     ("psamd_fill_particles", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
     ("psamd_uniform_cloud", C.c_int, [_vp, _i64, C.c_uint32, _vp]),
@@ -158,6 +159,24 @@ def default_config(**over):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def describe(cfg):
+    """Host-only geometry of a configuration: sizes, cell table [num_cells, 3], package
+    table [num_chunks, 54], initial QUEUE_INFO records and queue array.  Needs no GPU."""
+    lib = load()
+    sizes = Sizes()
+    st = lib.psamd_describe(C.byref(cfg), C.byref(sizes), None, None, None, None)
+    if st != 0:
+        raise PsamdError(st, lib.psamd_status_string(st).decode())
+    table = np.zeros((sizes.num_cells, 3), np.int32)
+    pkg = np.zeros((sizes.num_chunks, 54), np.int32)
+    qi = np.zeros(sizes.queue_info_size, Q_DTYPE)
+    q = np.zeros(sizes.container_size, np.int32)
+    st = lib.psamd_describe(C.byref(cfg), None, _ptr(table), _ptr(pkg), _ptr(qi), _ptr(q))
+    if st != 0:
+        raise PsamdError(st, lib.psamd_status_string(st).decode())
+    return sizes, table, pkg, qi, q
 
 
 class ParticleSystem:

@@ -41,6 +41,7 @@ struct psamd_ctx {
     bool host_queues_valid = true;    // host mirror == device copy
     FrameScalars *h_fs = nullptr;     // pinned host copy of the per-frame scalars
     int64_t processed_total = 0;      // sum over steps of the live particles at build_grid
+    int64_t max_bucket_seen = 0;
     char *snapshot = nullptr;         // device image for snapshot_save / _restore
     int snapshot_step = 0;
     void *staging = nullptr;          // device staging for AoS transfers
@@ -361,10 +362,8 @@ int psamd_destroy(psamd_ctx *c)
 
 const char *psamd_last_error(const psamd_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
-int psamd_get_sizes(const psamd_ctx *c, psamd_sizes *o)
+static void fill_sizes(const Geometry &g, psamd_sizes *o)
 {
-    if (!c || !o) return PSAMD_ERR_INVALID_ARG;
-    const Geometry &g = c->geo;
     std::memset(o, 0, sizeof *o);
     o->grid_dim = g.G; o->num_cells = g.num_cells; o->num_chunks = g.num_chunks;
     o->cells_per_chunk = g.cells_per_chunk; o->max_per_cell = g.max_per_cell; o->max_per_chunk = g.max_per_chunk;
@@ -373,6 +372,35 @@ int psamd_get_sizes(const psamd_ctx *c, psamd_sizes *o)
     o->n_cellgrid = (int64_t)g.num_cells * (1 + (int64_t)g.max_per_cell);
     o->n_pkgdistrib = g.num_chunks * 27;
     for (int k = 0; k < 4; k++) { o->seg_count[k] = g.seg_count[k]; o->seg_size_t[k] = g.seg_size_t[k]; o->seg_size[k] = g.seg_size[k]; }
+}
+
+int psamd_describe(const psamd_config *cfg, psamd_sizes *sizes, int32_t *cell_table3, int32_t *pkg,
+                   void *queue_info24, int32_t *queue)
+{
+    if (!cfg) return PSAMD_ERR_INVALID_ARG;
+    Geometry g;
+    if (!g.init(*cfg)) return PSAMD_ERR_INVALID_ARG;
+    if (sizes) fill_sizes(g, sizes);
+    if (cell_table3)
+        for (int i = 0; i < g.num_cells; i++) {
+            const CellInfo ci = g.cell_info(i);
+            cell_table3[3 * i] = ci.chunk; cell_table3[3 * i + 1] = ci.seg_type; cell_table3[3 * i + 2] = ci.seg_tid;
+        }
+    if (pkg) for (int ch = 0; ch < g.num_chunks; ch++) g.chunk_segments(ch, (Pair *)pkg + (size_t)ch * 27);
+    if (queue_info24 || queue) {
+        std::vector<QueueInfo> qi;
+        std::vector<int32_t> q;
+        g.initial_queues(qi, q);
+        if (queue_info24) std::memcpy(queue_info24, qi.data(), qi.size() * sizeof(QueueInfo));
+        if (queue) std::memcpy(queue, q.data(), q.size() * sizeof(int32_t));
+    }
+    return PSAMD_OK;
+}
+
+int psamd_get_sizes(const psamd_ctx *c, psamd_sizes *o)
+{
+    if (!c || !o) return PSAMD_ERR_INVALID_ARG;
+    fill_sizes(c->geo, o);
     return PSAMD_OK;
 }
 
@@ -679,6 +707,7 @@ int psamd_calc_forces_apply(psamd_ctx *c)
     c->live_at_build = c->h_fs->live;
     c->live_bound = std::min<int64_t>(c->geo.container, (int64_t)c->h_fs->live + c->h_fs->n_moves);   // births <= moves
     c->processed_total += c->h_fs->live;
+    c->max_bucket_seen = std::max<int64_t>(c->max_bucket_seen, c->h_fs->max_bucket);
     if (c->h_fs->error) return check_device_errors(c);
     if (c->h_fs->n_ops > 0 || c->h_fs->n_moves > 0) {
         PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos, c->h_fs->n_ops, c->h_fs->n_moves,
@@ -748,6 +777,7 @@ int psamd_get_counters(psamd_ctx *c, psamd_counters *o)
     o->cell_overflow_kills = (int64_t)d.cell_overflow_kills;
     o->steps = c->steps_total;
     o->particles_processed = c->processed_total;
+    o->max_ops_one_queue = c->max_bucket_seen;
     return PSAMD_OK;
 }
 

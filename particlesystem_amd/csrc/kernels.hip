@@ -632,6 +632,11 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
 #pragma unroll 4
             for (int jj = 0; jj < n; jj++) {
                 const float4 q = tile[jj];
+                // The other modes let a particle meet itself (r = 0 adds +0, exactly nothing)
+                // because 1/sqrt(eps2^3) is finite on the range they are allowed on; the
+                // generic mode also serves softening lengths where it is not, so it skips
+                // the self pair explicitly, as the reference does by id (ps.cpp:1258).
+                if (MODE == 0 && c_nb + c_t0 + jj == gi) continue;
                 const float d2 = MODE == 2 ? pair_fast(me.x, me.y, me.z, q, eps2f, ax, ay, az)
                                            : pair_exact(me.x, me.y, me.z, q, P.eps2, ax, ay, az);
                 dmin = fminf(dmin, d2);
@@ -1386,7 +1391,8 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
 hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi, int covered,
                         bool sharded)
 {
-    if (P.flags & PSAMD_FLAG_FAST_MATH) return launch_pairs_mode<2, 4>(st, P, d, lo, hi, covered, sharded);
+    // fast math shares the lean modes' validity range (finite 1/sqrt(eps2^3))
+    if ((P.flags & PSAMD_FLAG_FAST_MATH) && P.lean_math) return launch_pairs_mode<2, 4>(st, P, d, lo, hi, covered, sharded);
     // 8 pairs per slow-branch test: measured 3 % (full GPU) to 5 % (a 1/8 share) faster than 4
     if (P.lean_math) return launch_pairs_mode<1, 8>(st, P, d, lo, hi, covered, sharded);
     return launch_pairs_mode<0, 4>(st, P, d, lo, hi, covered, sharded);

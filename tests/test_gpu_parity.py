@@ -331,3 +331,54 @@ def test_sharded_step_ordered_by_a_shared_torch_stream():
         for r, g in enumerate(ranks):
             compare_all(g, o, "stream-ordered rank %d step %d" % (r, step + 1))
     torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+@pytest.mark.parametrize("eps2", [1e-20, 0.01, 0.37, 1.0, 3.0])
+def test_other_softening_lengths(eps2):
+    """EPS2 decides which arithmetic path the pair kernel takes: 1e-20 is outside the range
+    the lean sqrt/rcp were checked on (generic compiler forms are used), the others pick a
+    different fp32-add threshold (validated on the device when the context is created)."""
+    n = 40000
+    xyz = cloud(n, 101)
+    rng = np.random.default_rng(101)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    g, o = make_pair(xyz, age=age, fert=1e6, eps2=eps2)
+    for k in range(2):
+        g.step(1); o.step(1)
+        compare_all(g, o, "eps2=%g step %d" % (eps2, k + 1))
+
+
+def test_big_segments_replay_in_global_memory():
+    """chunk_dim = 8: interior segments hold 216 cells x 514 slots, more than the LDS queue
+    window, so their free-slot queues are replayed in global memory."""
+    over = {"chunk_factor": 2, "chunk_dim": 8}
+    n = 60000
+    xyz = cloud(n, 111)
+    rng = np.random.default_rng(111)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    v = rng.uniform(-60, 60, (n, 3)).astype(np.float32)
+    g, o = make_pair(xyz, age=age, fert=1e6, vxyz=v, **over)
+    assert max(g.sizes.seg_size_t) > 6144
+    for k in range(3):
+        g.step(1); o.step(1)
+        compare_all(g, o, "chunk_dim 8 step %d" % (k + 1))
+    assert g.counters["relocations"] > 1000
+
+
+def test_long_operation_lists_take_the_sorted_fallback():
+    """3000 fast particles fill the corner segment at the box centre (its 8 cells are
+    [-5,5)^3) and move one cell along every axis: 7/8 of them leave it in one step -- more
+    queue operations on one record than the in-LDS replay holds (2048), so the radix-sort +
+    serial-walk path runs."""
+    rng = np.random.default_rng(121)
+    blob = rng.uniform(-4.9, 4.9, (3000, 3)).astype(np.float32)
+    rest = cloud(5000, 122)
+    xyz = np.concatenate([blob, rest])
+    v = np.zeros_like(xyz)
+    v[:3000] = 300.0                                                  # clamped to one cell per step
+    g, o = make_pair(xyz, age=3.0, fert=1e6, vxyz=v, collision_radius=0.0)
+    for k in range(2):
+        g.step(1); o.step(1)
+        compare_all(g, o, "long list step %d" % (k + 1))
+    assert g.counters["relocations"] > 2500
+    assert g.counters["max_ops_one_queue"] > 2048      # the fallback really ran

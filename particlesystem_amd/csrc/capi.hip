@@ -833,15 +833,24 @@ static int snapshot_copy(psamd_ctx *c, bool save)
 {
     const size_t C = (size_t)c->geo.container;
     char *p = c->snapshot;
-    struct { void *dev; size_t bytes; } parts[] = {
-        {c->d.pos4, C * sizeof(float4)}, {c->d.vel4, C * sizeof(float4)}, {c->d.acc4, C * sizeof(float4)},
-        {c->d.cell, C * sizeof(int)}, {c->d.qinfo, (size_t)c->geo.queue_infos * sizeof(QueueInfo)},
-        {c->d.queue, C * sizeof(int)}, {c->d.pflags, C},
-    };
-    for (auto &part : parts) {
-        if (save) PS_HIP(c, hipMemcpyAsync(p, part.dev, part.bytes, hipMemcpyDeviceToDevice, c->stream));
-        else PS_HIP(c, hipMemcpyAsync(part.dev, p, part.bytes, hipMemcpyDeviceToDevice, c->stream));
-        p += part.bytes;
+    char *s_pos = p, *s_vel = s_pos + C * sizeof(float4), *s_acc = s_vel + C * sizeof(float4);
+    char *s_cell = s_acc + C * sizeof(float4);
+    char *s_qinfo = s_cell + C * sizeof(int);
+    char *s_queue = s_qinfo + (size_t)c->geo.queue_infos * sizeof(QueueInfo);
+    char *s_flags = s_queue + C * sizeof(int);
+    if (save) {
+        struct { void *dev; char *snap; size_t bytes; } parts[] = {
+            {c->d.pos4, s_pos, C * sizeof(float4)}, {c->d.vel4, s_vel, C * sizeof(float4)},
+            {c->d.acc4, s_acc, C * sizeof(float4)}, {c->d.cell, s_cell, C * sizeof(int)},
+            {c->d.pflags, s_flags, C},
+        };
+        for (auto &part : parts) PS_HIP(c, hipMemcpyAsync(part.snap, part.dev, part.bytes, hipMemcpyDeviceToDevice, c->stream));
+        PS_HIP(c, hipMemcpyAsync(s_qinfo, c->d.qinfo, (size_t)c->geo.queue_infos * sizeof(QueueInfo), hipMemcpyDeviceToDevice, c->stream));
+        PS_HIP(c, hipMemcpyAsync(s_queue, c->d.queue, C * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        PS_HIP(c, launch_restore(c->stream, (int)C, s_pos, s_vel, s_acc, s_cell, s_flags, c->d));
+        PS_HIP(c, hipMemcpyAsync(c->d.qinfo, s_qinfo, (size_t)c->geo.queue_infos * sizeof(QueueInfo), hipMemcpyDeviceToDevice, c->stream));
+        PS_HIP(c, hipMemcpyAsync(c->d.queue, s_queue, C * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
     }
     return PSAMD_OK;
 }

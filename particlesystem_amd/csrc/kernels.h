@@ -62,6 +62,8 @@ hipError_t launch_pack_aos(hipStream_t st, void *aos, int first, int count, int 
 hipError_t launch_place(hipStream_t st, int n, const int *ids, const float4 *p, const float4 *v, const float4 *a,
                         const int *cells, const DeviceState &d);
 hipError_t launch_fill_int(hipStream_t st, int *p, int v, size_t n);
+hipError_t launch_restore(hipStream_t st, int n, const void *s_pos, const void *s_vel, const void *s_acc,
+                          const void *s_cell, const void *s_flags, const DeviceState &d);
 hipError_t launch_validate_eps(hipStream_t st, uint32_t lo_bits, uint32_t hi_bits, double eps2, float eps2f,
                                unsigned long long *out);
 hipError_t launch_selftest_math(hipStream_t st, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out24);

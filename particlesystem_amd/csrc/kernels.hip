@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "device_types.h"
 #include "geometry.hpp"
@@ -103,6 +104,30 @@ __global__ void k_place(int n, const int *__restrict__ ids, const float4 *__rest
     const int slot = ids[i];
     pos4[slot] = p[i]; vel4[slot] = v[i]; acc4[slot] = a[i];
     cell[slot] = cells[i]; pflags[slot] = 0;
+}
+
+// snapshot_restore: a slot that is free both now and in the snapshot holds the same
+// (all-zero) record in both, so only slots occupied on either side are copied
+__global__ void k_restore(int n, const float4 *__restrict__ s_pos, const float4 *__restrict__ s_vel,
+                          const float4 *__restrict__ s_acc, const int *__restrict__ s_cell,
+                          const uint8_t *__restrict__ s_flags,
+                          float4 *pos4, float4 *vel4, float4 *acc4, int *cell, uint8_t *pflags)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int cs = s_cell[i];
+    if (cs < 0 && cell[i] < 0) return;
+    pos4[i] = s_pos[i]; vel4[i] = s_vel[i]; acc4[i] = s_acc[i];
+    cell[i] = cs; pflags[i] = s_flags[i];
+}
+
+hipError_t launch_restore(hipStream_t st, int n, const void *s_pos, const void *s_vel, const void *s_acc,
+                          const void *s_cell, const void *s_flags, const DeviceState &d)
+{
+    k_restore<<<(n + 255) / 256, 256, 0, st>>>(n, (const float4 *)s_pos, (const float4 *)s_vel, (const float4 *)s_acc,
+                                              (const int *)s_cell, (const uint8_t *)s_flags, d.pos4, d.vel4, d.acc4,
+                                              d.cell, d.pflags);
+    return hipGetLastError();
 }
 
 __global__ void k_fill_int(int *p, int v, size_t n)

@@ -154,7 +154,15 @@ int check_device_errors(psamd_ctx *c)   // after a sync: sticky error bits raise
     FrameScalars fs{};
     PS_HIP(c, hipMemcpy(&fs, c->d.fs, sizeof fs, hipMemcpyDeviceToHost));
     c->live_at_build = fs.live;
-    if (fs.error & ERR_BAD_ID) return fail(c, PSAMD_ERR_INVALID_ARG, "uploaded particle with id != slot index");
+    if (fs.error & (ERR_BAD_ID | ERR_BAD_POS)) {
+        // an upload error is reported once and then cleared: the rejected records stay in the
+        // container, the caller is expected to upload valid ones over them
+        const int bits = fs.error;
+        const int cleared = fs.error & ~(ERR_BAD_ID | ERR_BAD_POS);
+        (void)hipMemcpy(&c->d.fs->error, &cleared, sizeof(int), hipMemcpyHostToDevice);
+        return fail(c, PSAMD_ERR_INVALID_ARG, (bits & ERR_BAD_ID) ? "uploaded particle with id != slot index"
+                                                                  : "uploaded live particle outside the box or with cell >= NUM_CELLS");
+    }
     if (fs.error & ERR_CELL_TOO_BIG) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "a cell holds more particles than the sort kernel ranks");
     if (fs.error & ERR_SHARD_BOUND) return fail(c, PSAMD_ERR_STATE, "more live particles than the shards cover (stale bound)");
     if (fs.error & ERR_OPS_OVERFLOW) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "lifecycle op buffer overflow");
@@ -496,7 +504,9 @@ int psamd_upload_particles(psamd_ctx *c, const void *p72, int64_t first, int64_t
     int rc = ensure_staging(c, (size_t)count * 72);
     if (rc != PSAMD_OK) return rc;
     PS_HIP(c, hipMemcpyAsync(c->staging, p72, (size_t)count * 72, hipMemcpyHostToDevice, c->stream));
-    PS_HIP(c, launch_unpack_aos(c->stream, c->staging, (int)first, (int)count, c->d));
+    // odd grids are not centred (G/2 is an integer division): allow the longer half
+    const float half_box = (float)((c->geo.G - c->geo.G / 2) * c->geo.cfg.cell_size);
+    PS_HIP(c, launch_unpack_aos(c->stream, c->staging, (int)first, (int)count, c->geo.num_cells, half_box, c->d));
     PS_HIP(c, hipStreamSynchronize(c->stream));
     c->grid_built = false; c->pairs_done = false;
     c->live_bound = -1;

@@ -70,6 +70,7 @@ enum : int32_t {
     ERR_BAD_ID = 2,         // uploaded P_DATA_TYPE with id != slot
     ERR_OPS_OVERFLOW = 4,   // lifecycle op buffer too small
     ERR_SHARD_BOUND = 8,    // more sorted particles than world * share
+    ERR_BAD_POS = 16,       // uploaded live particle outside the box (or cell out of range)
 };
 
 // A free-slot-queue operation produced by calc_forces is a (key, arg) pair kept in

@@ -57,7 +57,8 @@ struct DeviceState {
     unsigned long long *trace = nullptr;  // 3 words per pair-kernel wave slot (diagnostic builds only)
 };
 
-hipError_t launch_unpack_aos(hipStream_t st, const void *aos, int first, int count, const DeviceState &d);
+hipError_t launch_unpack_aos(hipStream_t st, const void *aos, int first, int count, int num_cells, float half_box,
+                             const DeviceState &d);
 hipError_t launch_pack_aos(hipStream_t st, void *aos, int first, int count, int num_cells, const DeviceState &d);
 hipError_t launch_place(hipStream_t st, int n, const int *ids, const float4 *p, const float4 *v, const float4 *a,
                         const int *cells, const DeviceState &d);

@@ -56,7 +56,7 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nb)
 // ------------------------------------------------------------------ AoS <-> SoA
 // P_DATA_TYPE is 18 dwords (common.h:94-120): id cell chunk seg_type seg_tid
 // {seg_fault,is_parent,pad,pad} w age fert x y z vx vy vz ax ay az.
-__global__ void k_unpack_aos(const uint32_t *__restrict__ aos, int first, int count,
+__global__ void k_unpack_aos(const uint32_t *__restrict__ aos, int first, int count, int num_cells, float half_box,
                              float4 *pos4, float4 *vel4, float4 *acc4, int *cell, uint8_t *pflags,
                              FrameScalars *fs)
 {
@@ -65,6 +65,13 @@ __global__ void k_unpack_aos(const uint32_t *__restrict__ aos, int first, int co
     const uint32_t *r = aos + (size_t)18 * i;
     const int slot = first + i;
     if ((int)r[0] != slot) atomicOr(&fs->error, ERR_BAD_ID);
+    // a live particle sits inside the box (set_pos_t wraps every position, app.cu:117-158);
+    // the pair arithmetic is validated for in-box distances only
+    if ((int)r[1] >= 0) {
+        const float x = __uint_as_float(r[9]), y = __uint_as_float(r[10]), z = __uint_as_float(r[11]);
+        if ((int)r[1] >= num_cells || !(fabsf(x) <= half_box) || !(fabsf(y) <= half_box) || !(fabsf(z) <= half_box))
+            atomicOr(&fs->error, ERR_BAD_POS);
+    }
     cell[slot] = (int)r[1];
     pflags[slot] = ((r[5] >> 8) & 0xffu) ? 1 : 0;
     pos4[slot] = make_float4(__uint_as_float(r[9]), __uint_as_float(r[10]), __uint_as_float(r[11]), __uint_as_float(r[6]));
@@ -1329,10 +1336,12 @@ static inline int blocks_for(size_t n, int threads, int cap = 4096)
     return b < 1 ? 1 : (int)b;
 }
 
-hipError_t launch_unpack_aos(hipStream_t st, const void *aos, int first, int count, const DeviceState &d)
+hipError_t launch_unpack_aos(hipStream_t st, const void *aos, int first, int count, int num_cells, float half_box,
+                             const DeviceState &d)
 {
     if (count <= 0) return hipSuccess;
-    k_unpack_aos<<<(count + 255) / 256, 256, 0, st>>>((const uint32_t *)aos, first, count, d.pos4, d.vel4, d.acc4,
+    k_unpack_aos<<<(count + 255) / 256, 256, 0, st>>>((const uint32_t *)aos, first, count, num_cells, half_box,
+                                                      d.pos4, d.vel4, d.acc4,
                                                       d.cell, d.pflags, d.fs);
     PS_LAUNCH_CHECK();
     return hipSuccess;

@@ -228,6 +228,17 @@ def test_errors_are_statuses():
     with pytest.raises(ps.PsamdError) as e:
         ps.ParticleSystem(ps.default_config(chunk_dim=2))
     assert e.value.status == 1
+    # uploads are validated: id must equal the slot, live particles must be inside the box
+    p = g.download_particles(0, 4)
+    bad = p.copy(); bad["id"][2] = 7
+    with pytest.raises(ps.PsamdError) as e:
+        g.upload_particles(bad)
+    assert e.value.status == 1
+    bad = p.copy(); bad["cell"][1] = 5; bad["x"][1] = 1e6
+    with pytest.raises(ps.PsamdError) as e:
+        g.upload_particles(bad)
+    assert e.value.status == 1
+    g.upload_particles(p)               # a valid upload afterwards is accepted
 
 
 def test_two_rank_contexts_share_the_pair_loop():

@@ -485,15 +485,12 @@ struct PairCtx {
 };
 
 template <int NQ>
-__device__ __forceinline__ void pairsN_exact_lean(const DevParams &P, const PairCtx &c, const float4 *__restrict__ t,
+__device__ __forceinline__ void pairsN_exact_lean(const DevParams &P, const PairCtx &c, const float4 (&q)[NQ],
                                                   int gj0, const float *__restrict__ snap_age,
                                                   const int *__restrict__ sorted_id,
                                                   float &ax, float &ay, float &az, int &flag)
 {
-    float4 q[NQ];
     float rx[NQ], ry[NQ], rz[NQ], d[NQ], e[NQ], sc[NQ];
-#pragma unroll
-    for (int i = 0; i < NQ; i++) q[i] = t[i];
     float dm = 3.0e38f;
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
@@ -654,9 +651,15 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
         if (have && lane < min(64, ncnt - t0)) pre = snap4[nb + t0 + lane];
         if (MODE == 1) {
             const PairCtx ctx = {me.x, me.y, me.z, age_i, id_i, gi, scan};
+            // groups of NQ tile entries (prefetching the next group's LDS reads into registers
+            // was measured 7-8 % slower: the registers cost more than the latency they hide)
             int jj = 0;
-            for (; jj + NQ <= n; jj += NQ)
-                pairsN_exact_lean<NQ>(P, ctx, tile + jj, c_nb + c_t0 + jj, snap_age, sorted_id, ax, ay, az, flag);
+            for (; jj + NQ <= n; jj += NQ) {
+                float4 q[NQ];
+#pragma unroll
+                for (int i = 0; i < NQ; i++) q[i] = tile[jj + i];
+                pairsN_exact_lean<NQ>(P, ctx, q, c_nb + c_t0 + jj, snap_age, sorted_id, ax, ay, az, flag);
+            }
             for (; jj < n; jj++)
                 pair1_exact_lean(P, ctx, tile[jj], c_nb + c_t0 + jj, snap_age, sorted_id, ax, ay, az, flag);
         } else {

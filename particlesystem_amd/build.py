@@ -28,10 +28,15 @@ def build(force=False, verbose=False, extra=()):
     extra = list(extra) + os.environ.get("PSAMD_EXTRA_FLAGS", "").split()
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    tmp = LIB + ".tmp"
+    cmd = [HIPCC] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
+    # a failed build must not leave a stale library behind to be tested by mistake
+    if os.path.exists(LIB):
+        os.remove(LIB)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)
     return LIB
 
 

@@ -226,58 +226,57 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
                                                 int *__restrict__ task_start, int *__restrict__ chunk_count,
                                                 const CellInfo *__restrict__ celltab, FrameScalars *fs)
 {
-    // two prefix sums at once, packed in 64 bits: particles per cell (low word) and
-    // 64-particle pair-kernel tasks per cell (high word)
+    // Two prefix sums at once, packed in 64 bits: particles per cell (low word) and
+    // 64-particle pair-kernel tasks per cell (high word).  Each thread owns a contiguous run
+    // of cells, so the whole scan needs one pass and two barriers.
     constexpr int LDS_CHUNKS = 4096;
     __shared__ long long wave_tot[16];
-    __shared__ long long carry_s;
     __shared__ int maxcell_s;
     __shared__ int chunk_s[LDS_CHUNKS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool chunks_in_lds = P.num_chunks <= LDS_CHUNKS;
-    if (tid == 0) { carry_s = 0; maxcell_s = 0; }
+    if (tid == 0) maxcell_s = 0;
     if (chunks_in_lds) for (int ch = tid; ch < P.num_chunks; ch += 1024) chunk_s[ch] = 0;
     __syncthreads();
+    const int per = (P.num_cells + 1023) / 1024;
+    const int c0 = min(P.num_cells, tid * per), c1 = min(P.num_cells, c0 + per);
+    long long mine = 0;
     int mymax = 0;
-    for (int base = 0; base < P.num_cells; base += 1024) {
-        const int c = base + tid;
-        const int v = (c < P.num_cells) ? cell_count[c] : 0;
+    for (int c = c0; c < c1; c++) {
+        const int v = cell_count[c];
         mymax = max(mymax, min(v, P.max_per_cell));
-        const long long both = ((long long)((min(v, P.max_per_cell) + 63) >> 6) << 32) | (long long)v;
-        long long incl = both;
-        for (int d = 1; d < 64; d <<= 1) {
-            const long long o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
+        mine += ((long long)((min(v, P.max_per_cell) + 63) >> 6) << 32) | (long long)v;
+        if (v > 0) {
+            if (chunks_in_lds) atomicAdd(&chunk_s[celltab[c].chunk], v);
+            else atomicAdd(&chunk_count[celltab[c].chunk], v);
         }
-        if (lane == 63) wave_tot[wv] = incl;
-        __syncthreads();
-        long long woff = 0;
-        for (int k = 0; k < wv; k++) woff += wave_tot[k];
-        const long long excl2 = carry_s + woff + incl - both;
-        const int excl = (int)(excl2 & 0xffffffffll);
-        if (c < P.num_cells) {
-            cell_start[c] = excl;
-            cursor[c] = excl;
-            task_start[c] = (int)(excl2 >> 32);
-            if (v > 0) {
-                if (chunks_in_lds) atomicAdd(&chunk_s[celltab[c].chunk], v);
-                else atomicAdd(&chunk_count[celltab[c].chunk], v);
-            }
-        }
-        __syncthreads();
-        if (tid == 1023) carry_s = excl2 + both;
-        __syncthreads();
     }
-    atomicMax(&maxcell_s, mymax);
+    long long incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    if (mymax) atomicMax(&maxcell_s, mymax);
     __syncthreads();
+    long long run = incl - mine, total = 0;
+    for (int k = 0; k < 16; k++) { if (k < wv) run += wave_tot[k]; total += wave_tot[k]; }
+    for (int c = c0; c < c1; c++) {
+        const int v = cell_count[c];
+        const int excl = (int)(run & 0xffffffffll);
+        cell_start[c] = excl;
+        cursor[c] = excl;
+        task_start[c] = (int)(run >> 32);
+        run += ((long long)((min(v, P.max_per_cell) + 63) >> 6) << 32) | (long long)v;
+    }
     if (tid == 0) {
-        cell_start[P.num_cells] = (int)(carry_s & 0xffffffffll);
-        task_start[P.num_cells] = (int)(carry_s >> 32);
-        fs->live = (int)(carry_s & 0xffffffffll);
-        fs->n_tasks = (int)(carry_s >> 32);
+        cell_start[P.num_cells] = (int)(total & 0xffffffffll);
+        task_start[P.num_cells] = (int)(total >> 32);
+        fs->live = (int)(total & 0xffffffffll);
+        fs->n_tasks = (int)(total >> 32);
         fs->gridmax[1] = maxcell_s;
     }
-    // chunk totals are complete once every thread passed the loop's last barrier
+    // chunk totals: complete after the barrier above (every thread added its cells before it)
     int cm = 0;
     if (chunks_in_lds) {
         for (int ch = tid; ch < P.num_chunks; ch += 1024) {

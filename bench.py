@@ -51,13 +51,17 @@ def make_inputs(ps, sysobj, n, seed):
     return xyz, age, fert
 
 
-def measured_traffic(kernel):
+def measured_traffic(kernel_prefix):
     """HBM bytes per launch from the committed rocprofv3 PMC capture (profiles/), or None."""
     try:
         with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
-            return float(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch_corrected"])
+            kernels = json.load(f)["kernels"]
+        for name, rec in kernels.items():
+            if name.startswith(kernel_prefix):
+                return float(rec["hbm_bytes_per_launch_corrected"])
     except Exception:
-        return None
+        pass
+    return None
 
 
 def pair_count(cellgrid_counts, G):
@@ -257,7 +261,7 @@ def main():
                        "cell_overflow_kills": ctr["cell_overflow_kills"]},
             "roofline": {"kernel": "k_pairs", "bound": "valu", "achieved": ach_tflops, "peak": VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach_tflops / VALU_PEAK_TFLOPS,
-                         "traffic": measured_traffic("k_pairs<1>") if world == 1 and not args.fast_math else None,
+                         "traffic": measured_traffic("k_pairs<1") if world == 1 and not args.fast_math else None,
                          "pairs_per_launch": pairs_rank, "flop_per_pair": FLOP_PER_PAIR, "us_per_launch": us_pairs},
             "roofline_streaming": {"kernel": "k_apply", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS, "traffic": measured_traffic("k_apply"),

@@ -393,3 +393,26 @@ def test_long_operation_lists_take_the_sorted_fallback():
         compare_all(g, o, "long list step %d" % (k + 1))
     assert g.counters["relocations"] > 2500
     assert g.counters["max_ops_one_queue"] > 2048      # the fallback really ran
+
+
+def test_long_free_run_with_births_and_collapse():
+    """A free-running cloud dense enough to collapse at its surface: cells hit the list
+    capacity (overflow kills into queue record 0), segments fill up (relocations and births
+    that find no free slot), long operation lists -- every step compared in full."""
+    n = 1 << 17
+    xyz = cloud(n, 131)
+    rng = np.random.default_rng(131)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    fert = rng.uniform(2.5, 12.0, n).astype(np.float32)
+    seed = 20261003
+    # a tight container (list capacity 40 for a mean of 32 particles per cell, 320 slots per
+    # 8-cell segment) overflows cells at once and fills segments as the cloud collapses
+    g, o = make_pair(xyz, age=age, fert=fert, flags=ps.FLAG_EXPLOSIONS, seed=seed, max_particles_num=80000)
+    o.set_rng(explosion_rng(seed))
+    for k in range(10):
+        g.step(1); o.step(1)
+        compare_all(g, o, "free run step %d" % (k + 1))
+    c = g.counters
+    print("free run counters:", {k: v for k, v in c.items() if v})
+    assert c["cell_overflow_kills"] > 0 and c["births"] > 0 and c["relocations"] > 0
+    assert c["relocations_lost"] + c["births_failed"] > 0

@@ -1,23 +1,24 @@
 // kernels.hip -- hand-written gfx950 (MI355X, CDNA4) kernels for the particle step.
 //
-// Step pipeline (one launch each, all on the context's stream):
-//   k_hist      count live particles per cell                      (streaming, HBM)
-//   k_scan      exclusive prefix over cells + hostGridMax          (tiny)
-//   k_scatter   slot ids into their cell's range                   (streaming, HBM)
+// Step pipeline (all on the context's stream):
+//   k_hist_lds / k_scatter_lds   counting sort of the live slots by cell, histogram
+//               private to a workgroup in LDS (k_hist / k_scatter with global atomics
+//               for grids of more than 8192 cells)                     (streaming, HBM)
+//   k_scan, k_build_tasks   prefix over cells, hostGridMax, the pair kernel's work list
 //   k_sort_cells   rank ids inside each cell (ascending = the reference's cell-list
 //               order, ps.cpp:1510-1516), gather the T_DATA snapshot in that order
-//   k_pairs     27-cell softened gravity + collision flags: one WAVE per 64
-//               particles of one cell, neighbour tiles staged through LDS and
-//               broadcast to the 64 lanes, serial fp32 accumulation in the
-//               reference's order (fp32 VALU bound; no MFMA: there is no
-//               contraction here, each pair needs its own rsqrt)
-//   k_apply     death / survive / integrate / wrap / re-hash       (streaming, HBM)
-//   k_ops_* / k_replay / k_moves_*   free-slot queues + relocation, replayed in
-//               the reference's serial order
+//   k_pairs     27-cell softened gravity + collision flags: one WAVE per 64 particles of
+//               one cell, neighbour tiles staged through LDS and broadcast to the 64
+//               lanes, serial fp32 accumulation in the reference's order (fp32 VALU
+//               bound; no MFMA: no contraction here, every pair needs its own rsqrt)
+//   k_apply     death / survive / integrate / wrap / re-hash, in slot order (streaming, HBM)
+//   k_ops_hist / k_ops_scan / k_ops_scatter / k_replay_bucket / k_moves_*
+//               free-slot queues + relocation, replayed in the reference's serial order
+//               (k_replay + a radix sort of the keys when one queue gets a very long list)
 //
-// Reference arithmetic is reproduced operation for operation: this file is built
-// with -ffp-contract=off and correctly rounded fp32 divide/sqrt, the two places
-// where the reference evaluates in double (EPS2 add, 0.5*a*t*t) do so here too.
+// Reference arithmetic is reproduced operation for operation: this file is built with
+// -ffp-contract=off; where the reference evaluates in double (EPS2 add, 0.5*a*t*t) so
+// does this, except where an fp32 form is proven bit-identical (see k_pairs).
 // Citations: ps.cpp = source/code/src/particleSystem.cpp of the reference.
 #include <hip/hip_runtime.h>
 
@@ -552,14 +553,18 @@ __global__ void k_shard_tasks(DevParams P, const int *__restrict__ cell_start, c
     fs->shard_task_n = task_start[c_hi + 1] - task_start[c_lo];
 }
 
-// One wave (one 64-thread workgroup) = 64 consecutive particles of one cell.
+// One wave = 64 consecutive particles of one cell (four such waves per workgroup).
 // Neighbour cells are visited in the reference's stencil order and their snapshot is
 // streamed through a 1 KiB LDS tile; every lane reads the same tile entry (broadcast)
 // and adds it to its own particle's sum, so each particle sees exactly the
 // reference's sequence of fp32 additions (ps.cpp:1247-1259).
-// MODE 0: exact, compiler's sqrt/div; 1: exact, lean sqrt/rcp; 2: fast math
-// no s_barrier: a wave only ever touches its own LDS tile, and a wave's LDS operations
-// complete in issue order, so a compiler-level fence is all the ordering it needs
+// MODE 0: exact with the compiler's correctly rounded sqrt/divide (any EPS2);
+//      1: exact with the short sqrt/reciprocal above, NQ pairs per slow-branch test;
+//      2: fast math (FMA + v_rsq), not bit-exact.
+// SHARDED: the launch covers only this rank's run of the task list.
+//
+// No s_barrier anywhere: a wave only ever touches its own LDS tile, and a wave's LDS
+// operations complete in issue order, so a compiler-level fence is all the ordering needed.
 #define PS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 template <int MODE, bool SHARDED, int NQ>

@@ -484,37 +484,95 @@ struct PairCtx {
     bool scan;
 };
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Two pairs per instruction slot: gfx950 has packed fp32 add/mul/fma, and the SoA tile hands
+// (x_j, x_j+1) over in one aligned register pair, so nothing is shuffled between registers.
+// Every packed operation rounds each half exactly like its scalar form.
+__device__ __forceinline__ v2f inv_sqrt_selected2(v2f six)
+{
+    v2f r; r.x = __builtin_amdgcn_rsqf(six.x); r.y = __builtin_amdgcn_rsqf(six.y);
+    const v2f g = six * r, h = 0.5f * r;
+    const v2f s = __builtin_elementwise_fma(__builtin_elementwise_fma(-g, g, six), h, g);   // sqrt_rn_short
+    v2f x; x.x = __builtin_amdgcn_rcpf(s.x); x.y = __builtin_amdgcn_rcpf(s.y);
+    const v2f one = {1.0f, 1.0f};
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(-s, x, one), x, x);          // rcp_rn_newton
+}
+
 template <int NQ>
-__device__ __forceinline__ void pairsN_exact_lean(const DevParams &P, const PairCtx &c, const float4 (&q)[NQ],
-                                                  int gj0, const float *__restrict__ snap_age,
+__device__ __forceinline__ void pairsN_exact_lean(const DevParams &P, const PairCtx &c, const v2f (&qx)[NQ / 2],
+                                                  const v2f (&qy)[NQ / 2], const v2f (&qz)[NQ / 2],
+                                                  const v2f (&qw)[NQ / 2], int gj0,
+                                                  const float *__restrict__ snap_age,
                                                   const int *__restrict__ sorted_id,
                                                   float &ax, float &ay, float &az, int &flag)
 {
-    float rx[NQ], ry[NQ], rz[NQ], d[NQ], e[NQ], sc[NQ];
+    constexpr int H = NQ / 2;
+    const v2f xi = {c.xi, c.xi}, yi = {c.yi, c.yi}, zi = {c.zi, c.zi};
+    v2f rx[H], ry[H], rz[H], d[H], e[H];
     float dm = 3.0e38f;
 #pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        rx[i] = q[i].x - c.xi; ry[i] = q[i].y - c.yi; rz[i] = q[i].z - c.zi;
+    for (int i = 0; i < H; i++) {
+        rx[i] = qx[i] - xi; ry[i] = qy[i] - yi; rz[i] = qz[i] - zi;
         d[i] = rx[i] * rx[i] + ry[i] * ry[i] + rz[i] * rz[i];
-        dm = fminf(dm, d[i]);
+        dm = fminf(fminf(dm, d[i].x), d[i].y);
     }
     if (__any(dm < P.slow_below)) {
 #pragma unroll
-        for (int i = 0; i < NQ; i++) e[i] = (float)((double)d[i] + P.eps2);
+        for (int i = 0; i < H; i++) {
+            e[i].x = (float)((double)d[i].x + P.eps2);
+            e[i].y = (float)((double)d[i].y + P.eps2);
+        }
         if (c.scan && !(dm > P.coll_d2_gate)) {
 #pragma unroll
-            for (int i = 0; i < NQ; i++)
-                if (!(d[i] > P.coll_d2_gate) && gj0 + i != c.gi)
-                    flag = max(flag, collide_exact(P, d[i], c.age_i, c.id_i, snap_age[gj0 + i], sorted_id[gj0 + i]));
+            for (int i = 0; i < NQ; i++) {
+                const float di = (i & 1) ? d[i >> 1].y : d[i >> 1].x;
+                if (!(di > P.coll_d2_gate) && gj0 + i != c.gi)
+                    flag = max(flag, collide_exact(P, di, c.age_i, c.id_i, snap_age[gj0 + i], sorted_id[gj0 + i]));
+            }
         }
     } else {
+        const v2f eps = {P.eps2f, P.eps2f};
 #pragma unroll
-        for (int i = 0; i < NQ; i++) e[i] = d[i] + P.eps2f;
+        for (int i = 0; i < H; i++) e[i] = d[i] + eps;
+    }
+    v2f sc[H];
+#pragma unroll
+    for (int i = 0; i < H; i++) sc[i] = qw[i] * inv_sqrt_selected2(e[i] * e[i] * e[i]);
+#pragma unroll
+    for (int i = 0; i < H; i++) {                       // sums in list order
+        const v2f px = rx[i] * sc[i], py = ry[i] * sc[i], pz = rz[i] * sc[i];
+        ax += px.x; ay += py.x; az += pz.x;
+        ax += px.y; ay += py.y; az += pz.y;
+    }
+}
+
+// Fast-math counterpart (FMA + v_rsq), two pairs per packed instruction; returns the
+// smallest squared distance of the group for the collision gate.
+template <int NQ>
+__device__ __forceinline__ float pairsN_fast(const PairCtx &c, const v2f (&qx)[NQ / 2], const v2f (&qy)[NQ / 2],
+                                             const v2f (&qz)[NQ / 2], const v2f (&qw)[NQ / 2], float eps2,
+                                             float &ax, float &ay, float &az)
+{
+    constexpr int H = NQ / 2;
+    const v2f xi = {c.xi, c.xi}, yi = {c.yi, c.yi}, zi = {c.zi, c.zi}, eps = {eps2, eps2};
+    v2f rx[H], ry[H], rz[H], sc[H];
+    float dm = 3.0e38f;
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+        rx[i] = qx[i] - xi; ry[i] = qy[i] - yi; rz[i] = qz[i] - zi;
+        const v2f d = __builtin_elementwise_fma(rz[i], rz[i], __builtin_elementwise_fma(ry[i], ry[i], rx[i] * rx[i]));
+        dm = fminf(fminf(dm, d.x), d.y);
+        const v2f e = d + eps;
+        v2f r; r.x = __builtin_amdgcn_rsqf(e.x); r.y = __builtin_amdgcn_rsqf(e.y);
+        sc[i] = qw[i] * (r * r * r);
     }
 #pragma unroll
-    for (int i = 0; i < NQ; i++) sc[i] = q[i].w * inv_sqrt_selected(e[i] * e[i] * e[i]);
-#pragma unroll
-    for (int i = 0; i < NQ; i++) { ax += rx[i] * sc[i]; ay += ry[i] * sc[i]; az += rz[i] * sc[i]; }   // in list order
+    for (int i = 0; i < H; i++) {
+        ax = fmaf(rx[i].x, sc[i].x, ax); ay = fmaf(ry[i].x, sc[i].x, ay); az = fmaf(rz[i].x, sc[i].x, az);
+        ax = fmaf(rx[i].y, sc[i].y, ax); ay = fmaf(ry[i].y, sc[i].y, ay); az = fmaf(rz[i].y, sc[i].y, az);
+    }
+    return dm;
 }
 
 __device__ __forceinline__ void pair1_exact_lean(const DevParams &P, const PairCtx &c, const float4 q, int gj,
@@ -579,9 +637,10 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
     // Workgroups of four INDEPENDENT waves (no workgroup barrier anywhere): the hardware
     // deals a workgroup's waves over the four SIMDs of its CU and workgroups over the
     // CUs, which keeps even a small share (a few waves per CU) evenly spread.
-    __shared__ float4 tiles[4][64];
+    __shared__ __attribute__((aligned(16))) float tiles[4][4][64];   // [wave][x,y,z,w][entry]
     const int wave = threadIdx.x >> 6;
-    float4 *tile = tiles[wave];
+    float *tx = tiles[wave][0], *ty = tiles[wave][1], *tz = tiles[wave][2], *tw = tiles[wave][3];
+    auto tile_at = [&](int j) { return make_float4(tx[j], ty[j], tz[j], tw[j]); };
     if (blockIdx.x == 0 && threadIdx.x == 0 && cell_start[P.num_cells] > covered) atomicOr(&fs->error, ERR_SHARD_BOUND);
     // The work list holds only non-empty (cell, slice) tasks; the first `ntask` workgroups
     // take one each (so the dispatcher deals the real work evenly over the CUs), spread
@@ -643,7 +702,7 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
     while (have) {
         const int c_nb = nb, c_t0 = t0, n = min(64, ncnt - t0);
         PS_WAVE_SYNC();                           // previous tile fully consumed
-        if (lane < n) tile[lane] = pre;
+        if (lane < n) { tx[lane] = pre.x; ty[lane] = pre.y; tz[lane] = pre.z; tw[lane] = pre.w; }
         PS_WAVE_SYNC();
         t0 += 64;                                 // advance to the next non-empty tile
         if (t0 >= ncnt) {
@@ -653,38 +712,64 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
         have = k < 27;
         // issued after the fences (they drain outstanding loads), consumed a tile later
         if (have && lane < min(64, ncnt - t0)) pre = snap4[nb + t0 + lane];
-        if (MODE == 1) {
+        if (MODE != 0) {
             const PairCtx ctx = {me.x, me.y, me.z, age_i, id_i, gi, scan};
             // groups of NQ tile entries (prefetching the next group's LDS reads into registers
             // was measured 7-8 % slower: the registers cost more than the latency they hide)
+            float dmin = 3.0e38f;
             int jj = 0;
             for (; jj + NQ <= n; jj += NQ) {
-                float4 q[NQ];
+                v2f qx[NQ / 2], qy[NQ / 2], qz[NQ / 2], qw[NQ / 2];   // 16-byte LDS reads, NQ is a multiple of 4
 #pragma unroll
-                for (int i = 0; i < NQ; i++) q[i] = tile[jj + i];
-                pairsN_exact_lean<NQ>(P, ctx, q, c_nb + c_t0 + jj, snap_age, sorted_id, ax, ay, az, flag);
+                for (int i = 0; i < NQ / 2; i += 2) {
+                    const float4 vx = *reinterpret_cast<const float4 *>(tx + jj + 2 * i);
+                    const float4 vy = *reinterpret_cast<const float4 *>(ty + jj + 2 * i);
+                    const float4 vz = *reinterpret_cast<const float4 *>(tz + jj + 2 * i);
+                    const float4 vw = *reinterpret_cast<const float4 *>(tw + jj + 2 * i);
+                    qx[i] = v2f{vx.x, vx.y}; qx[i + 1] = v2f{vx.z, vx.w};
+                    qy[i] = v2f{vy.x, vy.y}; qy[i + 1] = v2f{vy.z, vy.w};
+                    qz[i] = v2f{vz.x, vz.y}; qz[i + 1] = v2f{vz.z, vz.w};
+                    qw[i] = v2f{vw.x, vw.y}; qw[i + 1] = v2f{vw.z, vw.w};
+                }
+                if (MODE == 1)
+                    pairsN_exact_lean<NQ>(P, ctx, qx, qy, qz, qw, c_nb + c_t0 + jj, snap_age, sorted_id, ax, ay, az, flag);
+                else
+                    dmin = fminf(dmin, pairsN_fast<NQ>(ctx, qx, qy, qz, qw, eps2f, ax, ay, az));
             }
-            for (; jj < n; jj++)
-                pair1_exact_lean(P, ctx, tile[jj], c_nb + c_t0 + jj, snap_age, sorted_id, ax, ay, az, flag);
+            for (; jj < n; jj++) {
+                if (MODE == 1)
+                    pair1_exact_lean(P, ctx, tile_at(jj), c_nb + c_t0 + jj, snap_age, sorted_id, ax, ay, az, flag);
+                else
+                    dmin = fminf(dmin, pair_fast(me.x, me.y, me.z, tile_at(jj), eps2f, ax, ay, az));
+            }
+            // fast math, rare: someone in this tile is within the collision gate of one of my lanes
+            if (MODE == 2 && __any(scan && !(dmin > P.coll_d2_gate))) {
+                if (scan && !(dmin > P.coll_d2_gate)) {
+                    for (int j = 0; j < n; j++) {
+                        const float4 q = tile_at(j);
+                        const float rx = q.x - me.x, ry = q.y - me.y, rz = q.z - me.z;
+                        const float d2 = rx * rx + ry * ry + rz * rz;
+                        const int gj = c_nb + c_t0 + j;
+                        if (!(d2 > P.coll_d2_gate) && gj != gi)
+                            flag = max(flag, collide_exact(P, d2, age_i, id_i, snap_age[gj], sorted_id[gj]));
+                    }
+                }
+            }
         } else {
+            // Generic exact mode (any EPS2).  The lean modes let a particle meet itself
+            // (r = 0 adds +0, exactly nothing) because 1/sqrt(eps2^3) is finite on the range
+            // they are allowed on; this one also serves softening lengths where it is not, so
+            // it skips the self pair explicitly, as the reference does by id (ps.cpp:1258).
             float dmin = 3.0e38f;
 #pragma unroll 4
             for (int jj = 0; jj < n; jj++) {
-                const float4 q = tile[jj];
-                // The other modes let a particle meet itself (r = 0 adds +0, exactly nothing)
-                // because 1/sqrt(eps2^3) is finite on the range they are allowed on; the
-                // generic mode also serves softening lengths where it is not, so it skips
-                // the self pair explicitly, as the reference does by id (ps.cpp:1258).
-                if (MODE == 0 && c_nb + c_t0 + jj == gi) continue;
-                const float d2 = MODE == 2 ? pair_fast(me.x, me.y, me.z, q, eps2f, ax, ay, az)
-                                           : pair_exact(me.x, me.y, me.z, q, P.eps2, ax, ay, az);
-                dmin = fminf(dmin, d2);
+                if (c_nb + c_t0 + jj == gi) continue;
+                dmin = fminf(dmin, pair_exact(me.x, me.y, me.z, tile_at(jj), P.eps2, ax, ay, az));
             }
-            // rare: someone in this tile is within the collision gate of one of my lanes
             if (__any(scan && !(dmin > P.coll_d2_gate))) {
                 if (scan && !(dmin > P.coll_d2_gate)) {
                     for (int jj = 0; jj < n; jj++) {
-                        const float4 q = tile[jj];
+                        const float4 q = tile_at(jj);
                         const float rx = q.x - me.x, ry = q.y - me.y, rz = q.z - me.z;
                         const float d2 = rx * rx + ry * ry + rz * rz;
                         const int gj = c_nb + c_t0 + jj;
@@ -1433,7 +1518,7 @@ hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d
                         bool sharded)
 {
     // fast math shares the lean modes' validity range (finite 1/sqrt(eps2^3))
-    if ((P.flags & PSAMD_FLAG_FAST_MATH) && P.lean_math) return launch_pairs_mode<2, 4>(st, P, d, lo, hi, covered, sharded);
+    if ((P.flags & PSAMD_FLAG_FAST_MATH) && P.lean_math) return launch_pairs_mode<2, 8>(st, P, d, lo, hi, covered, sharded);
     // 8 pairs per slow-branch test: measured 3 % (full GPU) to 5 % (a 1/8 share) faster than 4
     if (P.lean_math) return launch_pairs_mode<1, 8>(st, P, d, lo, hi, covered, sharded);
     return launch_pairs_mode<0, 4>(st, P, d, lo, hi, covered, sharded);

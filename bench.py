@@ -77,14 +77,37 @@ def pair_count(cellgrid_counts, G):
 
 
 def cpu_baseline(args, xyz, age, fert, cfg_over):
-    """The oracle (CPU port of the reference `_host` path) on a bounded sample of the
-    SAME workload: whole chunks of calc_forces until ~args.cpu_seconds have passed."""
+    """The oracle (CPU port of the reference `_host` path) on bounded samples of the SAME
+    workload.  `cpu_baseline`: one thread, whole chunks of calc_forces until ~args.cpu_seconds
+    have passed.  `cpu_baseline_all_cores`: the read-only pair pass (collision scan + force
+    loop, >99.9 % of the CPU step) on every usable host core, contiguous shares per thread."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     o = O.System(O.default_config(**cfg_over))
     o.fill(xyz, age=age, fert_age=fert)
     o.init_iframe()
     o.build_grid()
+    many = None
+    cores = min(len(os.sched_getaffinity(0)), args.cpu_threads)
+    if cores > 1:
+        total = o.sorted_count()
+        f = np.zeros((total + 8, 4), np.float32)
+        probe = min(total, cores * 512)
+        t0 = time.perf_counter()
+        o.calc_pairs_threads(0, probe, f, cores)
+        rate = probe / max(time.perf_counter() - t0, 1e-6)
+        share = int(min(total, max(probe, rate * args.cpu_seconds * 0.6)))
+        segs = 8 if share < total else 1          # spread over the box: edge cells are cheaper than interior ones
+        seg = share // segs
+        t0 = time.perf_counter()
+        for k in range(segs):
+            lo = k * total // segs
+            o.calc_pairs_threads(lo, lo + seg, f, cores)
+        tm = time.perf_counter() - t0
+        many = {"value": seg * segs / tm, "unit": "particle-updates/s", "cores": cores, "kind": "port",
+                "sample": "pair pass (collision scan + force loop) of %d particles (%d runs of cells spread over the "
+                          "box) of the same N=%d cloud on %d host threads, %.1f s" % (seg * segs, segs, len(xyz), cores, tm)}
+        del f
     gm = int(o.gridmax[0])
     counts = o.chunkgrid[:, 0].copy()
     done, t = 0, 0.0
@@ -96,10 +119,11 @@ def cpu_baseline(args, xyz, age, fert, cfg_over):
         chunks += 1
         t = time.perf_counter() - t0
     o.close()
-    return {"value": done / t if t > 0 else 0.0, "unit": "particle-updates/s", "cores": 1, "kind": "port",
-            "sample": "calc_forces of chunks 0..%d of the same N=%d cloud (%d particles, %.1f s), "
-                      "1 thread; grid build excluded (0.07%% of the CPU step)" % (chunks - 1, len(xyz), done, t),
-            "host_cpus": os.cpu_count()}
+    one = {"value": done / t if t > 0 else 0.0, "unit": "particle-updates/s", "cores": 1, "kind": "port",
+           "sample": "calc_forces of chunks 0..%d of the same N=%d cloud (%d particles, %.1f s), "
+                     "1 thread; grid build excluded (0.07%% of the CPU step)" % (chunks - 1, len(xyz), done, t),
+           "host_cpus": os.cpu_count()}
+    return one, many
 
 
 def main():
@@ -110,6 +134,7 @@ def main():
     ap.add_argument("--n", type=int, default=1 << 20)
     ap.add_argument("--fast-math", action="store_true", help="FMA/rsq pair arithmetic (not bit-exact)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-threads", type=int, default=64, help="cap on host threads for the all-core CPU figure")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--chunk-factor", type=int, default=4, help="grid = (chunk_factor*chunk_dim)^3 cells (reference: 4)")
@@ -269,7 +294,7 @@ def main():
             "kernel_us_per_step": {k: v / max(launches, 1) for k, v in tim.items()},
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args, xyz, age, fert, cfg_over)
+            out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(args, xyz, age, fert, cfg_over)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

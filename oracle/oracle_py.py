@@ -96,6 +96,8 @@ def lib():
         L.pso_sorted_count.argtypes = [vp]
         L.pso_sorted_count.restype = ci
         L.pso_calc_pairs.argtypes = [vp, ci, ci, vp]
+        L.pso_calc_pairs_threads.argtypes = [vp, ci, ci, vp, ci]
+        L.pso_calc_pairs_threads.restype = ci
         L.pso_apply_forces.argtypes = [vp, vp]
         L.pso_step.argtypes = [vp, ci]
         L.pso_set_rng.argtypes = [vp, RNG_FN, vp]
@@ -283,6 +285,12 @@ class System:
     def calc_pairs(self, lo, hi, force4):
         assert force4.dtype == np.float32 and force4.flags["C_CONTIGUOUS"]
         self.L.pso_calc_pairs(self.h, lo, hi, force4.ctypes.data)
+
+    def calc_pairs_threads(self, lo, hi, force4, nthreads):
+        """calc_pairs with the range split over host threads (bench.py's all-core figure)."""
+        assert force4.dtype == np.float32 and force4.flags.c_contiguous
+        if self.L.pso_calc_pairs_threads(self.h, lo, hi, force4.ctypes.data, nthreads) != 0:
+            raise RuntimeError("pso_calc_pairs_threads failed")
 
     def apply_forces(self, force4):
         assert force4.dtype == np.float32 and force4.flags["C_CONTIGUOUS"]

@@ -13,6 +13,7 @@
 #include "ps_oracle.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -578,7 +579,7 @@ void pso_build_grid(pso_system *s)
 }
 
 /* neighbour id list of a cell: fill_cells + fill_particles, app.cu:370-452 */
-static int gather_neighbours(pso_system *s, int cell)
+static int gather_neighbours(const pso_system *s, int cell, int *neib)
 {
     const pso_derived *d = &s->d;
     const int cstride = 1 + d->max_per_cell;
@@ -587,14 +588,15 @@ static int gather_neighbours(pso_system *s, int cell)
         const int *cl = s->cellgrid + (size_t)cells[i] * cstride;
         int t, cnt = cl[0];
         for (t = 1; t <= cnt; t++)
-            if (nn < d->max_neib_particles) s->neib[nn++] = cl[t];
+            if (nn < d->max_neib_particles) neib[nn++] = cl[t];
     }
     return nn;
 }
 
 /* death + collision scan (ps.cpp:1182-1208) and force loop (ps.cpp:1247-1259) of one
  * particle over the gathered list; nothing is modified.  Returns the collision flag. */
-static int scan_and_accumulate(pso_system *s, const pso_particle *me, int nn, float acc[3], int *died_of_age)
+static int scan_and_accumulate(const pso_system *s, const pso_particle *me, const int *neib, int nn, float acc[3],
+                               int *died_of_age)
 {
     const pso_config *c = &s->cfg;
     const pso_derived *d = &s->d;
@@ -603,7 +605,7 @@ static int scan_and_accumulate(pso_system *s, const pso_particle *me, int nn, fl
     *died_of_age = 0;
     if ((double)me->age > d->particle_life) { *died_of_age = 1; return 2; }
     for (i = 0; i < nn; i++) {
-        const pso_tdata *nb = &s->tdata[s->neib[i]];
+        const pso_tdata *nb = &s->tdata[neib[i]];
         int flag = 0;
         if (me->id != nb->id) flag = pso_body_body_collision(c, d, me, nb);
         if (flag > collision_flag) collision_flag = flag;
@@ -611,7 +613,7 @@ static int scan_and_accumulate(pso_system *s, const pso_particle *me, int nn, fl
     }
     if (collision_flag > 0) return collision_flag;
     for (i = 0; i < nn; i++) {
-        const pso_tdata *nb = &s->tdata[s->neib[i]];
+        const pso_tdata *nb = &s->tdata[neib[i]];
         if (me->id != nb->id) pso_body_body_interaction(c, d, me, nb, acc);
     }
     return 0;
@@ -699,8 +701,8 @@ void pso_calc_forces_chunk(pso_system *s, int chunk, int subtask_elems)
         if (pid < 0) continue;
         me = &s->particles[pid];
         if (!(me->cell >= 0 && me->cell < d->num_cells)) continue;
-        nn = gather_neighbours(s, me->cell);
-        flag = scan_and_accumulate(s, me, nn, acc, &aged);
+        nn = gather_neighbours(s, me->cell, s->neib);
+        flag = scan_and_accumulate(s, me, s->neib, nn, acc, &aged);
         finish_particle(s, me, flag, aged, acc);
     }
 }
@@ -714,7 +716,7 @@ int pso_sorted_count(const pso_system *s)
     return n;
 }
 
-void pso_calc_pairs(pso_system *s, int lo, int hi, float *force4)
+static void calc_pairs_range(const pso_system *s, int lo, int hi, float *force4, int *neib)
 {
     const pso_derived *d = &s->d;
     const int cstride = 1 + d->max_per_cell;
@@ -729,13 +731,54 @@ void pso_calc_pairs(pso_system *s, int lo, int hi, float *force4)
             float acc[3];
             union { int i; float f; } bits;
             if (gi < lo || gi >= hi) continue;
-            nn = gather_neighbours(s, c);
-            flag = scan_and_accumulate(s, me, nn, acc, &aged);
+            nn = gather_neighbours(s, c, neib);
+            flag = scan_and_accumulate(s, me, neib, nn, acc, &aged);
             bits.i = flag;
             force4[4 * gi] = acc[0]; force4[4 * gi + 1] = acc[1]; force4[4 * gi + 2] = acc[2];
             force4[4 * gi + 3] = bits.f;
         }
     }
+}
+
+void pso_calc_pairs(pso_system *s, int lo, int hi, float *force4)
+{
+    calc_pairs_range(s, lo, hi, force4, s->neib);
+}
+
+/* The same read-only pass on several host threads (contiguous shares of [lo, hi), one
+ * scratch list each): what pmlib gets from running chunk subtasks on all cores.  Used by
+ * bench.py for the all-core CPU figure; results are those of pso_calc_pairs. */
+typedef struct { const pso_system *s; int lo, hi; float *force4; int *neib; } pairs_job;
+
+static void *pairs_worker(void *arg)
+{
+    pairs_job *j = (pairs_job *)arg;
+    calc_pairs_range(j->s, j->lo, j->hi, j->force4, j->neib);
+    return NULL;
+}
+
+int pso_calc_pairs_threads(pso_system *s, int lo, int hi, float *force4, int nthreads)
+{
+    pthread_t *tid;
+    pairs_job *job;
+    int k, started = 0, rc = 0;
+    if (nthreads < 1) nthreads = 1;
+    if (hi < lo) hi = lo;
+    tid = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    job = (pairs_job *)calloc((size_t)nthreads, sizeof(pairs_job));
+    if (!tid || !job) { free(tid); free(job); return -1; }
+    for (k = 0; k < nthreads; k++) {
+        job[k].s = s; job[k].force4 = force4;
+        job[k].lo = lo + (int)((long long)(hi - lo) * k / nthreads);
+        job[k].hi = lo + (int)((long long)(hi - lo) * (k + 1) / nthreads);
+        job[k].neib = (int *)malloc(sizeof(int) * (size_t)s->d.max_neib_particles);
+        if (!job[k].neib || pthread_create(&tid[k], NULL, pairs_worker, &job[k]) != 0) { rc = -1; break; }
+        started++;
+    }
+    for (k = 0; k < started; k++) pthread_join(tid[k], NULL);
+    for (k = 0; k < nthreads; k++) free(job[k].neib);
+    free(tid); free(job);
+    return rc;
 }
 
 void pso_apply_forces(pso_system *s, const float *force4)

@@ -122,6 +122,8 @@ void pso_step(pso_system *s, int nsteps);
  * pairs(0, n) followed by apply is exactly pso_calc_forces. */
 int  pso_sorted_count(const pso_system *s);
 void pso_calc_pairs(pso_system *s, int lo, int hi, float *force4);
+/* same results, the range split over `nthreads` host threads; 0 on success */
+int pso_calc_pairs_threads(pso_system *s, int lo, int hi, float *force4, int nthreads);
 void pso_apply_forces(pso_system *s, const float *force4);
 
 void pso_set_rng(pso_system *s, pso_rng_fn fn, void *user);

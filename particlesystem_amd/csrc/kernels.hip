@@ -548,7 +548,7 @@ __device__ __forceinline__ void pairsN_exact_lean(const DevParams &P, const Pair
 }
 
 // Fast-math counterpart (FMA + v_rsq), two pairs per packed instruction; returns the
-// smallest squared distance of the group for the collision gate.
+// smallest softened squared distance (d2 + eps2) of the group for the collision gate.
 template <int NQ>
 __device__ __forceinline__ float pairsN_fast(const PairCtx &c, const v2f (&qx)[NQ / 2], const v2f (&qy)[NQ / 2],
                                              const v2f (&qz)[NQ / 2], const v2f (&qw)[NQ / 2], float eps2,
@@ -561,9 +561,9 @@ __device__ __forceinline__ float pairsN_fast(const PairCtx &c, const v2f (&qx)[N
 #pragma unroll
     for (int i = 0; i < H; i++) {
         rx[i] = qx[i] - xi; ry[i] = qy[i] - yi; rz[i] = qz[i] - zi;
-        const v2f d = __builtin_elementwise_fma(rz[i], rz[i], __builtin_elementwise_fma(ry[i], ry[i], rx[i] * rx[i]));
-        dm = fminf(fminf(dm, d.x), d.y);
-        const v2f e = d + eps;
+        // softening folded into the first fma; the caller gates on d2 + eps2
+        const v2f e = __builtin_elementwise_fma(rz[i], rz[i], __builtin_elementwise_fma(ry[i], ry[i], __builtin_elementwise_fma(rx[i], rx[i], eps)));
+        dm = fminf(fminf(dm, e.x), e.y);
         v2f r; r.x = __builtin_amdgcn_rsqf(e.x); r.y = __builtin_amdgcn_rsqf(e.y);
         sc[i] = qw[i] * (r * r * r);
     }
@@ -740,11 +740,13 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
                 if (MODE == 1)
                     pair1_exact_lean(P, ctx, tile_at(jj), c_nb + c_t0 + jj, snap_age, sorted_id, ax, ay, az, flag);
                 else
-                    dmin = fminf(dmin, pair_fast(me.x, me.y, me.z, tile_at(jj), eps2f, ax, ay, az));
+                    dmin = fminf(dmin, pair_fast(me.x, me.y, me.z, tile_at(jj), eps2f, ax, ay, az) + eps2f);
             }
-            // fast math, rare: someone in this tile is within the collision gate of one of my lanes
-            if (MODE == 2 && __any(scan && !(dmin > P.coll_d2_gate))) {
-                if (scan && !(dmin > P.coll_d2_gate)) {
+            // fast math, rare: someone in this tile is within the (widened) collision gate of
+            // one of my lanes; the exact rule is then evaluated on unfused distances
+            const float gate_soft = (P.coll_d2_gate + eps2f) * 1.0001f;
+            if (MODE == 2 && __any(scan && !(dmin > gate_soft))) {
+                if (scan && !(dmin > gate_soft)) {
                     for (int j = 0; j < n; j++) {
                         const float4 q = tile_at(j);
                         const float rx = q.x - me.x, ry = q.y - me.y, rz = q.z - me.z;

@@ -59,6 +59,22 @@ def test_pair_pass_plus_apply_is_calc_forces():
     assert a.counters["relocations"] > 0 and a.counters["deaths_collision"] > 0
 
 
+def test_threaded_pair_pass_matches_serial():
+    o = make()
+    o.step(3)
+    o.init_iframe(); o.build_grid()
+    n = o.sorted_count()
+    want = np.zeros((n + 8, 4), np.float32)
+    got = np.zeros_like(want)
+    o.calc_pairs(0, n, want)
+    o.calc_pairs_threads(0, n, got, 5)
+    assert want.tobytes() == got.tobytes()
+    part = np.zeros_like(want)
+    o.calc_pairs_threads(100, n - 77, part, 3)          # a sub-range leaves the rest untouched
+    assert part[100:n - 77].tobytes() == want[100:n - 77].tobytes()
+    assert not part[:100].any() and not part[n - 77:].any()
+
+
 class OracleRank:
     """Stage interface of ParticleSystem on top of the oracle, for one rank."""
 

@@ -293,6 +293,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.sorted_id, C));
     PS_HIP(c, dev_alloc(c, &d.rank_of_slot, C));
     PS_HIP(c, dev_alloc(c, &d.snap4, C));
+    PS_HIP(c, dev_alloc(c, &d.snap_soa, 4 * C + 64));   // + slack: scalar loads fetch whole groups
     PS_HIP(c, dev_alloc(c, &d.snap_age, C));
     PS_HIP(c, dev_alloc(c, &d.force4, C));
     c->own_force4 = d.force4;

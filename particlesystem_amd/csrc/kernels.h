@@ -38,6 +38,7 @@ struct DeviceState {
     int *sorted_id = nullptr;     // [container] cell-major, id ascending inside a cell
     int *rank_of_slot = nullptr;  // [container] inverse of sorted_id for the slots of this frame
     float4 *snap4 = nullptr;      // [container] sorted order: x,y,z,w_eff
+    float *snap_soa = nullptr;    // [4][container] the same as four arrays (what k_pairs streams)
     float *snap_age = nullptr;    // [container] sorted order
     float4 *force4 = nullptr;     // [container] sorted order: ax,ay,az,flag
     CellInfo *celltab = nullptr;  // [num_cells]

@@ -8,9 +8,9 @@
 //   k_sort_cells   rank ids inside each cell (ascending = the reference's cell-list
 //               order, ps.cpp:1510-1516), gather the T_DATA snapshot in that order
 //   k_pairs     27-cell softened gravity + collision flags: one WAVE per 64 particles of
-//               one cell, neighbour tiles staged through LDS and broadcast to the 64
-//               lanes, serial fp32 accumulation in the reference's order (fp32 VALU
-//               bound; no MFMA: no contraction here, every pair needs its own rsqrt)
+//               one cell; neighbour bodies arrive by scalar loads (SGPR operands of packed
+//               fp32 instructions), serial fp32 accumulation in the reference's order (fp32
+//               VALU bound; no MFMA: no contraction here, every pair needs its own rsqrt)
 //   k_apply     death / survive / integrate / wrap / re-hash, in slot order (streaming, HBM)
 //   k_ops_hist / k_ops_scan / k_ops_scatter / k_replay_bucket / k_moves_*
 //               free-slot queues + relocation, replayed in the reference's serial order
@@ -325,7 +325,8 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
                                                      int *__restrict__ sorted_id,
                                                      float4 *pos4, float4 *vel4, float4 *acc4,
                                                      int *cell_arr, uint8_t *pflags,
-                                                     float4 *__restrict__ snap4, float *__restrict__ snap_age,
+                                                     float4 *__restrict__ snap4, float *__restrict__ snap_soa,
+                                                     float *__restrict__ snap_age,
                                                      uint32_t *__restrict__ tdata, int *__restrict__ rank_of_slot,
                                                      uint64_t *op_keys, int *op_args, int ops_cap,
                                                      FrameScalars *fs, DevCounters *ctr)
@@ -369,6 +370,12 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
             sorted_id[start + e] = id;
             rank_of_slot[id] = start + e;
             snap4[start + e] = make_float4(p.x, p.y, p.z, (age < P.kid_thr) ? 0.0f : p.w);
+            {   // the same four values as separate arrays: what the pair kernel streams
+                const size_t cap = (size_t)P.container;
+                const float w_eff = (age < P.kid_thr) ? 0.0f : p.w;
+                snap_soa[start + e] = p.x; snap_soa[cap + start + e] = p.y;
+                snap_soa[2 * cap + start + e] = p.z; snap_soa[3 * cap + start + e] = w_eff;
+            }
             snap_age[start + e] = age;
         } else {
             sorted_id[start + e] = -1;
@@ -499,6 +506,90 @@ __device__ __forceinline__ v2f inv_sqrt_selected2(v2f six)
     return __builtin_elementwise_fma(__builtin_elementwise_fma(-s, x, one), x, x);          // rcp_rn_newton
 }
 
+// NQ pairs in two stages, so that a caller can start fetching the next group's bodies
+// between them: distances first (the only use of the positions), then everything else.
+template <int NQ>
+struct PairRows {
+    v2f rx[NQ / 2], ry[NQ / 2], rz[NQ / 2], d[NQ / 2];
+    float dm;                                   // smallest d of the group
+};
+
+// SOFTENED: d = fma chain started at eps2 (fast math); else the reference's unfused r.r
+template <int NQ, bool SOFTENED>
+__device__ __forceinline__ void pairs_dist(const PairCtx &c, const v2f (&qx)[NQ / 2], const v2f (&qy)[NQ / 2],
+                                           const v2f (&qz)[NQ / 2], float eps2, PairRows<NQ> &r)
+{
+    const v2f xi = {c.xi, c.xi}, yi = {c.yi, c.yi}, zi = {c.zi, c.zi}, eps = {eps2, eps2};
+    r.dm = 3.0e38f;
+#pragma unroll
+    for (int i = 0; i < NQ / 2; i++) {
+        r.rx[i] = qx[i] - xi; r.ry[i] = qy[i] - yi; r.rz[i] = qz[i] - zi;
+        if (SOFTENED)
+            r.d[i] = __builtin_elementwise_fma(r.rz[i], r.rz[i], __builtin_elementwise_fma(r.ry[i], r.ry[i], __builtin_elementwise_fma(r.rx[i], r.rx[i], eps)));
+        else
+            r.d[i] = r.rx[i] * r.rx[i] + r.ry[i] * r.ry[i] + r.rz[i] * r.rz[i];
+        r.dm = fminf(fminf(r.dm, r.d[i].x), r.d[i].y);
+    }
+}
+
+template <int NQ>
+__device__ __forceinline__ void pairs_finish_exact(const DevParams &P, const PairCtx &c, const PairRows<NQ> &r,
+                                                   const v2f (&qw)[NQ / 2], int gj0,
+                                                   const float *__restrict__ snap_age,
+                                                   const int *__restrict__ sorted_id,
+                                                   float &ax, float &ay, float &az, int &flag)
+{
+    constexpr int H = NQ / 2;
+    v2f e[H];
+    if (__any(r.dm < P.slow_below)) {
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            e[i].x = (float)((double)r.d[i].x + P.eps2);
+            e[i].y = (float)((double)r.d[i].y + P.eps2);
+        }
+        if (c.scan && !(r.dm > P.coll_d2_gate)) {
+#pragma unroll
+            for (int i = 0; i < NQ; i++) {
+                const float di = (i & 1) ? r.d[i >> 1].y : r.d[i >> 1].x;
+                if (!(di > P.coll_d2_gate) && gj0 + i != c.gi)
+                    flag = max(flag, collide_exact(P, di, c.age_i, c.id_i, snap_age[gj0 + i], sorted_id[gj0 + i]));
+            }
+        }
+    } else {
+        const v2f eps = {P.eps2f, P.eps2f};
+#pragma unroll
+        for (int i = 0; i < H; i++) e[i] = r.d[i] + eps;
+    }
+    v2f sc[H];
+#pragma unroll
+    for (int i = 0; i < H; i++) sc[i] = qw[i] * inv_sqrt_selected2(e[i] * e[i] * e[i]);
+#pragma unroll
+    for (int i = 0; i < H; i++) {                       // sums in list order
+        const v2f px = r.rx[i] * sc[i], py = r.ry[i] * sc[i], pz = r.rz[i] * sc[i];
+        ax += px.x; ay += py.x; az += pz.x;
+        ax += px.y; ay += py.y; az += pz.y;
+    }
+}
+
+// Fast-math finish (FMA + v_rsq) on softened distances.
+template <int NQ>
+__device__ __forceinline__ void pairs_finish_fast(const PairRows<NQ> &r, const v2f (&qw)[NQ / 2],
+                                                  float &ax, float &ay, float &az)
+{
+    constexpr int H = NQ / 2;
+    v2f sc[H];
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+        v2f q; q.x = __builtin_amdgcn_rsqf(r.d[i].x); q.y = __builtin_amdgcn_rsqf(r.d[i].y);
+        sc[i] = qw[i] * (q * q * q);
+    }
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+        ax = fmaf(r.rx[i].x, sc[i].x, ax); ay = fmaf(r.ry[i].x, sc[i].x, ay); az = fmaf(r.rz[i].x, sc[i].x, az);
+        ax = fmaf(r.rx[i].y, sc[i].y, ax); ay = fmaf(r.ry[i].y, sc[i].y, ay); az = fmaf(r.rz[i].y, sc[i].y, az);
+    }
+}
+
 template <int NQ>
 __device__ __forceinline__ void pairsN_exact_lean(const DevParams &P, const PairCtx &c, const v2f (&qx)[NQ / 2],
                                                   const v2f (&qy)[NQ / 2], const v2f (&qz)[NQ / 2],
@@ -507,72 +598,21 @@ __device__ __forceinline__ void pairsN_exact_lean(const DevParams &P, const Pair
                                                   const int *__restrict__ sorted_id,
                                                   float &ax, float &ay, float &az, int &flag)
 {
-    constexpr int H = NQ / 2;
-    const v2f xi = {c.xi, c.xi}, yi = {c.yi, c.yi}, zi = {c.zi, c.zi};
-    v2f rx[H], ry[H], rz[H], d[H], e[H];
-    float dm = 3.0e38f;
-#pragma unroll
-    for (int i = 0; i < H; i++) {
-        rx[i] = qx[i] - xi; ry[i] = qy[i] - yi; rz[i] = qz[i] - zi;
-        d[i] = rx[i] * rx[i] + ry[i] * ry[i] + rz[i] * rz[i];
-        dm = fminf(fminf(dm, d[i].x), d[i].y);
-    }
-    if (__any(dm < P.slow_below)) {
-#pragma unroll
-        for (int i = 0; i < H; i++) {
-            e[i].x = (float)((double)d[i].x + P.eps2);
-            e[i].y = (float)((double)d[i].y + P.eps2);
-        }
-        if (c.scan && !(dm > P.coll_d2_gate)) {
-#pragma unroll
-            for (int i = 0; i < NQ; i++) {
-                const float di = (i & 1) ? d[i >> 1].y : d[i >> 1].x;
-                if (!(di > P.coll_d2_gate) && gj0 + i != c.gi)
-                    flag = max(flag, collide_exact(P, di, c.age_i, c.id_i, snap_age[gj0 + i], sorted_id[gj0 + i]));
-            }
-        }
-    } else {
-        const v2f eps = {P.eps2f, P.eps2f};
-#pragma unroll
-        for (int i = 0; i < H; i++) e[i] = d[i] + eps;
-    }
-    v2f sc[H];
-#pragma unroll
-    for (int i = 0; i < H; i++) sc[i] = qw[i] * inv_sqrt_selected2(e[i] * e[i] * e[i]);
-#pragma unroll
-    for (int i = 0; i < H; i++) {                       // sums in list order
-        const v2f px = rx[i] * sc[i], py = ry[i] * sc[i], pz = rz[i] * sc[i];
-        ax += px.x; ay += py.x; az += pz.x;
-        ax += px.y; ay += py.y; az += pz.y;
-    }
+    PairRows<NQ> r;
+    pairs_dist<NQ, false>(c, qx, qy, qz, 0.f, r);
+    pairs_finish_exact<NQ>(P, c, r, qw, gj0, snap_age, sorted_id, ax, ay, az, flag);
 }
 
-// Fast-math counterpart (FMA + v_rsq), two pairs per packed instruction; returns the
-// smallest softened squared distance (d2 + eps2) of the group for the collision gate.
+// returns the smallest softened squared distance (d2 + eps2) of the group, for the collision gate
 template <int NQ>
 __device__ __forceinline__ float pairsN_fast(const PairCtx &c, const v2f (&qx)[NQ / 2], const v2f (&qy)[NQ / 2],
                                              const v2f (&qz)[NQ / 2], const v2f (&qw)[NQ / 2], float eps2,
                                              float &ax, float &ay, float &az)
 {
-    constexpr int H = NQ / 2;
-    const v2f xi = {c.xi, c.xi}, yi = {c.yi, c.yi}, zi = {c.zi, c.zi}, eps = {eps2, eps2};
-    v2f rx[H], ry[H], rz[H], sc[H];
-    float dm = 3.0e38f;
-#pragma unroll
-    for (int i = 0; i < H; i++) {
-        rx[i] = qx[i] - xi; ry[i] = qy[i] - yi; rz[i] = qz[i] - zi;
-        // softening folded into the first fma; the caller gates on d2 + eps2
-        const v2f e = __builtin_elementwise_fma(rz[i], rz[i], __builtin_elementwise_fma(ry[i], ry[i], __builtin_elementwise_fma(rx[i], rx[i], eps)));
-        dm = fminf(fminf(dm, e.x), e.y);
-        v2f r; r.x = __builtin_amdgcn_rsqf(e.x); r.y = __builtin_amdgcn_rsqf(e.y);
-        sc[i] = qw[i] * (r * r * r);
-    }
-#pragma unroll
-    for (int i = 0; i < H; i++) {
-        ax = fmaf(rx[i].x, sc[i].x, ax); ay = fmaf(ry[i].x, sc[i].x, ay); az = fmaf(rz[i].x, sc[i].x, az);
-        ax = fmaf(rx[i].y, sc[i].y, ax); ay = fmaf(ry[i].y, sc[i].y, ay); az = fmaf(rz[i].y, sc[i].y, az);
-    }
-    return dm;
+    PairRows<NQ> r;
+    pairs_dist<NQ, true>(c, qx, qy, qz, eps2, r);
+    pairs_finish_fast<NQ>(r, qw, ax, ay, az);
+    return r.dm;
 }
 
 __device__ __forceinline__ void pair1_exact_lean(const DevParams &P, const PairCtx &c, const float4 q, int gj,
@@ -611,49 +651,48 @@ __global__ void k_shard_tasks(DevParams P, const int *__restrict__ cell_start, c
     fs->shard_task_n = task_start[c_hi + 1] - task_start[c_lo];
 }
 
-// One wave = 64 consecutive particles of one cell (four such waves per workgroup).
-// Neighbour cells are visited in the reference's stencil order and their snapshot is
-// streamed through a 1 KiB LDS tile; every lane reads the same tile entry (broadcast)
-// and adds it to its own particle's sum, so each particle sees exactly the
-// reference's sequence of fp32 additions (ps.cpp:1247-1259).
+// One wave = 64 consecutive particles of one cell (four independent waves per workgroup).
+// Neighbour cells are visited in the reference's stencil order, their bodies in list
+// order, and every lane adds each body to its own particle's sum: each particle sees
+// exactly the reference's sequence of fp32 additions (ps.cpp:1247-1259).
 // MODE 0: exact with the compiler's correctly rounded sqrt/divide (any EPS2);
 //      1: exact with the short sqrt/reciprocal above, NQ pairs per slow-branch test;
 //      2: fast math (FMA + v_rsq), not bit-exact.
 // SHARDED: the launch covers only this rank's run of the task list.
 //
-// No s_barrier anywhere: a wave only ever touches its own LDS tile, and a wave's LDS
-// operations complete in issue order, so a compiler-level fence is all the ordering needed.
+// Modes 1 and 2 never stage neighbour data at all.  It is the same for all 64 lanes, the
+// ranges are wave-uniform, so the loads are scalar loads (s_load_dwordx8 from the SoA
+// snapshot, straight out of L2 into SGPRs) and the packed fp32 instructions take the SGPR
+// pairs as operands: no LDS, no vector registers for the bodies.  (An LDS tile read with
+// ds_read_b128 by four waves per CU kept the LDS pipe ~70 % busy -- 16 cycles per wave
+// read, scripts/microbench/lds_groups.hip -- and cost 4 % more time.)
+// Mode 0, the fallback for softening lengths outside the lean range, streams 64-body
+// tiles through 1 KiB of LDS per wave.  No s_barrier: a wave only ever touches its own
+// tile, and a wave's LDS operations complete in issue order, so a compiler-level fence
+// is all the ordering needed.
 #define PS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-template <int MODE, bool SHARDED, int NQ>
-__global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restrict__ cell_start,
-                                               const float4 *__restrict__ snap4,
-                                               const float *__restrict__ snap_age,
-                                               const int *__restrict__ sorted_id,
-                                               const int *__restrict__ task_list,
-                                               float4 *__restrict__ force4, int lo, int hi, int covered,
-                                               FrameScalars *fs, unsigned long long *trace)
-{
-    // Workgroups of four INDEPENDENT waves (no workgroup barrier anywhere): the hardware
-    // deals a workgroup's waves over the four SIMDs of its CU and workgroups over the
-    // CUs, which keeps even a small share (a few waves per CU) evenly spread.
-    __shared__ __attribute__((aligned(16))) float tiles[4][4][64];   // [wave][x,y,z,w][entry]
-    const int wave = threadIdx.x >> 6;
-    float *tx = tiles[wave][0], *ty = tiles[wave][1], *tz = tiles[wave][2], *tw = tiles[wave][3];
-    auto tile_at = [&](int j) { return make_float4(tx[j], ty[j], tz[j], tw[j]); };
-    if (blockIdx.x == 0 && threadIdx.x == 0 && cell_start[P.num_cells] > covered) atomicOr(&fs->error, ERR_SHARD_BOUND);
-    // The work list holds only non-empty (cell, slice) tasks; the first `ntask` workgroups
-    // take one each (so the dispatcher deals the real work evenly over the CUs), spread
-    // over all eight XCDs with each XCD walking a contiguous run of cells.
-    const int ntask = SHARDED ? fs->shard_task_n : fs->n_tasks;
-    const int nwg = (ntask + 3) >> 2;
-    if ((int)blockIdx.x >= nwg) return;
-    const int slot = xcd_contiguous(blockIdx.x, nwg) * 4 + wave;
-    if (slot >= ntask) return;
-    const int task = task_list[(SHARDED ? fs->shard_task_lo : 0) + slot];
-#ifdef PSAMD_WAVE_TRACE
-    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
+#ifdef PSAMD_WAVE_TRACE   // diagnostic build only: when and where did this wave run
+#define PS_TRACE_BEGIN() const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime()
+#define PS_TRACE_END() do { if ((threadIdx.x & 63) == 0) { \
+        unsigned long long *t_ = trace + (size_t)3 * (blockIdx.x * 4 + (threadIdx.x >> 6)); \
+        t_[0] = trace_t0; t_[1] = __builtin_amdgcn_s_memrealtime(); \
+        t_[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32)   /* XCC_ID */ \
+                | __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4); } } while (0)               /* HW_ID */
+#else
+#define PS_TRACE_BEGIN() do {} while (0)
+#define PS_TRACE_END() do {} while (0)
 #endif
+
+// One task: 64 consecutive particles of one cell against the cell's stencil.
+template <int MODE, int NQ>
+__device__ __forceinline__ void pairs_task(const DevParams &P, const int *__restrict__ cell_start,
+                                           const float4 *__restrict__ snap4, const float *__restrict__ snap_soa,
+                                           const float *__restrict__ snap_age, const int *__restrict__ sorted_id,
+                                           float4 *__restrict__ force4, int lo, int hi, int task,
+                                           float4 *tile, unsigned long long *trace)
+{
+    PS_TRACE_BEGIN();
     const int c = task / P.slices, slice = task - c * P.slices;
     const int base = cell_start[c];
     const int cnt = min(cell_start[c + 1] - base, P.max_per_cell);
@@ -690,88 +729,90 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
             my_cnt = min(cell_start[nc + 1] - my_nb, P.max_per_cell);
         }
     }
-    // Tiles of 64 snapshot entries, in stencil order then list order.  The next tile's
-    // global load is issued before the current tile is consumed, so its latency hides
-    // behind ~64 x 32 VALU instructions even when only a couple of waves share a SIMD.
-    int k = 0, t0 = 0;
-    int nb = __shfl(my_nb, 0), ncnt = __shfl(my_cnt, 0);
-    while (ncnt == 0 && ++k < 27) { nb = __shfl(my_nb, k); ncnt = __shfl(my_cnt, k); }
-    bool have = k < 27;
-    float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (have && lane < min(64, ncnt)) pre = snap4[nb + lane];
-    while (have) {
-        const int c_nb = nb, c_t0 = t0, n = min(64, ncnt - t0);
-        PS_WAVE_SYNC();                           // previous tile fully consumed
-        if (lane < n) { tx[lane] = pre.x; ty[lane] = pre.y; tz[lane] = pre.z; tw[lane] = pre.w; }
-        PS_WAVE_SYNC();
-        t0 += 64;                                 // advance to the next non-empty tile
-        if (t0 >= ncnt) {
-            t0 = 0; ncnt = 0;
-            while (ncnt == 0 && ++k < 27) { nb = __shfl(my_nb, k); ncnt = __shfl(my_cnt, k); }
-        }
-        have = k < 27;
-        // issued after the fences (they drain outstanding loads), consumed a tile later
-        if (have && lane < min(64, ncnt - t0)) pre = snap4[nb + t0 + lane];
-        if (MODE != 0) {
-            const PairCtx ctx = {me.x, me.y, me.z, age_i, id_i, gi, scan};
-            // groups of NQ tile entries (prefetching the next group's LDS reads into registers
-            // was measured 7-8 % slower: the registers cost more than the latency they hide)
+    if (MODE != 0) {
+        const PairCtx ctx = {me.x, me.y, me.z, age_i, id_i, gi, scan};
+        const size_t cap = (size_t)P.container;
+        for (int k = 0; k < 27; k++) {
+            const int nb = __builtin_amdgcn_readlane(my_nb, k), n = __builtin_amdgcn_readlane(my_cnt, k);
+            const float *sx = snap_soa + nb, *sy = sx + cap, *sz = sy + cap, *sw = sz + cap;   // wave-uniform
             float dmin = 3.0e38f;
             int jj = 0;
+            // NQ bodies per group.  (Fetching the next group between the distance stage and
+            // the rest -- scalar loads return out of order, so it cannot go out any earlier --
+            // was measured 3 % slower for the exact arithmetic on a full GPU and no faster
+            // on a 1/8 share.)
             for (; jj + NQ <= n; jj += NQ) {
-                v2f qx[NQ / 2], qy[NQ / 2], qz[NQ / 2], qw[NQ / 2];   // 16-byte LDS reads, NQ is a multiple of 4
+                v2f qx[NQ / 2], qy[NQ / 2], qz[NQ / 2], qw[NQ / 2];
 #pragma unroll
-                for (int i = 0; i < NQ / 2; i += 2) {
-                    const float4 vx = *reinterpret_cast<const float4 *>(tx + jj + 2 * i);
-                    const float4 vy = *reinterpret_cast<const float4 *>(ty + jj + 2 * i);
-                    const float4 vz = *reinterpret_cast<const float4 *>(tz + jj + 2 * i);
-                    const float4 vw = *reinterpret_cast<const float4 *>(tw + jj + 2 * i);
-                    qx[i] = v2f{vx.x, vx.y}; qx[i + 1] = v2f{vx.z, vx.w};
-                    qy[i] = v2f{vy.x, vy.y}; qy[i + 1] = v2f{vy.z, vy.w};
-                    qz[i] = v2f{vz.x, vz.y}; qz[i + 1] = v2f{vz.z, vz.w};
-                    qw[i] = v2f{vw.x, vw.y}; qw[i + 1] = v2f{vw.z, vw.w};
+                for (int i = 0; i < NQ / 2; i++) {
+                    qx[i] = v2f{sx[jj + 2 * i], sx[jj + 2 * i + 1]};
+                    qy[i] = v2f{sy[jj + 2 * i], sy[jj + 2 * i + 1]};
+                    qz[i] = v2f{sz[jj + 2 * i], sz[jj + 2 * i + 1]};
+                    qw[i] = v2f{sw[jj + 2 * i], sw[jj + 2 * i + 1]};
                 }
                 if (MODE == 1)
-                    pairsN_exact_lean<NQ>(P, ctx, qx, qy, qz, qw, c_nb + c_t0 + jj, snap_age, sorted_id, ax, ay, az, flag);
+                    pairsN_exact_lean<NQ>(P, ctx, qx, qy, qz, qw, nb + jj, snap_age, sorted_id, ax, ay, az, flag);
                 else
                     dmin = fminf(dmin, pairsN_fast<NQ>(ctx, qx, qy, qz, qw, eps2f, ax, ay, az));
             }
             for (; jj < n; jj++) {
+                const float4 q = make_float4(sx[jj], sy[jj], sz[jj], sw[jj]);
                 if (MODE == 1)
-                    pair1_exact_lean(P, ctx, tile_at(jj), c_nb + c_t0 + jj, snap_age, sorted_id, ax, ay, az, flag);
+                    pair1_exact_lean(P, ctx, q, nb + jj, snap_age, sorted_id, ax, ay, az, flag);
                 else
-                    dmin = fminf(dmin, pair_fast(me.x, me.y, me.z, tile_at(jj), eps2f, ax, ay, az) + eps2f);
+                    dmin = fminf(dmin, pair_fast(me.x, me.y, me.z, q, eps2f, ax, ay, az) + eps2f);
             }
-            // fast math, rare: someone in this tile is within the (widened) collision gate of
+            // fast math, rare: someone in this cell is within the (widened) collision gate of
             // one of my lanes; the exact rule is then evaluated on unfused distances
             const float gate_soft = (P.coll_d2_gate + eps2f) * 1.0001f;
             if (MODE == 2 && __any(scan && !(dmin > gate_soft))) {
                 if (scan && !(dmin > gate_soft)) {
                     for (int j = 0; j < n; j++) {
-                        const float4 q = tile_at(j);
-                        const float rx = q.x - me.x, ry = q.y - me.y, rz = q.z - me.z;
+                        const float rx = sx[j] - me.x, ry = sy[j] - me.y, rz = sz[j] - me.z;
                         const float d2 = rx * rx + ry * ry + rz * rz;
-                        const int gj = c_nb + c_t0 + j;
-                        if (!(d2 > P.coll_d2_gate) && gj != gi)
-                            flag = max(flag, collide_exact(P, d2, age_i, id_i, snap_age[gj], sorted_id[gj]));
+                        if (!(d2 > P.coll_d2_gate) && nb + j != gi)
+                            flag = max(flag, collide_exact(P, d2, age_i, id_i, snap_age[nb + j], sorted_id[nb + j]));
                     }
                 }
             }
-        } else {
-            // Generic exact mode (any EPS2).  The lean modes let a particle meet itself
-            // (r = 0 adds +0, exactly nothing) because 1/sqrt(eps2^3) is finite on the range
-            // they are allowed on; this one also serves softening lengths where it is not, so
-            // it skips the self pair explicitly, as the reference does by id (ps.cpp:1258).
+        }
+    } else {
+        // Generic exact mode: tiles of 64 snapshot entries, in stencil order then list order.
+        // The next tile's global load is issued before the current tile is consumed.  The lean
+        // modes let a particle meet itself (r = 0 adds +0, exactly nothing) because
+        // 1/sqrt(eps2^3) is finite on the range they are allowed on; this one also serves
+        // softening lengths where it is not, so it skips the self pair explicitly, as the
+        // reference does by id (ps.cpp:1258).
+        int k = 0, t0 = 0;
+        int nb = __shfl(my_nb, 0), ncnt = __shfl(my_cnt, 0);
+        while (ncnt == 0 && ++k < 27) { nb = __shfl(my_nb, k); ncnt = __shfl(my_cnt, k); }
+        bool have = k < 27;
+        float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have && lane < min(64, ncnt)) pre = snap4[nb + lane];
+        while (have) {
+            const int c_nb = nb, c_t0 = t0, n = min(64, ncnt - t0);
+            PS_WAVE_SYNC();                           // previous tile fully consumed
+            if (lane < n) tile[lane] = pre;
+            PS_WAVE_SYNC();
+            t0 += 64;                                 // advance to the next non-empty tile
+            if (t0 >= ncnt) {
+                t0 = 0; ncnt = 0;
+                while (ncnt == 0 && ++k < 27) { nb = __shfl(my_nb, k); ncnt = __shfl(my_cnt, k); }
+            }
+            have = k < 27;
+            // issued after the fences (they drain outstanding loads), consumed a tile later
+            if (have && lane < min(64, ncnt - t0)) pre = snap4[nb + t0 + lane];
             float dmin = 3.0e38f;
 #pragma unroll 4
             for (int jj = 0; jj < n; jj++) {
                 if (c_nb + c_t0 + jj == gi) continue;
-                dmin = fminf(dmin, pair_exact(me.x, me.y, me.z, tile_at(jj), P.eps2, ax, ay, az));
+                dmin = fminf(dmin, pair_exact(me.x, me.y, me.z, tile[jj], P.eps2, ax, ay, az));
             }
+            // rare: someone in this tile is within the collision gate of one of my lanes
             if (__any(scan && !(dmin > P.coll_d2_gate))) {
                 if (scan && !(dmin > P.coll_d2_gate)) {
                     for (int jj = 0; jj < n; jj++) {
-                        const float4 q = tile_at(jj);
+                        const float4 q = tile[jj];
                         const float rx = q.x - me.x, ry = q.y - me.y, rz = q.z - me.z;
                         const float d2 = rx * rx + ry * ry + rz * rz;
                         const int gj = c_nb + c_t0 + jj;
@@ -785,14 +826,40 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
     if (dead) flag = 2;
     if (kid) { ax = 0.f; ay = 0.f; az = 0.f; }   // every term is skipped for a kid (app_common.cu:240)
     if (valid && gi >= lo && gi < hi) force4[gi] = make_float4(ax, ay, az, __int_as_float(flag));
-#ifdef PSAMD_WAVE_TRACE
-    if (lane == 0) {   // diagnostic build only: when and where did this wave run
-        unsigned long long *t = trace + (size_t)3 * (blockIdx.x * 4 + wave);
-        t[0] = trace_t0; t[1] = __builtin_amdgcn_s_memrealtime();
-        t[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32)   // XCC_ID
-               | __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);                             // HW_ID
-    }
-#endif
+    PS_TRACE_END();
+}
+
+template <int MODE, bool SHARDED, int NQ>
+__global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restrict__ cell_start,
+                                               const float4 *__restrict__ snap4,
+                                               const float *__restrict__ snap_soa,
+                                               const float *__restrict__ snap_age,
+                                               const int *__restrict__ sorted_id,
+                                               const int *__restrict__ task_list,
+                                               float4 *__restrict__ force4, int lo, int hi, int covered,
+                                               FrameScalars *fs, unsigned long long *trace)
+{
+    // Workgroups of four INDEPENDENT waves (no workgroup barrier anywhere): the hardware
+    // deals a workgroup's waves over the four SIMDs of its CU and workgroups over the
+    // CUs, which keeps even a small share (a few waves per CU) evenly spread.
+    __shared__ float4 tiles[MODE == 0 ? 4 : 1][MODE == 0 ? 64 : 1];   // mode 0 only
+    const int wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && cell_start[P.num_cells] > covered) atomicOr(&fs->error, ERR_SHARD_BOUND);
+    // The work list holds only non-empty (cell, slice) tasks, cell-major (a sharded launch
+    // covers this rank's run of it).  Workgroups are dealt round-robin over the eight XCDs
+    // (b and b + 8 share an L2), so workgroup b takes its four tasks from XCD (b & 7)'s
+    // contiguous eighth of the list: neighbouring cells' snapshots then sit in that XCD's L2.
+    // (Eighths of equal WORK instead of equal length -- the outer planes of the grid have
+    // fewer neighbours, so the two XCDs holding them go idle for the last sixth of the
+    // launch -- were tried: the XCDs then finish together, yet the launch was only 1 %
+    // shorter and the extra prefix sum cost k_scan 10 us.)
+    const int ntask = SHARDED ? fs->shard_task_n : fs->n_tasks;
+    const int nwg = (ntask + 3) >> 2;
+    if ((int)blockIdx.x >= nwg) return;
+    const int slot = xcd_contiguous(blockIdx.x, nwg) * 4 + wave;
+    if (slot >= ntask) return;
+    pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, lo, hi,
+                         task_list[(SHARDED ? fs->shard_task_lo : 0) + slot], tiles[MODE == 0 ? wave : 0], trace);
 }
 
 // ------------------------------------------------------------------ apply
@@ -1494,7 +1561,7 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[3], st);
     k_sort_cells<<<P.num_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
-                                               d.pflags, d.snap4, d.snap_age, d.tdata, d.rank_of_slot, d.op_keys, d.op_args, d.ops_cap, d.fs, d.ctr);
+                                               d.pflags, d.snap4, d.snap_soa, d.snap_age, d.tdata, d.rank_of_slot, d.op_keys, d.op_args, d.ops_cap, d.fs, d.ctr);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[4], st);
     return hipSuccess;
@@ -1507,10 +1574,10 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     const int tasks = P.num_cells * P.slices;
     if (sharded) {
         k_shard_tasks<<<1, 64, 0, st>>>(P, d.cell_start, d.task_start, lo, hi, d.fs);
-        k_pairs<MODE, true, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.task_list, d.force4,
+        k_pairs<MODE, true, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, d.task_list, d.force4,
                                                    lo, hi, covered, d.fs, d.trace);
     } else {
-        k_pairs<MODE, false, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.task_list, d.force4,
+        k_pairs<MODE, false, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, d.task_list, d.force4,
                                                     lo, hi, covered, d.fs, d.trace);
     }
     return hipGetLastError();

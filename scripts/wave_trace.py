@@ -31,3 +31,7 @@ print("dur us: min %.1f p50 %.1f p99 %.1f max %.1f" % (dur.min(), np.median(dur)
 u, cnt = np.unique(where, return_counts=True)
 print("distinct SIMDs used", len(u), "waves per SIMD: min %d p50 %d max %d" % (cnt.min(), np.median(cnt), cnt.max()))
 print("distinct CUs", len(np.unique(where >> 2)), "XCCs", np.unique(xcc))
+end = (t[:, 1] - t0) / 100.0
+for x in np.unique(xcc):
+    m = xcc == x
+    print("XCC %d: waves %d  busy wave-us %.0f  last end %.1f us  p50 dur %.1f" % (x, m.sum(), dur[m].sum(), end[m].max(), np.median(dur[m])))

@@ -9,9 +9,10 @@
 
 constexpr int ITER = 4096;
 
-template <int OP>
+template <int OP, int LANES = 64>
 __global__ __launch_bounds__(256) void k(float *out, float seed, unsigned long long *clk)
 {
+    if ((int)(threadIdx.x & 63) >= LANES) return;   // the rest of the wave runs with a partial EXEC mask
     float a[8];
     double d[8];
     for (int i = 0; i < 8; i++) { a[i] = seed + threadIdx.x * 1e-3f + i; d[i] = a[i]; }
@@ -58,16 +59,16 @@ __global__ __launch_bounds__(256) void k(float *out, float seed, unsigned long l
     if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
 }
 
-template <int OP>
+template <int OP, int LANES = 64>
 int run(const char *name, int per_iter, float *out, unsigned long long *clk)
 {
     const int blocks = 256 * 8, threads = 256;   // 8 waves per SIMD
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    k<OP><<<blocks, threads>>>(out, 1.0001f, clk);
+    k<OP, LANES><<<blocks, threads>>>(out, 1.0001f, clk);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    k<OP><<<blocks, threads>>>(out, 1.0001f, clk);
+    k<OP, LANES><<<blocks, threads>>>(out, 1.0001f, clk);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms = 0;
@@ -101,5 +102,9 @@ int main()
     run<10>("v_fma_f64", 8, out, clk);
     run<11>("v_pk_fma_f32 (2 fma)", 4, out, clk);
     run<12>("v_pk_mul_f32 (2 mul)", 4, out, clk);
+    run<0, 32>("v_fma_f32, 32 lanes active", 8, out, clk);
+    run<0, 16>("v_fma_f32, 16 lanes active", 8, out, clk);
+    run<11, 32>("v_pk_fma_f32, 32 lanes active", 4, out, clk);
+    run<3, 32>("v_rsq_f32, 32 lanes active", 8, out, clk);
     return 0;
 }

@@ -35,6 +35,7 @@ struct DeviceState {
     int *cursor = nullptr;        // [num_cells]
     int *task_start = nullptr;    // [num_cells+1] prefix of 64-particle slices per cell
     int *task_list = nullptr;     // [num_cells * slices] non-empty (cell, slice) tasks, cell-major
+    int *task_done = nullptr;     // [num_cells * slices] legs finished so far of a split task (sharded launches)
     int *sorted_id = nullptr;     // [container] cell-major, id ascending inside a cell
     int *rank_of_slot = nullptr;  // [container] inverse of sorted_id for the slots of this frame
     float4 *snap4 = nullptr;      // [container] sorted order: x,y,z,w_eff

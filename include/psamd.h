@@ -210,9 +210,6 @@ int psamd_bind_force4(psamd_ctx *ctx, void *device_ptr, int64_t n_float4);
 int psamd_get_counters(psamd_ctx *ctx, psamd_counters *out);
 int psamd_live_count(psamd_ctx *ctx, int64_t *out);
 int psamd_device_view_get(psamd_ctx *ctx, psamd_device_view *out);
-/* Per-kernel device time of the most recent step in microseconds, measured with
- * HIP events on the context's stream: hist, scan, scatter, sort, pairs, apply,
- * lifecycle.  Enabled by psamd_set_timing(ctx, 1). */
 /* Diagnostic builds (-DPSAMD_WAVE_TRACE) record per pair-kernel wave: start, end
  * (100 MHz real-time counter) and hardware id; 3 words per wave slot.  Zeros otherwise. */
 int psamd_debug_wave_trace(psamd_ctx *ctx, uint64_t *out, int64_t n_words);
@@ -223,8 +220,13 @@ int psamd_debug_wave_trace(psamd_ctx *ctx, uint64_t *out, int64_t n_words);
  * composition RN(1/RN(sqrt x)) as used; [3] = mismatches of a rejected shortcut (for the
  * record); [8..15], [16..23] = first offending inputs of the sqrt and the composition. */
 int psamd_selftest_math(psamd_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t out24[24]);
+/* Device time per kernel group, accumulated over the steps since psamd_set_timing, in
+ * microseconds, measured with HIP events on the context's stream: hist, scan, scatter,
+ * sort, pairs, apply, lifecycle, frame reset.  level 0: off; 1: pairs, apply and lifecycle
+ * only (three events per step); 2: every stage (an event between two kernels costs a few
+ * microseconds of idle GPU, so this is for diagnosis).  Never makes a step wait. */
 #define PSAMD_NUM_TIMERS 8
-int psamd_set_timing(psamd_ctx *ctx, int enabled);
+int psamd_set_timing(psamd_ctx *ctx, int level);
 int psamd_get_timing(psamd_ctx *ctx, double us_out[PSAMD_NUM_TIMERS], int64_t *launches);
 
 #ifdef __cplusplus

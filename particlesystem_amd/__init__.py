@@ -365,8 +365,10 @@ class ParticleSystem:
         self._ck(self.lib.psamd_selftest_math(self.h, lo_bits, hi_bits, out))
         return list(out)
 
-    def set_timing(self, on=True):
-        self._ck(self.lib.psamd_set_timing(self.h, 1 if on else 0))
+    def set_timing(self, on=True, every_stage=False):
+        """HIP-event timing of the step's kernels: pair pass, apply and life cycle, or every
+        stage (an event between every two kernels costs ~6 us of idle GPU each)."""
+        self._ck(self.lib.psamd_set_timing(self.h, (2 if every_stage else 1) if on else 0))
 
     def timing(self):
         us = (C.c_double * NUM_TIMERS)()

@@ -55,8 +55,10 @@ struct psamd_ctx {
     // sharded path needs no read-back between build and pair pass (-1 = unknown)
     int64_t live_bound = 0, snapshot_live_bound = 0;
     // timing
-    bool timing = false;
-    hipEvent_t ev[11]{};
+    int timing = 0;                    // 0 off, 1 pair pass / apply / life cycle, 2 every stage
+    hipEvent_t ev[13]{};               // 10 frame reset | 0 hist 1 scan 2 scatter 3 sort 4 | 5 pairs 6 | 7 apply 8,11 | life cycle 9,12
+    bool lifecycle_pending[2] = {false, false};   // ev[8|11] -> ev[9|12] recorded, not yet read
+    hipEvent_t ev_scalars = nullptr;   // the per-step read-back of FrameScalars has landed
     bool ev_made = false;
     double t_us[PSAMD_NUM_TIMERS]{};
     int64_t t_launches = 0;
@@ -180,6 +182,20 @@ void shard_range(const psamd_ctx *c, int64_t bound, int64_t &lo, int64_t &hi, in
     hi = lo + share;
 }
 
+// life-cycle interval of the step of parity `par`, if one is outstanding
+void collect_lifecycle_time(psamd_ctx *c, int par)
+{
+    if (!c->lifecycle_pending[par]) return;
+    // called one step later (the interval ended long ago, this returns at once) or by
+    // get_timing (waits for the last step's life cycle)
+    (void)hipEventSynchronize(c->ev[par ? 12 : 9]);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[par ? 11 : 8], c->ev[par ? 12 : 9]) == hipSuccess) {
+        c->t_us[6] += 1000.0 * ms;
+        c->lifecycle_pending[par] = false;
+    }
+}
+
 void make_events(psamd_ctx *c)
 {
     if (c->ev_made) return;
@@ -235,6 +251,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, hipSetDevice(cfg->device));
     PS_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    PS_HIP(c, hipEventCreateWithFlags(&c->ev_scalars, hipEventDisableTiming));
 
     DevParams &P = c->P;
     P.G = g.G; P.num_cells = g.num_cells; P.num_chunks = g.num_chunks; P.container = g.container;
@@ -367,6 +384,7 @@ int psamd_destroy(psamd_ctx *c)
     if (c->staging) (void)hipFree(c->staging);
     if (c->h_fs) (void)hipHostFree(c->h_fs);
     if (c->ev_made) for (auto &e : c->ev) (void)hipEventDestroy(e);
+    if (c->ev_scalars) (void)hipEventDestroy(c->ev_scalars);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return PSAMD_OK;
@@ -650,11 +668,9 @@ int psamd_init_iframe(psamd_ctx *c)
     if (!c) return PSAMD_ERR_INVALID_ARG;
     const Geometry &g = c->geo;
     const size_t frame_ints = (size_t)g.num_cells + g.num_chunks + g.queue_infos;
-    if (c->timing) { make_events(c); (void)hipEventRecord(c->ev[10], c->stream); }
-    PS_HIP(c, hipMemsetAsync(c->d.cell_count, 0, frame_ints * sizeof(int), c->stream));
-    // keep the sticky error word across frames: only the per-frame scalars are cleared
-    PS_HIP(c, hipMemsetAsync(c->d.fs, 0, offsetof(FrameScalars, error), c->stream));
-    PS_HIP(c, hipMemsetAsync(&c->d.fs->n_ops, 0, 3 * sizeof(int32_t), c->stream));
+    if (c->timing >= 2) { make_events(c); (void)hipEventRecord(c->ev[10], c->stream); }
+    // cell / chunk / queue-record counts and the per-frame scalars (the sticky error word stays)
+    PS_HIP(c, launch_frame_reset(c->stream, c->d, frame_ints));
     c->frame_reset = true; c->grid_built = false; c->pairs_done = false;
     return PSAMD_OK;
 }
@@ -664,7 +680,7 @@ int psamd_build_grid(psamd_ctx *c)
     if (!c) return PSAMD_ERR_INVALID_ARG;
     if (!c->frame_reset) return fail(c, PSAMD_ERR_STATE, "build_grid needs init_iframe first");
     if (c->timing) make_events(c);
-    PS_HIP(c, launch_build_grid(c->stream, c->P, c->d, c->timing ? c->ev : nullptr));
+    PS_HIP(c, launch_build_grid(c->stream, c->P, c->d, c->timing >= 2 ? c->ev : nullptr));
     c->frame_reset = false; c->grid_built = true; c->pairs_done = false;
     c->live_at_build = -1;
     return PSAMD_OK;
@@ -712,30 +728,37 @@ int psamd_calc_forces_apply(psamd_ctx *c)
     if (!c->grid_built || !c->pairs_done) return fail(c, PSAMD_ERR_STATE, "apply needs build_grid and the pair pass first");
     if (c->timing) (void)hipEventRecord(c->ev[7], c->stream);
     PS_HIP(c, launch_apply(c->stream, c->P, c->S, c->d, c->step, c->geo.container));
-    if (c->timing) (void)hipEventRecord(c->ev[8], c->stream);
+    const int par = (int)(c->steps_total & 1);   // not c->step: a snapshot restore rewinds that
+    if (c->timing) (void)hipEventRecord(c->ev[par ? 11 : 8], c->stream);
     PS_HIP(c, launch_ops_census(c->stream, c->P, c->d, c->geo.queue_infos));
     // one small read-back per step, as the reference's driver does for hostGridMax
-    // (ps.cpp:1878-1900): live count, sticky errors and the sizes of the op lists
+    // (ps.cpp:1878-1900): live count, sticky errors and the sizes of the op lists.  The
+    // life-cycle kernels are enqueued behind it without waiting (they size themselves from
+    // the same scalars on the device), so the GPU is busy while the host catches up.
     PS_HIP(c, hipMemcpyAsync(c->h_fs, c->d.fs, sizeof(FrameScalars), hipMemcpyDeviceToHost, c->stream));
-    PS_HIP(c, hipStreamSynchronize(c->stream));
+    PS_HIP(c, hipEventRecord(c->ev_scalars, c->stream));
+    // live_bound < 0: unknown (state was uploaded) -> size for a full container
+    PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos,
+                               c->live_bound >= 0 ? c->live_bound : (int64_t)c->geo.container));
+    c->host_queues_valid = false;
+    PS_HIP(c, hipEventSynchronize(c->ev_scalars));
     c->live_at_build = c->h_fs->live;
     c->live_bound = std::min<int64_t>(c->geo.container, (int64_t)c->h_fs->live + c->h_fs->n_moves);   // births <= moves
     c->processed_total += c->h_fs->live;
     c->max_bucket_seen = std::max<int64_t>(c->max_bucket_seen, c->h_fs->max_bucket);
     if (c->h_fs->error) return check_device_errors(c);
-    if (c->h_fs->n_ops > 0 || c->h_fs->n_moves > 0) {
-        PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos, c->h_fs->n_ops, c->h_fs->n_moves,
-                                    c->h_fs->max_bucket));
-        c->host_queues_valid = false;
-    }
+    if (c->h_fs->max_bucket > BUCKET_MAX)      // rare: the kernels above stood down
+        PS_HIP(c, launch_lifecycle_sorted(c->stream, c->P, c->d, c->step, c->geo.queue_infos, c->h_fs->n_ops, c->h_fs->n_moves));
     if (c->timing) {
-        (void)hipEventRecord(c->ev[9], c->stream);
-        PS_HIP(c, hipEventSynchronize(c->ev[9]));
-        // ev: 10 frame reset | 0 hist 1 scan 2 scatter 3 sort 4 | 5 pairs 6 | 7 apply 8 lifecycle 9
-        const int a[PSAMD_NUM_TIMERS] = {0, 1, 2, 3, 5, 7, 8, 10}, b[PSAMD_NUM_TIMERS] = {1, 2, 3, 4, 6, 8, 9, 0};
-        for (int k = 0; k < PSAMD_NUM_TIMERS; k++) {
+        // No wait for the end of the step: everything up to `apply` was complete when the
+        // scalars landed; the life-cycle interval is read one step later (or by get_timing).
+        (void)hipEventRecord(c->ev[par ? 12 : 9], c->stream);
+        c->lifecycle_pending[par] = true;
+        collect_lifecycle_time(c, par ^ 1);
+        const int a[] = {0, 1, 2, 3, 5, 7, 10}, b[] = {1, 2, 3, 4, 6, par ? 11 : 8, 0}, slot[] = {0, 1, 2, 3, 4, 5, 7};
+        for (int k = (c->timing >= 2 ? 0 : 4); k < (c->timing >= 2 ? 7 : 6); k++) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, c->ev[a[k]], c->ev[b[k]]) == hipSuccess) c->t_us[k] += 1000.0 * ms;
+            if (hipEventElapsedTime(&ms, c->ev[a[k]], c->ev[b[k]]) == hipSuccess) c->t_us[slot[k]] += 1000.0 * ms;
         }
         c->t_launches++;
     }
@@ -932,16 +955,19 @@ int psamd_selftest_math(psamd_ctx *c, uint32_t lo_bits, uint32_t hi_bits, uint64
 int psamd_set_timing(psamd_ctx *c, int enabled)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
-    c->timing = enabled != 0;
+    c->timing = enabled < 0 ? 0 : enabled > 2 ? 2 : enabled;
     if (c->timing) make_events(c);
     for (double &v : c->t_us) v = 0.0;
     c->t_launches = 0;
+    c->lifecycle_pending[0] = c->lifecycle_pending[1] = false;
     return PSAMD_OK;
 }
 
 int psamd_get_timing(psamd_ctx *c, double us_out[PSAMD_NUM_TIMERS], int64_t *launches)
 {
     if (!c || !us_out) return PSAMD_ERR_INVALID_ARG;
+    collect_lifecycle_time(c, 0);
+    collect_lifecycle_time(c, 1);
     for (int k = 0; k < PSAMD_NUM_TIMERS; k++) us_out[k] = c->t_us[k];
     if (launches) *launches = c->t_launches;
     return PSAMD_OK;

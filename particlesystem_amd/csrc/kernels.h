@@ -79,10 +79,13 @@ hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step,
                         int live_bound);
 // after apply, before the per-step read-back: ops per queue record, their prefix and maximum
+hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints);
 hipError_t launch_ops_census(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec);
 // n_ops / n_moves / max_bucket are the counts read back from FrameScalars
 hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
-                            int n_ops, int n_moves, int max_bucket);
+                            int64_t live_bound);
+hipError_t launch_lifecycle_sorted(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
+                                   int n_ops, int n_moves);
 // lifecycle_sort.hip (rocPRIM radix sort of the op keys; library code, not a hot path)
 hipError_t sort_ops_tmp_bytes(size_t n, int key_bits, size_t *bytes);
 hipError_t sort_ops(hipStream_t st, const DeviceState &d, int n, int key_bits);

@@ -1247,12 +1247,21 @@ __global__ __launch_bounds__(1024) void k_ops_scan(int nrec, const int *__restri
     if (tid == 0) { rec_start[nrec] = carry_s; fs->max_bucket = max_s; }
 }
 
+// The life-cycle kernels below are launched BEFORE the host has read the step's counts back
+// (the grid covers the most the step can have produced): they take the counts from the
+// frame scalars themselves, and stand down when a queue's list is too long for the bucketed
+// replay -- the host then runs the sort-based path once it has seen the counts.
+__device__ __forceinline__ bool lifecycle_deferred(const FrameScalars *fs) { return fs->max_bucket > BUCKET_MAX; }
+
 __global__ __launch_bounds__(1024) void k_ops_scatter(const uint64_t *__restrict__ keys, const int *__restrict__ args,
-                                                       int n, int rec_shift, int nrec, int *rec_cursor,
+                                                       const FrameScalars *__restrict__ fs, int rec_shift, int nrec,
+                                                       int *rec_cursor,
                                                        uint64_t *__restrict__ keys_out, int *__restrict__ args_out)
 {
     __shared__ int h[LDS_CELLS];
+    const int n = fs->n_ops;
     const int tid = threadIdx.x, base = blockIdx.x * SLOTS_PER_WG;
+    if (base >= n || lifecycle_deferred(fs)) return;
     const bool lds = nrec <= LDS_CELLS;
     int mine[SLOTS_PER_WG / 1024];
     if (lds) { for (int r = tid; r < nrec; r += 1024) h[r] = 0; __syncthreads(); }
@@ -1286,7 +1295,7 @@ __global__ __launch_bounds__(256) void k_replay_bucket(const int *__restrict__ r
                                                         const uint64_t *__restrict__ keys,
                                                         const int *__restrict__ args,
                                                         QueueInfo *qinfo, int *queue, MoveRec *moves,
-                                                        DevCounters *ctr)
+                                                        DevCounters *ctr, const FrameScalars *__restrict__ fs)
 {
     __shared__ __attribute__((aligned(16))) uint64_t kbuf[BUCKET_MAX + 2];   // keys; later reused as ins_arg
     __shared__ int abuf[BUCKET_MAX];
@@ -1296,6 +1305,7 @@ __global__ __launch_bounds__(256) void k_replay_bucket(const int *__restrict__ r
     __shared__ int wave_tot[4];
     __shared__ int s_bad;
     const int rec = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (lifecycle_deferred(fs)) return;
     const int start = rec_start[rec];
     const int n = min(rec_start[rec + 1] - start, BUCKET_MAX);
     if (n == 0) return;
@@ -1421,11 +1431,13 @@ __global__ __launch_bounds__(256) void k_replay_bucket(const int *__restrict__ r
 // Relocation phase 1a: read every moving particle (copy_particle, ps.cpp:1363) and
 // every parent of a child to be born.  Read-only on the particle arrays, so a
 // parent that also relocates this step is seen intact by both of its records.
-__global__ void k_moves_stage(MoveRec *moves, int n,
+__global__ void k_moves_stage(MoveRec *moves, int n_host, const FrameScalars *__restrict__ fs,
                               const float4 *pos4, const float4 *vel4, const float4 *acc4,
                               const uint8_t *pflags, float4 *stage)
 {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_host < 0 && lifecycle_deferred(fs)) return;
+    const int n = n_host < 0 ? fs->n_moves : n_host;
     if (m >= n) return;
     const MoveRec r = moves[m];
     float4 *s = stage + (size_t)3 * m;
@@ -1434,10 +1446,12 @@ __global__ void k_moves_stage(MoveRec *moves, int n,
 }
 
 // Relocation phase 1b: reset_particle on the vacated slots (ps.cpp:1367).
-__global__ void k_moves_reset(const MoveRec *__restrict__ moves, int n,
+__global__ void k_moves_reset(const MoveRec *__restrict__ moves, int n_host, const FrameScalars *__restrict__ fs,
                               float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr, uint8_t *pflags)
 {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_host < 0 && lifecycle_deferred(fs)) return;
+    const int n = n_host < 0 ? fs->n_moves : n_host;
     if (m >= n) return;
     const MoveRec r = moves[m];
     if ((r.kind & 0xff) != 0) return;
@@ -1448,11 +1462,13 @@ __global__ void k_moves_reset(const MoveRec *__restrict__ moves, int n,
 }
 
 // Relocation phase 2: drop each particle into the slot the queue replay assigned.
-__global__ void k_moves_commit(DevParams P, int step, const MoveRec *__restrict__ moves, int n,
+__global__ void k_moves_commit(DevParams P, int step, const MoveRec *__restrict__ moves, int n_host, const FrameScalars *__restrict__ fs,
                                float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr,
                                uint8_t *pflags, const float4 *__restrict__ stage)
 {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_host < 0 && lifecycle_deferred(fs)) return;
+    const int n = n_host < 0 ? fs->n_moves : n_host;
     if (m >= n) return;
     const MoveRec r = moves[m];
     if (r.dst < 0) return;
@@ -1576,6 +1592,25 @@ hipError_t launch_place(hipStream_t st, int n, const int *ids, const float4 *p, 
     return hipSuccess;
 }
 
+// init_iframe: zero the per-frame counts (cells, chunks, queue records: one array) and the
+// per-frame scalars; the sticky error word survives
+__global__ void k_frame_reset(int *frame, size_t n, FrameScalars *fs)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) frame[i] = 0;
+    if (i == 0) {
+        const int err = fs->error;
+        *fs = FrameScalars{};
+        fs->error = err;
+    }
+}
+
+hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints)
+{
+    k_frame_reset<<<(unsigned)((frame_ints + 1023) / 1024), 1024, 0, st>>>(d.cell_count, frame_ints, d.fs);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill_int(hipStream_t st, int *p, int v, size_t n)
 {
     if (n == 0) return hipSuccess;
@@ -1674,19 +1709,38 @@ hipError_t launch_ops_census(hipStream_t st, const DevParams &P, const DeviceSta
     return hipSuccess;
 }
 
+// Usual case, enqueued without waiting for the host: every queue's operations fit one
+// workgroup's LDS.  `live_bound` >= live particles of the step: at most 3 queue operations
+// and 2 move records each.
 hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
-                            int n_ops, int n_moves, int max_bucket)
+                            int64_t live_bound)
 {
-    if (n_ops > 0 && max_bucket <= BUCKET_MAX) {
-        // usual case: every queue's operations fit one workgroup's LDS
-        k_ops_scatter<<<(n_ops + SLOTS_PER_WG - 1) / SLOTS_PER_WG, 1024, 0, st>>>(
-            d.op_keys, d.op_args, n_ops, P.key_rec_shift, nrec, d.rec_cursor, d.op_keys_sorted, d.op_args_sorted);
+    const int64_t max_ops = std::min<int64_t>(d.ops_cap, 3 * live_bound), max_moves = std::min<int64_t>(d.moves_cap, 2 * live_bound);
+    if (max_ops <= 0) return hipSuccess;
+    k_ops_scatter<<<(int)((max_ops + SLOTS_PER_WG - 1) / SLOTS_PER_WG), 1024, 0, st>>>(
+        d.op_keys, d.op_args, d.fs, P.key_rec_shift, nrec, d.rec_cursor, d.op_keys_sorted, d.op_args_sorted);
+    PS_LAUNCH_CHECK();
+    k_replay_bucket<<<nrec, 256, 0, st>>>(d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
+                                          d.moves, d.ctr, d.fs);
+    PS_LAUNCH_CHECK();
+    const int nb = (int)((max_moves + 255) / 256);
+    if (nb > 0) {
+        k_moves_stage<<<nb, 256, 0, st>>>(d.moves, -1, d.fs, d.pos4, d.vel4, d.acc4, d.pflags, d.stage);
         PS_LAUNCH_CHECK();
-        k_replay_bucket<<<nrec, 256, 0, st>>>(d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
-                                              d.moves, d.ctr);
+        k_moves_reset<<<nb, 256, 0, st>>>(d.moves, -1, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags);
         PS_LAUNCH_CHECK();
-    } else if (n_ops > 0) {
-        // a queue with a very long list (e.g. record 0 during a collapse): global sort + serial walk
+        k_moves_commit<<<nb, 256, 0, st>>>(P, step, d.moves, -1, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
+        PS_LAUNCH_CHECK();
+    }
+    return hipSuccess;
+}
+
+// A queue with a very long list (e.g. record 0 during a collapse; the kernels above stood
+// down): global sort + serial walk, sized by the counts the host has read back.
+hipError_t launch_lifecycle_sorted(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
+                                   int n_ops, int n_moves)
+{
+    if (n_ops > 0) {
         hipError_t e = sort_ops(st, d, n_ops, P.key_bits);
         if (e != hipSuccess) return e;
         k_replay<<<nrec, 256, 0, st>>>(P, n_ops, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue, d.moves, d.ctr);
@@ -1694,11 +1748,11 @@ hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceStat
     }
     if (n_moves > 0) {
         const int nb = (n_moves + 255) / 256;
-        k_moves_stage<<<nb, 256, 0, st>>>(d.moves, n_moves, d.pos4, d.vel4, d.acc4, d.pflags, d.stage);
+        k_moves_stage<<<nb, 256, 0, st>>>(d.moves, n_moves, d.fs, d.pos4, d.vel4, d.acc4, d.pflags, d.stage);
         PS_LAUNCH_CHECK();
-        k_moves_reset<<<nb, 256, 0, st>>>(d.moves, n_moves, d.pos4, d.vel4, d.acc4, d.cell, d.pflags);
+        k_moves_reset<<<nb, 256, 0, st>>>(d.moves, n_moves, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags);
         PS_LAUNCH_CHECK();
-        k_moves_commit<<<nb, 256, 0, st>>>(P, step, d.moves, n_moves, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
+        k_moves_commit<<<nb, 256, 0, st>>>(P, step, d.moves, n_moves, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
         PS_LAUNCH_CHECK();
     }
     return hipSuccess;

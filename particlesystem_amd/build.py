@@ -42,7 +42,24 @@ def build(force=False, verbose=False, extra=()):
     return LIB
 
 
+DRIVER_SRC = os.path.join(os.path.dirname(HERE), "host", "ps_driver.cpp")
+DRIVER = os.path.join(os.path.dirname(HERE), "host", "ps_driver")
+
+
+def build_driver(force=False):
+    """host/ps_driver: the reference's driver loop in C++ on top of the C ABI (plain g++,
+    links libpsamd.so by relative rpath so the pair travels together)."""
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    if not force and os.path.exists(DRIVER) and os.path.getmtime(DRIVER) > max(
+            os.path.getmtime(DRIVER_SRC), os.path.getmtime(os.path.join(inc, "psamd.h")), os.path.getmtime(LIB)):
+        return DRIVER
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I" + inc, DRIVER_SRC, "-L" + HERE, "-lpsamd",
+                           "-Wl,-rpath,$ORIGIN/../particlesystem_amd", "-Wl,-rpath-link,/opt/rocm/lib", "-o", DRIVER])
+    return DRIVER
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True,
           extra=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else ())
     print(LIB)
+    print(build_driver(force=True))

@@ -1,0 +1,58 @@
+"""host/ps_driver: the reference's driver loop (DoParallelProcess, ps.cpp:1843-1928) in C++
+on the C ABI.  CPU: it builds with plain g++ against include/psamd.h and its host-only mode
+agrees with the library's geometry.  GPU: ten iterations of the golden cloud end in the
+oracle's state, with and without the reference's per-stage fetch-back."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import particlesystem_amd as ps
+from particlesystem_amd import _build as psbuild
+from util import GOLDEN, O, g2_cloud
+
+CLOUD = os.path.join(GOLDEN, "g2_cloud_n4096_seed12345.f32")
+
+
+def digest(particles):
+    """state_digest of host/ps_driver.cpp on a P_DATA_TYPE array."""
+    w = np.ascontiguousarray(particles).view(np.uint32).reshape(-1, 18).copy()
+    w[:, 5] &= 0x0000FFFF
+    flat = w.reshape(-1).astype(np.uint64)
+    k = np.arange(flat.size, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        return int((flat * (k % np.uint64(65521) + np.uint64(1))).sum(dtype=np.uint64))
+
+
+def run_driver(*args):
+    exe = psbuild.build_driver()
+    out = subprocess.run([exe, *args], check=True, capture_output=True, text=True, timeout=600).stdout
+    return out
+
+
+def test_driver_builds_and_describes_the_default_geometry():
+    out = run_driver("--describe")
+    s = ps.describe(ps.default_config())[0]
+    m = re.search(r"grid (\d+)\^3 cells, (\d+) chunks, container (\d+) slots, (\d+) queue records, cell list (\d+), chunk list (\d+)", out)
+    assert m, out
+    assert [int(v) for v in m.groups()] == [s.grid_dim, s.num_chunks, s.container_size, s.queue_info_size,
+                                            s.max_per_cell, s.max_per_chunk]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fetch_back", [False, True])
+def test_driver_ends_in_the_oracle_state(fetch_back):
+    xyz = g2_cloud()
+    dt = 0.01
+    o = O.System(dt=dt)
+    o.fill(xyz, age=np.float32(40 * dt), fert_age=(1e6 + np.arange(len(xyz))).astype(np.float32))
+    o.step(10)
+    args = ["--cloud", CLOUD, "--iters", "10", "--dt", str(dt)] + (["--fetch-back"] if fetch_back else [])
+    out = run_driver(*args)
+    m = re.search(r"state-hash ([0-9a-f]{16}) live (\d+)", out)
+    assert m, out
+    assert int(m.group(2)) == int((o.particles["cell"] >= 0).sum())
+    assert int(m.group(1), 16) == digest(o.particles), out
+    assert out.count(">>>>>>>>>>> Execution time of iteration (sec):") == 10    # the reference's per-iteration print

@@ -126,6 +126,28 @@ def cpu_baseline(args, xyz, age, fert, cfg_over):
     return one, many
 
 
+def fast_math_rate(ps, cfg_over, device, xyz, age, fert, steps=5):
+    """For the record, never the headline: the same timed loop with PSAMD_FLAG_FAST_MATH
+    (FMA + v_rsq pair arithmetic: accelerations within 1e-5 relative of the oracle,
+    tests/test_gpu_fast.py; the headline runs the bit-exact arithmetic)."""
+    g = ps.ParticleSystem(ps.default_config(device=device, flags=ps.FLAG_FAST_MATH, **cfg_over))
+    g.fill_particles(xyz, age=age, fert_age=fert)
+    g.snapshot_save()
+    for _ in range(2):
+        g.snapshot_restore(); g.step(1)
+    g.synchronize()
+    p0 = g.counters["particles_processed"]
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.snapshot_restore(); g.step(1)
+    g.synchronize()
+    dt = time.perf_counter() - t0
+    done = g.counters["particles_processed"] - p0
+    g.close()
+    return {"arithmetic": "PSAMD_FLAG_FAST_MATH (FMA + v_rsq), within 1e-5 relative of the oracle; not the headline",
+            "value": done / dt, "unit": "particle-updates/s", "ms_per_step": 1e3 * dt / steps, "steps": steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,6 +318,8 @@ def main():
             "kernel_us_per_step": {k: v / max(launches, 1) for k, v in tim.items() if v > 0},
         }
         if world == 1 and not args.no_cpu:
+            if not args.fast_math and not args.evolve and not args.sim_world:
+                out["within_tolerance_mode"] = fast_math_rate(ps, cfg_over, local_rank, xyz, age, fert)
             out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(args, xyz, age, fert, cfg_over)
         else:
             out["cpu_baseline"] = None

@@ -1,7 +1,9 @@
-"""BASELINE-size checks (N = 2^20, the reference's default box): properties that do not
-need the oracle to run a whole 136-second CPU step, plus an exact comparison of a
-sample of the sorted range with the oracle's pair pass."""
+"""BASELINE-size checks (N = 2^20, the reference's default box): size-independent properties,
+an exact comparison of a sample of the sorted range with the oracle's pair pass, and two
+WHOLE steps against the oracle byte for byte (its read-only pair pass spread over the host's
+cores, integrate + life cycle serial as in the reference)."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -106,3 +108,23 @@ def test_step_is_deterministic_and_shard_invariant(big):
         h.calc_forces_pairs()
         assert np.array_equal(h.download_force4(lo, hi - lo).view(np.uint32), whole[lo:hi].view(np.uint32))
         h.close()
+
+
+def test_two_whole_steps_match_the_oracle_bitwise(big):
+    g, xyz, age, fert, ids = big
+    g.snapshot_restore()
+    o = O.System(oracle_cfg_from(g.cfg))
+    assert np.array_equal(o.fill(xyz, age=age, fert_age=fert), ids)
+    threads = max(1, min(64, len(os.sched_getaffinity(0))))
+    for step in range(2):
+        o.init_iframe(); o.build_grid()
+        total = o.sorted_count()
+        f = np.zeros((total + 8, 4), np.float32)
+        o.calc_pairs_threads(0, total, f, threads)
+        o.apply_forces(f)
+        g.step(1)
+        assert g.download_particles().tobytes() == o.particles.tobytes(), "particles differ after step %d" % (step + 1)
+        qi, q = g.download_queues()
+        assert qi.tobytes() == o.queue_info.tobytes() and np.array_equal(q, o.queue), "queues differ after step %d" % (step + 1)
+    assert int((o.particles["cell"] >= 0).sum()) < N        # the cloud has started to collapse
+    o.close()

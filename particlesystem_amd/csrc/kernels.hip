@@ -673,14 +673,17 @@ __global__ void k_shard_tasks(DevParams P, const int *__restrict__ cell_start, c
 #define PS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 #ifdef PSAMD_WAVE_TRACE   // diagnostic build only: when and where did this wave run
-#define PS_TRACE_BEGIN() const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime()
+#define PS_TRACE_BEGIN() const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime(); unsigned long long trace_wait = 0
+#define PS_TRACE_WAITED() trace_wait = __builtin_amdgcn_s_memrealtime() - trace_t0
 #define PS_TRACE_END() do { if ((threadIdx.x & 63) == 0) { \
         unsigned long long *t_ = trace + (size_t)3 * (blockIdx.x * 4 + (threadIdx.x >> 6)); \
         t_[0] = trace_t0; t_[1] = __builtin_amdgcn_s_memrealtime(); \
-        t_[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32)   /* XCC_ID */ \
+        t_[2] = (trace_wait << 40)                                              /* ticks spent waiting for the previous leg */ \
+                | ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf) << 32)   /* XCC_ID */ \
                 | __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4); } } while (0)               /* HW_ID */
 #else
 #define PS_TRACE_BEGIN() do {} while (0)
+#define PS_TRACE_WAITED() do {} while (0)
 #define PS_TRACE_END() do {} while (0)
 #endif
 
@@ -732,6 +735,7 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
             if (++spins > (1 << 20)) { if (lane == 0) atomicOr(&fs->error, ERR_PHASE_WAIT); return; }   // never hang
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        PS_TRACE_WAITED();
         if (mine) {
             const float4 part = force4[gi];
             ax = part.x; ay = part.y; az = part.z; flag = __float_as_int(part.w);

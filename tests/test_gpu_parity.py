@@ -416,3 +416,25 @@ def test_long_free_run_with_births_and_collapse():
     print("free run counters:", {k: v for k, v in c.items() if v})
     assert c["cell_overflow_kills"] > 0 and c["births"] > 0 and c["relocations"] > 0
     assert c["relocations_lost"] + c["births_failed"] > 0
+
+
+def test_timing_levels_report_without_stalling_steps():
+    """psamd_set_timing: level 1 brackets the pair pass, apply and the life cycle only; level 2
+    every stage; intervals are accumulated over steps and the life-cycle one is read late."""
+    xyz = cloud(20000, 91)
+    g = ps.ParticleSystem(ps.default_config())
+    g.fill_particles(xyz, age=np.float32(3.0), fert_age=np.full(len(xyz), 1e6, np.float32))
+    g.step(1)
+    g.set_timing(True)
+    g.step(3)
+    t, n = g.timing()
+    assert n == 3 and t["pairs"] > 0 and t["apply"] > 0 and t["lifecycle"] > 0
+    assert t["hist"] == 0 and t["sort_cells"] == 0
+    g.set_timing(True, every_stage=True)
+    g.step(2)
+    t, n = g.timing()
+    assert n == 2 and all(v > 0 for v in t.values()), t
+    g.set_timing(False)
+    g.step(1)
+    assert g.timing()[1] == 0
+    g.close()

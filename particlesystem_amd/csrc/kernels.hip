@@ -1295,18 +1295,33 @@ __global__ __launch_bounds__(1024) void k_ops_scatter(const uint64_t *__restrict
 // the circular FIFO has a closed form -- the k-th remove takes logical element k, the
 // k-th insert becomes logical element count0 + k -- and all of them are applied at once;
 // otherwise one lane walks the list exactly as q_insert / q_remove do.
-__global__ __launch_bounds__(256) void k_replay_bucket(const int *__restrict__ rec_start,
+constexpr int REPLAY_THREADS = 512;
+__global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(const int *__restrict__ rec_start,
                                                         const uint64_t *__restrict__ keys,
                                                         const int *__restrict__ args,
                                                         QueueInfo *qinfo, int *queue, MoveRec *moves,
-                                                        DevCounters *ctr, const FrameScalars *__restrict__ fs)
+                                                        DevCounters *ctr, const FrameScalars *__restrict__ fs,
+                                                        unsigned long long *trace)
 {
-    __shared__ __attribute__((aligned(16))) uint64_t kbuf[BUCKET_MAX + 2];   // keys; later reused as ins_arg
-    __shared__ int abuf[BUCKET_MAX];
+#ifdef PSAMD_REPLAY_TRACE
+    unsigned long long tk[6]; int ti = 0;
+#define RT() do { if (threadIdx.x == 0 && ti < 6) tk[ti++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RT() do {} while (0)
+#endif
+    RT();
+    // keys + args while sorting; afterwards the same bytes hold ins_arg (closed form) or the
+    // copy of the segment the serial walk works on
+    constexpr int KEY_BYTES = (BUCKET_MAX + 2) * 8, SORT_BYTES = KEY_BYTES + BUCKET_MAX * 4;
+    constexpr int RAW_BYTES = SORT_BYTES > QUEUE_WINDOW * 4 ? SORT_BYTES : QUEUE_WINDOW * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char raw[RAW_BYTES];
+    uint64_t *kbuf = reinterpret_cast<uint64_t *>(raw);
+    int *abuf = reinterpret_cast<int *>(raw + KEY_BYTES);
+    int *window = reinterpret_cast<int *>(raw);
     __shared__ int s_arg[BUCKET_MAX];
     __shared__ unsigned char s_sub[BUCKET_MAX];
-    __shared__ int window[QUEUE_WINDOW];
-    __shared__ int wave_tot[4];
+    constexpr int NT = REPLAY_THREADS;
+    __shared__ int wave_tot[NT / 64];
     __shared__ int s_bad;
     const int rec = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (lifecycle_deferred(fs)) return;
@@ -1315,18 +1330,18 @@ __global__ __launch_bounds__(256) void k_replay_bucket(const int *__restrict__ r
     if (n == 0) return;
     QueueInfo q = qinfo[rec];
     const bool in_lds = q.seg_size <= QUEUE_WINDOW;
-    for (int e = tid; e < n; e += 256) { kbuf[e] = keys[start + e]; abuf[e] = args[start + e]; }
-    if (in_lds) for (int e = tid; e < q.seg_size; e += 256) window[e] = queue[q.rloc + e];
+    for (int e = tid; e < n; e += NT) { kbuf[e] = keys[start + e]; abuf[e] = args[start + e]; }
     if (tid == 0) s_bad = 0;
     __syncthreads();
+    RT();
     // bitonic sort of (key, arg) in LDS, padded to a power of two with +inf keys
     int np = 2;
     while (np < n) np <<= 1;
-    for (int e = n + tid; e < np; e += 256) { kbuf[e] = ~0ull; abuf[e] = -1; }
+    for (int e = n + tid; e < np; e += NT) { kbuf[e] = ~0ull; abuf[e] = -1; }
     __syncthreads();
     for (int k = 2; k <= np; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (np >> 1); t += 256) {
+            for (int t = tid; t < (np >> 1); t += NT) {
                 // t-th compare-exchange pair of this stage: e has bit j clear
                 const int e = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const int partner = e | j;
@@ -1337,14 +1352,22 @@ __global__ __launch_bounds__(256) void k_replay_bucket(const int *__restrict__ r
                     const int x = abuf[e]; abuf[e] = abuf[partner]; abuf[partner] = x;
                 }
             }
-            __syncthreads();
+            // For j <= 64 both elements of pair p lie in the 128-element chunk p >> 6, and all 64
+            // pairs of a chunk belong to one wave (p = t + m * NT, NT a multiple of 64): such
+            // stages need no workgroup barrier, only the wave's own order -- 56 of the 66 stages
+            // at 2048 operations, and the barriers were what a long list cost.
+            const int next_j = j > 1 ? (j >> 1) : k;              // the next k starts at j = k
+            if (j > 64 || next_j > 64) __syncthreads();
+            else PS_WAVE_SYNC();
         }
-    for (int e = tid; e < n; e += 256) { s_arg[e] = abuf[e]; s_sub[e] = (unsigned char)(kbuf[e] & 3ull); }
     __syncthreads();
+    for (int e = tid; e < n; e += NT) { s_arg[e] = abuf[e]; s_sub[e] = (unsigned char)(kbuf[e] & 3ull); }
+    __syncthreads();
+    RT();
     int *ins_arg = (int *)kbuf;                        // keys no longer needed
 
     // prefix counts of inserts / removes before each of my (up to 8 consecutive) operations
-    const int per = (n + 255) / 256, e0 = tid * per, e1 = min(n, e0 + per);
+    const int per = (n + NT - 1) / NT, e0 = tid * per, e1 = min(n, e0 + per);
     int my_ins = 0, my_rem = 0;
     for (int e = e0; e < e1; e++) { if (s_sub[e] == 2) my_ins++; else my_rem++; }
     const int packed = my_ins | (my_rem << 16);
@@ -1352,14 +1375,14 @@ __global__ __launch_bounds__(256) void k_replay_bucket(const int *__restrict__ r
     if (lane == 63) wave_tot[wv] = incl;
     __syncthreads();
     int off = 0, total = 0;
-    for (int k = 0; k < 4; k++) { if (k < wv) off += wave_tot[k]; total += wave_tot[k]; }
+    for (int k = 0; k < NT / 64; k++) { if (k < wv) off += wave_tot[k]; total += wave_tot[k]; }
     const int excl = off + incl - packed;
     int ins_b = excl & 0xffff, rem_b = excl >> 16;
     const int I = total & 0xffff, R = total >> 16;
     const int count0 = q.count, size = q.seg_size;
     {   // would any operation meet an empty or a full queue?
         int ib = ins_b, rb = rem_b;
-        bool bad = (count0 <= 0) || !in_lds;
+        bool bad = (count0 <= 0);
         for (int e = e0; e < e1; e++) {
             const int c = count0 + ib - rb;
             if (s_sub[e] == 2) { bad |= !(c < size); ib++; } else { bad |= !(c >= 2); rb++; }
@@ -1367,8 +1390,12 @@ __global__ __launch_bounds__(256) void k_replay_bucket(const int *__restrict__ r
         if (bad) s_bad = 1;
     }
     __syncthreads();
+    RT();
     unsigned long long lost = 0, reloc = 0, births = 0, births_failed = 0;
     if (s_bad) {
+        // rare (a queue about to run empty or fill up): one lane walks the list exactly as
+        // q_insert / q_remove do, on a copy of the segment in LDS when it fits
+        if (in_lds) { for (int e = tid; e < q.seg_size; e += NT) window[e] = queue[q.rloc + e]; __syncthreads(); }
         if (tid == 0) {
             for (int e = 0; e < n; e++) {
                 const int sub = s_sub[e], arg = s_arg[e];
@@ -1396,22 +1423,25 @@ __global__ __launch_bounds__(256) void k_replay_bucket(const int *__restrict__ r
                 }
             }
         }
+        if (in_lds) { __syncthreads(); for (int e = tid; e < q.seg_size; e += NT) queue[q.rloc + e] = window[e]; }
     } else {
+        // closed form, straight on the queue in global memory: only the R + I touched entries move
+        int *seg = queue + q.rloc;
         const int F = q.front - q.rloc;                // offset of logical element 0
         for (int e = e0, ib = ins_b; e < e1; e++) if (s_sub[e] == 2) ins_arg[ib++] = s_arg[e];
         __syncthreads();
         for (int e = e0, rb = rem_b; e < e1; e++)
             if (s_sub[e] != 2) {
-                const int item = (rb < count0) ? window[(F + rb) % size] : ins_arg[rb - count0];
+                const int item = (rb < count0) ? seg[(F + rb) % size] : ins_arg[rb - count0];
                 moves[s_arg[e]].dst = item;
                 if (s_sub[e] == 1) reloc++; else births++;
                 rb++;
             }
         __syncthreads();
-        for (int r = tid; r < R; r += 256) window[(F + r) % size] = -1;          // every removed element
+        for (int r = tid; r < R; r += NT) seg[(F + r) % size] = -1;             // every removed element
         __syncthreads();
-        for (int k = tid; k < I; k += 256)                                        // inserts that stayed
-            if (count0 + k >= R) window[(F + count0 + k) % size] = ins_arg[k];
+        for (int k = tid; k < I; k += NT)                                        // inserts that stayed
+            if (count0 + k >= R) seg[(F + count0 + k) % size] = ins_arg[k];
         if (tid == 0) {
             q.count = count0 + I - R;
             q.front = q.rloc + (F + R) % size;
@@ -1419,7 +1449,7 @@ __global__ __launch_bounds__(256) void k_replay_bucket(const int *__restrict__ r
         }
     }
     __syncthreads();
-    if (in_lds) for (int e = tid; e < q.seg_size; e += 256) queue[q.rloc + e] = window[e];
+    RT();
     if (tid == 0) qinfo[rec] = q;
     DevCounters *mine = ctr + (blockIdx.x % COUNTER_COPIES);
     reloc = (unsigned long long)wave_incl_scan((int)reloc); births = (unsigned long long)wave_incl_scan((int)births);
@@ -1430,6 +1460,11 @@ __global__ __launch_bounds__(256) void k_replay_bucket(const int *__restrict__ r
         if (lost) atomicAdd(&mine->relocations_lost, lost);
         if (births_failed) atomicAdd(&mine->births_failed, births_failed);
     }
+    RT();
+#ifdef PSAMD_REPLAY_TRACE
+    if (threadIdx.x == 0) { for (int i = 0; i < 6; i++) trace[(size_t)8 * rec + i] = tk[i]; trace[(size_t)8 * rec + 6] = (unsigned long long)n; }
+#endif
+#undef RT
 }
 
 // Relocation phase 1a: read every moving particle (copy_particle, ps.cpp:1363) and
@@ -1724,8 +1759,8 @@ hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceStat
     k_ops_scatter<<<(int)((max_ops + SLOTS_PER_WG - 1) / SLOTS_PER_WG), 1024, 0, st>>>(
         d.op_keys, d.op_args, d.fs, P.key_rec_shift, nrec, d.rec_cursor, d.op_keys_sorted, d.op_args_sorted);
     PS_LAUNCH_CHECK();
-    k_replay_bucket<<<nrec, 256, 0, st>>>(d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
-                                          d.moves, d.ctr, d.fs);
+    k_replay_bucket<<<nrec, REPLAY_THREADS, 0, st>>>(d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
+                                          d.moves, d.ctr, d.fs, d.trace);
     PS_LAUNCH_CHECK();
     const int nb = (int)((max_moves + 255) / 256);
     if (nb > 0) {

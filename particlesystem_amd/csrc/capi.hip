@@ -280,6 +280,12 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
         const double L = (double)g.G * cfg->cell_size;
         const double lo = cfg->eps2 * cfg->eps2 * cfg->eps2, hi = std::pow(3.0 * (2.0 * L) * (2.0 * L) + cfg->eps2, 3.0);
         P.lean_math = (lo > std::ldexp(1.0, -60) && hi < std::ldexp(1.0, 60)) ? 1 : 0;
+        // Collision flags before forces (lean modes): a collision needs two bodies within
+        // COLLISION_RADIUS, so only bodies that close to a cell face concern the cell beyond it;
+        // 2.5 % + 1e-3 of slack covers every rounding between here and the exact test.  Needs
+        // the radius to be small against the cell (else the halo is the whole neighbour).
+        P.halo_reach = (float)(cfg->collision_radius * 1.025 + 1e-3);
+        P.two_pass = (P.lean_math && P.halo_reach < 0.25 * cfg->cell_size && !std::getenv("PSAMD_ONE_PASS")) ? 1 : 0;
     }
     if (P.key_bits > 63) return fail(c, PSAMD_ERR_UNSUPPORTED, "queue-op key does not fit 64 bits for this configuration");
     for (int k = 0; k < 5; k++) { c->S.seg_base[k] = g.seg_base[k]; c->S.info_base[k] = g.info_base[k]; }
@@ -290,7 +296,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     d.ops_cap = (int)std::min<size_t>(3 * C, (size_t)INT32_MAX / 2);
     d.moves_cap = (int)std::min<size_t>(2 * C, (size_t)INT32_MAX / 2);
     int *frame = nullptr;
-    const size_t frame_ints = (size_t)g.num_cells + g.num_chunks + g.queue_infos;
+    const size_t frame_ints = (size_t)g.num_cells + g.num_chunks + g.queue_infos + g.num_cells;   // + halo counts
     PS_HIP(c, dev_alloc(c, &d.pos4, C));
     PS_HIP(c, dev_alloc(c, &d.vel4, C));
     PS_HIP(c, dev_alloc(c, &d.acc4, C));
@@ -301,6 +307,14 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.queue, C));
     PS_HIP(c, dev_alloc(c, &frame, frame_ints));
     d.cell_count = frame; d.chunk_count = frame + g.num_cells; d.rec_count = d.chunk_count + g.num_chunks;
+    d.halo_count = d.rec_count + g.queue_infos;
+    PS_HIP(c, dev_alloc(c, &d.halo_f, (size_t)4 * g.num_cells * HALO_CAP + 64));   // + slack: scalar loads fetch whole groups
+    PS_HIP(c, dev_alloc(c, &d.halo_id, (size_t)g.num_cells * HALO_CAP + 64));
+    PS_HIP(c, dev_alloc(c, &d.active_list, C + 64));
+    PS_HIP(c, dev_alloc(c, &d.pair_flag, C));
+    PS_HIP(c, dev_alloc(c, &d.active_count, (size_t)g.num_cells));
+    PS_HIP(c, dev_alloc(c, &d.task_start2, (size_t)g.num_cells + 1));
+    PS_HIP(c, dev_alloc(c, &d.task_list2, (size_t)g.num_cells * P.slices));
     PS_HIP(c, dev_alloc(c, &d.rec_start, (size_t)g.queue_infos + 1));
     PS_HIP(c, dev_alloc(c, &d.rec_cursor, (size_t)g.queue_infos));
     PS_HIP(c, dev_alloc(c, &d.fs, 1));
@@ -667,7 +681,7 @@ int psamd_init_iframe(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
     const Geometry &g = c->geo;
-    const size_t frame_ints = (size_t)g.num_cells + g.num_chunks + g.queue_infos;
+    const size_t frame_ints = (size_t)g.num_cells + g.num_chunks + g.queue_infos + g.num_cells;
     if (c->timing >= 2) { make_events(c); (void)hipEventRecord(c->ev[10], c->stream); }
     // cell / chunk / queue-record counts and the per-frame scalars (the sticky error word stays)
     PS_HIP(c, launch_frame_reset(c->stream, c->d, frame_ints));

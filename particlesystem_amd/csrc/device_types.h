@@ -40,6 +40,8 @@ struct DevParams {
     float eps2f;
     float eps_f32_from;
     float slow_below;        // max(eps_f32_from, just above coll_d2_gate): closer pairs take the slow branch
+    float halo_reach;        // bodies this close to a cell face are collision candidates of the cell beyond it
+    int32_t two_pass;        // 1: collision flags first (k_collide), forces only for the particles that move
     float pad_f;
 };
 
@@ -54,6 +56,7 @@ struct FrameScalars {
     int32_t n_tasks;        // non-empty (cell, slice) tasks of the pair kernel this frame
     int32_t shard_task_lo;  // first pair-kernel task (cell * slices) of this rank's share
     int32_t shard_task_n;   // number of tasks from there that can hold a particle of the share
+    int32_t n_tasks2;       // two-pass mode: (cell, 64-slice) tasks over the particles that need a force
 };
 
 // Cumulative event counters, mirrors psamd_counters.  Kept in COUNTER_COPIES copies on
@@ -91,5 +94,6 @@ constexpr int SORT_MAX = 4096;   // ids one cell may hold for the in-LDS ranking
 constexpr int REPLAY_CHUNK = 2048;   // queue ops staged through LDS at a time
 constexpr int QUEUE_WINDOW = 6144;   // largest segment (slots) whose queue is replayed in LDS
 constexpr int BUCKET_MAX = 2048;     // ops per segment the one-workgroup fast replay sorts in LDS
+constexpr int HALO_CAP = 768;        // collision candidates one cell can list from its neighbours (else: full stencil)
 
 }  // namespace psamd

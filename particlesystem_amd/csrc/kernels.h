@@ -35,6 +35,15 @@ struct DeviceState {
     int *cursor = nullptr;        // [num_cells]
     int *task_start = nullptr;    // [num_cells+1] prefix of 64-particle slices per cell
     int *task_list = nullptr;     // [num_cells * slices] non-empty (cell, slice) tasks, cell-major
+    // two-pass pair stage (lean modes): collision flags first, forces only where they are used
+    int *halo_count = nullptr;    // [num_cells] collision candidates listed by the neighbours (zeroed with the frame)
+    float *halo_f = nullptr;      // [4][num_cells * HALO_CAP] x, y, z, age of those candidates
+    int *halo_id = nullptr;       // [num_cells * HALO_CAP] their slot ids
+    int *pair_flag = nullptr;     // [container] sorted order: 0 needs a force, -1 kid (moves, no force), 1 survives, 2 dies
+    int *active_list = nullptr;   // [container] per cell (at cell_start[c]): sorted indices of the particles that need a force
+    int *active_count = nullptr;  // [num_cells]
+    int *task_start2 = nullptr;   // [num_cells + 1] prefix of 64-slices of the active lists
+    int *task_list2 = nullptr;    // [num_cells * slices]
     int *task_done = nullptr;     // [num_cells * slices] legs finished so far of a split task (sharded launches)
     int *sorted_id = nullptr;     // [container] cell-major, id ascending inside a cell
     int *rank_of_slot = nullptr;  // [container] inverse of sorted_id for the slots of this frame

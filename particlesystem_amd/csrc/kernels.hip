@@ -54,6 +54,17 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nb)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    const int lane = (int)__lane_id();
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
 // ------------------------------------------------------------------ AoS <-> SoA
 // P_DATA_TYPE is 18 dwords (common.h:94-120): id cell chunk seg_type seg_tid
 // {seg_fault,is_parent,pad,pad} w age fert x y z vx vy vz ax ay az.
@@ -313,6 +324,44 @@ __global__ void k_build_tasks(DevParams P, const int *__restrict__ task_start, i
     for (int s = 0; s < n; s++) task_list[t0 + s] = c * P.slices + s;
 }
 
+// Halo bookkeeping of the two-pass pair stage.  Cell axes: i2 ~ +x, i1 ~ -y, i3 ~ -z
+// (set_pos_t, app.cu:117-158).  halo_dirs packs, two bits per axis (i2, i1, i3), whether a
+// body lies within P.halo_reach of the low (1) or high (2) face of cell c on that axis; an
+// axis whose neighbour would be outside the grid reports 0 (the stencil is not periodic).
+__device__ __forceinline__ int halo_dirs(const DevParams &P, int c, float x, float y, float z)
+{
+    const int G = P.G;
+    const int i3 = c / (G * G), rem = c - i3 * G * G, i1 = rem / G, i2 = rem - i1 * G;
+    const float cs = (float)P.cell_size, half = (float)(G / 2), reach = P.halo_reach;
+    const float u2 = (x / cs + half - (float)i2) * cs, u1 = (-y / cs + half - (float)i1) * cs,
+                u3 = (-z / cs + half - (float)i3) * cs;                         // offsets inside the cell, [0, cs)
+    int n2 = u2 < reach ? 1 : (cs - u2 < reach ? 2 : 0), n1 = u1 < reach ? 1 : (cs - u1 < reach ? 2 : 0),
+        n3 = u3 < reach ? 1 : (cs - u3 < reach ? 2 : 0);
+    if ((n2 == 1 && i2 == 0) || (n2 == 2 && i2 == G - 1)) n2 = 0;
+    if ((n1 == 1 && i1 == 0) || (n1 == 2 && i1 == G - 1)) n1 = 0;
+    if ((n3 == 1 && i3 == 0) || (n3 == 2 && i3 == G - 1)) n3 = 0;
+    return n2 | (n1 << 2) | (n3 << 4);
+}
+
+// Direction index 0..26 ((d3+1)*9 + (d1+1)*3 + (d2+1)) of the neighbour reached by moving
+// along the axes in subset m (bit 0: i2, bit 1: i1, bit 2: i3), or -1 if the body is not
+// near a face on one of those axes.
+__device__ __forceinline__ int halo_dir_of_subset(int dirs, int m)
+{
+    const int n2 = dirs & 3, n1 = (dirs >> 2) & 3, n3 = (dirs >> 4) & 3;
+    if (((m & 1) && !n2) || ((m & 2) && !n1) || ((m & 4) && !n3)) return -1;
+    const int d2 = (m & 1) ? (n2 == 1 ? -1 : 1) : 0, d1 = (m & 2) ? (n1 == 1 ? -1 : 1) : 0,
+              d3 = (m & 4) ? (n3 == 1 ? -1 : 1) : 0;
+    return (d3 + 1) * 9 + (d1 + 1) * 3 + (d2 + 1);
+}
+
+__device__ __forceinline__ int halo_neighbour(const DevParams &P, int c, int dir)
+{
+    const int G = P.G;
+    const int d3 = dir / 9 - 1, d1 = (dir / 3) % 3 - 1, d2 = dir % 3 - 1;
+    return c + d3 * G * G + d1 * G + d2;
+}
+
 // One workgroup per cell.  The scatter left the cell's ids in arrival order; the
 // reference's list is in slot order (build_grid walks slots 0..CONTAINER_SIZE-1), so
 // rank each id among the cell's ids.  Then gather the snapshot the pair kernel reads
@@ -329,11 +378,15 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
                                                      float *__restrict__ snap_age,
                                                      uint32_t *__restrict__ tdata, int *__restrict__ rank_of_slot,
                                                      uint64_t *op_keys, int *op_args, int ops_cap,
+                                                     int *__restrict__ halo_count, float *__restrict__ halo_f,
+                                                     int *__restrict__ halo_id,
                                                      FrameScalars *fs, DevCounters *ctr)
 {
     __shared__ __attribute__((aligned(16))) int ids[SORT_MAX + 4];
     __shared__ int ordered[SORT_MAX];
+    __shared__ int s_halo[27], s_halo_base[27];    // bodies this cell lists in each neighbour's halo
     const int c = blockIdx.x, tid = threadIdx.x;
+    if (tid < 27) s_halo[tid] = 0;
     const int start = cell_start[c];
     int n = cell_start[c + 1] - start;
     if (n == 0) return;
@@ -377,6 +430,15 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
                 snap_soa[2 * cap + start + e] = p.z; snap_soa[3 * cap + start + e] = w_eff;
             }
             snap_age[start + e] = age;
+            if (halo_count) {
+                const int m3 = halo_dirs(P, c, p.x, p.y, p.z);
+                if (m3) {
+                    for (int m = 1; m < 8; m++) {
+                        const int dir = halo_dir_of_subset(m3, m);
+                        if (dir >= 0) atomicAdd(&s_halo[dir], 1);
+                    }
+                }
+            }
         } else {
             sorted_id[start + e] = -1;
             cell_arr[id] = -1; pflags[id] = 0;
@@ -388,6 +450,41 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
             const int k = atomicAdd(&fs->n_ops, 1);
             if (k < ops_cap) { op_keys[k] = ((uint64_t)(uint32_t)id << 2) | 2ull; op_args[k] = id; }
             else atomicOr(&fs->error, ERR_OPS_OVERFLOW);
+        }
+    }
+    if (!halo_count) return;
+    // Collision candidates of the neighbour cells (k_collide): a body within HALO_REACH of a
+    // face, edge or corner of its cell is listed in the halo of the cell(s) beyond it.  Two
+    // bodies in different cells can only collide (distance <= COLLISION_RADIUS < HALO_REACH) if
+    // each is in the other's halo.  The loop above counted this cell's contributions per
+    // direction; one global atomic per direction reserves the room, then the bodies are
+    // written (positions re-read from the snapshot row just stored).
+    __syncthreads();
+    if (tid < 27) {
+        int base = 0;
+        const int cnt = s_halo[tid];
+        if (cnt > 0) base = atomicAdd(&halo_count[halo_neighbour(P, c, tid)], cnt);
+        s_halo_base[tid] = base;
+        s_halo[tid] = 0;
+    }
+    __syncthreads();
+    const int kept = min(n, P.max_per_cell);
+    for (int e = tid; e < kept; e += 256) {
+        const float4 q = snap4[start + e];
+        const int m3 = halo_dirs(P, c, q.x, q.y, q.z);
+        if (!m3) continue;
+        const float age = snap_age[start + e];
+        const int id = ordered[e];
+        for (int m = 1; m < 8; m++) {
+            const int dir = halo_dir_of_subset(m3, m);
+            if (dir < 0) continue;
+            const int k = s_halo_base[dir] + atomicAdd(&s_halo[dir], 1);
+            if (k < HALO_CAP) {
+                const size_t at = (size_t)halo_neighbour(P, c, dir) * HALO_CAP + k, plane = (size_t)P.num_cells * HALO_CAP;
+                halo_f[at] = q.x; halo_f[plane + at] = q.y; halo_f[2 * plane + at] = q.z;
+                halo_f[3 * plane + at] = age;
+                halo_id[at] = id;
+            }
         }
     }
 }
@@ -651,6 +748,161 @@ __global__ void k_shard_tasks(DevParams P, const int *__restrict__ cell_start, c
     fs->shard_task_n = task_start[c_hi + 1] - task_start[c_lo];
 }
 
+// ------------------------------------------------------------------ two-pass pair stage
+// The reference scans a particle's neighbours for collisions first and runs the force loop
+// only if there was none (ps.cpp:1182-1263): a particle that dies or "survives" a collision
+// this step is not integrated and its acceleration is never looked at.  In a dense cloud
+// that is a large share (42 % in the first step of the N = 2^20 benchmark cloud).  The lean
+// modes do the same: k_collide settles every particle's flag from the few bodies that can
+// reach it -- its own cell and the neighbours' bodies near the shared faces (the halo lists
+// k_sort_cells filled) -- then k_build_active lists, per cell, the particles that still need
+// a force, and the force pass walks the 27-cell stencil for those only.
+//
+// Distance tests of one particle against `n` bodies given as arrays (wave-uniform pointers,
+// so the loads are scalar loads): returns the updated collision flag.
+__device__ __forceinline__ int collide_scan(const DevParams &P, float xi, float yi, float zi, float age_i, int id_i,
+                                            bool scan, int self, const float *__restrict__ bx,
+                                            const float *__restrict__ by, const float *__restrict__ bz,
+                                            const float *__restrict__ bage, const int *__restrict__ bid, int n, int flag)
+{
+    constexpr int NB = 16;                      // bodies per group: 3 x 16 dwords of scalar loads in flight
+    const v2f x2 = {xi, xi}, y2 = {yi, yi}, z2 = {zi, zi};
+    int j = 0;
+    for (; j + NB <= n; j += NB) {
+        v2f d[NB / 2];
+        float dm = 3.0e38f;
+#pragma unroll
+        for (int i = 0; i < NB / 2; i++) {
+            const v2f rx = v2f{bx[j + 2 * i], bx[j + 2 * i + 1]} - x2, ry = v2f{by[j + 2 * i], by[j + 2 * i + 1]} - y2,
+                      rz = v2f{bz[j + 2 * i], bz[j + 2 * i + 1]} - z2;
+            d[i] = rx * rx + ry * ry + rz * rz;
+            dm = fminf(fminf(dm, d[i].x), d[i].y);
+        }
+        if (__any(scan && !(dm > P.coll_d2_gate))) {
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                const float di = (i & 1) ? d[i >> 1].y : d[i >> 1].x;
+                if (scan && !(di > P.coll_d2_gate) && j + i != self)
+                    flag = max(flag, collide_exact(P, di, age_i, id_i, bage[j + i], bid[j + i]));
+            }
+        }
+    }
+    for (; j < n; j++) {
+        const float rx = bx[j] - xi, ry = by[j] - yi, rz = bz[j] - zi;
+        const float d2 = rx * rx + ry * ry + rz * rz;
+        if (scan && !(d2 > P.coll_d2_gate) && j != self)
+            flag = max(flag, collide_exact(P, d2, age_i, id_i, bage[j], bid[j]));
+    }
+    return flag;
+}
+
+// One wave per (cell, 64-particle slice) of the ordinary task list.  Writes the flag of every
+// particle and, for those that will not be integrated or feel no force (kids), the final
+// force4 record.
+__global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restrict__ cell_start,
+                                                 const float *__restrict__ snap_soa, const float *__restrict__ snap_age,
+                                                 const int *__restrict__ sorted_id, const int *__restrict__ task_list,
+                                                 const int *__restrict__ halo_count, const float *__restrict__ halo_f,
+                                                 const int *__restrict__ halo_id, int *__restrict__ flag_out,
+                                                 float4 *__restrict__ force4, const FrameScalars *__restrict__ fs)
+{
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= fs->n_tasks) return;
+    const int task = task_list[slot];
+    const int c = task / P.slices, slice = task - c * P.slices;
+    const int base = cell_start[c];
+    const int cnt = min(cell_start[c + 1] - base, P.max_per_cell);
+    const int first = slice * 64;
+    if (first >= cnt) return;
+    const int lane = threadIdx.x & 63;
+    const bool valid = lane < cnt - first;
+    const int gi = base + first + (valid ? lane : 0);
+    const size_t cap = (size_t)P.container;
+    const float xi = snap_soa[gi], yi = snap_soa[cap + gi], zi = snap_soa[2 * cap + gi];
+    const float age_i = snap_age[gi];
+    const int id_i = sorted_id[gi];
+    const bool dead = age_i > P.life_thr, kid = age_i < P.kid_thr;
+    const bool scan = valid && !dead && !kid;
+    int flag = 0;
+    // own cell (the particle itself is entry gi - base: skipped by index)
+    flag = collide_scan(P, xi, yi, zi, age_i, id_i, scan, gi - base, snap_soa + base, snap_soa + cap + base,
+                        snap_soa + 2 * cap + base, snap_age + base, sorted_id + base, cnt, flag);
+    const int nh = halo_count[c];
+    if (nh <= HALO_CAP) {
+        const size_t at = (size_t)c * HALO_CAP, plane = (size_t)P.num_cells * HALO_CAP;
+        flag = collide_scan(P, xi, yi, zi, age_i, id_i, scan, -1, halo_f + at, halo_f + plane + at, halo_f + 2 * plane + at,
+                            halo_f + 3 * plane + at, halo_id + at, nh, flag);
+    } else {
+        // the halo list overflowed (denser than the container admits in steady state): whole stencil
+        const int G = P.G;
+        const int i3 = c / (G * G), rem = c - i3 * G * G, i1 = rem / G, i2 = rem - i1 * G;
+        for (int k = 1; k < 27; k++) {
+            const int n2 = i2 + c_stencil[k][0], n1 = i1 + c_stencil[k][1], n3 = i3 + c_stencil[k][2];
+            if (n1 < 0 || n1 >= G || n2 < 0 || n2 >= G || n3 < 0 || n3 >= G) continue;
+            const int nc = n3 * G * G + n1 * G + n2, nb = cell_start[nc];
+            const int n = min(cell_start[nc + 1] - nb, P.max_per_cell);
+            flag = collide_scan(P, xi, yi, zi, age_i, id_i, scan, -1, snap_soa + nb, snap_soa + cap + nb,
+                                snap_soa + 2 * cap + nb, snap_age + nb, sorted_id + nb, n, flag);
+        }
+    }
+    if (dead) flag = 2;                                          // ps.cpp:1183
+    if (valid) {
+        flag_out[gi] = (flag == 0 && kid) ? -1 : flag;           // -1: moves, but every force term is skipped
+        force4[gi] = make_float4(0.f, 0.f, 0.f, __int_as_float(flag));   // final unless the force pass overwrites it
+    }
+}
+
+// One workgroup per cell: the sorted indices of the particles the force pass has to visit
+// (flag 0 and not a kid), packed at active_list[cell_start[c] ...], and their number.
+__global__ __launch_bounds__(256) void k_build_active(DevParams P, const int *__restrict__ cell_start,
+                                                      const int *__restrict__ flag_in, int *__restrict__ active_list,
+                                                      int *__restrict__ active_count)
+{
+    __shared__ int s_n;
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int base = cell_start[c];
+    const int cnt = min(cell_start[c + 1] - base, P.max_per_cell);
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int e0 = 0; e0 < cnt; e0 += 256) {
+        const int e = e0 + tid;
+        const bool on = e < cnt && flag_in[base + e] == 0;
+        const unsigned long long m = __ballot(on);
+        int wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(&s_n, __popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (on) active_list[base + wbase + __popcll(m & ((1ull << lane) - 1ull))] = base + e;
+        __syncthreads();
+    }
+    if (tid == 0) active_count[c] = s_n;
+}
+
+// One workgroup: prefix of the active lists' 64-slices over the cells and the task list of
+// the force pass.
+__global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *__restrict__ active_count,
+                                                       int *__restrict__ task_start2, int *__restrict__ task_list2,
+                                                       FrameScalars *fs)
+{
+    __shared__ int wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (P.num_cells + 1023) / 1024;
+    const int c0 = min(P.num_cells, tid * per), c1 = min(P.num_cells, c0 + per);
+    int mine = 0;
+    for (int c = c0; c < c1; c++) mine += (active_count[c] + 63) >> 6;
+    const int incl = wave_incl_scan(mine);
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    int run = incl - mine, total = 0;
+    for (int k = 0; k < 16; k++) { if (k < wv) run += wave_tot[k]; total += wave_tot[k]; }
+    for (int c = c0; c < c1; c++) {
+        const int n = (active_count[c] + 63) >> 6;
+        task_start2[c] = run;
+        for (int sl = 0; sl < n; sl++) task_list2[run + sl] = c * P.slices + sl;
+        run += n;
+    }
+    if (tid == 0) { task_start2[P.num_cells] = total; fs->n_tasks2 = total; }
+}
+
 // One wave = 64 consecutive particles of one cell (four independent waves per workgroup).
 // Neighbour cells are visited in the reference's stencil order, their bodies in list
 // order, and every lane adds each body to its own particle's sum: each particle sees
@@ -694,27 +946,28 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
                                            const float *__restrict__ snap_age, const int *__restrict__ sorted_id,
                                            float4 *__restrict__ force4, int lo, int hi, int task,
                                            float4 *tile, unsigned long long *trace,
-                                           int phase = 0, int nphase = 1, int *done = nullptr, FrameScalars *fs = nullptr)
+                                           int phase = 0, int nphase = 1, int *done = nullptr, FrameScalars *fs = nullptr,
+                                           const int *__restrict__ active_list = nullptr,
+                                           const int *__restrict__ active_count = nullptr)
 {
     PS_TRACE_BEGIN();
     const int c = task / P.slices, slice = task - c * P.slices;
     const int base = cell_start[c];
-    const int cnt = min(cell_start[c + 1] - base, P.max_per_cell);
+    // two-pass mode: the slice is cut from the cell's list of particles that need a force
+    const int cnt = active_list ? active_count[c] : min(cell_start[c + 1] - base, P.max_per_cell);
     const int first = slice * 64;
     if (first >= cnt) return;
     const int nvalid = min(64, cnt - first);
-    const int gi0 = base + first;
-    if (gi0 + nvalid <= lo || gi0 >= hi) return;   // another rank's share
-
     const int lane = threadIdx.x & 63;
     const bool valid = lane < nvalid;
-    const int gi = gi0 + (valid ? lane : 0);
+    const int gi = active_list ? active_list[base + first + (valid ? lane : 0)] : base + first + (valid ? lane : 0);
+    if (!__any(valid && gi >= lo && gi < hi)) return;   // another rank's share
     const float4 me = snap4[gi];
     const float age_i = snap_age[gi];
     const int id_i = sorted_id[gi];
     const bool dead = age_i > P.life_thr;                      // ps.cpp:1183
     const bool kid = age_i < P.kid_thr;
-    const bool scan = valid && !dead && !kid;
+    const bool scan = valid && !dead && !kid && !active_list;   // two-pass mode: flags are settled already
 
     const int G = P.G;
     const int i3 = c / (G * G), rem = c - i3 * G * G, i1 = rem / G, i2 = rem - i1 * G;
@@ -869,7 +1122,8 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
                                                const int *__restrict__ sorted_id,
                                                const int *__restrict__ task_list,
                                                float4 *__restrict__ force4, int lo, int hi, int covered,
-                                               FrameScalars *fs, unsigned long long *trace, int nphase, int *task_done)
+                                               FrameScalars *fs, unsigned long long *trace, int nphase, int *task_done,
+                                               const int *__restrict__ active_list, const int *__restrict__ active_count)
 {
     // Workgroups of four INDEPENDENT waves (no workgroup barrier anywhere): the hardware
     // deals a workgroup's waves over the four SIMDs of its CU and workgroups over the
@@ -904,16 +1158,16 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
         if (slot >= ntask) return;
         pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, lo, hi,
                              task_list[fs->shard_task_lo + slot], tiles[MODE == 0 ? wave : 0], trace,
-                             MODE == 0 ? 0 : phase, MODE == 0 ? 1 : nphase, task_done + slot, fs);
+                             MODE == 0 ? 0 : phase, MODE == 0 ? 1 : nphase, task_done + slot, fs, active_list, active_count);
         return;
     }
-    const int ntask = fs->n_tasks;
+    const int ntask = active_list ? fs->n_tasks2 : fs->n_tasks;
     const int nwg = (ntask + 3) >> 2;
     if ((int)blockIdx.x >= nwg) return;
     const int slot = xcd_contiguous(blockIdx.x, nwg) * 4 + wave;
     if (slot >= ntask) return;
     pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, lo, hi,
-                         task_list[slot], tiles[MODE == 0 ? wave : 0], trace);
+                         task_list[slot], tiles[MODE == 0 ? wave : 0], trace, 0, 1, nullptr, nullptr, active_list, active_count);
 }
 
 // ------------------------------------------------------------------ apply
@@ -944,16 +1198,6 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
     return x ^ (x >> 31);
 }
 
-// inclusive prefix sum across the 64 lanes of a wave
-__device__ __forceinline__ int wave_incl_scan(int v)
-{
-    const int lane = (int)__lane_id();
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(v, d);
-        if (lane >= d) v += o;
-    }
-    return v;
-}
 
 // Death, survival, integration, wrap and re-hash for every particle of the frame
 // (ps.cpp:1182-1242, 1261-1302), one thread per SLOT so that the particle arrays stream
@@ -1685,7 +1929,8 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[3], st);
     k_sort_cells<<<P.num_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
-                                               d.pflags, d.snap4, d.snap_soa, d.snap_age, d.tdata, d.rank_of_slot, d.op_keys, d.op_args, d.ops_cap, d.fs, d.ctr);
+                                               d.pflags, d.snap4, d.snap_soa, d.snap_age, d.tdata, d.rank_of_slot, d.op_keys, d.op_args, d.ops_cap,
+                                               P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.fs, d.ctr);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[4], st);
     return hipSuccess;
@@ -1696,6 +1941,17 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
                                     int covered, bool sharded)
 {
     const int tasks = P.num_cells * P.slices;
+    const bool two = MODE != 0 && P.two_pass;
+    if (two) {
+        // collision flags of every particle (cheap, so every rank of a sharded run does them
+        // all), then the per-cell lists and tasks of the particles that need a force
+        k_collide<<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.task_list,
+                                                   d.halo_count, d.halo_f, d.halo_id, d.pair_flag, d.force4, d.fs);
+        k_build_active<<<P.num_cells, 256, 0, st>>>(P, d.cell_start, d.pair_flag, d.active_list, d.active_count);
+        k_active_tasks<<<1, 1024, 0, st>>>(P, d.active_count, d.task_start2, d.task_list2, d.fs);
+    }
+    const int *task_start = two ? d.task_start2 : d.task_start, *task_list = two ? d.task_list2 : d.task_list;
+    const int *active_list = two ? d.active_list : nullptr, *active_count = two ? d.active_count : nullptr;
     if (sharded) {
         // slices of the share: at most one partial slice per cell on top of the full ones
         const long long share_tasks = std::min<long long>(tasks, (long long)std::max(0, std::min(hi, covered) - lo) / 64 + P.num_cells + 8);
@@ -1708,12 +1964,12 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
         const long long real_tasks = std::max(1, std::min(hi, covered) - lo) / 57 + 1;
         int nphase = MODE == 0 ? 1 : real_tasks >= 16 * 1024 ? 1 : real_tasks >= 6 * 1024 ? 2 : 4;
         if (forced > 0 && MODE != 0) nphase = std::min(forced, 9);
-        k_shard_tasks<<<1, 64, 0, st>>>(P, d.cell_start, d.task_start, lo, hi, d.fs);
-        k_pairs<MODE, true, NQ><<<per_phase * nphase, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, d.task_list, d.force4,
-                                                   lo, hi, covered, d.fs, d.trace, nphase, d.task_done);
+        k_shard_tasks<<<1, 64, 0, st>>>(P, d.cell_start, task_start, lo, hi, d.fs);
+        k_pairs<MODE, true, NQ><<<per_phase * nphase, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
+                                                   lo, hi, covered, d.fs, d.trace, nphase, d.task_done, active_list, active_count);
     } else {
-        k_pairs<MODE, false, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, d.task_list, d.force4,
-                                                    lo, hi, covered, d.fs, d.trace, 1, d.task_done);
+        k_pairs<MODE, false, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
+                                                    lo, hi, covered, d.fs, d.trace, 1, d.task_done, active_list, active_count);
     }
     return hipGetLastError();
 }

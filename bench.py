@@ -64,16 +64,19 @@ def measured_traffic(kernel_prefix):
     return None
 
 
-def pair_count(cellgrid_counts, G):
-    """pairs one pair-kernel launch evaluates: sum_c n_c * sum_{c' in stencil(c)} n_c'."""
+def pair_count(cellgrid_counts, force_counts, G):
+    """Force terms one pair pass evaluates: sum_c f_c * sum_{c' in stencil(c)} n_c', with n the
+    particles per cell and f those among them the pass computes a force for (all of them in the
+    one-pass modes; in the two-pass mode the ones the reference's force loop runs for)."""
     c = cellgrid_counts.astype(np.int64).reshape(G, G, G)
+    f = force_counts.astype(np.int64).reshape(G, G, G)
     p = np.pad(c, 1)
     nb = np.zeros_like(c)
     for a in range(3):
         for b in range(3):
             for d in range(3):
                 nb += p[a:a + G, b:b + G, d:d + G]
-    return int((c * nb).sum())
+    return int((f * nb).sum())
 
 
 def cpu_baseline(args, xyz, age, fert, cfg_over):
@@ -259,8 +262,22 @@ def main():
     # pairs per launch, measured on the state the timed steps start from
     if not args.evolve:
         g.snapshot_restore()
-    g.init_iframe(); g.build_grid()
-    counts0 = g.download_cellgrid()[:, 0].copy()
+    def frame_counts():
+        g.init_iframe(); g.build_grid()
+        n = g.download_cellgrid()[:, 0].copy()
+        if world > 1 or args.sim_world:
+            g.force_shard()
+        g.calc_forces_pairs()
+        f = g.download_force_counts()
+        if use_dist and world > 1:        # a rank lists only its own share's particles
+            t = torch.from_numpy(f.astype(np.int64)).cuda()
+            dist.all_reduce(t)
+            f = t.cpu().numpy()
+        elif args.sim_world:              # one rank's share timed alone: scale to the whole for the rate below
+            f = f * args.sim_world
+        return n, f
+
+    counts0, fcounts0 = frame_counts()
     g.set_timing(True, every_stage=args.kernel_times)
     sync()
     processed0 = g.counters["particles_processed"]
@@ -274,8 +291,7 @@ def main():
     ctr = g.counters
     if not args.evolve:
         g.snapshot_restore()
-    g.init_iframe(); g.build_grid()
-    counts1 = g.download_cellgrid()[:, 0].copy()
+    counts1, fcounts1 = frame_counts()
     live = int(counts1.sum())
 
     if use_dist:
@@ -288,7 +304,7 @@ def main():
         # not constant (cell-overflow and full-segment losses as the cloud collapses)
         updates = float(g.counters["particles_processed"] - processed0)
         value = updates / elapsed
-        pairs = 0.5 * (pair_count(counts0, G) + pair_count(counts1, G))
+        pairs = 0.5 * (pair_count(counts0, fcounts0, G) + pair_count(counts1, fcounts1, G))
         pairs_rank = pairs / world
         us_pairs = tim["pairs"] / max(launches, 1)
         us_apply = tim["apply"] / max(launches, 1)
@@ -306,6 +322,7 @@ def main():
                        "arithmetic": "fast-math" if args.fast_math else "reference-exact fp32 (bitwise parity mode)",
                        "parallelism": "pair loop sharded x%d + RCCL all-gather of float4 results" % world if world > 1 else "single GPU",
                        "updates_in_timed_region": updates, "live_after": live,
+                       "particles_with_a_force_term": int(fcounts1.sum()),
                        "relocations": ctr["relocations"], "relocations_lost": ctr["relocations_lost"],
                        "cell_overflow_kills": ctr["cell_overflow_kills"]},
             "roofline": {"kernel": "k_pairs", "bound": "valu", "achieved": ach_tflops, "peak": VALU_PEAK_TFLOPS,

@@ -157,6 +157,10 @@ int psamd_download_queues(psamd_ctx *ctx, void *queue_info24, int32_t *queue);
 /* int[n_cellgrid] / int[n_chunkgrid], element 0 of each row = count (ps.cpp:1502-1516) */
 int psamd_download_cellgrid(psamd_ctx *ctx, int32_t *out);
 int psamd_download_chunkgrid(psamd_ctx *ctx, int32_t *out);
+/* int[num_cells]: per cell, the particles the last pair pass computed a force for (those the
+ * reference's force loop runs for, ps.cpp:1242-1263: no collision this step, not a kid).
+ * Valid after psamd_calc_forces_pairs of the same frame. */
+int psamd_download_force_counts(psamd_ctx *ctx, int32_t *out);
 /* PAIR[num_chunks*27] (app_common.cu:150-232) and the cell -> (chunk, seg_type,
  * seg_tid) table (get_cell_info, app_common.cu:50-148), 3 ints per cell */
 int psamd_get_pkgdistrib(const psamd_ctx *ctx, int32_t *pairs_out);
@@ -222,10 +226,11 @@ int psamd_debug_wave_trace(psamd_ctx *ctx, uint64_t *out, int64_t n_words);
 int psamd_selftest_math(psamd_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t out24[24]);
 /* Device time per kernel group, accumulated over the steps since psamd_set_timing, in
  * microseconds, measured with HIP events on the context's stream: hist, scan, scatter,
- * sort, pairs, apply, lifecycle, frame reset.  level 0: off; 1: pairs, apply and lifecycle
- * only (three events per step); 2: every stage (an event between two kernels costs a few
+ * sort, pairs (the force pass), apply, lifecycle, frame reset, collide (collision flags and the
+ * lists of the particles that need a force: the two-pass prologue of the pair stage).  level 0: off; 1: collide, pairs, apply and lifecycle
+ * only (four events per step); 2: every stage (an event between two kernels costs a few
  * microseconds of idle GPU, so this is for diagnosis).  Never makes a step wait. */
-#define PSAMD_NUM_TIMERS 8
+#define PSAMD_NUM_TIMERS 9
 int psamd_set_timing(psamd_ctx *ctx, int level);
 int psamd_get_timing(psamd_ctx *ctx, double us_out[PSAMD_NUM_TIMERS], int64_t *launches);
 

@@ -22,8 +22,8 @@ LIB_PATH = os.path.join(HERE, "libpsamd.so")
 
 FLAG_EXPLOSIONS = 0x1
 FLAG_FAST_MATH = 0x2
-NUM_TIMERS = 8
-TIMER_NAMES = ("hist", "scan", "scatter", "sort_cells", "pairs", "apply", "lifecycle", "init_iframe")
+NUM_TIMERS = 9
+TIMER_NAMES = ("hist", "scan", "scatter", "sort_cells", "pairs", "apply", "lifecycle", "init_iframe", "collide")
 
 # numpy images of the reference's records (common.h:94-145)
 P_DTYPE = np.dtype({
@@ -99,6 +99,7 @@ ABI = [
     ("psamd_download_queues", C.c_int, [_vp, _vp, _vp]),
     ("psamd_download_cellgrid", C.c_int, [_vp, _vp]),
     ("psamd_download_chunkgrid", C.c_int, [_vp, _vp]),
+    ("psamd_download_force_counts", C.c_int, [_vp, _vp]),
     ("psamd_get_pkgdistrib", C.c_int, [_vp, _vp]),
     ("psamd_get_cell_table", C.c_int, [_vp, _vp]),
     ("psamd_get_gridmax", C.c_int, [_vp, _ip]),
@@ -273,6 +274,12 @@ class ParticleSystem:
         out = np.zeros(self.sizes.n_chunkgrid, np.int32)
         self._ck(self.lib.psamd_download_chunkgrid(self.h, _ptr(out)))
         return out.reshape(self.sizes.num_chunks, -1)
+
+    def download_force_counts(self):
+        """Per cell: particles the last pair pass computed a force for."""
+        out = np.zeros(self.sizes.num_cells, np.int32)
+        self._ck(self.lib.psamd_download_force_counts(self.h, _ptr(out)))
+        return out
 
     def pkgdistrib(self):
         out = np.zeros(self.sizes.n_pkgdistrib * 2, np.int32)

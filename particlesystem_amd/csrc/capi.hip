@@ -56,7 +56,7 @@ struct psamd_ctx {
     int64_t live_bound = 0, snapshot_live_bound = 0;
     // timing
     int timing = 0;                    // 0 off, 1 pair pass / apply / life cycle, 2 every stage
-    hipEvent_t ev[13]{};               // 10 frame reset | 0 hist 1 scan 2 scatter 3 sort 4 | 5 pairs 6 | 7 apply 8,11 | life cycle 9,12
+    hipEvent_t ev[14]{};               // 10 frame reset | 0 hist 1 scan 2 scatter 3 sort 4 | 5 collide 13 force pass 6 | 7 apply 8,11 | life cycle 9,12
     bool lifecycle_pending[2] = {false, false};   // ev[8|11] -> ev[9|12] recorded, not yet read
     hipEvent_t ev_scalars = nullptr;   // the per-step read-back of FrameScalars has landed
     bool ev_made = false;
@@ -619,6 +619,25 @@ int psamd_download_cellgrid(psamd_ctx *c, int32_t *out)
     return PSAMD_OK;
 }
 
+int psamd_download_force_counts(psamd_ctx *c, int32_t *out)
+{
+    if (!c || !out) return PSAMD_ERR_INVALID_ARG;
+    if (!c->pairs_done) return fail(c, PSAMD_ERR_STATE, "force counts requested before the pair pass of this frame");
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    const Geometry &g = c->geo;
+    const bool two = c->P.two_pass && c->P.lean_math;
+    if (two) {
+        PS_HIP(c, hipMemcpy(out, c->d.active_count, sizeof(int32_t) * (size_t)g.num_cells, hipMemcpyDeviceToHost));
+        return PSAMD_OK;
+    }
+    // one-pass modes evaluate every particle's sum (and discard what is not used)
+    std::vector<int> start((size_t)g.num_cells + 1);
+    PS_HIP(c, hipMemcpy(start.data(), c->d.cell_start, start.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int cell = 0; cell < g.num_cells; cell++)
+        out[cell] = std::min(start[(size_t)cell + 1] - start[(size_t)cell], g.max_per_cell);
+    return PSAMD_OK;
+}
+
 int psamd_download_chunkgrid(psamd_ctx *c, int32_t *out)
 {
     if (!c || !out) return PSAMD_ERR_INVALID_ARG;
@@ -730,7 +749,7 @@ int psamd_calc_forces_pairs(psamd_ctx *c)
         lo = (int)b; hi = (int)e; covered = (int)std::min<int64_t>(s * c->geo.cfg.world, INT32_MAX);
     }
     if (c->timing) (void)hipEventRecord(c->ev[5], c->stream);
-    PS_HIP(c, launch_pairs(c->stream, c->P, c->d, lo, hi, covered, c->geo.cfg.world > 1));
+    PS_HIP(c, launch_pairs(c->stream, c->P, c->d, lo, hi, covered, c->geo.cfg.world > 1, c->timing ? c->ev[13] : nullptr));
     if (c->timing) (void)hipEventRecord(c->ev[6], c->stream);
     c->pairs_done = true;
     return PSAMD_OK;
@@ -769,8 +788,10 @@ int psamd_calc_forces_apply(psamd_ctx *c)
         (void)hipEventRecord(c->ev[par ? 12 : 9], c->stream);
         c->lifecycle_pending[par] = true;
         collect_lifecycle_time(c, par ^ 1);
-        const int a[] = {0, 1, 2, 3, 5, 7, 10}, b[] = {1, 2, 3, 4, 6, par ? 11 : 8, 0}, slot[] = {0, 1, 2, 3, 4, 5, 7};
-        for (int k = (c->timing >= 2 ? 0 : 4); k < (c->timing >= 2 ? 7 : 6); k++) {
+        // slots: hist scan scatter sort | force pass, apply | frame reset | flags + active lists (two-pass prologue)
+        const int a[] = {0, 1, 2, 3, 13, 7, 10, 5}, b[] = {1, 2, 3, 4, 6, par ? 11 : 8, 0, 13}, slot[] = {0, 1, 2, 3, 4, 5, 7, 8};
+        for (int k = (c->timing >= 2 ? 0 : 4); k < 8; k++) {
+            if (c->timing < 2 && k == 6) continue;
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, c->ev[a[k]], c->ev[b[k]]) == hipSuccess) c->t_us[slot[k]] += 1000.0 * ms;
         }

@@ -84,7 +84,7 @@ hipError_t launch_init_tdata(hipStream_t st, const DeviceState &d, int n);
 hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev);
 // lo/hi: this rank's sorted range; covered = world * share (all ranks' ranges together)
 hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi, int covered,
-                        bool sharded);
+                        bool sharded, hipEvent_t ev_force);
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step,
                         int live_bound);
 // after apply, before the per-step read-back: ops per queue record, their prefix and maximum

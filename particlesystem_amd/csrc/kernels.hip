@@ -737,7 +737,7 @@ __global__ void k_shard_tasks(DevParams P, const int *__restrict__ cell_start, c
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int total = cell_start[P.num_cells];
     lo = min(lo, total); hi = min(hi, total);
-    if (hi <= lo) { fs->shard_task_lo = 0; fs->shard_task_n = 0; return; }
+    if (hi <= lo) { fs->shard_task_lo = 0; fs->shard_task_n = 0; fs->shard_cell_lo = 0; fs->shard_cell_hi = -1; return; }
     auto cell_of = [&](int gi) {          // largest c with cell_start[c] <= gi
         int a = 0, b = P.num_cells - 1;
         while (a < b) { const int m = (a + b + 1) >> 1; if (cell_start[m] <= gi) a = m; else b = m - 1; }
@@ -746,6 +746,7 @@ __global__ void k_shard_tasks(DevParams P, const int *__restrict__ cell_start, c
     const int c_lo = cell_of(lo), c_hi = cell_of(hi - 1);
     fs->shard_task_lo = task_start[c_lo];
     fs->shard_task_n = task_start[c_hi + 1] - task_start[c_lo];
+    fs->shard_cell_lo = c_lo; fs->shard_cell_hi = c_hi;
 }
 
 // ------------------------------------------------------------------ two-pass pair stage
@@ -779,11 +780,15 @@ __device__ __forceinline__ int collide_scan(const DevParams &P, float xi, float 
             dm = fminf(fminf(dm, d[i].x), d[i].y);
         }
         if (__any(scan && !(dm > P.coll_d2_gate))) {
+            // some lane has a body of this group inside the gate (or meets itself): find which
+            // bodies, wave-uniformly, and run the exact rule only for those
 #pragma unroll
             for (int i = 0; i < NB; i++) {
                 const float di = (i & 1) ? d[i >> 1].y : d[i >> 1].x;
-                if (scan && !(di > P.coll_d2_gate) && j + i != self)
-                    flag = max(flag, collide_exact(P, di, age_i, id_i, bage[j + i], bid[j + i]));
+                const bool hit = scan && !(di > P.coll_d2_gate) && j + i != self;
+                if (__any(hit)) {
+                    if (hit) flag = max(flag, collide_exact(P, di, age_i, id_i, bage[j + i], bid[j + i]));
+                }
             }
         }
     }
@@ -804,14 +809,19 @@ __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restr
                                                  const int *__restrict__ sorted_id, const int *__restrict__ task_list,
                                                  const int *__restrict__ halo_count, const float *__restrict__ halo_f,
                                                  const int *__restrict__ halo_id, int *__restrict__ flag_out,
-                                                 float4 *__restrict__ force4, const FrameScalars *__restrict__ fs)
+                                                 float4 *__restrict__ force4, const FrameScalars *__restrict__ fs,
+                                                 int sharded, int lo, int hi)
 {
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (slot >= fs->n_tasks) return;
-    const int task = task_list[slot];
+    // (readfirstlane: the wave index is uniform but the compiler cannot know; with uniform
+    // ranges the body loads below become scalar loads)
+    // a rank of a sharded run settles the flags of its own share only (the others arrive with
+    // the all-gather of force4)
+    const int slot = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (slot >= (sharded ? fs->shard_task_n : fs->n_tasks)) return;
+    const int task = task_list[(sharded ? fs->shard_task_lo : 0) + slot];
     const int c = task / P.slices, slice = task - c * P.slices;
-    const int base = cell_start[c];
-    const int cnt = min(cell_start[c + 1] - base, P.max_per_cell);
+    const int base = __builtin_amdgcn_readfirstlane(cell_start[c]);
+    const int cnt = __builtin_amdgcn_readfirstlane(min(cell_start[c + 1] - base, P.max_per_cell));
     const int first = slice * 64;
     if (first >= cnt) return;
     const int lane = threadIdx.x & 63;
@@ -827,7 +837,7 @@ __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restr
     // own cell (the particle itself is entry gi - base: skipped by index)
     flag = collide_scan(P, xi, yi, zi, age_i, id_i, scan, gi - base, snap_soa + base, snap_soa + cap + base,
                         snap_soa + 2 * cap + base, snap_age + base, sorted_id + base, cnt, flag);
-    const int nh = halo_count[c];
+    const int nh = __builtin_amdgcn_readfirstlane(halo_count[c]);
     if (nh <= HALO_CAP) {
         const size_t at = (size_t)c * HALO_CAP, plane = (size_t)P.num_cells * HALO_CAP;
         flag = collide_scan(P, xi, yi, zi, age_i, id_i, scan, -1, halo_f + at, halo_f + plane + at, halo_f + 2 * plane + at,
@@ -839,14 +849,14 @@ __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restr
         for (int k = 1; k < 27; k++) {
             const int n2 = i2 + c_stencil[k][0], n1 = i1 + c_stencil[k][1], n3 = i3 + c_stencil[k][2];
             if (n1 < 0 || n1 >= G || n2 < 0 || n2 >= G || n3 < 0 || n3 >= G) continue;
-            const int nc = n3 * G * G + n1 * G + n2, nb = cell_start[nc];
-            const int n = min(cell_start[nc + 1] - nb, P.max_per_cell);
+            const int nc = n3 * G * G + n1 * G + n2, nb = __builtin_amdgcn_readfirstlane(cell_start[nc]);
+            const int n = __builtin_amdgcn_readfirstlane(min(cell_start[nc + 1] - nb, P.max_per_cell));
             flag = collide_scan(P, xi, yi, zi, age_i, id_i, scan, -1, snap_soa + nb, snap_soa + cap + nb,
                                 snap_soa + 2 * cap + nb, snap_age + nb, sorted_id + nb, n, flag);
         }
     }
     if (dead) flag = 2;                                          // ps.cpp:1183
-    if (valid) {
+    if (valid && gi >= lo && gi < hi) {
         flag_out[gi] = (flag == 0 && kid) ? -1 : flag;           // -1: moves, but every force term is skipped
         force4[gi] = make_float4(0.f, 0.f, 0.f, __int_as_float(flag));   // final unless the force pass overwrites it
     }
@@ -856,17 +866,22 @@ __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restr
 // (flag 0 and not a kid), packed at active_list[cell_start[c] ...], and their number.
 __global__ __launch_bounds__(256) void k_build_active(DevParams P, const int *__restrict__ cell_start,
                                                       const int *__restrict__ flag_in, int *__restrict__ active_list,
-                                                      int *__restrict__ active_count)
+                                                      int *__restrict__ active_count, const FrameScalars *__restrict__ fs,
+                                                      int sharded, int lo, int hi)
 {
     __shared__ int s_n;
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    if (sharded && (c < fs->shard_cell_lo || c > fs->shard_cell_hi)) {       // another rank's cells
+        if (tid == 0) active_count[c] = 0;
+        return;
+    }
     const int base = cell_start[c];
     const int cnt = min(cell_start[c + 1] - base, P.max_per_cell);
     if (tid == 0) s_n = 0;
     __syncthreads();
     for (int e0 = 0; e0 < cnt; e0 += 256) {
         const int e = e0 + tid;
-        const bool on = e < cnt && flag_in[base + e] == 0;
+        const bool on = e < cnt && base + e >= lo && base + e < hi && flag_in[base + e] == 0;
         const unsigned long long m = __ballot(on);
         int wbase = 0;
         if (lane == 0 && m) wbase = atomicAdd(&s_n, __popcll(m));
@@ -881,7 +896,7 @@ __global__ __launch_bounds__(256) void k_build_active(DevParams P, const int *__
 // the force pass.
 __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *__restrict__ active_count,
                                                        int *__restrict__ task_start2, int *__restrict__ task_list2,
-                                                       FrameScalars *fs)
+                                                       FrameScalars *fs, int sharded)
 {
     __shared__ int wave_tot[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -901,6 +916,18 @@ __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *_
         run += n;
     }
     if (tid == 0) { task_start2[P.num_cells] = total; fs->n_tasks2 = total; }
+    if (sharded) {                       // the force pass's run of this list: the share's cells
+        __syncthreads();
+        if (tid == 0) {
+            const int c_lo = fs->shard_cell_lo, c_hi = fs->shard_cell_hi;
+            if (c_hi < c_lo) { fs->shard_task_lo = 0; fs->shard_task_n = 0; }
+            else {
+                const int end = c_hi + 1 < P.num_cells ? task_start2[c_hi + 1] : total;
+                fs->shard_task_lo = task_start2[c_lo];
+                fs->shard_task_n = end - task_start2[c_lo];
+            }
+        }
+    }
 }
 
 // One wave = 64 consecutive particles of one cell (four independent waves per workgroup).
@@ -1938,18 +1965,22 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
 
 template <int MODE, int NQ>
 static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi,
-                                    int covered, bool sharded)
+                                    int covered, bool sharded, hipEvent_t ev_force)
 {
     const int tasks = P.num_cells * P.slices;
     const bool two = MODE != 0 && P.two_pass;
     if (two) {
-        // collision flags of every particle (cheap, so every rank of a sharded run does them
-        // all), then the per-cell lists and tasks of the particles that need a force
+        // collision flags (a rank of a sharded run: of its own share), then the per-cell lists
+        // and the tasks of the particles that need a force
+        if (sharded) k_shard_tasks<<<1, 64, 0, st>>>(P, d.cell_start, d.task_start, lo, hi, d.fs);
         k_collide<<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.task_list,
-                                                   d.halo_count, d.halo_f, d.halo_id, d.pair_flag, d.force4, d.fs);
-        k_build_active<<<P.num_cells, 256, 0, st>>>(P, d.cell_start, d.pair_flag, d.active_list, d.active_count);
-        k_active_tasks<<<1, 1024, 0, st>>>(P, d.active_count, d.task_start2, d.task_list2, d.fs);
+                                                   d.halo_count, d.halo_f, d.halo_id, d.pair_flag, d.force4, d.fs,
+                                                   sharded ? 1 : 0, lo, hi);
+        k_build_active<<<P.num_cells, 256, 0, st>>>(P, d.cell_start, d.pair_flag, d.active_list, d.active_count, d.fs,
+                                                    sharded ? 1 : 0, lo, hi);
+        k_active_tasks<<<1, 1024, 0, st>>>(P, d.active_count, d.task_start2, d.task_list2, d.fs, sharded ? 1 : 0);
     }
+    if (ev_force) (void)hipEventRecord(ev_force, st);      // timing: the force pass proper starts here
     const int *task_start = two ? d.task_start2 : d.task_start, *task_list = two ? d.task_list2 : d.task_list;
     const int *active_list = two ? d.active_list : nullptr, *active_count = two ? d.active_count : nullptr;
     if (sharded) {
@@ -1964,7 +1995,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
         const long long real_tasks = std::max(1, std::min(hi, covered) - lo) / 57 + 1;
         int nphase = MODE == 0 ? 1 : real_tasks >= 16 * 1024 ? 1 : real_tasks >= 6 * 1024 ? 2 : 4;
         if (forced > 0 && MODE != 0) nphase = std::min(forced, 9);
-        k_shard_tasks<<<1, 64, 0, st>>>(P, d.cell_start, task_start, lo, hi, d.fs);
+        if (!two) k_shard_tasks<<<1, 64, 0, st>>>(P, d.cell_start, task_start, lo, hi, d.fs);   // two-pass: done above
         k_pairs<MODE, true, NQ><<<per_phase * nphase, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
                                                    lo, hi, covered, d.fs, d.trace, nphase, d.task_done, active_list, active_count);
     } else {
@@ -1975,13 +2006,13 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
 }
 
 hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi, int covered,
-                        bool sharded)
+                        bool sharded, hipEvent_t ev_force)
 {
     // fast math shares the lean modes' validity range (finite 1/sqrt(eps2^3))
-    if ((P.flags & PSAMD_FLAG_FAST_MATH) && P.lean_math) return launch_pairs_mode<2, 8>(st, P, d, lo, hi, covered, sharded);
+    if ((P.flags & PSAMD_FLAG_FAST_MATH) && P.lean_math) return launch_pairs_mode<2, 8>(st, P, d, lo, hi, covered, sharded, ev_force);
     // 8 pairs per slow-branch test: measured 3 % (full GPU) to 5 % (a 1/8 share) faster than 4
-    if (P.lean_math) return launch_pairs_mode<1, 8>(st, P, d, lo, hi, covered, sharded);
-    return launch_pairs_mode<0, 4>(st, P, d, lo, hi, covered, sharded);
+    if (P.lean_math) return launch_pairs_mode<1, 8>(st, P, d, lo, hi, covered, sharded, ev_force);
+    return launch_pairs_mode<0, 4>(st, P, d, lo, hi, covered, sharded, ev_force);
 }
 
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step,

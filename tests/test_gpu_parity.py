@@ -438,3 +438,40 @@ def test_timing_levels_report_without_stalling_steps():
     g.step(1)
     assert g.timing()[1] == 0
     g.close()
+
+
+def test_two_pass_halo_overflow_and_kids():
+    """Two-pass pair stage: (a) a cell whose neighbours crowd more bodies against its faces
+    than its halo list holds falls back to scanning the whole stencil; (b) kids sit among
+    colliding adults (no force, no collision, still integrated).  Both byte-exact."""
+    rng = np.random.default_rng(123)
+    # cell (8,8,8) of the 16^3 grid spans [0,5)^3 in (x, -y, -z); crowd its 26 neighbours' near sides
+    centre = np.array([2.5, -2.5, -2.5], np.float32)
+    pts = []
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                if dx == dy == dz == 0:
+                    continue
+                lo = np.array([2.5 + 5 * dx, -2.5 + 5 * dy, -2.5 + 5 * dz]) - 2.5
+                p = rng.uniform(0.0, 5.0, (60, 3))
+                for ax, d in enumerate((dx, dy, dz)):
+                    if d == -1: p[:, ax] = rng.uniform(4.75, 4.999, 60)     # hug the face towards the centre cell
+                    if d == +1: p[:, ax] = rng.uniform(0.001, 0.25, 60)
+                pts.append(lo + p)
+    crowd = np.concatenate(pts).astype(np.float32)                 # 26 * 60 = 1560 bodies within 0.25 of the cell
+    inside = (centre + rng.uniform(-2.45, 2.45, (300, 3))).astype(np.float32)
+    rest = cloud(20000, 124)
+    xyz = np.concatenate([crowd, inside, rest])
+    age = rng.choice(np.array([0.5, 1.4, 3.0, 3.0, 3.0, 6.0], np.float32), len(xyz))
+    g, o = make_pair(xyz, age=age, fert=1e6)
+    for k in range(3):
+        g.step(1); o.step(1)
+        compare_all(g, o, "halo overflow / kids step %d" % (k + 1))
+    assert g.counters["deaths_collision"] > 0
+    # the getter of the force pass's per-cell counts: never more than the cell holds
+    g.init_iframe(); g.build_grid(); g.calc_forces_pairs()
+    fc, cg = g.download_force_counts(), g.download_cellgrid()[:, 0]
+    assert (fc <= cg).all() and 0 < fc.sum() < cg.sum()
+    g.calc_forces_apply()
+    g.close(); o.close()

@@ -315,6 +315,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.active_count, (size_t)g.num_cells));
     PS_HIP(c, dev_alloc(c, &d.task_start2, (size_t)g.num_cells + 1));
     PS_HIP(c, dev_alloc(c, &d.task_list2, (size_t)g.num_cells * P.slices));
+    PS_HIP(c, dev_alloc(c, &d.merged_tasks, (size_t)g.num_cells));
     PS_HIP(c, dev_alloc(c, &d.rec_start, (size_t)g.queue_infos + 1));
     PS_HIP(c, dev_alloc(c, &d.rec_cursor, (size_t)g.queue_infos));
     PS_HIP(c, dev_alloc(c, &d.fs, 1));

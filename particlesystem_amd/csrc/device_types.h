@@ -57,6 +57,7 @@ struct FrameScalars {
     int32_t shard_task_lo;  // first pair-kernel task (cell * slices) of this rank's share
     int32_t shard_task_n;   // number of tasks from there that can hold a particle of the share
     int32_t n_tasks2;       // two-pass mode: (cell, 64-slice) tasks over the particles that need a force
+    int32_t n_merged;       // ... and merged tasks (up to four cells' partly filled last slices in one wave)
     int32_t shard_cell_lo, shard_cell_hi;   // cells that hold this rank's share of the sorted particles
 };
 

@@ -893,29 +893,57 @@ __global__ __launch_bounds__(256) void k_build_active(DevParams P, const int *__
 }
 
 // One workgroup: prefix of the active lists' 64-slices over the cells and the task list of
-// the force pass.
+// the force pass.  With `merge`, only full slices become ordinary tasks; the leftovers (a cell's
+// last, partly filled slice: 20 of 64 lanes on average once the collided particles are gone)
+// are packed, up to four cells to a wave, into the merged tasks of k_pairs_merged.
 __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *__restrict__ active_count,
                                                        int *__restrict__ task_start2, int *__restrict__ task_list2,
-                                                       FrameScalars *fs, int sharded)
+                                                       int4 *__restrict__ merged_tasks, FrameScalars *fs, int sharded,
+                                                       int merge)
 {
-    __shared__ int wave_tot[16];
+    __shared__ long long wave_tot[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int per = (P.num_cells + 1023) / 1024;
     const int c0 = min(P.num_cells, tid * per), c1 = min(P.num_cells, c0 + per);
-    int mine = 0;
-    for (int c = c0; c < c1; c++) mine += (active_count[c] + 63) >> 6;
-    const int incl = wave_incl_scan(mine);
+    // the first 256 threads each pack the leftovers of a longer run of cells greedily, in
+    // cell order (longer runs leave fewer half-empty packs at their ends)
+    const int pper = (P.num_cells + 255) / 256;
+    const int p0 = tid < 256 ? min(P.num_cells, tid * pper) : 0, p1 = tid < 256 ? min(P.num_cells, p0 + pper) : 0;
+    auto pack = [&](int4 *out) -> int {
+        int npack = 0, used = 0, ng = 0;
+        int4 cur = make_int4(-1, -1, -1, -1);
+        for (int c = p0; c < p1; c++) {
+            const int r = active_count[c] & 63;
+            if (r == 0) continue;
+            if (ng == 4 || used + r > 64) { if (out) out[npack] = cur; npack++; cur = make_int4(-1, -1, -1, -1); used = 0; ng = 0; }
+            if (ng == 0) cur.x = c; else if (ng == 1) cur.y = c; else if (ng == 2) cur.z = c; else cur.w = c;
+            ng++; used += r;
+        }
+        if (ng) { if (out) out[npack] = cur; npack++; }
+        return npack;
+    };
+    long long mine = 0;                       // tasks (low word) and merged tasks (high word)
+    for (int c = c0; c < c1; c++) mine += merge ? (active_count[c] >> 6) : ((active_count[c] + 63) >> 6);
+    if (merge) mine |= (long long)pack(nullptr) << 32;
+    long long incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
     if (lane == 63) wave_tot[wv] = incl;
     __syncthreads();
-    int run = incl - mine, total = 0;
-    for (int k = 0; k < 16; k++) { if (k < wv) run += wave_tot[k]; total += wave_tot[k]; }
+    long long run2 = incl - mine, total2 = 0;
+    for (int k = 0; k < 16; k++) { if (k < wv) run2 += wave_tot[k]; total2 += wave_tot[k]; }
+    int run = (int)(run2 & 0xffffffffll);
+    const int total = (int)(total2 & 0xffffffffll);
     for (int c = c0; c < c1; c++) {
-        const int n = (active_count[c] + 63) >> 6;
+        const int n = merge ? (active_count[c] >> 6) : ((active_count[c] + 63) >> 6);
         task_start2[c] = run;
         for (int sl = 0; sl < n; sl++) task_list2[run + sl] = c * P.slices + sl;
         run += n;
     }
-    if (tid == 0) { task_start2[P.num_cells] = total; fs->n_tasks2 = total; }
+    if (merge) pack(merged_tasks + (int)(run2 >> 32));
+    if (tid == 0) { task_start2[P.num_cells] = total; fs->n_tasks2 = total; fs->n_merged = (int)(total2 >> 32); }
     if (sharded) {                       // the force pass's run of this list: the share's cells
         __syncthreads();
         if (tid == 0) {
@@ -1195,6 +1223,116 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
     if (slot >= ntask) return;
     pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, lo, hi,
                          task_list[slot], tiles[MODE == 0 ? wave : 0], trace, 0, 1, nullptr, nullptr, active_list, active_count);
+}
+
+// Merged task of the two-pass force pass: the partly filled last slices of up to four cells
+// share one wave, each cell's particles in their own run of lanes.  Every lane group has its
+// own stencil, so the bodies cannot come as scalar operands here: each group's current 64
+// bodies sit in its own LDS tile (SoA, the groups' tiles skewed by 16 bytes so that they use
+// different banks -- scripts/microbench/lds_groups.hip) and a lane reads its group's tile.
+// All groups walk stencil step k together, tile by tile, for as many rows as the longest of
+// their lists; shorter lists are padded with massless bodies far outside the box: such a
+// row adds r * 0 = +-0 to a sum that started at +0 (bit-identical, as for kids).  Launched
+// on its own (different register budget from k_pairs).
+constexpr int MERGE_TILE = 4 * 64 + 4;          // floats per lane group: x[64] y[64] z[64] w[64] + skew
+
+template <int MODE, int NQ>
+__global__ __launch_bounds__(256) void k_pairs_merged(DevParams P, const int *__restrict__ cell_start,
+                                                      const float4 *__restrict__ snap4,
+                                                      const int *__restrict__ active_list,
+                                                      const int *__restrict__ active_count,
+                                                      const int4 *__restrict__ merged_tasks,
+                                                      float4 *__restrict__ force4, const FrameScalars *__restrict__ fs)
+{
+    __shared__ __attribute__((aligned(16))) float tiles[4][4 * MERGE_TILE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + wave;
+    if (slot >= fs->n_merged) return;
+    float *tile = tiles[wave];
+    const int4 pk = merged_tasks[slot];
+    const int cells[4] = {pk.x, pk.y, pk.z, pk.w};
+    // lane ranges of the groups
+    int off[5] = {0, 0, 0, 0, 0}, ng = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int r = cells[k] >= 0 ? (active_count[cells[k]] & 63) : 0;
+        off[k + 1] = off[k] + r;
+        if (cells[k] >= 0) ng = k + 1;
+    }
+    const int g = (lane >= off[1]) + (lane >= off[2]) + (lane >= off[3]);       // a lane past the last group: 3, invalid
+    const bool valid = lane < off[4];
+    const int c = valid ? (g == 0 ? cells[0] : g == 1 ? cells[1] : g == 2 ? cells[2] : cells[3]) : cells[0];
+    const int l = valid ? lane - (g == 0 ? off[0] : g == 1 ? off[1] : g == 2 ? off[2] : off[3]) : 0;
+    const int gi = active_list[cell_start[c] + (active_count[c] & ~63) + l];
+    const float4 me = snap4[gi];
+    const float eps2f = (float)P.eps2;
+
+    // neighbour ranges of all groups: entry e = group * 27 + stencil step, held by lane e % 64
+    const int G = P.G;
+    int tab_nb[2] = {0, 0}, tab_cnt[2] = {0, 0};
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int e = lane + 64 * r, eg = e / 27, ek = e - eg * 27;
+        const int ec = eg == 0 ? cells[0] : eg == 1 ? cells[1] : eg == 2 ? cells[2] : eg == 3 ? cells[3] : -1;
+        if (ec >= 0) {
+            const int i3 = ec / (G * G), rem = ec - i3 * G * G, i1 = rem / G, i2 = rem - i1 * G;
+            const int n2 = i2 + c_stencil[ek][0], n1 = i1 + c_stencil[ek][1], n3 = i3 + c_stencil[ek][2];
+            if (n1 >= 0 && n1 < G && n2 >= 0 && n2 < G && n3 >= 0 && n3 < G) {
+                const int nc = n3 * G * G + n1 * G + n2;
+                tab_nb[r] = cell_start[nc];
+                tab_cnt[r] = min(cell_start[nc + 1] - tab_nb[r], P.max_per_cell);
+            }
+        }
+    }
+    const float *tx = tile + (valid ? g : 0) * MERGE_TILE, *ty = tx + 64, *tz = tx + 128, *tw = tx + 192;
+    const float far = 1.0e6f;                                       // padding body, mass 0
+    const PairCtx ctx = {me.x, me.y, me.z, 0.f, 0, gi, false};
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    int flag = 0;
+    for (int k = 0; k < 27; k++) {
+        int nbs[4], cnts[4], longest = 0;
+#pragma unroll
+        for (int gg = 0; gg < 4; gg++) {
+            const int e = gg * 27 + k;
+            nbs[gg] = __builtin_amdgcn_readlane(e < 64 ? tab_nb[0] : tab_nb[1], e & 63);
+            cnts[gg] = gg < ng ? __builtin_amdgcn_readlane(e < 64 ? tab_cnt[0] : tab_cnt[1], e & 63) : 0;
+            longest = max(longest, cnts[gg]);
+        }
+        for (int t0 = 0; t0 < longest; t0 += 64) {
+            PS_WAVE_SYNC();                                         // previous tiles fully consumed
+#pragma unroll
+            for (int gg = 0; gg < 4; gg++) {
+                if (gg < ng) {
+                    float4 v = make_float4(far, far, far, 0.f);
+                    if (lane < cnts[gg] - t0) v = snap4[nbs[gg] + t0 + lane];
+                    float *t = tile + gg * MERGE_TILE + lane;
+                    t[0] = v.x; t[64] = v.y; t[128] = v.z; t[192] = v.w;
+                }
+            }
+            PS_WAVE_SYNC();
+            const int n = (min(64, longest - t0) + NQ - 1) & ~(NQ - 1);
+            float dmin = 3.0e38f;
+            for (int jj = 0; jj < n; jj += NQ) {
+                v2f qx[NQ / 2], qy[NQ / 2], qz[NQ / 2], qw[NQ / 2];   // 16-byte LDS reads, NQ is a multiple of 4
+#pragma unroll
+                for (int i = 0; i < NQ / 2; i += 2) {
+                    const float4 vx = *reinterpret_cast<const float4 *>(tx + jj + 2 * i);
+                    const float4 vy = *reinterpret_cast<const float4 *>(ty + jj + 2 * i);
+                    const float4 vz = *reinterpret_cast<const float4 *>(tz + jj + 2 * i);
+                    const float4 vw = *reinterpret_cast<const float4 *>(tw + jj + 2 * i);
+                    qx[i] = v2f{vx.x, vx.y}; qx[i + 1] = v2f{vx.z, vx.w};
+                    qy[i] = v2f{vy.x, vy.y}; qy[i + 1] = v2f{vy.z, vy.w};
+                    qz[i] = v2f{vz.x, vz.y}; qz[i + 1] = v2f{vz.z, vz.w};
+                    qw[i] = v2f{vw.x, vw.y}; qw[i + 1] = v2f{vw.z, vw.w};
+                }
+                if (MODE == 1)
+                    pairsN_exact_lean<NQ>(P, ctx, qx, qy, qz, qw, 0, nullptr, nullptr, ax, ay, az, flag);
+                else
+                    dmin = fminf(dmin, pairsN_fast<NQ>(ctx, qx, qy, qz, qw, eps2f, ax, ay, az));
+            }
+        }
+    }
+    if (valid) force4[gi] = make_float4(ax, ay, az, 0.f);
 }
 
 // ------------------------------------------------------------------ apply
@@ -1969,6 +2107,9 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
 {
     const int tasks = P.num_cells * P.slices;
     const bool two = MODE != 0 && P.two_pass;
+    // leftover slices of several cells in one wave: single-GPU launches only (a shard's task run is cut by cells)
+    static const bool merge_off = std::getenv("PSAMD_NO_MERGE") != nullptr;
+    const bool merge = two && !sharded && !merge_off;
     if (two) {
         // collision flags (a rank of a sharded run: of its own share), then the per-cell lists
         // and the tasks of the particles that need a force
@@ -1978,7 +2119,8 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
                                                    sharded ? 1 : 0, lo, hi);
         k_build_active<<<P.num_cells, 256, 0, st>>>(P, d.cell_start, d.pair_flag, d.active_list, d.active_count, d.fs,
                                                     sharded ? 1 : 0, lo, hi);
-        k_active_tasks<<<1, 1024, 0, st>>>(P, d.active_count, d.task_start2, d.task_list2, d.fs, sharded ? 1 : 0);
+        k_active_tasks<<<1, 1024, 0, st>>>(P, d.active_count, d.task_start2, d.task_list2, d.merged_tasks, d.fs, sharded ? 1 : 0,
+                                           merge ? 1 : 0);
     }
     if (ev_force) (void)hipEventRecord(ev_force, st);      // timing: the force pass proper starts here
     const int *task_start = two ? d.task_start2 : d.task_start, *task_list = two ? d.task_list2 : d.task_list;
@@ -2001,6 +2143,9 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     } else {
         k_pairs<MODE, false, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
                                                     lo, hi, covered, d.fs, d.trace, 1, d.task_done, active_list, active_count);
+        if (merge)
+            k_pairs_merged<MODE == 0 ? 1 : MODE, NQ><<<(P.num_cells + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.active_list,
+                                                                                            d.active_count, d.merged_tasks, d.force4, d.fs);
     }
     return hipGetLastError();
 }

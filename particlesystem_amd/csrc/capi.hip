@@ -252,6 +252,9 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     PS_HIP(c, hipEventCreateWithFlags(&c->ev_scalars, hipEventDisableTiming));
+    PS_HIP(c, hipStreamCreateWithFlags(&c->d.side_stream, hipStreamNonBlocking));
+    PS_HIP(c, hipEventCreateWithFlags(&c->d.ev_fork, hipEventDisableTiming));
+    PS_HIP(c, hipEventCreateWithFlags(&c->d.ev_join, hipEventDisableTiming));
 
     DevParams &P = c->P;
     P.G = g.G; P.num_cells = g.num_cells; P.num_chunks = g.num_chunks; P.container = g.container;
@@ -400,6 +403,9 @@ int psamd_destroy(psamd_ctx *c)
     if (c->h_fs) (void)hipHostFree(c->h_fs);
     if (c->ev_made) for (auto &e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_scalars) (void)hipEventDestroy(c->ev_scalars);
+    if (c->d.ev_fork) (void)hipEventDestroy(c->d.ev_fork);
+    if (c->d.ev_join) (void)hipEventDestroy(c->d.ev_join);
+    if (c->d.side_stream) (void)hipStreamDestroy(c->d.side_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return PSAMD_OK;

@@ -45,6 +45,9 @@ struct DeviceState {
     int *task_start2 = nullptr;   // [num_cells + 1] prefix of 64-slices of the active lists
     int *task_list2 = nullptr;    // [num_cells * slices]
     int4 *merged_tasks = nullptr; // [num_cells] cells whose leftover slices share one wave (-1: unused)
+    // the merged tasks run beside k_pairs on a stream of their own (fork / join by events)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int *task_done = nullptr;     // [num_cells * slices] legs finished so far of a split task (sharded launches)
     int *sorted_id = nullptr;     // [container] cell-major, id ascending inside a cell
     int *rank_of_slot = nullptr;  // [container] inverse of sorted_id for the slots of this frame

@@ -2141,11 +2141,19 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
         k_pairs<MODE, true, NQ><<<per_phase * nphase, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
                                                    lo, hi, covered, d.fs, d.trace, nphase, d.task_done, active_list, active_count);
     } else {
+        if (merge) {
+            // fork: the merged tasks run beside the ordinary ones (their waves stall on tile loads
+            // that the ordinary waves' arithmetic covers); the join below puts everything that
+            // follows on `st` after both
+            (void)hipEventRecord(d.ev_fork, st);
+            (void)hipStreamWaitEvent(d.side_stream, d.ev_fork, 0);
+            k_pairs_merged<MODE == 0 ? 1 : MODE, NQ><<<(P.num_cells + 3) / 4, 256, 0, d.side_stream>>>(
+                P, d.cell_start, d.snap4, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
+            (void)hipEventRecord(d.ev_join, d.side_stream);
+        }
         k_pairs<MODE, false, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
                                                     lo, hi, covered, d.fs, d.trace, 1, d.task_done, active_list, active_count);
-        if (merge)
-            k_pairs_merged<MODE == 0 ? 1 : MODE, NQ><<<(P.num_cells + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.active_list,
-                                                                                            d.active_count, d.merged_tasks, d.force4, d.fs);
+        if (merge) (void)hipStreamWaitEvent(st, d.ev_join, 0);
     }
     return hipGetLastError();
 }

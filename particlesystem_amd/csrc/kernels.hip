@@ -2107,9 +2107,12 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
 {
     const int tasks = P.num_cells * P.slices;
     const bool two = MODE != 0 && P.two_pass;
-    // leftover slices of several cells in one wave: single-GPU launches only (a shard's task run is cut by cells)
+    // leftover slices of several cells in one wave (k_pairs_merged).
+    // A rank's share: only while it is big (half the cloud: 1.46 -> 1.41 ms).  A merged wave is
+    // long and stalls on its tile loads; with a 1/4 or 1/8 share there is too little other
+    // work to cover that and it becomes the critical path (measured 0.86 -> 0.92, 0.64 -> 0.74 ms).
     static const bool merge_off = std::getenv("PSAMD_NO_MERGE") != nullptr;
-    const bool merge = two && !sharded && !merge_off;
+    const bool merge = two && !merge_off && (!sharded || (std::min(hi, covered) - lo) / 57 >= 8192);
     if (two) {
         // collision flags (a rank of a sharded run: of its own share), then the per-cell lists
         // and the tasks of the particles that need a force
@@ -2138,8 +2141,16 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
         int nphase = MODE == 0 ? 1 : real_tasks >= 16 * 1024 ? 1 : real_tasks >= 6 * 1024 ? 2 : 4;
         if (forced > 0 && MODE != 0) nphase = std::min(forced, 9);
         if (!two) k_shard_tasks<<<1, 64, 0, st>>>(P, d.cell_start, task_start, lo, hi, d.fs);   // two-pass: done above
+        if (merge) {
+            (void)hipEventRecord(d.ev_fork, st);
+            (void)hipStreamWaitEvent(d.side_stream, d.ev_fork, 0);
+            k_pairs_merged<MODE == 0 ? 1 : MODE, NQ><<<(P.num_cells + 3) / 4, 256, 0, d.side_stream>>>(
+                P, d.cell_start, d.snap4, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
+            (void)hipEventRecord(d.ev_join, d.side_stream);
+        }
         k_pairs<MODE, true, NQ><<<per_phase * nphase, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
                                                    lo, hi, covered, d.fs, d.trace, nphase, d.task_done, active_list, active_count);
+        if (merge) (void)hipStreamWaitEvent(st, d.ev_join, 0);
     } else {
         if (merge) {
             // fork: the merged tasks run beside the ordinary ones (their waves stall on tile loads

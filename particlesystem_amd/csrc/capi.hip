@@ -288,6 +288,16 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
         // 2.5 % + 1e-3 of slack covers every rounding between here and the exact test.  Needs
         // the radius to be small against the cell (else the halo is the whole neighbour).
         P.halo_reach = (float)(cfg->collision_radius * 1.025 + 1e-3);
+        {   // largest float t with (double)sqrtf(t) <= COLLISION_RADIUS (sqrtf: correctly rounded, monotone)
+            auto collides = [&](float t) { return !((double)std::sqrt(t) > cfg->collision_radius); };
+            uint32_t lo_b = 0u, hi_b = 0x7f7fffffu;                 // bit patterns of non-negative floats order like the floats
+            auto as_f = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+            if (!collides(0.0f)) P.coll_d2_max = -1.0f;
+            else {
+                while (lo_b < hi_b) { const uint32_t mid = lo_b + (hi_b - lo_b + 1) / 2; if (collides(as_f(mid))) lo_b = mid; else hi_b = mid - 1; }
+                P.coll_d2_max = as_f(lo_b);
+            }
+        }
         P.two_pass = (P.lean_math && P.halo_reach < 0.25 * cfg->cell_size && !std::getenv("PSAMD_ONE_PASS")) ? 1 : 0;
     }
     if (P.key_bits > 63) return fail(c, PSAMD_ERR_UNSUPPORTED, "queue-op key does not fit 64 bits for this configuration");
@@ -311,10 +321,11 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &frame, frame_ints));
     d.cell_count = frame; d.chunk_count = frame + g.num_cells; d.rec_count = d.chunk_count + g.num_chunks;
     d.halo_count = d.rec_count + g.queue_infos;
-    PS_HIP(c, dev_alloc(c, &d.halo_f, (size_t)4 * g.num_cells * HALO_CAP + 64));   // + slack: scalar loads fetch whole groups
+    PS_HIP(c, dev_alloc(c, &d.halo_f, (size_t)3 * g.num_cells * HALO_CAP + 64));   // + slack: scalar loads fetch whole groups
     PS_HIP(c, dev_alloc(c, &d.halo_id, (size_t)g.num_cells * HALO_CAP + 64));
     PS_HIP(c, dev_alloc(c, &d.active_list, C + 64));
     PS_HIP(c, dev_alloc(c, &d.pair_flag, C));
+    PS_HIP(c, dev_alloc(c, &d.snap_cid, C + 64));
     PS_HIP(c, dev_alloc(c, &d.active_count, (size_t)g.num_cells));
     PS_HIP(c, dev_alloc(c, &d.task_start2, (size_t)g.num_cells + 1));
     PS_HIP(c, dev_alloc(c, &d.task_list2, (size_t)g.num_cells * P.slices));

@@ -37,8 +37,9 @@ struct DeviceState {
     int *task_list = nullptr;     // [num_cells * slices] non-empty (cell, slice) tasks, cell-major
     // two-pass pair stage (lean modes): collision flags first, forces only where they are used
     int *halo_count = nullptr;    // [num_cells] collision candidates listed by the neighbours (zeroed with the frame)
-    float *halo_f = nullptr;      // [4][num_cells * HALO_CAP] x, y, z, age of those candidates
+    float *halo_f = nullptr;      // [3][num_cells * HALO_CAP] x, y, z of those candidates
     int *halo_id = nullptr;       // [num_cells * HALO_CAP] their slot ids
+    int *snap_cid = nullptr;      // [container] sorted order: slot id, or -1 for a body that can never collide
     int *pair_flag = nullptr;     // [container] sorted order: 0 needs a force, -1 kid (moves, no force), 1 survives, 2 dies
     int *active_list = nullptr;   // [container] per cell (at cell_start[c]): sorted indices of the particles that need a force
     int *active_count = nullptr;  // [num_cells]

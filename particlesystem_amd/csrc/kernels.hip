@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
                                                      uint32_t *__restrict__ tdata, int *__restrict__ rank_of_slot,
                                                      uint64_t *op_keys, int *op_args, int ops_cap,
                                                      int *__restrict__ halo_count, float *__restrict__ halo_f,
-                                                     int *__restrict__ halo_id,
+                                                     int *__restrict__ halo_id, int *__restrict__ snap_cid,
                                                      FrameScalars *fs, DevCounters *ctr)
 {
     __shared__ __attribute__((aligned(16))) int ids[SORT_MAX + 4];
@@ -431,7 +431,10 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
             }
             snap_age[start + e] = age;
             if (halo_count) {
-                const int m3 = halo_dirs(P, c, p.x, p.y, p.z);
+                // collision id: the slot id, or -1 for a body that can never collide (kid, over age)
+                const bool collides = !(age < P.kid_thr) && !(age > P.life_thr);
+                snap_cid[start + e] = collides ? id : -1;
+                const int m3 = collides ? halo_dirs(P, c, p.x, p.y, p.z) : 0;
                 if (m3) {
                     for (int m = 1; m < 8; m++) {
                         const int dir = halo_dir_of_subset(m3, m);
@@ -470,10 +473,10 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
     __syncthreads();
     const int kept = min(n, P.max_per_cell);
     for (int e = tid; e < kept; e += 256) {
+        if (snap_cid[start + e] < 0) continue;
         const float4 q = snap4[start + e];
         const int m3 = halo_dirs(P, c, q.x, q.y, q.z);
         if (!m3) continue;
-        const float age = snap_age[start + e];
         const int id = ordered[e];
         for (int m = 1; m < 8; m++) {
             const int dir = halo_dir_of_subset(m3, m);
@@ -482,7 +485,6 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
             if (k < HALO_CAP) {
                 const size_t at = (size_t)halo_neighbour(P, c, dir) * HALO_CAP + k, plane = (size_t)P.num_cells * HALO_CAP;
                 halo_f[at] = q.x; halo_f[plane + at] = q.y; halo_f[2 * plane + at] = q.z;
-                halo_f[3 * plane + at] = age;
                 halo_id[at] = id;
             }
         }
@@ -759,46 +761,43 @@ __global__ void k_shard_tasks(DevParams P, const int *__restrict__ cell_start, c
 // k_sort_cells filled) -- then k_build_active lists, per cell, the particles that still need
 // a force, and the force pass walks the 27-cell stencil for those only.
 //
-// Distance tests of one particle against `n` bodies given as arrays (wave-uniform pointers,
-// so the loads are scalar loads): returns the updated collision flag.
-__device__ __forceinline__ int collide_scan(const DevParams &P, float xi, float yi, float zi, float age_i, int id_i,
-                                            bool scan, int self, const float *__restrict__ bx,
-                                            const float *__restrict__ by, const float *__restrict__ bz,
-                                            const float *__restrict__ bage, const int *__restrict__ bid, int n, int flag)
+// One particle against `n` bodies given as arrays (wave-uniform pointers, so the loads are
+// scalar loads).  bodyBodyCollision (app_common.cu:269-301) without a branch: the reference's
+// test (double)sqrtf(r.r) > COLLISION_RADIUS is, sqrtf being correctly rounded and monotone,
+// r.r > coll_d2_max for a float found by bisection when the context is created; a body that can
+// never collide (kid, over age) carries cid = -1, otherwise its slot id; and "flag = max over
+// the hits of (id_i > id_j ? 1 : 2)" is two lane masks: met someone with a higher id (2, the
+// lower id dies), met someone with a lower one (1).  The particle itself drops out because
+// neither id comparison holds for it.
+__device__ __forceinline__ void collide_scan(const DevParams &P, float xi, float yi, float zi, int id_i, bool scan,
+                                             const float *__restrict__ bx, const float *__restrict__ by,
+                                             const float *__restrict__ bz, const int *__restrict__ bcid, int n,
+                                             bool &met_higher, bool &met_lower)
 {
-    constexpr int NB = 16;                      // bodies per group: 3 x 16 dwords of scalar loads in flight
+    constexpr int NB = 16;                      // bodies per group: 4 x 16 dwords of scalar loads in flight
     const v2f x2 = {xi, xi}, y2 = {yi, yi}, z2 = {zi, zi};
+    const float dmax = P.coll_d2_max;
     int j = 0;
     for (; j + NB <= n; j += NB) {
-        v2f d[NB / 2];
-        float dm = 3.0e38f;
 #pragma unroll
         for (int i = 0; i < NB / 2; i++) {
             const v2f rx = v2f{bx[j + 2 * i], bx[j + 2 * i + 1]} - x2, ry = v2f{by[j + 2 * i], by[j + 2 * i + 1]} - y2,
                       rz = v2f{bz[j + 2 * i], bz[j + 2 * i + 1]} - z2;
-            d[i] = rx * rx + ry * ry + rz * rz;
-            dm = fminf(fminf(dm, d[i].x), d[i].y);
-        }
-        if (__any(scan && !(dm > P.coll_d2_gate))) {
-            // some lane has a body of this group inside the gate (or meets itself): find which
-            // bodies, wave-uniformly, and run the exact rule only for those
-#pragma unroll
-            for (int i = 0; i < NB; i++) {
-                const float di = (i & 1) ? d[i >> 1].y : d[i >> 1].x;
-                const bool hit = scan && !(di > P.coll_d2_gate) && j + i != self;
-                if (__any(hit)) {
-                    if (hit) flag = max(flag, collide_exact(P, di, age_i, id_i, bage[j + i], bid[j + i]));
-                }
-            }
+            const v2f d = rx * rx + ry * ry + rz * rz;
+            const int c0 = bcid[j + 2 * i], c1 = bcid[j + 2 * i + 1];
+            const bool h0 = scan && !(d.x > dmax), h1 = scan && !(d.y > dmax);
+            met_higher |= (h0 && c0 > id_i) || (h1 && c1 > id_i);
+            met_lower |= (h0 && c0 >= 0 && c0 < id_i) || (h1 && c1 >= 0 && c1 < id_i);
         }
     }
     for (; j < n; j++) {
         const float rx = bx[j] - xi, ry = by[j] - yi, rz = bz[j] - zi;
         const float d2 = rx * rx + ry * ry + rz * rz;
-        if (scan && !(d2 > P.coll_d2_gate) && j != self)
-            flag = max(flag, collide_exact(P, d2, age_i, id_i, bage[j], bid[j]));
+        const int cj = bcid[j];
+        const bool h = scan && !(d2 > dmax);
+        met_higher |= h && cj > id_i;
+        met_lower |= h && cj >= 0 && cj < id_i;
     }
-    return flag;
 }
 
 // One wave per (cell, 64-particle slice) of the ordinary task list.  Writes the flag of every
@@ -806,7 +805,8 @@ __device__ __forceinline__ int collide_scan(const DevParams &P, float xi, float 
 // force4 record.
 __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restrict__ cell_start,
                                                  const float *__restrict__ snap_soa, const float *__restrict__ snap_age,
-                                                 const int *__restrict__ sorted_id, const int *__restrict__ task_list,
+                                                 const int *__restrict__ sorted_id, const int *__restrict__ snap_cid,
+                                                 const int *__restrict__ task_list,
                                                  const int *__restrict__ halo_count, const float *__restrict__ halo_f,
                                                  const int *__restrict__ halo_id, int *__restrict__ flag_out,
                                                  float4 *__restrict__ force4, const FrameScalars *__restrict__ fs,
@@ -833,15 +833,15 @@ __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restr
     const int id_i = sorted_id[gi];
     const bool dead = age_i > P.life_thr, kid = age_i < P.kid_thr;
     const bool scan = valid && !dead && !kid;
-    int flag = 0;
-    // own cell (the particle itself is entry gi - base: skipped by index)
-    flag = collide_scan(P, xi, yi, zi, age_i, id_i, scan, gi - base, snap_soa + base, snap_soa + cap + base,
-                        snap_soa + 2 * cap + base, snap_age + base, sorted_id + base, cnt, flag);
+    bool met_higher = false, met_lower = false;
+    // own cell
+    collide_scan(P, xi, yi, zi, id_i, scan, snap_soa + base, snap_soa + cap + base, snap_soa + 2 * cap + base,
+                 snap_cid + base, cnt, met_higher, met_lower);
     const int nh = __builtin_amdgcn_readfirstlane(halo_count[c]);
     if (nh <= HALO_CAP) {
         const size_t at = (size_t)c * HALO_CAP, plane = (size_t)P.num_cells * HALO_CAP;
-        flag = collide_scan(P, xi, yi, zi, age_i, id_i, scan, -1, halo_f + at, halo_f + plane + at, halo_f + 2 * plane + at,
-                            halo_f + 3 * plane + at, halo_id + at, nh, flag);
+        collide_scan(P, xi, yi, zi, id_i, scan, halo_f + at, halo_f + plane + at, halo_f + 2 * plane + at, halo_id + at, nh,
+                     met_higher, met_lower);
     } else {
         // the halo list overflowed (denser than the container admits in steady state): whole stencil
         const int G = P.G;
@@ -851,10 +851,11 @@ __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restr
             if (n1 < 0 || n1 >= G || n2 < 0 || n2 >= G || n3 < 0 || n3 >= G) continue;
             const int nc = n3 * G * G + n1 * G + n2, nb = __builtin_amdgcn_readfirstlane(cell_start[nc]);
             const int n = __builtin_amdgcn_readfirstlane(min(cell_start[nc + 1] - nb, P.max_per_cell));
-            flag = collide_scan(P, xi, yi, zi, age_i, id_i, scan, -1, snap_soa + nb, snap_soa + cap + nb,
-                                snap_soa + 2 * cap + nb, snap_age + nb, sorted_id + nb, n, flag);
+            collide_scan(P, xi, yi, zi, id_i, scan, snap_soa + nb, snap_soa + cap + nb, snap_soa + 2 * cap + nb, snap_cid + nb, n,
+                         met_higher, met_lower);
         }
     }
+    int flag = met_higher ? 2 : met_lower ? 1 : 0;
     if (dead) flag = 2;                                          // ps.cpp:1183
     if (valid && gi >= lo && gi < hi) {
         flag_out[gi] = (flag == 0 && kid) ? -1 : flag;           // -1: moves, but every force term is skipped
@@ -2095,7 +2096,7 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     if (ev) (void)hipEventRecord(ev[3], st);
     k_sort_cells<<<P.num_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
                                                d.pflags, d.snap4, d.snap_soa, d.snap_age, d.tdata, d.rank_of_slot, d.op_keys, d.op_args, d.ops_cap,
-                                               P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.fs, d.ctr);
+                                               P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.snap_cid, d.fs, d.ctr);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[4], st);
     return hipSuccess;
@@ -2117,7 +2118,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
         // collision flags (a rank of a sharded run: of its own share), then the per-cell lists
         // and the tasks of the particles that need a force
         if (sharded) k_shard_tasks<<<1, 64, 0, st>>>(P, d.cell_start, d.task_start, lo, hi, d.fs);
-        k_collide<<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.task_list,
+        k_collide<<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.snap_cid, d.task_list,
                                                    d.halo_count, d.halo_f, d.halo_id, d.pair_flag, d.force4, d.fs,
                                                    sharded ? 1 : 0, lo, hi);
         k_build_active<<<P.num_cells, 256, 0, st>>>(P, d.cell_start, d.pair_flag, d.active_list, d.active_count, d.fs,

@@ -168,7 +168,6 @@ int check_device_errors(psamd_ctx *c)   // after a sync: sticky error bits raise
     if (fs.error & ERR_CELL_TOO_BIG) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "a cell holds more particles than the sort kernel ranks");
     if (fs.error & ERR_SHARD_BOUND) return fail(c, PSAMD_ERR_STATE, "more live particles than the shards cover (stale bound)");
     if (fs.error & ERR_OPS_OVERFLOW) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "lifecycle op buffer overflow");
-    if (fs.error & ERR_PHASE_WAIT) return fail(c, PSAMD_ERR_STATE, "pair kernel: a split task's leg timed out waiting for the previous leg");
     return PSAMD_OK;
 }
 
@@ -337,8 +336,6 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.cursor, (size_t)g.num_cells));
     PS_HIP(c, dev_alloc(c, &d.task_start, (size_t)g.num_cells + 1));
     PS_HIP(c, dev_alloc(c, &d.task_list, (size_t)g.num_cells * P.slices));
-    PS_HIP(c, dev_alloc(c, &d.task_done, (size_t)g.num_cells * P.slices));
-    PS_HIP(c, hipMemset(d.task_done, 0, (size_t)g.num_cells * P.slices * sizeof(int)));   // the legs leave it zero
     PS_HIP(c, dev_alloc(c, &d.sorted_id, C));
     PS_HIP(c, dev_alloc(c, &d.rank_of_slot, C));
     PS_HIP(c, dev_alloc(c, &d.snap4, C));

@@ -77,7 +77,6 @@ enum : int32_t {
     ERR_OPS_OVERFLOW = 4,   // lifecycle op buffer too small
     ERR_SHARD_BOUND = 8,    // more sorted particles than world * share
     ERR_BAD_POS = 16,       // uploaded live particle outside the box (or cell out of range)
-    ERR_PHASE_WAIT = 32,    // a leg of a split pair task gave up waiting for the previous leg
 };
 
 // A free-slot-queue operation produced by calc_forces is a (key, arg) pair kept in

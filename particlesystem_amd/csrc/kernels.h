@@ -49,7 +49,6 @@ struct DeviceState {
     // the merged tasks run beside k_pairs on a stream of their own (fork / join by events)
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int *task_done = nullptr;     // [num_cells * slices] legs finished so far of a split task (sharded launches)
     int *sorted_id = nullptr;     // [container] cell-major, id ascending inside a cell
     int *rank_of_slot = nullptr;  // [container] inverse of sorted_id for the slots of this frame
     float4 *snap4 = nullptr;      // [container] sorted order: x,y,z,w_eff

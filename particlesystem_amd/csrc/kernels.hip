@@ -981,17 +981,14 @@ __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *_
 #define PS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 #ifdef PSAMD_WAVE_TRACE   // diagnostic build only: when and where did this wave run
-#define PS_TRACE_BEGIN() const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime(); unsigned long long trace_wait = 0
-#define PS_TRACE_WAITED() trace_wait = __builtin_amdgcn_s_memrealtime() - trace_t0
+#define PS_TRACE_BEGIN() const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime()
 #define PS_TRACE_END() do { if ((threadIdx.x & 63) == 0) { \
         unsigned long long *t_ = trace + (size_t)3 * (blockIdx.x * 4 + (threadIdx.x >> 6)); \
         t_[0] = trace_t0; t_[1] = __builtin_amdgcn_s_memrealtime(); \
-        t_[2] = (trace_wait << 40)                                              /* ticks spent waiting for the previous leg */ \
-                | ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf) << 32)   /* XCC_ID */ \
+        t_[2] = ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf) << 32)   /* XCC_ID */ \
                 | __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4); } } while (0)               /* HW_ID */
 #else
 #define PS_TRACE_BEGIN() do {} while (0)
-#define PS_TRACE_WAITED() do {} while (0)
 #define PS_TRACE_END() do {} while (0)
 #endif
 
@@ -1002,7 +999,6 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
                                            const float *__restrict__ snap_age, const int *__restrict__ sorted_id,
                                            float4 *__restrict__ force4, int lo, int hi, int task,
                                            float4 *tile, unsigned long long *trace,
-                                           int phase = 0, int nphase = 1, int *done = nullptr, FrameScalars *fs = nullptr,
                                            const int *__restrict__ active_list = nullptr,
                                            const int *__restrict__ active_count = nullptr)
 {
@@ -1030,26 +1026,7 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
     float ax = 0.f, ay = 0.f, az = 0.f;
     int flag = 0;
     const float eps2f = (float)P.eps2;
-    // A sharded launch may walk the stencil in `nphase` legs, each leg a task of its own
-    // (see k_pairs): a later leg picks the sums up where the previous one left them, so the
-    // order of additions is unchanged.
-    const int k_first = 27 * phase / nphase, k_end = 27 * (phase + 1) / nphase;
     const bool mine = valid && gi >= lo && gi < hi;
-    if (phase > 0) {
-        int spins = 0;
-        // poll relaxed (an acquire per poll would invalidate the CU's caches under the waves
-        // that are working), one acquire fence once the leg before is done
-        while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase) {
-            __builtin_amdgcn_s_sleep(127);
-            if (++spins > (1 << 20)) { if (lane == 0) atomicOr(&fs->error, ERR_PHASE_WAIT); return; }   // never hang
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        PS_TRACE_WAITED();
-        if (mine) {
-            const float4 part = force4[gi];
-            ax = part.x; ay = part.y; az = part.z; flag = __float_as_int(part.w);
-        }
-    }
 
     // Lane k (< 27) looks up neighbour cell k of the stencil once: its range in the
     // sorted order, or an empty range if it lies outside the grid.
@@ -1065,7 +1042,7 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
     if (MODE != 0) {
         const PairCtx ctx = {me.x, me.y, me.z, age_i, id_i, gi, scan};
         const size_t cap = (size_t)P.container;
-        for (int k = k_first; k < k_end; k++) {
+        for (int k = 0; k < 27; k++) {
             const int nb = __builtin_amdgcn_readlane(my_nb, k), n = __builtin_amdgcn_readlane(my_cnt, k);
             const float *sx = snap_soa + nb, *sy = sx + cap, *sz = sy + cap, *sw = sz + cap;   // wave-uniform
             float dmin = 3.0e38f;
@@ -1156,17 +1133,9 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
             }
         }
     }
-    if (phase + 1 < nphase) {                      // hand the running sums to the next leg
-        if (mine) force4[gi] = make_float4(ax, ay, az, __int_as_float(flag));
-        __threadfence();
-        if (lane == 0) __hip_atomic_store(done, phase + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        PS_TRACE_END();
-        return;
-    }
     if (dead) flag = 2;
     if (kid) { ax = 0.f; ay = 0.f; az = 0.f; }   // every term is skipped for a kid (app_common.cu:240)
     if (mine) force4[gi] = make_float4(ax, ay, az, __int_as_float(flag));
-    if (nphase > 1 && lane == 0) __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next step
     PS_TRACE_END();
 }
 
@@ -1178,7 +1147,7 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
                                                const int *__restrict__ sorted_id,
                                                const int *__restrict__ task_list,
                                                float4 *__restrict__ force4, int lo, int hi, int covered,
-                                               FrameScalars *fs, unsigned long long *trace, int nphase, int *task_done,
+                                               FrameScalars *fs, unsigned long long *trace,
                                                const int *__restrict__ active_list, const int *__restrict__ active_count)
 {
     // Workgroups of four INDEPENDENT waves (no workgroup barrier anywhere): the hardware
@@ -1196,25 +1165,13 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
     // launch -- were tried: the XCDs then finish together, yet the launch was only 1 %
     // shorter and the extra prefix sum cost k_scan 10 us.)
     if (SHARDED) {
-        // A rank's share is only a few tasks per SIMD (1/8 of N = 2^20: 2300 tasks of up to
-        // 230 us for 1024 SIMDs), so the launch lasts as long as the SIMDs that were dealt
-        // three.  To cut the grain, the stencil walk of every task is split into `nphase` legs
-        // that are tasks of their own: the grid is nphase equal blocks of workgroups, block p
-        // holds leg p of every task, and leg p of a task waits for leg p-1 of the same task
-        // (a counter per task, written with release / read with acquire).  Workgroups are
-        // dispatched in index order, so a leg only ever waits for a wave that is already
-        // running or done; the wait is bounded all the same and reports ERR_PHASE_WAIT.
-        // gridDim.x / nphase is a multiple of 8, so a task's legs run on the same XCD.
+        // this rank's run of the list, cut into eight contiguous runs like the whole list below
         const int ntask = fs->shard_task_n, nwg = (ntask + 3) >> 2;
-        const int per_phase = gridDim.x / nphase;
-        const int phase = blockIdx.x / per_phase, b = blockIdx.x - phase * per_phase;
-        if (blockIdx.x == 0 && threadIdx.x == 0 && nwg > per_phase) atomicOr(&fs->error, ERR_SHARD_BOUND);
-        if (b >= nwg) return;
-        const int slot = xcd_contiguous(b, nwg) * 4 + wave;
+        if ((int)blockIdx.x >= nwg) return;
+        const int slot = xcd_contiguous(blockIdx.x, nwg) * 4 + wave;
         if (slot >= ntask) return;
         pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, lo, hi,
-                             task_list[fs->shard_task_lo + slot], tiles[MODE == 0 ? wave : 0], trace,
-                             MODE == 0 ? 0 : phase, MODE == 0 ? 1 : nphase, task_done + slot, fs, active_list, active_count);
+                             task_list[fs->shard_task_lo + slot], tiles[MODE == 0 ? wave : 0], trace, active_list, active_count);
         return;
     }
     const int ntask = active_list ? fs->n_tasks2 : fs->n_tasks;
@@ -1223,7 +1180,7 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
     const int slot = xcd_contiguous(blockIdx.x, nwg) * 4 + wave;
     if (slot >= ntask) return;
     pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, lo, hi,
-                         task_list[slot], tiles[MODE == 0 ? wave : 0], trace, 0, 1, nullptr, nullptr, active_list, active_count);
+                         task_list[slot], tiles[MODE == 0 ? wave : 0], trace, active_list, active_count);
 }
 
 // Merged task of the two-pass force pass: the partly filled last slices of up to four cells
@@ -2132,15 +2089,6 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     if (sharded) {
         // slices of the share: at most one partial slice per cell on top of the full ones
         const long long share_tasks = std::min<long long>(tasks, (long long)std::max(0, std::min(hi, covered) - lo) / 64 + P.num_cells + 8);
-        const int per_phase = (int)((share_tasks + 31) / 32) * 8;      // workgroups, a multiple of 8
-        // legs per task (lean modes), from the expected number of tasks (~ particles / (64 * 0.89))
-        // per SIMD.  Measured at N = 2^20 on one GPU doing one rank's share, pair pass in us for
-        // 1 / 2 / 4 / 6 legs: 1/8 share 873 / 785 / 759 / 799, 1/4 share 1284 / 1216 / 1191 / 1291,
-        // 1/2 share 2256 / 2196 / - / -.  PSAMD_PAIR_PHASES overrides (diagnostic).
-        static const int forced = std::getenv("PSAMD_PAIR_PHASES") ? std::atoi(std::getenv("PSAMD_PAIR_PHASES")) : 0;
-        const long long real_tasks = std::max(1, std::min(hi, covered) - lo) / 57 + 1;
-        int nphase = MODE == 0 ? 1 : real_tasks >= 16 * 1024 ? 1 : real_tasks >= 6 * 1024 ? 2 : 4;
-        if (forced > 0 && MODE != 0) nphase = std::min(forced, 9);
         if (!two) k_shard_tasks<<<1, 64, 0, st>>>(P, d.cell_start, task_start, lo, hi, d.fs);   // two-pass: done above
         if (merge) {
             (void)hipEventRecord(d.ev_fork, st);
@@ -2149,8 +2097,8 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
                 P, d.cell_start, d.snap4, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
             (void)hipEventRecord(d.ev_join, d.side_stream);
         }
-        k_pairs<MODE, true, NQ><<<per_phase * nphase, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
-                                                   lo, hi, covered, d.fs, d.trace, nphase, d.task_done, active_list, active_count);
+        k_pairs<MODE, true, NQ><<<(int)((share_tasks + 3) / 4), 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
+                                                   lo, hi, covered, d.fs, d.trace, active_list, active_count);
         if (merge) (void)hipStreamWaitEvent(st, d.ev_join, 0);
     } else {
         if (merge) {
@@ -2164,7 +2112,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
             (void)hipEventRecord(d.ev_join, d.side_stream);
         }
         k_pairs<MODE, false, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
-                                                    lo, hi, covered, d.fs, d.trace, 1, d.task_done, active_list, active_count);
+                                                    lo, hi, covered, d.fs, d.trace, active_list, active_count);
         if (merge) (void)hipStreamWaitEvent(st, d.ev_join, 0);
     }
     return hipGetLastError();

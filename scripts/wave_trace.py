@@ -23,7 +23,6 @@ start = (t[:, 0] - t0) / 100.0   # us
 dur = (t[:, 1] - t[:, 0]) / 100.0
 hw = t[:, 2] & 0xffffffff
 xcc = (t[:, 2] >> 32) & 0xf
-waited = (t[:, 2] >> 40) / 100.0   # us a leg spent waiting for the previous leg of its task
 cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 0x3
 where = (xcc.astype(np.int64) << 12) | (se.astype(np.int64) << 8) | (sh.astype(np.int64) << 6) | (cu.astype(np.int64) << 2) | simd.astype(np.int64)
 print("waves", len(t), "kernel span us %.1f" % ((t[:, 1].max() - t0) / 100.0))
@@ -36,9 +35,7 @@ end = (t[:, 1] - t0) / 100.0
 for x in np.unique(xcc):
     m = xcc == x
     print("XCC %d: waves %d  busy wave-us %.0f  last end %.1f us  p50 dur %.1f" % (x, m.sum(), dur[m].sum(), end[m].max(), np.median(dur[m])))
-print("legs that waited: %d of %d, wait us p50 %.1f p99 %.1f max %.1f, sum %.0f wave-us (work: %.0f wave-us)" % (
-    (waited > 0).sum(), len(t), np.median(waited), np.percentile(waited, 99), waited.max(), waited.sum(), (dur - waited).sum()))
-work = dur - waited
+work = dur
 u2, inv = np.unique(where, return_inverse=True)
 per_simd = np.bincount(inv, weights=work)
 last_end = np.zeros(len(u2)); np.maximum.at(last_end, inv, end)

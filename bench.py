@@ -154,8 +154,8 @@ def fast_math_rate(ps, cfg_over, device, xyz, age, fert, steps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=1 << 20)
     ap.add_argument("--fast-math", action="store_true", help="FMA/rsq pair arithmetic (not bit-exact)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)

@@ -475,3 +475,21 @@ def test_two_pass_halo_overflow_and_kids():
     assert (fc <= cg).all() and 0 < fc.sum() < cg.sum()
     g.calc_forces_apply()
     g.close(); o.close()
+
+
+def test_single_walk_pair_stage_still_matches(monkeypatch):
+    """PSAMD_ONE_PASS keeps the lean arithmetic but settles collisions inside the force walk
+    (what a configuration whose collision radius is large against the cell falls back to)."""
+    monkeypatch.setenv("PSAMD_ONE_PASS", "1")
+    xyz = cloud(30000, 131)
+    rng = np.random.default_rng(131)
+    age = rng.choice(np.array([0.5, 3.0, 3.0, 6.0, 15.5], np.float32), len(xyz))
+    g, o = make_pair(xyz, age=age, fert=1e6)
+    monkeypatch.delenv("PSAMD_ONE_PASS")
+    for k in range(3):
+        g.step(1); o.step(1)
+        compare_all(g, o, "single-walk step %d" % (k + 1))
+    g.init_iframe(); g.build_grid(); g.calc_forces_pairs()
+    assert np.array_equal(g.download_force_counts(), g.download_cellgrid()[:, 0])   # every particle's sum is evaluated
+    g.calc_forces_apply()
+    g.close(); o.close()

@@ -779,15 +779,28 @@ __device__ __forceinline__ void collide_scan(const DevParams &P, float xi, float
     const float dmax = P.coll_d2_max;
     int j = 0;
     for (; j + NB <= n; j += NB) {
+        // distances of the whole group first; the ids are looked at only for the bodies some
+        // lane is actually within reach of (a couple per group at the benchmark's density)
+        v2f d[NB / 2];
+        float dm = 3.0e38f;
 #pragma unroll
         for (int i = 0; i < NB / 2; i++) {
             const v2f rx = v2f{bx[j + 2 * i], bx[j + 2 * i + 1]} - x2, ry = v2f{by[j + 2 * i], by[j + 2 * i + 1]} - y2,
                       rz = v2f{bz[j + 2 * i], bz[j + 2 * i + 1]} - z2;
-            const v2f d = rx * rx + ry * ry + rz * rz;
-            const int c0 = bcid[j + 2 * i], c1 = bcid[j + 2 * i + 1];
-            const bool h0 = scan && !(d.x > dmax), h1 = scan && !(d.y > dmax);
-            met_higher |= (h0 && c0 > id_i) || (h1 && c1 > id_i);
-            met_lower |= (h0 && c0 >= 0 && c0 < id_i) || (h1 && c1 >= 0 && c1 < id_i);
+            d[i] = rx * rx + ry * ry + rz * rz;
+            dm = fminf(fminf(dm, d[i].x), d[i].y);
+        }
+        if (__any(scan && !(dm > dmax))) {
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                const float di = (i & 1) ? d[i >> 1].y : d[i >> 1].x;
+                const bool h = scan && !(di > dmax);
+                if (__any(h)) {
+                    const int cj = bcid[j + i];
+                    met_higher |= h && cj > id_i;
+                    met_lower |= h && cj >= 0 && cj < id_i;
+                }
+            }
         }
     }
     for (; j < n; j++) {

@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define PSAMD_ABI_VERSION 1
+#define PSAMD_ABI_VERSION 2
+
+#define PSAMD_MAX_RANKS 64
 
 typedef enum psamd_status {
     PSAMD_OK = 0,
@@ -65,10 +67,16 @@ typedef struct psamd_config {
     int32_t  device;             /* HIP device ordinal                    */
     uint32_t flags;              /* PSAMD_FLAG_*                          */
     uint64_t seed;               /* explosion RNG seed (RAND_SEED, common.h:56) */
-    /* multi-GPU sharding of the pair loop: this context evaluates forces only
-     * for sorted particles [rank*ceil(n/world), ...); see psamd_calc_forces_* */
+    /* Multi-GPU: world > 1 makes this context ONE SLAB of the system (see "slab partition"
+     * below): it holds only the segments of its cell layers -- their slots, particles and
+     * free-slot queues -- and steps through the psamd_slab_* stage calls.  cuts[0..world]
+     * (cell-layer boundaries along i3, cuts[0] = 0, cuts[world] = grid_dim, at least two
+     * layers per rank) overrides the balanced partition when cuts[world] != 0. */
     int32_t  rank;
     int32_t  world;
+    int32_t  halo_cap_cell;      /* bodies per cell a halo message has room for; 0 = MAX_PARTICLES_PER_CELL (never overflows) */
+    int32_t  xfer_cap;           /* particles per step and direction that may change owner; 0 = 32 per cell of a layer */
+    int32_t  cuts[PSAMD_MAX_RANKS + 1];
 } psamd_config;
 
 /* Sizes DoInit derives (ps.cpp:2204-2222), in elements. */
@@ -95,6 +103,7 @@ typedef struct psamd_counters {
 /* Raw device pointers of the SoA state, for plumbing (collectives, interop).
  * Valid until psamd_destroy.  Layouts are described in DESIGN.md section 3. */
 typedef struct psamd_device_view {
+    /* slot arrays hold the OWNED slots only, back to back (world == 1: the whole container) */
     void    *pos4;        /* float4[container]  x,y,z,w                         */
     void    *vel4;        /* float4[container]  vx,vy,vz,age                    */
     void    *acc4;        /* float4[container]  ax,ay,az,fertility_age          */
@@ -172,27 +181,20 @@ int psamd_get_gridmax(psamd_ctx *ctx, int32_t out2[2]);
 int psamd_init_iframe(psamd_ctx *ctx);  /* task 3, ps.cpp:1574-1606 / psCUDA.cu:104-150 */
 int psamd_build_grid(psamd_ctx *ctx);   /* task 8, ps.cpp:1468-1537 / psCUDA.cu:442-499 */
 int psamd_calc_forces(psamd_ctx *ctx);  /* task 6, ps.cpp:1120-1383 / psCUDA.cu:152-423 */
-/* calc_forces split at the point where ranks exchange results (multi-GPU):
- * _pairs fills force4 for this rank's share of the sorted particles,
- * _apply integrates every particle from a complete force4 and runs the
- * lifecycle.  psamd_calc_forces == _pairs then _apply when world == 1. */
+/* calc_forces in its two halves: _pairs fills the sorted-order force array (collision
+ * flag + acceleration of every particle, ps.cpp:1182-1263), _apply does everything after the
+ * two neighbour loops (kill / survive / integrate / explosion / relocation, ps.cpp:1210-1374).
+ * psamd_calc_forces == _pairs then _apply. */
 int psamd_calc_forces_pairs(psamd_ctx *ctx);
 int psamd_calc_forces_apply(psamd_ctx *ctx);
-/* Sorted-index range [begin,end) whose force4 entries this rank produces, and the
- * per-rank share (same on every rank) for an equal-sized all-gather.  The ranges are cut
- * from an upper bound of the live count that the context tracks on the host (no
- * read-back), so the last ranges may extend past the live particles. */
-int psamd_force_shard(psamd_ctx *ctx, int64_t *begin, int64_t *end, int64_t *share);
 /* nsteps x {init_iframe, build_grid, calc_forces}; asynchronous on the context's
  * stream unless lifecycle bookkeeping forces a sync. */
 int psamd_step(psamd_ctx *ctx, int32_t nsteps);
 int psamd_synchronize(psamd_ctx *ctx);
 
 /* float4 (ax, ay, az, flag-as-int-bits) entries [first, first+count) of the sorted-order
- * force array, to or from host memory: lets ranks exchange their shards through any
- * transport (the benchmark uses RCCL on device memory instead, psamd_bind_force4). */
+ * force array (diagnostics). */
 int psamd_download_force4(psamd_ctx *ctx, void *out_float4, int64_t first, int64_t count);
-int psamd_upload_force4(psamd_ctx *ctx, const void *in_float4, int64_t first, int64_t count);
 
 /* ---- checkpoint / resume --------------------------------------------------------- */
 /* The reference keeps its whole state in the nine buffers; the
@@ -201,14 +203,73 @@ int psamd_upload_force4(psamd_ctx *ctx, const void *in_float4, int64_t first, in
 int psamd_snapshot_save(psamd_ctx *ctx);
 int psamd_snapshot_restore(psamd_ctx *ctx);
 
-/* ---- plumbing for collectives (multi-GPU) -------------------------------------- */
+/* ---- slab partition (multi-GPU) ---------------------------------------------------- */
+/* The reference distributes by segment: a chunk subtask subscribes to its interior segment
+ * and the 26 face / edge / corner segments around it (ps.cpp:380-487, set_pkg_segments
+ * app_common.cu:150-232), each one contiguous slot range with its own free-slot queue.
+ * Here the same segments are dealt to the GPUs of a node in slabs of cell layers along i3
+ * (the slowest cell index, so a slab is one contiguous run of the cell-major order):
+ *   - STATE layers: the segments whose particles, slots and queues live on the rank.  The
+ *     reference numbers segments plane by plane, so a rank owns one slot range and one run of
+ *     QUEUE_INFO records per segment type.  Every queue has exactly one owner, which replays
+ *     its operations in the reference's serial order.
+ *   - COMPUTE layers: the cells whose collision flags and forces the rank evaluates; cut for
+ *     balance, anywhere.  Where a cut falls inside a segment group, the upper layers are
+ *     computed by the rank above ("lent"): their snapshot travels up with the halo layer and
+ *     their (ax, ay, az, flag) records come back before the owner integrates.
+ * Per step a rank exchanges, with its two neighbours only: the snapshot (x, y, z, mass, age,
+ * id) of its boundary layers; the force records of lent layers; and the particles whose new
+ * segment belongs to the neighbour (periodic box: the ring closes), keyed so that the
+ * neighbour's queue hands out their slots in the reference's order.  Nothing is replicated
+ * but the O(cells) tables.  Messages have fixed sizes; the transport (RCCL send/recv on
+ * device memory, or anything else) is the caller's: see particlesystem_amd/slab.py. */
+typedef struct psamd_slab_plan {
+    int32_t world, rank, grid_dim;
+    int32_t cut_lo, cut_hi;          /* compute layers [lo, hi)                                  */
+    int32_t state_lo, state_hi;      /* layers whose particles live here                         */
+    int32_t below_lo, below_hi;      /* layers received from rank-1: halo layer, then lent layers */
+    int32_t above_lo, above_hi;      /* halo layer received from rank+1 (group-aligned cut only)  */
+    int32_t lentin_lo, lentin_hi;    /* the part of `below` this rank computes for rank-1         */
+    int32_t lentout_lo, lentout_hi;  /* own layers computed by rank+1                             */
+    int32_t send_up_lo, send_up_hi;      /* own layers whose snapshot goes to rank+1              */
+    int32_t send_down_lo, send_down_hi;  /* own layers whose snapshot goes to rank-1              */
+    int32_t slot_lo[4], slot_hi[4];  /* owned slot range per segment type (1, 2, 4, 8)            */
+    int32_t rec_lo[4], rec_hi[4];    /* owned QUEUE_INFO records per segment type                 */
+    int32_t up_rank, down_rank;      /* ring neighbours for particles that change owner; -1: none */
+} psamd_slab_plan;
+/* host only, no device needed: the plan of cfg->rank in a world of cfg->world ranks */
+int psamd_slab_plan_describe(const psamd_config *cfg, psamd_slab_plan *out);
+int psamd_get_slab_plan(const psamd_ctx *ctx, psamd_slab_plan *out);
+
+/* Message buffers (device memory owned by the context; bytes = 0: this rank has no such
+ * message).  Index 0 = the neighbour below (rank-1), 1 = the neighbour above (rank+1). */
+typedef struct psamd_slab_buffers {
+    void   *halo_out[2], *halo_in[2];      /* layer snapshots                                    */
+    int64_t halo_out_bytes[2], halo_in_bytes[2];
+    void   *force_out, *force_in;          /* force records of lent layers: out to rank-1, in from rank+1 */
+    int64_t force_out_bytes, force_in_bytes;
+    void   *xfer_out[2], *xfer_in[2];      /* particles changing owner (ring: down_rank / up_rank) */
+    int64_t xfer_bytes;                    /* all four the same size                              */
+} psamd_slab_buffers;
+int psamd_slab_buffers_get(psamd_ctx *ctx, psamd_slab_buffers *out);
+
+/* One step = build, [exchange halo_out -> neighbours' halo_in], pairs, [force_out -> rank-1's
+ * force_in], apply, [xfer_out -> neighbours' xfer_in], finish.  All asynchronous on the
+ * context's stream except finish, which ends with the per-step read-back.  With world == 1
+ * the four calls are psamd_step(1) cut in four and no message exists. */
+int psamd_slab_build(psamd_ctx *ctx);   /* init_iframe + build_grid of the own layers; packs halo_out   */
+int psamd_slab_pairs(psamd_ctx *ctx);   /* unpacks halo_in; collision flags + forces; packs force_out   */
+int psamd_slab_apply(psamd_ctx *ctx);   /* unpacks force_in; integrate ... (calc_forces' tail); closes xfer_out */
+int psamd_slab_finish(psamd_ctx *ctx);  /* merges xfer_in; queue replay and relocation                  */
+/* Transport through host memory (tests, two processes sharing one GPU): copy message buffer
+ * `which` to / from the host.  which: 0/1 halo_out[0/1], 2/3 halo_in[0/1], 4 force_out,
+ * 5 force_in, 6/7 xfer_out[0/1], 8/9 xfer_in[0/1]. */
+int psamd_slab_msg_download(psamd_ctx *ctx, int which, void *host, int64_t bytes);
+int psamd_slab_msg_upload(psamd_ctx *ctx, int which, const void *host, int64_t bytes);
+
 /* Enqueue all further work on the caller's HIP stream (e.g. the one RCCL orders
  * against) instead of the context's own.  NULL restores the context's stream. */
 int psamd_set_stream(psamd_ctx *ctx, void *hip_stream);
-/* Use caller-owned device memory (>= n_float4 float4 elements, n_float4 >=
- * container_size) as the force4 array, so a collective can fill it in place. NULL
- * restores the context's own buffer. */
-int psamd_bind_force4(psamd_ctx *ctx, void *device_ptr, int64_t n_float4);
 
 /* ---- introspection -------------------------------------------------------- */
 int psamd_get_counters(psamd_ctx *ctx, psamd_counters *out);

@@ -26,6 +26,10 @@ T_DTYPE = np.dtype([("id", "<i4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w
 Q_DTYPE = np.dtype([("front", "<i4"), ("rear", "<i4"), ("count", "<i4"), ("lock", "<i4"),
                     ("rloc", "<i4"), ("seg_size", "<i4")])
 PAIR_DTYPE = np.dtype([("c", "<i4"), ("p", "<i4")])
+# pso_op: one deferred queue operation (ps_oracle.h); 104 bytes
+OP_DTYPE = np.dtype([("key", "<u8"), ("rec", "<i4"), ("kind", "<i4"), ("slot", "<i4"), ("dst", "<i4"),
+                     ("old_cell", "<i4"), ("pad", "<i4"), ("body", P_DTYPE)])
+assert OP_DTYPE.itemsize == 104
 
 
 class Config(C.Structure):
@@ -99,6 +103,10 @@ def lib():
         L.pso_calc_pairs_threads.argtypes = [vp, ci, ci, vp, ci]
         L.pso_calc_pairs_threads.restype = ci
         L.pso_apply_forces.argtypes = [vp, vp]
+        L.pso_apply_collect.argtypes = [vp, vp, vp, ci]
+        L.pso_apply_collect.restype = ci
+        L.pso_replay_ops.argtypes = [vp, vp, ci]
+        L.pso_advance_step.argtypes = [vp]
         L.pso_step.argtypes = [vp, ci]
         L.pso_set_rng.argtypes = [vp, RNG_FN, vp]
         L.pso_set_explosions.argtypes = [vp, ci]
@@ -295,6 +303,24 @@ class System:
     def apply_forces(self, force4):
         assert force4.dtype == np.float32 and force4.flags["C_CONTIGUOUS"]
         self.L.pso_apply_forces(self.h, force4.ctypes.data)
+
+    def apply_collect(self, force4):
+        """calc_forces' tail with every queue operation deferred: returns them (OP_DTYPE)."""
+        assert force4.dtype == np.float32 and force4.flags["C_CONTIGUOUS"]
+        ops = np.zeros(3 * max(1, int(self.chunkgrid[:, 0].sum())) + 8, OP_DTYPE)
+        n = self.L.pso_apply_collect(self.h, force4.ctypes.data, ops.ctypes.data, len(ops))
+        if n < 0:
+            raise RuntimeError("pso_apply_collect failed (%d)" % n)
+        return ops[:n].copy()
+
+    def replay_ops(self, ops):
+        """Execute deferred operations queue by queue in key order; fills in ops['dst']."""
+        ops = np.ascontiguousarray(ops, OP_DTYPE)
+        self.L.pso_replay_ops(self.h, ops.ctypes.data, len(ops))
+        return ops
+
+    def advance_step(self):
+        self.L.pso_advance_step(self.h)
 
     def step(self, n=1):
         self.L.pso_step(self.h, n)

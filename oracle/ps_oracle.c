@@ -820,6 +820,157 @@ void pso_apply_forces(pso_system *s, const float *force4)
     free(rank);
 }
 
+/* ---- the life cycle with its queue operations deferred (test support for the slab-partitioned
+ * multi-GPU path).  pso_apply_collect does what pso_apply_forces does, in the same serial order,
+ * except that nothing touches a free-slot queue and nothing is placed in a new slot: every
+ * q_insert / q_remove the reference would execute is recorded as an operation keyed by its
+ * place in that serial order (chunk, slot, sub-step: birth remove 0, relocation remove 1,
+ * insert 2 -- ps.cpp:1232, 1319, 1355, 1369).  pso_replay_ops then executes a set of operations
+ * queue by queue in key order and places the particles.  Within one queue that is exactly the
+ * order pso_apply_forces executes them in, and queues do not interact, so
+ *     collect + replay  ==  pso_apply_forces                (tests/test_oracle_deferred.py)
+ * and the operations on a queue may come from several systems that each hold a slab, as long
+ * as all of them are handed to the queue's owner. */
+static unsigned long long op_key(int chunk, int slot, int sub)
+{
+    return ((unsigned long long)(unsigned)(chunk + 1) << 34) | ((unsigned long long)(unsigned)slot << 2) | (unsigned)sub;
+}
+
+int pso_apply_collect(pso_system *s, const float *force4, pso_op *ops, int cap)
+{
+    const pso_config *c = &s->cfg;
+    const pso_derived *d = &s->d;
+    const int cstride = 1 + d->max_per_cell;
+    int *rank = (int *)malloc(sizeof(int) * (size_t)d->container_size);
+    int cc, gi = 0, ch, biggest = s->gridmax[0], n = 0;
+    if (!rank) return -1;
+    for (cc = 0; cc < d->container_size; cc++) rank[cc] = -1;
+    for (cc = 0; cc < d->num_cells; cc++) {
+        const int *cl = s->cellgrid + (size_t)cc * cstride;
+        int t;
+        for (t = 1; t <= cl[0]; t++) rank[cl[t]] = gi++;
+    }
+    for (ch = 0; ch < d->num_chunks; ch++) {
+        const int *row = s->chunkgrid + (size_t)ch * (1 + d->max_per_chunk);
+        int tid;
+        for (tid = 0; tid < biggest; tid++) {
+            pso_particle *me;
+            union { int i; float f; } bits;
+            int pid, k, aged, seg[2], old_cell;
+            if (tid > row[0] - 1 || tid >= d->max_per_chunk) continue;
+            pid = row[tid + 1];
+            if (pid < 0) continue;
+            me = &s->particles[pid];
+            if (!(me->cell >= 0 && me->cell < d->num_cells)) continue;
+            k = rank[pid];
+            if (k < 0) continue;
+            bits.f = force4[4 * k + 3];
+            aged = (double)me->age > d->particle_life;
+            old_cell = me->cell;
+            if (n + 3 > cap) { free(rank); return -2; }
+            if (bits.i == 2) {                                   /* kill, ps.cpp:1210-1235 */
+                if (aged) s->ctr.deaths_age++; else s->ctr.deaths_collision++;
+                pso_get_id_info(d, pid, seg);
+                pso_reset_particle(me);
+                ops[n].key = op_key(ch, pid, 2); ops[n].rec = pso_get_info_rloc(d, seg[0], seg[1]);
+                ops[n].kind = 0; ops[n].slot = pid; ops[n].dst = -1; ops[n].old_cell = old_cell; n++;
+                continue;
+            }
+            if (bits.i == 1) { pso_survive_particle(me); s->ctr.survives++; continue; }
+            me->ax = force4[4 * k]; me->ay = force4[4 * k + 1]; me->az = force4[4 * k + 2];
+            pso_integrate(c, d, me);
+            s->ctr.integrated++;
+            if (s->explosions && (me->age >= me->fertility_age) && !me->is_parent) {   /* ps.cpp:1306-1333 */
+                if (!s->rng) s->ctr.explosions_skipped++;
+                else {
+                    int ri[3]; double u = 0.0;
+                    float ux, uy, uz, mag, vx, vy, vz, lo, hi;
+                    s->rng(s->rng_user, pid, s->step, ri, &u);
+                    ux = (float)(ri[0] * 1.0); uy = (float)(ri[1] * 1.0); uz = (float)(ri[2] * 1.0);
+                    mag = sqrtf((float)(ux * ux * 1.0 + uy * uy * 1.0 + uz * uz * 1.0));
+                    ux /= mag; uy /= mag; uz /= mag;
+                    vx = (float)(ux * c->explosion_speed); vy = (float)(uy * c->explosion_speed); vz = (float)(uz * c->explosion_speed);
+                    me->is_parent = 1;
+                    me->vx = vx; me->vy = vy; me->vz = vz;
+                    lo = (float)d->min_fertility_age; hi = (float)d->max_fertility_age;
+                    ops[n].key = op_key(ch, pid, 0); ops[n].rec = pso_get_info_rloc(d, me->seg_type, me->seg_tid);
+                    ops[n].kind = 2; ops[n].slot = pid; ops[n].dst = -1; ops[n].old_cell = old_cell;
+                    memset(&ops[n].body, 0, sizeof(pso_particle));
+                    create_particle(c, d, &ops[n].body, (float)c->particle_weight, 0.0f, (float)(lo + u * (hi - lo)),
+                                    me->x, me->y, me->z, (float)(-1.0 * vx), (float)(-1.0 * vy), (float)(-1.0 * vz));
+                    n++;
+                }
+            }
+            if (me->seg_fault) {                                /* ps.cpp:1335-1374 */
+                pso_get_id_info(d, pid, seg);
+                ops[n].key = op_key(ch, pid, 1); ops[n].rec = pso_get_info_rloc(d, me->seg_type, me->seg_tid);
+                ops[n].kind = 1; ops[n].slot = pid; ops[n].dst = -1; ops[n].old_cell = old_cell; ops[n].body = *me; n++;
+                pso_reset_particle(me);
+                ops[n].key = op_key(ch, pid, 2); ops[n].rec = pso_get_info_rloc(d, seg[0], seg[1]);
+                ops[n].kind = 0; ops[n].slot = pid; ops[n].dst = -1; ops[n].old_cell = old_cell; n++;
+            }
+        }
+    }
+    free(rank);
+    return n;
+}
+
+static int op_order(const void *a, const void *b)
+{
+    const pso_op *x = (const pso_op *)a, *y = (const pso_op *)b;
+    if (x->rec != y->rec) return x->rec < y->rec ? -1 : 1;
+    return x->key < y->key ? -1 : x->key > y->key ? 1 : 0;
+}
+
+void pso_replay_ops(pso_system *s, pso_op *ops, int n)
+{
+    const pso_config *c = &s->cfg;
+    const pso_derived *d = &s->d;
+    int i;
+    qsort(ops, (size_t)n, sizeof(pso_op), op_order);
+    for (i = 0; i < n; i++) {
+        pso_op *o = &ops[i];
+        pso_queue_info *q = &s->queue_info[o->rec];
+        if (o->kind == 0) {                                      /* q_insert, app_common.cu:346-376 */
+            if (q->count == q->seg_size) continue;
+            if (q->count == 0) { q->front = q->rloc; q->rear = q->rloc; }
+            else if (q->rear == q->rloc + q->seg_size - 1) q->rear = q->rloc;
+            else q->rear++;
+            q->count++;
+            s->queue[q->rear] = o->slot;
+        } else {                                                 /* q_remove, app_common.cu:305-339 */
+            int item = -1;
+            if (q->count > 0) {
+                int pos = q->front;
+                if (q->count == 1) { q->front = -1; q->rear = -1; }
+                else if (q->front == q->rloc + q->seg_size - 1) q->front = q->rloc;
+                else q->front++;
+                q->count--;
+                item = s->queue[pos];
+                s->queue[pos] = -1;
+            }
+            o->dst = item;
+            if (o->kind == 1) {
+                if (item >= 0) {
+                    pso_particle *dst = &s->particles[item];
+                    int keep = dst->id;
+                    *dst = o->body; dst->id = keep; dst->seg_fault = 0;
+                    memset((char *)dst + 22, 0, 2);          /* the two pad bytes: an op list that went through numpy carries noise there */
+                    s->ctr.relocations++;
+                } else s->ctr.relocations_lost++;
+            } else {
+                if (item >= 0) {
+                    const pso_particle *b = &o->body;
+                    create_particle(c, d, &s->particles[item], b->w, b->age, b->fertility_age, b->x, b->y, b->z, b->vx, b->vy, b->vz);
+                    s->ctr.births++;
+                } else s->ctr.births_failed++;
+            }
+        }
+    }
+}
+
+void pso_advance_step(pso_system *s) { s->step++; }
+
 /* the batches of ps.cpp:1900-1912 visit chunks 0..NUM_CHUNKS-1 in order */
 void pso_calc_forces(pso_system *s)
 {

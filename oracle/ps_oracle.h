@@ -126,6 +126,25 @@ void pso_calc_pairs(pso_system *s, int lo, int hi, float *force4);
 int pso_calc_pairs_threads(pso_system *s, int lo, int hi, float *force4, int nthreads);
 void pso_apply_forces(pso_system *s, const float *force4);
 
+/* calc_forces' tail with the queue operations deferred (test support for the slab-partitioned
+ * path): pso_apply_collect = pso_apply_forces minus every q_insert / q_remove and every
+ * placement, which come out as operations keyed by their place in the reference's serial
+ * order; pso_replay_ops executes operations (own and received) queue by queue in key order.
+ * collect + replay of the same list == pso_apply_forces. */
+typedef struct pso_op {
+    unsigned long long key;   /* (chunk + 1) << 34 | source slot << 2 | sub-step                  */
+    int rec;                  /* QUEUE_INFO record the operation acts on                          */
+    int kind;                 /* 0 insert `slot`; 1 remove for the relocation of `body`; 2 remove for the birth of `body` */
+    int slot;                 /* insert: the slot freed; remove: the source slot (parent)          */
+    int dst;                  /* filled in by the replay: the slot handed out, or -1               */
+    int old_cell;             /* cell of the source particle before the step                       */
+    int pad;
+    pso_particle body;
+} pso_op;
+int  pso_apply_collect(pso_system *s, const float *force4, pso_op *ops, int cap); /* ops written, < 0: cap too small */
+void pso_replay_ops(pso_system *s, pso_op *ops, int n);
+void pso_advance_step(pso_system *s);   /* what pso_step does after calc_forces */
+
 void pso_set_rng(pso_system *s, pso_rng_fn fn, void *user);
 void pso_set_explosions(pso_system *s, int enabled);
 

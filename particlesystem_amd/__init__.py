@@ -20,6 +20,7 @@ from . import build as _build
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpsamd.so")
 
+MAX_RANKS = 64
 FLAG_EXPLOSIONS = 0x1
 FLAG_FAST_MATH = 0x2
 NUM_TIMERS = 9
@@ -45,7 +46,9 @@ class Config(C.Structure):
                 ("particle_weight", C.c_double), ("dt", C.c_double), ("max_v", C.c_double),
                 ("explosion_speed", C.c_double), ("life_steps", C.c_double),
                 ("device", C.c_int32), ("flags", C.c_uint32), ("seed", C.c_uint64),
-                ("rank", C.c_int32), ("world", C.c_int32)]
+                ("rank", C.c_int32), ("world", C.c_int32),
+                ("halo_cap_cell", C.c_int32), ("xfer_cap", C.c_int32),
+                ("cuts", C.c_int32 * (MAX_RANKS + 1))]
 
 
 class Sizes(C.Structure):
@@ -68,6 +71,28 @@ class DeviceView(C.Structure):
                 ("pos4", "vel4", "acc4", "cell", "pflags", "sorted_id", "snap4", "force4", "cell_start")] + \
                [("container_size", C.c_int64), ("num_cells", C.c_int32), ("live", C.c_int32),
                 ("stream", C.c_void_p)]
+
+
+class SlabPlan(C.Structure):
+    """psamd_slab_plan: which cell layers, slots and queue records one rank holds."""
+    _fields_ = [(n, C.c_int32) for n in
+                ("world", "rank", "grid_dim", "cut_lo", "cut_hi", "state_lo", "state_hi", "below_lo", "below_hi",
+                 "above_lo", "above_hi", "lentin_lo", "lentin_hi", "lentout_lo", "lentout_hi",
+                 "send_up_lo", "send_up_hi", "send_down_lo", "send_down_hi")] + \
+               [("slot_lo", C.c_int32 * 4), ("slot_hi", C.c_int32 * 4), ("rec_lo", C.c_int32 * 4), ("rec_hi", C.c_int32 * 4),
+                ("up_rank", C.c_int32), ("down_rank", C.c_int32)]
+
+
+class SlabBuffers(C.Structure):
+    _fields_ = [("halo_out", C.c_void_p * 2), ("halo_in", C.c_void_p * 2),
+                ("halo_out_bytes", C.c_int64 * 2), ("halo_in_bytes", C.c_int64 * 2),
+                ("force_out", C.c_void_p), ("force_in", C.c_void_p),
+                ("force_out_bytes", C.c_int64), ("force_in_bytes", C.c_int64),
+                ("xfer_out", C.c_void_p * 2), ("xfer_in", C.c_void_p * 2), ("xfer_bytes", C.c_int64)]
+
+
+# psamd_slab_msg_download / _upload `which`
+MSG_HALO_OUT, MSG_HALO_IN, MSG_FORCE_OUT, MSG_FORCE_IN, MSG_XFER_OUT, MSG_XFER_IN = 0, 2, 4, 5, 6, 8
 
 
 class PsamdError(RuntimeError):
@@ -108,15 +133,21 @@ ABI = [
     ("psamd_calc_forces", C.c_int, [_vp]),
     ("psamd_calc_forces_pairs", C.c_int, [_vp]),
     ("psamd_calc_forces_apply", C.c_int, [_vp]),
-    ("psamd_force_shard", C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     ("psamd_step", C.c_int, [_vp, _i32]),
     ("psamd_synchronize", C.c_int, [_vp]),
     ("psamd_download_force4", C.c_int, [_vp, _vp, _i64, _i64]),
-    ("psamd_upload_force4", C.c_int, [_vp, _vp, _i64, _i64]),
     ("psamd_snapshot_save", C.c_int, [_vp]),
     ("psamd_snapshot_restore", C.c_int, [_vp]),
     ("psamd_set_stream", C.c_int, [_vp, _vp]),
-    ("psamd_bind_force4", C.c_int, [_vp, _vp, _i64]),
+    ("psamd_slab_plan_describe", C.c_int, [C.POINTER(Config), C.POINTER(SlabPlan)]),
+    ("psamd_get_slab_plan", C.c_int, [_vp, C.POINTER(SlabPlan)]),
+    ("psamd_slab_buffers_get", C.c_int, [_vp, C.POINTER(SlabBuffers)]),
+    ("psamd_slab_build", C.c_int, [_vp]),
+    ("psamd_slab_pairs", C.c_int, [_vp]),
+    ("psamd_slab_apply", C.c_int, [_vp]),
+    ("psamd_slab_finish", C.c_int, [_vp]),
+    ("psamd_slab_msg_download", C.c_int, [_vp, C.c_int, _vp, _i64]),
+    ("psamd_slab_msg_upload", C.c_int, [_vp, C.c_int, _vp, _i64]),
     ("psamd_get_counters", C.c_int, [_vp, C.POINTER(Counters)]),
     ("psamd_live_count", C.c_int, [_vp, C.POINTER(_i64)]),
     ("psamd_device_view_get", C.c_int, [_vp, C.POINTER(DeviceView)]),
@@ -154,8 +185,22 @@ def default_config(**over):
     cfg = Config()
     load().psamd_default_config(C.byref(cfg))
     for k, v in over.items():
-        setattr(cfg, k, v)
+        if k == "cuts":
+            for i, c in enumerate(v):
+                cfg.cuts[i] = c
+        else:
+            setattr(cfg, k, v)
     return cfg
+
+
+def slab_plan(cfg):
+    """Host-only: the slab plan of cfg.rank in a world of cfg.world ranks (no GPU needed)."""
+    lib = load()
+    plan = SlabPlan()
+    st = lib.psamd_slab_plan_describe(C.byref(cfg), C.byref(plan))
+    if st != 0:
+        raise PsamdError(st, lib.psamd_status_string(st).decode())
+    return plan
 
 
 def _ptr(a):
@@ -312,10 +357,46 @@ class ParticleSystem:
     def calc_forces_apply(self):
         self._ck(self.lib.psamd_calc_forces_apply(self.h))
 
-    def force_shard(self):
-        b, e, s = C.c_int64(), C.c_int64(), C.c_int64()
-        self._ck(self.lib.psamd_force_shard(self.h, C.byref(b), C.byref(e), C.byref(s)))
-        return b.value, e.value, s.value
+    # ---- slab stages (multi-GPU; see include/psamd.h "slab partition") ------
+    def slab_plan(self):
+        plan = SlabPlan()
+        self._ck(self.lib.psamd_get_slab_plan(self.h, C.byref(plan)))
+        return plan
+
+    def slab_buffers(self):
+        b = SlabBuffers()
+        self._ck(self.lib.psamd_slab_buffers_get(self.h, C.byref(b)))
+        return b
+
+    def slab_build(self):
+        self._ck(self.lib.psamd_slab_build(self.h))
+
+    def slab_pairs(self):
+        self._ck(self.lib.psamd_slab_pairs(self.h))
+
+    def slab_apply(self):
+        self._ck(self.lib.psamd_slab_apply(self.h))
+
+    def slab_finish(self):
+        self._ck(self.lib.psamd_slab_finish(self.h))
+
+    def msg_bytes(self, which):
+        """Size of message buffer `which` (psamd_slab_msg_download numbering); 0: no such message."""
+        if getattr(self, "_msg_bytes", None) is None:
+            b = self.slab_buffers()
+            self._msg_bytes = [b.halo_out_bytes[0], b.halo_out_bytes[1], b.halo_in_bytes[0], b.halo_in_bytes[1],
+                               b.force_out_bytes, b.force_in_bytes] + [b.xfer_bytes] * 4
+        return self._msg_bytes[which]
+
+    def msg_download(self, which, nbytes=None):
+        nbytes = self.msg_bytes(which) if nbytes is None else nbytes
+        out = np.zeros(nbytes // 4, np.int32)
+        self._ck(self.lib.psamd_slab_msg_download(self.h, which, _ptr(out), nbytes))
+        return out
+
+    def msg_upload(self, which, words):
+        words = np.ascontiguousarray(words, np.int32)
+        self._ck(self.lib.psamd_slab_msg_upload(self.h, which, _ptr(words), words.nbytes))
 
     def step(self, n=1):
         self._ck(self.lib.psamd_step(self.h, n))
@@ -328,10 +409,6 @@ class ParticleSystem:
         self._ck(self.lib.psamd_download_force4(self.h, _ptr(out), first, count))
         return out
 
-    def upload_force4(self, arr, first):
-        arr = np.ascontiguousarray(arr, np.float32).reshape(-1, 4)
-        self._ck(self.lib.psamd_upload_force4(self.h, _ptr(arr), first, len(arr)))
-
     def snapshot_save(self):
         self._ck(self.lib.psamd_snapshot_save(self.h))
 
@@ -340,9 +417,6 @@ class ParticleSystem:
 
     def set_stream(self, hip_stream):
         self._ck(self.lib.psamd_set_stream(self.h, hip_stream))
-
-    def bind_force4(self, device_ptr, n_float4):
-        self._ck(self.lib.psamd_bind_force4(self.h, device_ptr, n_float4))
 
     # ---- introspection ------------------------------------------------------
     @property

@@ -21,6 +21,7 @@
 #include "device_types.h"
 #include "geometry.hpp"
 #include "kernels.h"
+#include "partition.hpp"
 
 using namespace psamd;
 
@@ -31,7 +32,18 @@ struct psamd_ctx {
     DeviceState d;
     hipStream_t stream = nullptr;       // stream in use
     hipStream_t own_stream = nullptr;   // the one this context created
-    float4 *own_force4 = nullptr;
+    SlabPlan plan;
+    // slab messages (device); index 0 = the rank below, 1 = the rank above
+    int *halo_out[2] = {nullptr, nullptr}, *halo_in[2] = {nullptr, nullptr};
+    size_t halo_out_bytes[2] = {0, 0}, halo_in_bytes[2] = {0, 0};
+    int halo_out_c0[2] = {0, 0}, halo_out_cells[2] = {0, 0}, halo_in_cells[2] = {0, 0};
+    int *force_out = nullptr, *force_in = nullptr;
+    size_t force_out_bytes = 0, force_in_bytes = 0;
+    int *xfer_out[2] = {nullptr, nullptr}, *xfer_in[2] = {nullptr, nullptr};
+    size_t xfer_bytes = 0;
+    int *pack_off[2] = {nullptr, nullptr}, *unpack_off[2] = {nullptr, nullptr};
+    int slab_stage = 0;               // 0 idle, 1 built, 2 pairs done, 3 applied
+    size_t frame_ints = 0;            // ints zeroed by init_iframe
     std::vector<void *> allocs;
     std::string err;
     // host mirrors
@@ -52,7 +64,7 @@ struct psamd_ctx {
     int64_t steps_total = 0;
     int live_at_build = -1;           // host copy of fs->live (valid after a sync)
     // upper bound of the live count at the next build_grid, kept on the host so that the
-    // sharded path needs no read-back between build and pair pass (-1 = unknown)
+    // life-cycle kernels can be sized without a read-back (-1 = unknown)
     int64_t live_bound = 0, snapshot_live_bound = 0;
     // timing
     int timing = 0;                    // 0 off, 1 pair pass / apply / life cycle, 2 every stage
@@ -118,12 +130,29 @@ int ensure_staging(psamd_ctx *c, size_t bytes)
     return PSAMD_OK;
 }
 
+// The device keeps the queue array for the owned segments only, back to back (like the slot
+// arrays); the host mirrors are whole-container arrays whose foreign parts are never used.
+template <typename F>
+void for_owned_ranges(const psamd_ctx *c, F fn)
+{
+    size_t off = 0;
+    for (int t = 0; t < 4; t++) {
+        const int n = c->P.slot_n[t];
+        if (n > 0) fn((size_t)c->P.slot_lo[t], (size_t)n, off);
+        off += (size_t)n;
+    }
+}
+
 int pull_queues(psamd_ctx *c)   // device -> host mirror
 {
     if (c->host_queues_valid) return PSAMD_OK;
     PS_HIP(c, hipStreamSynchronize(c->stream));
     PS_HIP(c, hipMemcpy(c->h_qinfo.data(), c->d.qinfo, c->h_qinfo.size() * sizeof(QueueInfo), hipMemcpyDeviceToHost));
-    PS_HIP(c, hipMemcpy(c->h_queue.data(), c->d.queue, c->h_queue.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    hipError_t e = hipSuccess;
+    for_owned_ranges(c, [&](size_t lo, size_t n, size_t off) {
+        if (e == hipSuccess) e = hipMemcpy(c->h_queue.data() + lo, c->d.queue + off, n * sizeof(int32_t), hipMemcpyDeviceToHost);
+    });
+    PS_HIP(c, e);
     c->host_queues_valid = true;
     return PSAMD_OK;
 }
@@ -131,7 +160,11 @@ int pull_queues(psamd_ctx *c)   // device -> host mirror
 int push_queues(psamd_ctx *c)   // host mirror -> device
 {
     PS_HIP(c, hipMemcpyAsync(c->d.qinfo, c->h_qinfo.data(), c->h_qinfo.size() * sizeof(QueueInfo), hipMemcpyHostToDevice, c->stream));
-    PS_HIP(c, hipMemcpyAsync(c->d.queue, c->h_queue.data(), c->h_queue.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    hipError_t e = hipSuccess;
+    for_owned_ranges(c, [&](size_t lo, size_t n, size_t off) {
+        if (e == hipSuccess) e = hipMemcpyAsync(c->d.queue + off, c->h_queue.data() + lo, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+    });
+    PS_HIP(c, e);
     PS_HIP(c, hipStreamSynchronize(c->stream));
     return PSAMD_OK;
 }
@@ -166,19 +199,13 @@ int check_device_errors(psamd_ctx *c)   // after a sync: sticky error bits raise
                                                                   : "uploaded live particle outside the box or with cell >= NUM_CELLS");
     }
     if (fs.error & ERR_CELL_TOO_BIG) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "a cell holds more particles than the sort kernel ranks");
-    if (fs.error & ERR_SHARD_BOUND) return fail(c, PSAMD_ERR_STATE, "more live particles than the shards cover (stale bound)");
+    if (fs.error & ERR_FOREIGN_CELL) return fail(c, PSAMD_ERR_STATE, "a particle stored on this rank sits in a cell layer the rank holds no state for");
+    if (fs.error & ERR_HALO_OVERFLOW) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "a slab message had no room (raise halo_cap_cell / xfer_cap)");
+    if (fs.error & ERR_SLAB_MISMATCH) return fail(c, PSAMD_ERR_STATE, "a slab message does not match the receiver's plan or counts");
+    if (fs.error & ERR_REMOTE_RECORD0) return fail(c, PSAMD_ERR_UNSUPPORTED, "cell-overflow kill on a rank that does not own queue record 0 (ps.cpp:1523-1526 frees into it)");
+    if (fs.error & ERR_CHUNK_CAP) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "a chunk list passed MAX_PARTICLES_PER_CHUNK: the reference skips its tail (ps.cpp:1502-1508), this library does not reproduce that");
     if (fs.error & ERR_OPS_OVERFLOW) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "lifecycle op buffer overflow");
     return PSAMD_OK;
-}
-
-// `bound` >= the number of sorted particles; entries past the real count are never
-// produced or consumed, so a loose bound only costs balance
-void shard_range(const psamd_ctx *c, int64_t bound, int64_t &lo, int64_t &hi, int64_t &share)
-{
-    const int world = std::max(1, c->geo.cfg.world), rank = c->geo.cfg.rank;
-    share = (bound + world - 1) / world;
-    lo = share * rank;
-    hi = lo + share;
 }
 
 // life-cycle interval of the step of parity `par`, if one is outstanding
@@ -233,6 +260,43 @@ int psamd_default_config(psamd_config *cfg)
     return PSAMD_OK;
 }
 
+static SlabPlan plan_for(const Geometry &g, const psamd_config &cfg)
+{
+    const bool given = cfg.world >= 1 && cfg.world <= PSAMD_MAX_RANKS && cfg.cuts[cfg.world] != 0;
+    return make_slab_plan(g.F, g.D, g.seg_base, g.seg_size_t, g.info_base, cfg.rank, cfg.world, given ? cfg.cuts : nullptr);
+}
+
+// DevParams fields that describe what this rank holds (partition.hpp -> device_types.h)
+static void fill_slab_params(const Geometry &g, const SlabPlan &pl, const psamd_config &cfg, DevParams &P)
+{
+    const int GG = g.G * g.G;
+    P.rank = pl.rank; P.world = pl.world; P.num_cells_global = g.num_cells;
+    const int first[4] = {pl.state_lo, pl.below_lo, pl.lentin_lo, pl.above_lo};
+    const int layers[4] = {pl.state_hi - pl.state_lo, pl.lentin_lo - pl.below_lo, pl.lentin_hi - pl.lentin_lo, pl.above_hi - pl.above_lo};
+    P.halo_cap_cell = (cfg.halo_cap_cell > 0 && cfg.halo_cap_cell < g.max_per_cell) ? cfg.halo_cap_cell : g.max_per_cell;
+    P.xfer_cap = pl.world > 1 ? (cfg.xfer_cap > 0 ? cfg.xfer_cap : 32 * GG) : 0;
+    int64_t slots = 0;
+    for (int t = 0; t < 4; t++) { P.slot_lo[t] = pl.slot_lo[t]; P.slot_n[t] = pl.slot_hi[t] - pl.slot_lo[t]; slots += P.slot_n[t];
+                                  P.rec_lo[t] = pl.rec_lo[t]; P.rec_hi[t] = pl.rec_hi[t]; }
+    P.slots_total = (int)slots;
+    int base = 0;
+    int64_t sorted = 0;
+    for (int r = 0; r < 4; r++) {
+        P.reg_first[r] = first[r]; P.reg_layers[r] = layers[r]; P.reg_base[r] = base; P.reg_sorted[r] = (int)sorted;
+        base += layers[r] * GG + 1;                                     // + the gap cell
+        // the own block can hold every owned slot (overflow-killed entries keep their place in
+        // the sorted order for the frame); a remote block what its messages can carry
+        sorted += r == 0 ? slots : (int64_t)layers[r] * GG * P.halo_cap_cell;
+    }
+    P.n_local_cells = base; P.n_own_cells = layers[0] * GG;
+    P.sorted_cap = (int)sorted;
+    P.comp_a0 = P.reg_base[2]; P.comp_a1 = P.reg_base[2] + layers[2] * GG;
+    P.comp_b0 = (std::max(pl.cut_lo, pl.state_lo) - pl.state_lo) * GG;
+    P.comp_b1 = (std::min(pl.cut_hi, pl.state_hi) - pl.state_lo) * GG;
+    if (P.comp_b1 < P.comp_b0) P.comp_b1 = P.comp_b0;
+    P.lentout_c0 = (pl.lentout_lo - pl.state_lo) * GG; P.lentout_c1 = (pl.lentout_hi - pl.state_lo) * GG;
+}
+
 int psamd_create(const psamd_config *cfg, psamd_ctx **out)
 {
     if (!cfg || !out) return PSAMD_ERR_INVALID_ARG;
@@ -241,8 +305,11 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     if (!c) return PSAMD_ERR_OUT_OF_MEMORY;
     *out = c;  // returned even on failure so psamd_last_error can explain; caller destroys it
     if (!c->geo.init(*cfg)) return fail(c, PSAMD_ERR_INVALID_ARG, "bad configuration (chunk_dim >= 3, sizes > 0, container < 2^31)");
-    if (cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world) return fail(c, PSAMD_ERR_INVALID_ARG, "rank/world");
+    if (cfg->world < 1 || cfg->world > PSAMD_MAX_RANKS || cfg->rank < 0 || cfg->rank >= cfg->world) return fail(c, PSAMD_ERR_INVALID_ARG, "rank/world");
     const Geometry &g = c->geo;
+    c->plan = plan_for(g, *cfg);
+    if (!c->plan.valid) return fail(c, PSAMD_ERR_UNSUPPORTED, "no slab partition for this grid and world size (every rank needs >= 2 cell layers "
+                                                                "and its neighbours must hold every layer it reads)");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(c, PSAMD_ERR_NO_DEVICE, "hipGetDeviceCount found none");
@@ -273,6 +340,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     P.cell_size = cfg->cell_size; P.eps2 = cfg->eps2; P.coll_radius = cfg->collision_radius;
     P.kid_age = g.kid_age; P.life = g.particle_life; P.expl_speed = cfg->explosion_speed;
     P.seed = cfg->seed;
+    fill_slab_params(g, c->plan, *cfg, P);
     auto bits_for = [](int64_t n) { int b = 1; while (((int64_t)1 << b) < n) b++; return b; };
     P.key_chunk_shift = 2 + bits_for(g.container);
     P.key_rec_shift = P.key_chunk_shift + bits_for((int64_t)g.num_chunks + 1);
@@ -304,11 +372,14 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     for (int k = 0; k < 4; k++) c->S.seg_size_t[k] = g.seg_size_t[k];
 
     DeviceState &d = c->d;
-    const size_t C = (size_t)g.container;
-    d.ops_cap = (int)std::min<size_t>(3 * C, (size_t)INT32_MAX / 2);
-    d.moves_cap = (int)std::min<size_t>(2 * C, (size_t)INT32_MAX / 2);
+    const size_t C = (size_t)P.slots_total;          // owned slots
+    const size_t SC = (size_t)P.sorted_cap + 64;     // sorted-order arrays (+ slack: scalar loads fetch whole groups)
+    const size_t LC = (size_t)P.n_local_cells;
+    const size_t xf = (size_t)P.xfer_cap;
+    d.ops_cap = (int)std::min<size_t>(3 * C + 2 * xf + 64, (size_t)INT32_MAX / 2);
+    d.moves_cap = (int)std::min<size_t>(2 * C + 2 * xf + 64, (size_t)INT32_MAX / 2);
     int *frame = nullptr;
-    const size_t frame_ints = (size_t)g.num_cells + g.num_chunks + g.queue_infos + g.num_cells;   // + halo counts
+    const size_t frame_ints = LC + g.num_chunks + g.queue_infos + LC;   // cell counts, chunk counts, record counts, halo counts
     PS_HIP(c, dev_alloc(c, &d.pos4, C));
     PS_HIP(c, dev_alloc(c, &d.vel4, C));
     PS_HIP(c, dev_alloc(c, &d.acc4, C));
@@ -318,31 +389,30 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.qinfo, (size_t)g.queue_infos));
     PS_HIP(c, dev_alloc(c, &d.queue, C));
     PS_HIP(c, dev_alloc(c, &frame, frame_ints));
-    d.cell_count = frame; d.chunk_count = frame + g.num_cells; d.rec_count = d.chunk_count + g.num_chunks;
+    d.cell_count = frame; d.chunk_count = frame + LC; d.rec_count = d.chunk_count + g.num_chunks;
     d.halo_count = d.rec_count + g.queue_infos;
-    PS_HIP(c, dev_alloc(c, &d.halo_f, (size_t)3 * g.num_cells * HALO_CAP + 64));   // + slack: scalar loads fetch whole groups
-    PS_HIP(c, dev_alloc(c, &d.halo_id, (size_t)g.num_cells * HALO_CAP + 64));
-    PS_HIP(c, dev_alloc(c, &d.active_list, C + 64));
-    PS_HIP(c, dev_alloc(c, &d.pair_flag, C));
-    PS_HIP(c, dev_alloc(c, &d.snap_cid, C + 64));
-    PS_HIP(c, dev_alloc(c, &d.active_count, (size_t)g.num_cells));
-    PS_HIP(c, dev_alloc(c, &d.task_start2, (size_t)g.num_cells + 1));
-    PS_HIP(c, dev_alloc(c, &d.task_list2, (size_t)g.num_cells * P.slices));
-    PS_HIP(c, dev_alloc(c, &d.merged_tasks, (size_t)g.num_cells));
+    c->frame_ints = frame_ints;
+    PS_HIP(c, dev_alloc(c, &d.halo_f, (size_t)3 * LC * HALO_CAP + 64));   // + slack: scalar loads fetch whole groups
+    PS_HIP(c, dev_alloc(c, &d.halo_id, LC * HALO_CAP + 64));
+    PS_HIP(c, dev_alloc(c, &d.active_list, SC));
+    PS_HIP(c, dev_alloc(c, &d.pair_flag, SC));
+    PS_HIP(c, dev_alloc(c, &d.snap_cid, SC));
+    PS_HIP(c, dev_alloc(c, &d.active_count, LC));
+    PS_HIP(c, dev_alloc(c, &d.task_list2, LC * P.slices));
+    PS_HIP(c, dev_alloc(c, &d.merged_tasks, LC));
     PS_HIP(c, dev_alloc(c, &d.rec_start, (size_t)g.queue_infos + 1));
     PS_HIP(c, dev_alloc(c, &d.rec_cursor, (size_t)g.queue_infos));
     PS_HIP(c, dev_alloc(c, &d.fs, 1));
-    PS_HIP(c, dev_alloc(c, &d.cell_start, (size_t)g.num_cells + 1));
-    PS_HIP(c, dev_alloc(c, &d.cursor, (size_t)g.num_cells));
-    PS_HIP(c, dev_alloc(c, &d.task_start, (size_t)g.num_cells + 1));
-    PS_HIP(c, dev_alloc(c, &d.task_list, (size_t)g.num_cells * P.slices));
-    PS_HIP(c, dev_alloc(c, &d.sorted_id, C));
+    PS_HIP(c, dev_alloc(c, &d.cell_start, LC + 1));
+    PS_HIP(c, dev_alloc(c, &d.cursor, LC));
+    PS_HIP(c, dev_alloc(c, &d.task_start, LC + 1));
+    PS_HIP(c, dev_alloc(c, &d.task_list, LC * P.slices));
+    PS_HIP(c, dev_alloc(c, &d.sorted_id, SC));
     PS_HIP(c, dev_alloc(c, &d.rank_of_slot, C));
-    PS_HIP(c, dev_alloc(c, &d.snap4, C));
-    PS_HIP(c, dev_alloc(c, &d.snap_soa, 4 * C + 64));   // + slack: scalar loads fetch whole groups
-    PS_HIP(c, dev_alloc(c, &d.snap_age, C));
-    PS_HIP(c, dev_alloc(c, &d.force4, C));
-    c->own_force4 = d.force4;
+    PS_HIP(c, dev_alloc(c, &d.snap4, SC));
+    PS_HIP(c, dev_alloc(c, &d.snap_soa, 4 * (size_t)P.sorted_cap + 64));
+    PS_HIP(c, dev_alloc(c, &d.snap_age, SC));
+    PS_HIP(c, dev_alloc(c, &d.force4, SC));
     PS_HIP(c, dev_alloc(c, &d.celltab, (size_t)g.num_cells));
     PS_HIP(c, dev_alloc(c, &d.op_keys, (size_t)d.ops_cap));
     PS_HIP(c, dev_alloc(c, &d.op_keys_sorted, (size_t)d.ops_cap));
@@ -354,8 +424,53 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.moves, (size_t)d.moves_cap));
     PS_HIP(c, dev_alloc(c, &d.stage, 3 * (size_t)d.moves_cap));
     PS_HIP(c, dev_alloc(c, &d.ctr, (size_t)COUNTER_COPIES));
-    PS_HIP(c, dev_alloc(c, &d.trace, 3 * ((size_t)g.num_cells * P.slices + 4)));
-    PS_HIP(c, hipMemsetAsync(d.trace, 0, 3 * ((size_t)g.num_cells * P.slices + 4) * sizeof(unsigned long long), c->stream));
+    PS_HIP(c, dev_alloc(c, &d.trace, 3 * (LC * P.slices + 4)));
+    PS_HIP(c, hipMemsetAsync(d.trace, 0, 3 * (LC * P.slices + 4) * sizeof(unsigned long long), c->stream));
+
+    // slab messages: sizes fixed by the plan (see kernels.hip "slab exchange")
+    if (P.world > 1) {
+        const SlabPlan &pl = c->plan;
+        const int GG = g.G * g.G;
+        auto halo_words = [&](int cells) { return (size_t)MSG_HEADER_WORDS + (size_t)cells + 6 * (size_t)cells * P.halo_cap_cell; };
+        // out: own layers for the rank below / above; in: what they hold for this rank
+        c->halo_out_cells[0] = (pl.send_down_hi - pl.send_down_lo) * GG; c->halo_out_c0[0] = (pl.send_down_lo - pl.state_lo) * GG;
+        c->halo_out_cells[1] = (pl.send_up_hi - pl.send_up_lo) * GG;     c->halo_out_c0[1] = (pl.send_up_lo - pl.state_lo) * GG;
+        c->halo_in_cells[0] = (pl.below_hi - pl.below_lo) * GG;
+        c->halo_in_cells[1] = (pl.above_hi - pl.above_lo) * GG;
+        for (int k = 0; k < 2; k++) {
+            if (c->halo_out_cells[k] > 0) {
+                c->halo_out_bytes[k] = halo_words(c->halo_out_cells[k]) * sizeof(int);
+                PS_HIP(c, dev_alloc(c, &c->halo_out[k], c->halo_out_bytes[k] / sizeof(int)));
+                PS_HIP(c, hipMemsetAsync(c->halo_out[k], 0, c->halo_out_bytes[k], c->stream));
+                PS_HIP(c, dev_alloc(c, &c->pack_off[k], (size_t)c->halo_out_cells[k] + 1));
+            }
+            if (c->halo_in_cells[k] > 0) {
+                c->halo_in_bytes[k] = halo_words(c->halo_in_cells[k]) * sizeof(int);
+                PS_HIP(c, dev_alloc(c, &c->halo_in[k], c->halo_in_bytes[k] / sizeof(int)));
+                PS_HIP(c, hipMemsetAsync(c->halo_in[k], 0, c->halo_in_bytes[k], c->stream));
+                PS_HIP(c, dev_alloc(c, &c->unpack_off[k], (size_t)c->halo_in_cells[k] + 1));
+            }
+        }
+        auto force_words = [&](int cells) { return (size_t)MSG_HEADER_WORDS + 4 * (size_t)cells * P.halo_cap_cell; };
+        if (P.reg_layers[2] > 0) {
+            c->force_out_bytes = force_words(P.reg_layers[2] * GG) * sizeof(int);
+            PS_HIP(c, dev_alloc(c, &c->force_out, c->force_out_bytes / sizeof(int)));
+            PS_HIP(c, hipMemsetAsync(c->force_out, 0, c->force_out_bytes, c->stream));
+        }
+        if (P.lentout_c1 > P.lentout_c0) {
+            c->force_in_bytes = force_words(P.lentout_c1 - P.lentout_c0) * sizeof(int);
+            PS_HIP(c, dev_alloc(c, &c->force_in, c->force_in_bytes / sizeof(int)));
+            PS_HIP(c, hipMemsetAsync(c->force_in, 0, c->force_in_bytes, c->stream));
+        }
+        c->xfer_bytes = ((size_t)MSG_HEADER_WORDS + xf * (sizeof(XferRec) / sizeof(int))) * sizeof(int);
+        for (int k = 0; k < 2; k++) {
+            PS_HIP(c, dev_alloc(c, &c->xfer_out[k], c->xfer_bytes / sizeof(int)));
+            PS_HIP(c, dev_alloc(c, &c->xfer_in[k], c->xfer_bytes / sizeof(int)));
+            PS_HIP(c, hipMemsetAsync(c->xfer_out[k], 0, c->xfer_bytes, c->stream));
+            PS_HIP(c, hipMemsetAsync(c->xfer_in[k], 0, c->xfer_bytes, c->stream));
+            d.xfer_out[k] = reinterpret_cast<XferRec *>(c->xfer_out[k] + MSG_HEADER_WORDS);
+        }
+    }
 
     // From which squared distance on is the fp32 add of EPS2 bit-identical to the
     // reference's double add?  Try a few candidates, each checked on the device for
@@ -382,16 +497,17 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     P.slow_below = std::max(P.eps_f32_from, std::nextafterf(P.coll_d2_gate, INFINITY));
 
     // init_particles (ps.cpp:722-753): every slot reset, cell = -1
-    PS_HIP(c, hipMemsetAsync(d.pos4, 0, C * sizeof(float4), c->stream));
-    PS_HIP(c, hipMemsetAsync(d.vel4, 0, C * sizeof(float4), c->stream));
-    PS_HIP(c, hipMemsetAsync(d.acc4, 0, C * sizeof(float4), c->stream));
-    PS_HIP(c, hipMemsetAsync(d.pflags, 0, C, c->stream));
-    PS_HIP(c, hipMemsetAsync(d.force4, 0, C * sizeof(float4), c->stream));
+    PS_HIP(c, hipMemsetAsync(d.pos4, 0, std::max<size_t>(C, 1) * sizeof(float4), c->stream));
+    PS_HIP(c, hipMemsetAsync(d.vel4, 0, std::max<size_t>(C, 1) * sizeof(float4), c->stream));
+    PS_HIP(c, hipMemsetAsync(d.acc4, 0, std::max<size_t>(C, 1) * sizeof(float4), c->stream));
+    PS_HIP(c, hipMemsetAsync(d.pflags, 0, std::max<size_t>(C, 1), c->stream));
+    PS_HIP(c, hipMemsetAsync(d.force4, 0, SC * sizeof(float4), c->stream));
     PS_HIP(c, hipMemsetAsync(d.fs, 0, sizeof(FrameScalars), c->stream));
     PS_HIP(c, hipMemsetAsync(d.ctr, 0, sizeof(DevCounters) * COUNTER_COPIES, c->stream));
     PS_HIP(c, hipMemsetAsync(frame, 0, frame_ints * sizeof(int), c->stream));
+    PS_HIP(c, hipMemsetAsync(d.cell_start, 0, (LC + 1) * sizeof(int), c->stream));
     PS_HIP(c, launch_fill_int(c->stream, d.cell, -1, C));
-    PS_HIP(c, launch_init_tdata(c->stream, d, g.container));
+    PS_HIP(c, launch_init_tdata(c->stream, P, d));
     // q_start_fast (ps.cpp:814-871) and the cell table
     g.initial_queues(c->h_qinfo, c->h_queue);
     c->celltab = g.cell_table();
@@ -501,17 +617,21 @@ int psamd_fill_particles(psamd_ctx *c, int64_t n, const float *xyz, const float 
     struct Rec { float4 p, v, a; int cell; };
     std::vector<int32_t> ids((size_t)n);
     std::vector<Rec> recs((size_t)n);
-    int64_t done = 0;
+    int64_t done = 0, placed = 0;
     int status = PSAMD_OK;
     for (; done < n; done++) {
         const float x = xyz[3 * done], y = xyz[3 * done + 1], z = xyz[3 * done + 2];
         int cell;
         if (!g.locate(x, y, z, cell)) { status = fail(c, PSAMD_ERR_OUTSIDE_BOX, "fill_particles"); break; }
         const CellInfo &ci = c->celltab[(size_t)cell];
+        Rec &r = recs[(size_t)done];
+        // a slab places only the particles of its own segments (their queues are its own: the
+        // order among them is the reference's), the others are their owners' business
+        if (!owns_record(c->P, g.segment_record(ci.seg_type, ci.seg_tid))) { ids[(size_t)done] = -1; r.cell = -1; continue; }
         const int nid = host_q_remove(c, ci.seg_type, ci.seg_tid);
         if (nid < 0) { status = fail(c, PSAMD_ERR_QUEUE_EMPTY, "fill_particles"); break; }
         ids[(size_t)done] = nid;
-        Rec &r = recs[(size_t)done];
+        placed++;
         r.cell = cell;
         r.p = make_float4(x, y, z, w ? w[done] : (float)g.cfg.particle_weight);
         r.v = make_float4(vxyz ? vxyz[3 * done] : 0.f, vxyz ? vxyz[3 * done + 1] : 0.f, vxyz ? vxyz[3 * done + 2] : 0.f,
@@ -536,15 +656,15 @@ int psamd_fill_particles(psamd_ctx *c, int64_t n, const float *xyz, const float 
         PS_HIP(c, hipMemcpyAsync(da, ha.data(), m * sizeof(float4), hipMemcpyHostToDevice, c->stream));
         PS_HIP(c, hipMemcpyAsync(dc, hc.data(), m * sizeof(int), hipMemcpyHostToDevice, c->stream));
         PS_HIP(c, hipMemcpyAsync(di, ids.data(), m * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        PS_HIP(c, launch_place(c->stream, (int)done, di, dp, dv, da, dc, c->d));
+        PS_HIP(c, launch_place(c->stream, c->P, (int)done, di, dp, dv, da, dc, c->d));
         PS_HIP(c, hipStreamSynchronize(c->stream));
     }
     rc = push_queues(c);
     if (rc != PSAMD_OK) return rc;
     if (ids_out) std::copy(ids.begin(), ids.begin() + done, ids_out);
     if (n_done) *n_done = done;
-    if (c->live_bound >= 0) c->live_bound += done;
-    c->grid_built = false; c->pairs_done = false;
+    if (c->live_bound >= 0) c->live_bound += placed;
+    c->grid_built = false; c->pairs_done = false; c->slab_stage = 0;
     return status;
 }
 
@@ -557,9 +677,9 @@ int psamd_upload_particles(psamd_ctx *c, const void *p72, int64_t first, int64_t
     PS_HIP(c, hipMemcpyAsync(c->staging, p72, (size_t)count * 72, hipMemcpyHostToDevice, c->stream));
     // odd grids are not centred (G/2 is an integer division): allow the longer half
     const float half_box = (float)((c->geo.G - c->geo.G / 2) * c->geo.cfg.cell_size);
-    PS_HIP(c, launch_unpack_aos(c->stream, c->staging, (int)first, (int)count, c->geo.num_cells, half_box, c->d));
+    PS_HIP(c, launch_unpack_aos(c->stream, c->P, c->staging, (int)first, (int)count, half_box, c->d));
     PS_HIP(c, hipStreamSynchronize(c->stream));
-    c->grid_built = false; c->pairs_done = false;
+    c->grid_built = false; c->pairs_done = false; c->slab_stage = 0;
     c->live_bound = -1;
     return check_device_errors(c);
 }
@@ -570,7 +690,7 @@ int psamd_download_particles(psamd_ctx *c, void *p72, int64_t first, int64_t cou
     if (count == 0) return PSAMD_OK;
     int rc = ensure_staging(c, (size_t)count * 72);
     if (rc != PSAMD_OK) return rc;
-    PS_HIP(c, launch_pack_aos(c->stream, c->staging, (int)first, (int)count, c->geo.num_cells, c->d));
+    PS_HIP(c, launch_pack_aos(c->stream, c->P, c->staging, (int)first, (int)count, c->d));
     PS_HIP(c, hipMemcpyAsync(p72, c->staging, (size_t)count * 72, hipMemcpyDeviceToHost, c->stream));
     PS_HIP(c, hipStreamSynchronize(c->stream));
     return PSAMD_OK;
@@ -580,8 +700,18 @@ int psamd_download_tdata(psamd_ctx *c, void *t24, int64_t first, int64_t count)
 {
     if (!c || !t24 || first < 0 || count < 0 || first + count > c->geo.container) return PSAMD_ERR_INVALID_ARG;
     if (count == 0) return PSAMD_OK;
-    PS_HIP(c, hipMemcpyAsync(t24, c->d.tdata + 6 * first, (size_t)count * 24, hipMemcpyDeviceToHost, c->stream));
     PS_HIP(c, hipStreamSynchronize(c->stream));
+    // rows of slots another rank owns: as init_particles left them (id, zeros; ps.cpp:743-748)
+    uint32_t *out = (uint32_t *)t24;
+    if (c->P.world > 1)
+        for (int64_t i = 0; i < count; i++) { uint32_t *r = out + 6 * i; r[0] = (uint32_t)(first + i); r[1] = r[2] = r[3] = r[4] = r[5] = 0u; }
+    hipError_t e = hipSuccess;
+    for_owned_ranges(c, [&](size_t lo, size_t n, size_t off) {
+        const int64_t a = std::max<int64_t>(first, (int64_t)lo), b = std::min<int64_t>(first + count, (int64_t)(lo + n));
+        if (a < b && e == hipSuccess)
+            e = hipMemcpy(out + 6 * (a - first), c->d.tdata + 6 * (off + (size_t)(a - (int64_t)lo)), (size_t)(b - a) * 24, hipMemcpyDeviceToHost);
+    });
+    PS_HIP(c, e);
     return PSAMD_OK;
 }
 
@@ -604,11 +734,12 @@ int psamd_download_queues(psamd_ctx *c, void *qi, int32_t *queue)
     return PSAMD_OK;
 }
 
-// Rebuild the reference's fixed-stride lists from the compact sorted arrays.
+// Rebuild the reference's fixed-stride lists from the compact sorted arrays.  start[] is
+// indexed by the own LOCAL cells (region 0); local cell lc is global cell lc + cell_off.
 static int fetch_sorted(psamd_ctx *c, std::vector<int> &start, std::vector<int> &ids)
 {
     if (!c->grid_built) return fail(c, PSAMD_ERR_STATE, "grid lists requested before build_grid");
-    start.resize((size_t)c->geo.num_cells + 1);
+    start.resize((size_t)c->P.n_own_cells + 1);
     PS_HIP(c, hipStreamSynchronize(c->stream));
     PS_HIP(c, hipMemcpy(start.data(), c->d.cell_start, start.size() * sizeof(int), hipMemcpyDeviceToHost));
     ids.resize((size_t)std::max(start.back(), 1));
@@ -624,12 +755,13 @@ int psamd_download_cellgrid(psamd_ctx *c, int32_t *out)
     if (rc != PSAMD_OK) return rc;
     const Geometry &g = c->geo;
     const size_t stride = 1 + (size_t)g.max_per_cell;
+    const int cell_off = c->P.reg_first[0] * g.G * g.G;
     std::memset(out, 0, sizeof(int32_t) * stride * (size_t)g.num_cells);
-    for (int cell = 0; cell < g.num_cells; cell++) {
-        const int n = std::min(start[(size_t)cell + 1] - start[(size_t)cell], g.max_per_cell);
-        int32_t *row = out + stride * (size_t)cell;
+    for (int lc = 0; lc < c->P.n_own_cells; lc++) {
+        const int n = std::min(start[(size_t)lc + 1] - start[(size_t)lc], g.max_per_cell);
+        int32_t *row = out + stride * (size_t)(lc + cell_off);
         row[0] = n;
-        for (int k = 0; k < n; k++) row[1 + k] = ids[(size_t)start[(size_t)cell] + k];
+        for (int k = 0; k < n; k++) row[1 + k] = ids[(size_t)start[(size_t)lc] + k];
     }
     return PSAMD_OK;
 }
@@ -640,16 +772,17 @@ int psamd_download_force_counts(psamd_ctx *c, int32_t *out)
     if (!c->pairs_done) return fail(c, PSAMD_ERR_STATE, "force counts requested before the pair pass of this frame");
     PS_HIP(c, hipStreamSynchronize(c->stream));
     const Geometry &g = c->geo;
-    const bool two = c->P.two_pass && c->P.lean_math;
-    if (two) {
-        PS_HIP(c, hipMemcpy(out, c->d.active_count, sizeof(int32_t) * (size_t)g.num_cells, hipMemcpyDeviceToHost));
-        return PSAMD_OK;
+    const DevParams &P = c->P;
+    const bool two = P.two_pass && P.lean_math;
+    std::memset(out, 0, sizeof(int32_t) * (size_t)g.num_cells);
+    std::vector<int> v((size_t)P.n_local_cells + 1);
+    if (two) PS_HIP(c, hipMemcpy(v.data(), c->d.active_count, sizeof(int) * (size_t)P.n_local_cells, hipMemcpyDeviceToHost));
+    else PS_HIP(c, hipMemcpy(v.data(), c->d.cell_start, sizeof(int) * ((size_t)P.n_local_cells + 1), hipMemcpyDeviceToHost));
+    for (int j = 0; j < comp_count(P); j++) {
+        const int lc = comp_cell(P, j);
+        // one-pass modes evaluate every particle's sum (and discard what is not used)
+        out[global_of_local(P, lc)] = two ? v[(size_t)lc] : std::min(v[(size_t)lc + 1] - v[(size_t)lc], g.max_per_cell);
     }
-    // one-pass modes evaluate every particle's sum (and discard what is not used)
-    std::vector<int> start((size_t)g.num_cells + 1);
-    PS_HIP(c, hipMemcpy(start.data(), c->d.cell_start, start.size() * sizeof(int), hipMemcpyDeviceToHost));
-    for (int cell = 0; cell < g.num_cells; cell++)
-        out[cell] = std::min(start[(size_t)cell + 1] - start[(size_t)cell], g.max_per_cell);
     return PSAMD_OK;
 }
 
@@ -661,13 +794,14 @@ int psamd_download_chunkgrid(psamd_ctx *c, int32_t *out)
     if (rc != PSAMD_OK) return rc;
     const Geometry &g = c->geo;
     const size_t stride = 1 + (size_t)g.max_per_chunk;
+    const int cell_off = c->P.reg_first[0] * g.G * g.G;
     std::memset(out, 0, sizeof(int32_t) * stride * (size_t)g.num_chunks);
     // the reference appends in slot order (ps.cpp:1502-1508): per chunk, ids ascending,
     // including the ones the cell-overflow rule then killed (stored as ~id in fetch order)
     std::vector<std::vector<int>> per((size_t)g.num_chunks);
-    for (int cell = 0; cell < g.num_cells; cell++) {
-        auto &v = per[(size_t)c->celltab[(size_t)cell].chunk];
-        for (int k = start[(size_t)cell]; k < start[(size_t)cell + 1]; k++) v.push_back(ids[(size_t)k]);
+    for (int lc = 0; lc < c->P.n_own_cells; lc++) {
+        auto &v = per[(size_t)c->celltab[(size_t)(lc + cell_off)].chunk];
+        for (int k = start[(size_t)lc]; k < start[(size_t)lc + 1]; k++) v.push_back(ids[(size_t)k]);
     }
     for (int ch = 0; ch < g.num_chunks; ch++) {
         auto &v = per[(size_t)ch];
@@ -711,21 +845,23 @@ int psamd_get_gridmax(psamd_ctx *c, int32_t out2[2])
 
 // ---- stages ---------------------------------------------------------------------
 
-int psamd_init_iframe(psamd_ctx *c)
+static int slab_only(psamd_ctx *c, const char *what)
 {
-    if (!c) return PSAMD_ERR_INVALID_ARG;
-    const Geometry &g = c->geo;
-    const size_t frame_ints = (size_t)g.num_cells + g.num_chunks + g.queue_infos + g.num_cells;
+    return fail(c, PSAMD_ERR_STATE, std::string(what) + ": this context is one slab of a multi-rank system; step it with psamd_slab_build / "
+                                                         "_pairs / _apply / _finish and exchange the messages in between");
+}
+
+static int do_init_iframe(psamd_ctx *c)
+{
     if (c->timing >= 2) { make_events(c); (void)hipEventRecord(c->ev[10], c->stream); }
     // cell / chunk / queue-record counts and the per-frame scalars (the sticky error word stays)
-    PS_HIP(c, launch_frame_reset(c->stream, c->d, frame_ints));
+    PS_HIP(c, launch_frame_reset(c->stream, c->d, c->frame_ints));
     c->frame_reset = true; c->grid_built = false; c->pairs_done = false;
     return PSAMD_OK;
 }
 
-int psamd_build_grid(psamd_ctx *c)
+static int do_build_grid(psamd_ctx *c)
 {
-    if (!c) return PSAMD_ERR_INVALID_ARG;
     if (!c->frame_reset) return fail(c, PSAMD_ERR_STATE, "build_grid needs init_iframe first");
     if (c->timing) make_events(c);
     PS_HIP(c, launch_build_grid(c->stream, c->P, c->d, c->timing >= 2 ? c->ev : nullptr));
@@ -734,50 +870,36 @@ int psamd_build_grid(psamd_ctx *c)
     return PSAMD_OK;
 }
 
-int psamd_force_shard(psamd_ctx *c, int64_t *begin, int64_t *end, int64_t *share)
+static int do_pairs(psamd_ctx *c)
 {
-    if (!c) return PSAMD_ERR_INVALID_ARG;
-    if (!c->grid_built) return fail(c, PSAMD_ERR_STATE, "force_shard needs build_grid first");
-    if (c->live_bound < 0) {            // e.g. after an upload: ask the device once
-        PS_HIP(c, hipStreamSynchronize(c->stream));
-        int rc = check_device_errors(c);
-        if (rc != PSAMD_OK) return rc;
-        c->live_bound = c->live_at_build;
-    }
-    int64_t lo, hi, sh;
-    shard_range(c, c->live_bound, lo, hi, sh);
-    if (begin) *begin = lo;
-    if (end) *end = hi;
-    if (share) *share = sh;
-    return PSAMD_OK;
-}
-
-int psamd_calc_forces_pairs(psamd_ctx *c)
-{
-    if (!c) return PSAMD_ERR_INVALID_ARG;
     if (!c->grid_built) return fail(c, PSAMD_ERR_STATE, "calc_forces needs build_grid first");
-    int lo = 0, hi = INT32_MAX, covered = INT32_MAX;
-    if (c->geo.cfg.world > 1) {
-        int64_t b, e, s;
-        int rc = psamd_force_shard(c, &b, &e, &s);
-        if (rc != PSAMD_OK) return rc;
-        lo = (int)b; hi = (int)e; covered = (int)std::min<int64_t>(s * c->geo.cfg.world, INT32_MAX);
-    }
     if (c->timing) (void)hipEventRecord(c->ev[5], c->stream);
-    PS_HIP(c, launch_pairs(c->stream, c->P, c->d, lo, hi, covered, c->geo.cfg.world > 1, c->timing ? c->ev[13] : nullptr));
+    PS_HIP(c, launch_pairs(c->stream, c->P, c->d, c->timing ? c->ev[13] : nullptr));
     if (c->timing) (void)hipEventRecord(c->ev[6], c->stream);
     c->pairs_done = true;
     return PSAMD_OK;
 }
 
-int psamd_calc_forces_apply(psamd_ctx *c)
+// kill / survive / integrate / explosion for every own particle; in slab mode the particles
+// that leave for a neighbour's segment are in the outboxes when this returns
+static int do_apply(psamd_ctx *c)
 {
-    if (!c) return PSAMD_ERR_INVALID_ARG;
     if (!c->grid_built || !c->pairs_done) return fail(c, PSAMD_ERR_STATE, "apply needs build_grid and the pair pass first");
     if (c->timing) (void)hipEventRecord(c->ev[7], c->stream);
-    PS_HIP(c, launch_apply(c->stream, c->P, c->S, c->d, c->step, c->geo.container));
+    PS_HIP(c, launch_apply(c->stream, c->P, c->S, c->d, c->step));
+    if (c->P.world > 1)
+        PS_HIP(c, launch_outbox_close(c->stream, c->P, c->d, c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total,
+                                      c->xfer_out[0], c->xfer_out[1]));
+    return PSAMD_OK;
+}
+
+// free-slot queues and relocation (in slab mode: after the arrivals were merged in)
+static int do_lifecycle(psamd_ctx *c)
+{
     const int par = (int)(c->steps_total & 1);   // not c->step: a snapshot restore rewinds that
     if (c->timing) (void)hipEventRecord(c->ev[par ? 11 : 8], c->stream);
+    if (c->P.world > 1)
+        for (int k = 0; k < 2; k++) PS_HIP(c, launch_inbox_merge(c->stream, c->P, c->d, c->xfer_in[k]));
     PS_HIP(c, launch_ops_census(c->stream, c->P, c->d, c->geo.queue_infos));
     // one small read-back per step, as the reference's driver does for hostGridMax
     // (ps.cpp:1878-1900): live count, sticky errors and the sizes of the op lists.  The
@@ -785,13 +907,13 @@ int psamd_calc_forces_apply(psamd_ctx *c)
     // the same scalars on the device), so the GPU is busy while the host catches up.
     PS_HIP(c, hipMemcpyAsync(c->h_fs, c->d.fs, sizeof(FrameScalars), hipMemcpyDeviceToHost, c->stream));
     PS_HIP(c, hipEventRecord(c->ev_scalars, c->stream));
-    // live_bound < 0: unknown (state was uploaded) -> size for a full container
-    PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos,
-                               c->live_bound >= 0 ? c->live_bound : (int64_t)c->geo.container));
+    // live_bound < 0: unknown (state was uploaded) -> size for every owned slot; arrivals on top
+    const int64_t bound = (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) + 2 * (int64_t)c->P.xfer_cap;
+    PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos, bound));
     c->host_queues_valid = false;
     PS_HIP(c, hipEventSynchronize(c->ev_scalars));
     c->live_at_build = c->h_fs->live;
-    c->live_bound = std::min<int64_t>(c->geo.container, (int64_t)c->h_fs->live + c->h_fs->n_moves);   // births <= moves
+    c->live_bound = std::min<int64_t>(c->P.slots_total, (int64_t)c->h_fs->live + c->h_fs->n_moves);   // births and arrivals <= moves
     c->processed_total += c->h_fs->live;
     c->max_bucket_seen = std::max<int64_t>(c->max_bucket_seen, c->h_fs->max_bucket);
     if (c->h_fs->error) return check_device_errors(c);
@@ -817,10 +939,39 @@ int psamd_calc_forces_apply(psamd_ctx *c)
     return PSAMD_OK;
 }
 
+int psamd_init_iframe(psamd_ctx *c)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (c->P.world > 1) return slab_only(c, "init_iframe");
+    return do_init_iframe(c);
+}
+
+int psamd_build_grid(psamd_ctx *c)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (c->P.world > 1) return slab_only(c, "build_grid");
+    return do_build_grid(c);
+}
+
+int psamd_calc_forces_pairs(psamd_ctx *c)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (c->P.world > 1) return slab_only(c, "calc_forces");
+    return do_pairs(c);
+}
+
+int psamd_calc_forces_apply(psamd_ctx *c)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (c->P.world > 1) return slab_only(c, "calc_forces");
+    int rc = do_apply(c);
+    if (rc != PSAMD_OK) return rc;
+    return do_lifecycle(c);
+}
+
 int psamd_calc_forces(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
-    if (c->geo.cfg.world > 1) return fail(c, PSAMD_ERR_STATE, "world > 1: call _pairs, exchange force4, then _apply");
     int rc = psamd_calc_forces_pairs(c);
     if (rc != PSAMD_OK) return rc;
     return psamd_calc_forces_apply(c);
@@ -835,6 +986,134 @@ int psamd_step(psamd_ctx *c, int32_t nsteps)
         if (rc == PSAMD_OK) rc = psamd_calc_forces(c);
         if (rc != PSAMD_OK) return rc;
     }
+    return PSAMD_OK;
+}
+
+// ---- slab stages: the step cut where neighbouring ranks exchange messages -----------------
+
+int psamd_slab_build(psamd_ctx *c)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    int rc = do_init_iframe(c);
+    if (rc == PSAMD_OK) rc = do_build_grid(c);
+    if (rc != PSAMD_OK) return rc;
+    for (int k = 0; k < 2; k++)
+        if (c->halo_out_cells[k] > 0)
+            PS_HIP(c, launch_pack_halo(c->stream, c->P, c->d, c->halo_out_c0[k], c->halo_out_cells[k], c->halo_out[k], c->pack_off[k]));
+    c->slab_stage = 1;
+    return PSAMD_OK;
+}
+
+int psamd_slab_pairs(psamd_ctx *c)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (c->slab_stage != 1) return fail(c, PSAMD_ERR_STATE, "slab_pairs needs slab_build (and the halo exchange) first");
+    const DevParams &P = c->P;
+    const int GG = P.G * P.G;
+    if (c->halo_in_cells[0] > 0)      // from the rank below: halo layer (region 1), then lent layers (region 2)
+        PS_HIP(c, launch_unpack_halo(c->stream, P, c->d, 1, 2, c->halo_in_cells[0], P.reg_layers[1] * GG, P.reg_layers[2] > 0,
+                                     c->halo_in[0], c->unpack_off[0]));
+    if (c->halo_in_cells[1] > 0)      // from the rank above: halo layer (region 3)
+        PS_HIP(c, launch_unpack_halo(c->stream, P, c->d, 3, -1, c->halo_in_cells[1], c->halo_in_cells[1], false,
+                                     c->halo_in[1], c->unpack_off[1]));
+    int rc = do_pairs(c);
+    if (rc != PSAMD_OK) return rc;
+    if (c->force_out) PS_HIP(c, launch_pack_force(c->stream, P, c->d, c->force_out, P.reg_layers[2] * GG * P.halo_cap_cell));
+    c->slab_stage = 2;
+    return PSAMD_OK;
+}
+
+int psamd_slab_apply(psamd_ctx *c)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (c->slab_stage != 2) return fail(c, PSAMD_ERR_STATE, "slab_apply needs slab_pairs (and the force exchange) first");
+    if (c->force_in)                  // lent-out layers are the tail of the snapshot that went up
+        PS_HIP(c, launch_unpack_force(c->stream, c->P, c->d, c->halo_out_cells[1] - (c->P.lentout_c1 - c->P.lentout_c0),
+                                      c->force_in, c->pack_off[1]));
+    int rc = do_apply(c);
+    if (rc != PSAMD_OK) return rc;
+    c->slab_stage = 3;
+    return PSAMD_OK;
+}
+
+int psamd_slab_finish(psamd_ctx *c)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (c->slab_stage != 3) return fail(c, PSAMD_ERR_STATE, "slab_finish needs slab_apply (and the transfer exchange) first");
+    c->slab_stage = 0;
+    return do_lifecycle(c);
+}
+
+int psamd_slab_plan_describe(const psamd_config *cfg, psamd_slab_plan *o)
+{
+    if (!cfg || !o) return PSAMD_ERR_INVALID_ARG;
+    Geometry g;
+    if (!g.init(*cfg)) return PSAMD_ERR_INVALID_ARG;
+    if (cfg->world < 1 || cfg->world > PSAMD_MAX_RANKS || cfg->rank < 0 || cfg->rank >= cfg->world) return PSAMD_ERR_INVALID_ARG;
+    const SlabPlan p = plan_for(g, *cfg);
+    if (!p.valid) return PSAMD_ERR_UNSUPPORTED;
+    std::memset(o, 0, sizeof *o);
+    o->world = p.world; o->rank = p.rank; o->grid_dim = p.G;
+    o->cut_lo = p.cut_lo; o->cut_hi = p.cut_hi; o->state_lo = p.state_lo; o->state_hi = p.state_hi;
+    o->below_lo = p.below_lo; o->below_hi = p.below_hi; o->above_lo = p.above_lo; o->above_hi = p.above_hi;
+    o->lentin_lo = p.lentin_lo; o->lentin_hi = p.lentin_hi; o->lentout_lo = p.lentout_lo; o->lentout_hi = p.lentout_hi;
+    o->send_up_lo = p.send_up_lo; o->send_up_hi = p.send_up_hi; o->send_down_lo = p.send_down_lo; o->send_down_hi = p.send_down_hi;
+    for (int t = 0; t < 4; t++) { o->slot_lo[t] = p.slot_lo[t]; o->slot_hi[t] = p.slot_hi[t]; o->rec_lo[t] = p.rec_lo[t]; o->rec_hi[t] = p.rec_hi[t]; }
+    o->up_rank = p.up_rank; o->down_rank = p.down_rank;
+    return PSAMD_OK;
+}
+
+int psamd_get_slab_plan(const psamd_ctx *c, psamd_slab_plan *o)
+{
+    if (!c || !o) return PSAMD_ERR_INVALID_ARG;
+    return psamd_slab_plan_describe(&c->geo.cfg, o);
+}
+
+int psamd_slab_buffers_get(psamd_ctx *c, psamd_slab_buffers *o)
+{
+    if (!c || !o) return PSAMD_ERR_INVALID_ARG;
+    std::memset(o, 0, sizeof *o);
+    for (int k = 0; k < 2; k++) {
+        o->halo_out[k] = c->halo_out[k]; o->halo_in[k] = c->halo_in[k];
+        o->halo_out_bytes[k] = (int64_t)c->halo_out_bytes[k]; o->halo_in_bytes[k] = (int64_t)c->halo_in_bytes[k];
+        o->xfer_out[k] = c->xfer_out[k]; o->xfer_in[k] = c->xfer_in[k];
+    }
+    o->force_out = c->force_out; o->force_in = c->force_in;
+    o->force_out_bytes = (int64_t)c->force_out_bytes; o->force_in_bytes = (int64_t)c->force_in_bytes;
+    o->xfer_bytes = (int64_t)c->xfer_bytes;
+    return PSAMD_OK;
+}
+
+static bool slab_msg(psamd_ctx *c, int which, int *&ptr, size_t &bytes)
+{
+    switch (which) {
+    case 0: case 1: ptr = c->halo_out[which]; bytes = c->halo_out_bytes[which]; return true;
+    case 2: case 3: ptr = c->halo_in[which - 2]; bytes = c->halo_in_bytes[which - 2]; return true;
+    case 4: ptr = c->force_out; bytes = c->force_out_bytes; return true;
+    case 5: ptr = c->force_in; bytes = c->force_in_bytes; return true;
+    case 6: case 7: ptr = c->xfer_out[which - 6]; bytes = c->xfer_bytes; return true;
+    case 8: case 9: ptr = c->xfer_in[which - 8]; bytes = c->xfer_bytes; return true;
+    }
+    return false;
+}
+
+int psamd_slab_msg_download(psamd_ctx *c, int which, void *host, int64_t bytes)
+{
+    int *p = nullptr; size_t n = 0;
+    if (!c || !host || !slab_msg(c, which, p, n) || bytes < 0 || (size_t)bytes > n || (!p && bytes > 0)) return PSAMD_ERR_INVALID_ARG;
+    if (bytes == 0) return PSAMD_OK;
+    PS_HIP(c, hipMemcpyAsync(host, p, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    return PSAMD_OK;
+}
+
+int psamd_slab_msg_upload(psamd_ctx *c, int which, const void *host, int64_t bytes)
+{
+    int *p = nullptr; size_t n = 0;
+    if (!c || !host || !slab_msg(c, which, p, n) || bytes < 0 || (size_t)bytes > n || (!p && bytes > 0)) return PSAMD_ERR_INVALID_ARG;
+    if (bytes == 0) return PSAMD_OK;
+    PS_HIP(c, hipMemcpyAsync(p, host, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    PS_HIP(c, hipStreamSynchronize(c->stream));
     return PSAMD_OK;
 }
 
@@ -872,10 +1151,10 @@ int psamd_live_count(psamd_ctx *c, int64_t *out)
 {
     if (!c || !out) return PSAMD_ERR_INVALID_ARG;
     PS_HIP(c, hipStreamSynchronize(c->stream));
-    std::vector<int> cells((size_t)c->geo.container);
-    PS_HIP(c, hipMemcpy(cells.data(), c->d.cell, cells.size() * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int> cells((size_t)std::max(c->P.slots_total, 1));
+    PS_HIP(c, hipMemcpy(cells.data(), c->d.cell, (size_t)c->P.slots_total * sizeof(int), hipMemcpyDeviceToHost));
     int64_t n = 0;
-    for (int v : cells) n += (v >= 0 && v < c->geo.num_cells) ? 1 : 0;
+    for (int i = 0; i < c->P.slots_total; i++) n += (cells[(size_t)i] >= 0 && cells[(size_t)i] < c->geo.num_cells) ? 1 : 0;
     *out = n;
     return PSAMD_OK;
 }
@@ -885,7 +1164,7 @@ int psamd_device_view_get(psamd_ctx *c, psamd_device_view *o)
     if (!c || !o) return PSAMD_ERR_INVALID_ARG;
     o->pos4 = c->d.pos4; o->vel4 = c->d.vel4; o->acc4 = c->d.acc4; o->cell = c->d.cell; o->pflags = c->d.pflags;
     o->sorted_id = c->d.sorted_id; o->snap4 = c->d.snap4; o->force4 = c->d.force4; o->cell_start = c->d.cell_start;
-    o->container_size = c->geo.container; o->num_cells = c->geo.num_cells;
+    o->container_size = c->P.slots_total; o->num_cells = c->P.n_own_cells;
     o->live = c->live_at_build;
     o->stream = (void *)c->stream;
     return PSAMD_OK;
@@ -893,18 +1172,9 @@ int psamd_device_view_get(psamd_ctx *c, psamd_device_view *o)
 
 int psamd_download_force4(psamd_ctx *c, void *out, int64_t first, int64_t count)
 {
-    if (!c || !out || first < 0 || count < 0 || first + count > c->geo.container) return PSAMD_ERR_INVALID_ARG;
+    if (!c || !out || first < 0 || count < 0 || first + count > c->P.sorted_cap) return PSAMD_ERR_INVALID_ARG;
     if (count == 0) return PSAMD_OK;
     PS_HIP(c, hipMemcpyAsync(out, c->d.force4 + first, (size_t)count * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-    PS_HIP(c, hipStreamSynchronize(c->stream));
-    return PSAMD_OK;
-}
-
-int psamd_upload_force4(psamd_ctx *c, const void *in, int64_t first, int64_t count)
-{
-    if (!c || !in || first < 0 || count < 0 || first + count > c->geo.container) return PSAMD_ERR_INVALID_ARG;
-    if (count == 0) return PSAMD_OK;
-    PS_HIP(c, hipMemcpyAsync(c->d.force4 + first, in, (size_t)count * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     PS_HIP(c, hipStreamSynchronize(c->stream));
     return PSAMD_OK;
 }
@@ -912,13 +1182,14 @@ int psamd_upload_force4(psamd_ctx *c, const void *in, int64_t first, int64_t cou
 // particles (pos4, vel4, acc4, cell, pflags) + QUEUE_INFO + queue, back to back
 static size_t snapshot_bytes(const psamd_ctx *c)
 {
-    const size_t C = (size_t)c->geo.container;
+    const size_t C = (size_t)c->P.slots_total;
     return C * (3 * sizeof(float4) + sizeof(int) + 1) + (size_t)c->geo.queue_infos * sizeof(QueueInfo) + C * sizeof(int);
 }
 
 static int snapshot_copy(psamd_ctx *c, bool save)
 {
-    const size_t C = (size_t)c->geo.container;
+    const size_t C = (size_t)c->P.slots_total;
+    if (C == 0) return PSAMD_OK;
     char *p = c->snapshot;
     char *s_pos = p, *s_vel = s_pos + C * sizeof(float4), *s_acc = s_vel + C * sizeof(float4);
     char *s_cell = s_acc + C * sizeof(float4);
@@ -958,7 +1229,7 @@ int psamd_snapshot_restore(psamd_ctx *c)
     c->step = c->snapshot_step;
     c->live_bound = c->snapshot_live_bound;
     c->host_queues_valid = false;
-    c->frame_reset = false; c->grid_built = false; c->pairs_done = false;
+    c->frame_reset = false; c->grid_built = false; c->pairs_done = false; c->slab_stage = 0;
     return snapshot_copy(c, false);
 }
 
@@ -970,19 +1241,10 @@ int psamd_set_stream(psamd_ctx *c, void *hip_stream)
     return PSAMD_OK;
 }
 
-int psamd_bind_force4(psamd_ctx *c, void *device_ptr, int64_t n_float4)
-{
-    if (!c) return PSAMD_ERR_INVALID_ARG;
-    if (device_ptr && n_float4 < c->geo.container) return fail(c, PSAMD_ERR_INVALID_ARG, "force4 buffer smaller than the container");
-    PS_HIP(c, hipStreamSynchronize(c->stream));
-    c->d.force4 = device_ptr ? (float4 *)device_ptr : c->own_force4;
-    return PSAMD_OK;
-}
-
 int psamd_debug_wave_trace(psamd_ctx *c, uint64_t *out, int64_t n_words)
 {
     if (!c || !out) return PSAMD_ERR_INVALID_ARG;
-    const int64_t have = 3 * ((int64_t)c->geo.num_cells * c->P.slices + 4);
+    const int64_t have = 3 * ((int64_t)c->P.n_local_cells * c->P.slices + 4);
     PS_HIP(c, hipStreamSynchronize(c->stream));
     PS_HIP(c, hipMemcpy(out, c->d.trace, (size_t)std::min(have, n_words) * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return PSAMD_OK;

@@ -44,7 +44,110 @@ struct DevParams {
     float coll_d2_max;       // (double)sqrtf(d2) > COLLISION_RADIUS  <=>  d2 > coll_d2_max (bisection at creation)
     int32_t two_pass;        // 1: collision flags first (k_collide), forces only for the particles that move
     float pad_f;
+    // ---- slab partition (partition.hpp); world == 1: one region, one slot range, the identity ----
+    // Cells are addressed by LOCAL index: four regions of whole cell layers, each followed by one
+    // empty "gap" cell so that cell_start stays a plain prefix array although every region has
+    // its own fixed block of the sorted arrays.  0: layers whose particles live here, 1: halo
+    // layer from the rank below, 2: layers lent by the rank below (computed here), 3: halo layer
+    // from the rank above.
+    int32_t reg_first[4];    // first global cell layer (i3) of the region
+    int32_t reg_layers[4];   // number of layers (0: region absent)
+    int32_t reg_base[4];     // local index of the region's first cell
+    int32_t reg_sorted[4];   // first sorted index of the region's block
+    int32_t n_local_cells;   // all regions and their gap cells
+    int32_t n_own_cells;     // cells of region 0
+    int32_t sorted_cap;      // capacity of the sorted-order arrays = plane stride of snap_soa
+    int32_t comp_a0, comp_a1;   // local cells this rank computes collisions / forces for: the lent ones ...
+    int32_t comp_b0, comp_b1;   // ... and its own (in this order in the work lists)
+    int32_t slot_lo[4], slot_n[4];   // owned slot range per segment type; storage index = position in their concatenation
+    int32_t slots_total;
+    int32_t rec_lo[4], rec_hi[4];    // owned QUEUE_INFO records per segment type
+    int32_t rank, world;
+    int32_t halo_cap_cell;   // bodies per cell a halo message has room for
+    int32_t xfer_cap;        // relocation records per direction and step
+    int32_t lentout_c0, lentout_c1;  // own local cells computed by the rank above (their force records come back)
+    int32_t num_cells_global;
 };
+
+// Which cells / slots / records a rank holds.  All device code goes through these.
+#if defined(__HIPCC__)
+#define PS_HD __host__ __device__ __forceinline__
+#else
+#define PS_HD inline
+#endif
+
+// local index of global cell (i3, i1, i2), or -1 if this rank does not hold its layer
+PS_HD int local_cell(const DevParams &P, int i3, int i1, int i2)
+{
+    if (i1 < 0 || i1 >= P.G || i2 < 0 || i2 >= P.G) return -1;
+    for (int r = 0; r < 4; r++) {
+        const int l = i3 - P.reg_first[r];
+        if (l >= 0 && l < P.reg_layers[r]) return P.reg_base[r] + (l * P.G + i1) * P.G + i2;
+    }
+    return -1;
+}
+
+PS_HD int local_of_global(const DevParams &P, int gc)
+{
+    const int GG = P.G * P.G, i3 = gc / GG, rem = gc - i3 * GG;
+    for (int r = 0; r < 4; r++) {
+        const int l = i3 - P.reg_first[r];
+        if (l >= 0 && l < P.reg_layers[r]) return P.reg_base[r] + l * GG + rem;
+    }
+    return -1;
+}
+
+// (i1, i2, i3) of a local cell (not a gap cell)
+PS_HD void cell_coords(const DevParams &P, int lc, int &i1, int &i2, int &i3)
+{
+    int r = 0;
+    for (int k = 1; k < 4; k++) if (P.reg_layers[k] > 0 && lc >= P.reg_base[k]) r = k;
+    const int rel = lc - P.reg_base[r], GG = P.G * P.G, l = rel / GG, rem = rel - l * GG;
+    i3 = P.reg_first[r] + l; i1 = rem / P.G; i2 = rem - i1 * P.G;
+}
+
+PS_HD int global_of_local(const DevParams &P, int lc)
+{
+    int i1, i2, i3;
+    cell_coords(P, lc, i1, i2, i3);
+    return (i3 * P.G + i1) * P.G + i2;
+}
+
+// j-th computed cell (lent ones first)
+PS_HD int comp_cell(const DevParams &P, int j)
+{
+    const int na = P.comp_a1 - P.comp_a0;
+    return j < na ? P.comp_a0 + j : P.comp_b0 + (j - na);
+}
+PS_HD int comp_count(const DevParams &P) { return (P.comp_a1 - P.comp_a0) + (P.comp_b1 - P.comp_b0); }
+
+// storage index of an owned slot (position in the concatenation of the four owned ranges), -1 if not owned
+PS_HD int slot_index(const DevParams &P, int slot)
+{
+    int off = 0;
+    for (int t = 0; t < 4; t++) {
+        const int d = slot - P.slot_lo[t];
+        if (d >= 0 && d < P.slot_n[t]) return off + d;
+        off += P.slot_n[t];
+    }
+    return -1;
+}
+
+// inverse: the slot stored at index idx (idx < slots_total)
+PS_HD int slot_of_index(const DevParams &P, int idx)
+{
+    for (int t = 0; t < 3; t++) {
+        if (idx < P.slot_n[t]) return P.slot_lo[t] + idx;
+        idx -= P.slot_n[t];
+    }
+    return P.slot_lo[3] + idx;
+}
+
+PS_HD bool owns_record(const DevParams &P, int rec)
+{
+    for (int t = 0; t < 4; t++) if (rec >= P.rec_lo[t] && rec < P.rec_hi[t]) return true;
+    return false;
+}
 
 // Per-frame scalars living in device memory (zeroed by init_iframe).
 struct FrameScalars {
@@ -55,11 +158,11 @@ struct FrameScalars {
     int32_t n_moves;        // relocation / birth records emitted  / 64-bit word (ops low)
     int32_t max_bucket;     // most queue operations any one segment received this step
     int32_t n_tasks;        // non-empty (cell, slice) tasks of the pair kernel this frame
-    int32_t shard_task_lo;  // first pair-kernel task (cell * slices) of this rank's share
-    int32_t shard_task_n;   // number of tasks from there that can hold a particle of the share
     int32_t n_tasks2;       // two-pass mode: (cell, 64-slice) tasks over the particles that need a force
     int32_t n_merged;       // ... and merged tasks (up to four cells' partly filled last slices in one wave)
-    int32_t shard_cell_lo, shard_cell_hi;   // cells that hold this rank's share of the sorted particles
+    int32_t n_out[2];       // slab mode: relocation / birth records leaving for the rank below [0] / above [1]
+    int32_t n_lent;         // slab mode: bodies in the lent-in region this frame
+    int32_t pad_i;
 };
 
 // Cumulative event counters, mirrors psamd_counters.  Kept in COUNTER_COPIES copies on
@@ -75,8 +178,12 @@ enum : int32_t {
     ERR_CELL_TOO_BIG = 1,   // a cell holds more ids than the sort kernel can rank
     ERR_BAD_ID = 2,         // uploaded P_DATA_TYPE with id != slot
     ERR_OPS_OVERFLOW = 4,   // lifecycle op buffer too small
-    ERR_SHARD_BOUND = 8,    // more sorted particles than world * share
     ERR_BAD_POS = 16,       // uploaded live particle outside the box (or cell out of range)
+    ERR_FOREIGN_CELL = 32,  // slab mode: a particle stored here sits in a layer this rank holds no state for
+    ERR_HALO_OVERFLOW = 64, // slab mode: a halo / force / relocation message had no room for what it must carry
+    ERR_SLAB_MISMATCH = 128,// slab mode: a message disagrees with the receiver's own counts
+    ERR_REMOTE_RECORD0 = 256,// slab mode: a cell-overflow kill on a rank that does not own queue record 0
+    ERR_CHUNK_CAP = 512,    // a chunk list passed MAX_PARTICLES_PER_CHUNK (the reference would skip its tail)
 };
 
 // A free-slot-queue operation produced by calc_forces is a (key, arg) pair kept in
@@ -87,10 +194,24 @@ enum : int32_t {
 // A particle that needs a new slot (segment change) or a child to be born.
 struct MoveRec {
     int32_t src;            // slot of the particle (parent for births)
-    int32_t dst;            // filled in by the queue replay: new slot or -1
-    int32_t kind;           // 0 relocation, 1 birth
+    int32_t dst;            // filled in by the queue replay: new slot or -1 (MOVE_OUT: index in the outbox)
+    int32_t kind;           // low byte: 0 relocation, 1 birth; flags below
     int32_t new_cell;
 };
+constexpr int MOVE_PARENT = 0x100;   // the relocating particle has is_parent set
+constexpr int MOVE_IN = 0x200;       // arrived from a neighbour rank: state already in the staging area, no local source
+constexpr int MOVE_OUT = 0x400;      // leaves for a neighbour rank (whose queue hands out the slot); | MOVE_UP: the rank above
+constexpr int MOVE_UP = 0x800;
+
+// One particle on its way to a segment another rank owns (relocation or birth): the queue
+// operation's key in the reference's serial order, and the state to place.  64 bytes.
+struct XferRec {
+    uint64_t key;           // record | chunk + 1 | source slot | sub-step, as in the op lists
+    int32_t new_cell;       // global cell
+    int32_t kind;           // 0 relocation (| MOVE_PARENT), 1 birth
+    float pos[4], vel[4], acc[4];   // relocation: the particle; birth: the parent's position and velocity
+};
+constexpr int MSG_HEADER_WORDS = 16;   // every message starts with 16 ints: [0] count, [1] bodies, [2] error bits
 
 constexpr int SORT_MAX = 4096;   // ids one cell may hold for the in-LDS ranking
 constexpr int REPLAY_CHUNK = 2048;   // queue ops staged through LDS at a time

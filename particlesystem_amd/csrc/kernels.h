@@ -43,7 +43,6 @@ struct DeviceState {
     int *pair_flag = nullptr;     // [container] sorted order: 0 needs a force, -1 kid (moves, no force), 1 survives, 2 dies
     int *active_list = nullptr;   // [container] per cell (at cell_start[c]): sorted indices of the particles that need a force
     int *active_count = nullptr;  // [num_cells]
-    int *task_start2 = nullptr;   // [num_cells + 1] prefix of 64-slices of the active lists
     int *task_list2 = nullptr;    // [num_cells * slices]
     int4 *merged_tasks = nullptr; // [num_cells] cells whose leftover slices share one wave (-1: unused)
     // the merged tasks run beside k_pairs on a stream of their own (fork / join by events)
@@ -68,14 +67,15 @@ struct DeviceState {
     MoveRec *moves = nullptr;
     int moves_cap = 0;
     float4 *stage = nullptr;      // 3 float4 per move
+    XferRec *xfer_out[2] = {nullptr, nullptr};   // slab mode: records leaving for the rank below / above (inside the messages)
     DevCounters *ctr = nullptr;
     unsigned long long *trace = nullptr;  // 3 words per pair-kernel wave slot (diagnostic builds only)
 };
 
-hipError_t launch_unpack_aos(hipStream_t st, const void *aos, int first, int count, int num_cells, float half_box,
+hipError_t launch_unpack_aos(hipStream_t st, const DevParams &P, const void *aos, int first, int count, float half_box,
                              const DeviceState &d);
-hipError_t launch_pack_aos(hipStream_t st, void *aos, int first, int count, int num_cells, const DeviceState &d);
-hipError_t launch_place(hipStream_t st, int n, const int *ids, const float4 *p, const float4 *v, const float4 *a,
+hipError_t launch_pack_aos(hipStream_t st, const DevParams &P, void *aos, int first, int count, const DeviceState &d);
+hipError_t launch_place(hipStream_t st, const DevParams &P, int n, const int *ids, const float4 *p, const float4 *v, const float4 *a,
                         const int *cells, const DeviceState &d);
 hipError_t launch_fill_int(hipStream_t st, int *p, int v, size_t n);
 hipError_t launch_restore(hipStream_t st, int n, const void *s_pos, const void *s_vel, const void *s_acc,
@@ -83,14 +83,11 @@ hipError_t launch_restore(hipStream_t st, int n, const void *s_pos, const void *
 hipError_t launch_validate_eps(hipStream_t st, uint32_t lo_bits, uint32_t hi_bits, double eps2, float eps2f,
                                unsigned long long *out);
 hipError_t launch_selftest_math(hipStream_t st, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out24);
-hipError_t launch_init_tdata(hipStream_t st, const DeviceState &d, int n);
+hipError_t launch_init_tdata(hipStream_t st, const DevParams &P, const DeviceState &d);
 // ev (optional) = 5 events recorded before hist, scan, scatter, sort and after sort
 hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev);
-// lo/hi: this rank's sorted range; covered = world * share (all ranks' ranges together)
-hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi, int covered,
-                        bool sharded, hipEvent_t ev_force);
-hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step,
-                        int live_bound);
+hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force);
+hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step);
 // after apply, before the per-step read-back: ops per queue record, their prefix and maximum
 hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints);
 hipError_t launch_ops_census(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec);
@@ -99,6 +96,14 @@ hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceStat
                             int64_t live_bound);
 hipError_t launch_lifecycle_sorted(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
                                    int n_ops, int n_moves);
+// slab exchange (messages are int arrays with a 16-word header, see kernels.hip)
+hipError_t launch_pack_halo(hipStream_t st, const DevParams &P, const DeviceState &d, int c0, int ncell, int *msg, int *pack_off);
+hipError_t launch_unpack_halo(hipStream_t st, const DevParams &P, const DeviceState &d, int r0, int r1, int ncell, int split,
+                              bool lent, const int *msg, int *unpack_off);
+hipError_t launch_pack_force(hipStream_t st, const DevParams &P, const DeviceState &d, int *msg, int cap_bodies);
+hipError_t launch_unpack_force(hipStream_t st, const DevParams &P, const DeviceState &d, int j0, const int *msg, const int *pack_off);
+hipError_t launch_outbox_close(hipStream_t st, const DevParams &P, const DeviceState &d, int64_t live_bound, int *msg_down, int *msg_up);
+hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *msg);
 // lifecycle_sort.hip (rocPRIM radix sort of the op keys; library code, not a hot path)
 hipError_t sort_ops_tmp_bytes(size_t n, int key_bits, size_t *bytes);
 hipError_t sort_ops(hipStream_t st, const DeviceState &d, int n, int key_bits);

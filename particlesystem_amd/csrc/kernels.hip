@@ -68,7 +68,7 @@ __device__ __forceinline__ int wave_incl_scan(int v)
 // ------------------------------------------------------------------ AoS <-> SoA
 // P_DATA_TYPE is 18 dwords (common.h:94-120): id cell chunk seg_type seg_tid
 // {seg_fault,is_parent,pad,pad} w age fert x y z vx vy vz ax ay az.
-__global__ void k_unpack_aos(const uint32_t *__restrict__ aos, int first, int count, int num_cells, float half_box,
+__global__ void k_unpack_aos(DevParams P, const uint32_t *__restrict__ aos, int first, int count, float half_box,
                              float4 *pos4, float4 *vel4, float4 *acc4, int *cell, uint8_t *pflags,
                              FrameScalars *fs)
 {
@@ -77,21 +77,24 @@ __global__ void k_unpack_aos(const uint32_t *__restrict__ aos, int first, int co
     const uint32_t *r = aos + (size_t)18 * i;
     const int slot = first + i;
     if ((int)r[0] != slot) atomicOr(&fs->error, ERR_BAD_ID);
+    const int si = slot_index(P, slot);
+    if (si < 0) return;                 // a slot another rank owns: its record is that rank's business
     // a live particle sits inside the box (set_pos_t wraps every position, app.cu:117-158);
     // the pair arithmetic is validated for in-box distances only
     if ((int)r[1] >= 0) {
         const float x = __uint_as_float(r[9]), y = __uint_as_float(r[10]), z = __uint_as_float(r[11]);
-        if ((int)r[1] >= num_cells || !(fabsf(x) <= half_box) || !(fabsf(y) <= half_box) || !(fabsf(z) <= half_box))
+        if ((int)r[1] >= P.num_cells_global || !(fabsf(x) <= half_box) || !(fabsf(y) <= half_box) || !(fabsf(z) <= half_box))
             atomicOr(&fs->error, ERR_BAD_POS);
     }
-    cell[slot] = (int)r[1];
-    pflags[slot] = ((r[5] >> 8) & 0xffu) ? 1 : 0;
-    pos4[slot] = make_float4(__uint_as_float(r[9]), __uint_as_float(r[10]), __uint_as_float(r[11]), __uint_as_float(r[6]));
-    vel4[slot] = make_float4(__uint_as_float(r[12]), __uint_as_float(r[13]), __uint_as_float(r[14]), __uint_as_float(r[7]));
-    acc4[slot] = make_float4(__uint_as_float(r[15]), __uint_as_float(r[16]), __uint_as_float(r[17]), __uint_as_float(r[8]));
+    cell[si] = (int)r[1];
+    pflags[si] = ((r[5] >> 8) & 0xffu) ? 1 : 0;
+    pos4[si] = make_float4(__uint_as_float(r[9]), __uint_as_float(r[10]), __uint_as_float(r[11]), __uint_as_float(r[6]));
+    vel4[si] = make_float4(__uint_as_float(r[12]), __uint_as_float(r[13]), __uint_as_float(r[14]), __uint_as_float(r[7]));
+    acc4[si] = make_float4(__uint_as_float(r[15]), __uint_as_float(r[16]), __uint_as_float(r[17]), __uint_as_float(r[8]));
 }
 
-__global__ void k_pack_aos(uint32_t *__restrict__ aos, int first, int count, int num_cells,
+// slots this rank does not own come out as free records (reset_particle, app.cu:239-256)
+__global__ void k_pack_aos(DevParams P, uint32_t *__restrict__ aos, int first, int count,
                            const float4 *pos4, const float4 *vel4, const float4 *acc4, const int *cell,
                            const uint8_t *pflags, const CellInfo *celltab)
 {
@@ -99,13 +102,15 @@ __global__ void k_pack_aos(uint32_t *__restrict__ aos, int first, int count, int
     if (i >= count) return;
     uint32_t *r = aos + (size_t)18 * i;
     const int slot = first + i;
-    const int c = cell[slot];
+    const int si = slot_index(P, slot);
+    const int c = si >= 0 ? cell[si] : -1;
     CellInfo ci = {-1, -1, -1, 0};
-    if (c >= 0 && c < num_cells) ci = celltab[c];
-    const float4 p = pos4[slot], v = vel4[slot], a = acc4[slot];
+    if (c >= 0 && c < P.num_cells_global) ci = celltab[c];
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 p = si >= 0 ? pos4[si] : zero, v = si >= 0 ? vel4[si] : zero, a = si >= 0 ? acc4[si] : zero;
     r[0] = (uint32_t)slot; r[1] = (uint32_t)c; r[2] = (uint32_t)ci.chunk;
     r[3] = (uint32_t)ci.seg_type; r[4] = (uint32_t)ci.seg_tid;
-    r[5] = pflags[slot] ? 0x100u : 0u;  // seg_fault is never set between stages
+    r[5] = (si >= 0 && pflags[si]) ? 0x100u : 0u;  // seg_fault is never set between stages
     r[6] = __float_as_uint(p.w); r[7] = __float_as_uint(v.w); r[8] = __float_as_uint(a.w);
     r[9] = __float_as_uint(p.x); r[10] = __float_as_uint(p.y); r[11] = __float_as_uint(p.z);
     r[12] = __float_as_uint(v.x); r[13] = __float_as_uint(v.y); r[14] = __float_as_uint(v.z);
@@ -113,16 +118,17 @@ __global__ void k_pack_aos(uint32_t *__restrict__ aos, int first, int count, int
 }
 
 // fill stage: drop freshly created particles into the slots the host dequeued
-__global__ void k_place(int n, const int *__restrict__ ids, const float4 *__restrict__ p,
+__global__ void k_place(DevParams P, int n, const int *__restrict__ ids, const float4 *__restrict__ p,
                         const float4 *__restrict__ v, const float4 *__restrict__ a,
                         const int *__restrict__ cells, float4 *pos4, float4 *vel4, float4 *acc4,
                         int *cell, uint8_t *pflags)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int slot = ids[i];
-    pos4[slot] = p[i]; vel4[slot] = v[i]; acc4[slot] = a[i];
-    cell[slot] = cells[i]; pflags[slot] = 0;
+    const int si = slot_index(P, ids[i]);
+    if (si < 0) return;
+    pos4[si] = p[i]; vel4[si] = v[i]; acc4[si] = a[i];
+    cell[si] = cells[i]; pflags[si] = 0;
 }
 
 // snapshot_restore: a slot that is free both now and in the snapshot holds the same
@@ -156,82 +162,96 @@ __global__ void k_fill_int(int *p, int v, size_t n)
     for (; i < n; i += stride) p[i] = v;
 }
 
-__global__ void k_init_tdata(uint32_t *tdata, int n)
+__global__ void k_init_tdata(DevParams P, uint32_t *tdata)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= P.slots_total) return;
     uint32_t *r = tdata + (size_t)6 * i;  // T_DATA_TYPE: id x y z w age (ps.cpp:743-748)
-    r[0] = (uint32_t)i; r[1] = r[2] = r[3] = r[4] = r[5] = 0u;
+    r[0] = (uint32_t)slot_of_index(P, i); r[1] = r[2] = r[3] = r[4] = r[5] = 0u;
 }
 
 // ------------------------------------------------------------------ grid build
-// ps.cpp:1491: a slot takes part when 0 <= cell < NUM_CELLS.
-__global__ void k_hist(const int *__restrict__ cell, int *__restrict__ cell_count, int container, int num_cells)
+// ps.cpp:1491: a slot takes part when 0 <= cell < NUM_CELLS.  A rank walks the slots it owns
+// (storage index order = slot order); their particles sit in the cell layers of region 0 by
+// construction (a particle that leaves them is handed to the rank that owns its new segment).
+__device__ __forceinline__ int own_local_cell(const DevParams &P, int gc, FrameScalars *fs)
+{
+    if (gc < 0 || gc >= P.num_cells_global) return -1;
+    const int lc = gc - P.reg_first[0] * P.G * P.G;
+    if (lc < 0 || lc >= P.n_own_cells) { atomicOr(&fs->error, ERR_FOREIGN_CELL); return -1; }
+    return lc;
+}
+
+__global__ void k_hist(DevParams P, const int *__restrict__ cell, int *__restrict__ cell_count, FrameScalars *fs)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = gridDim.x * blockDim.x;
-    for (; i < container; i += stride) {
-        const int c = cell[i];
-        if (c >= 0 && c < num_cells) atomicAdd(&cell_count[c], 1);
+    for (; i < P.slots_total; i += stride) {
+        const int c = own_local_cell(P, cell[i], fs);
+        if (c >= 0) atomicAdd(&cell_count[c], 1);
     }
 }
 
-// Same two kernels with a workgroup-private histogram in LDS (grids of <= LDS_CELLS
+// Same two kernels with a workgroup-private histogram in LDS (at most LDS_CELLS own
 // cells): a workgroup owns SLOTS_PER_WG consecutive slots, which by the container's
 // construction belong to one or two segments, i.e. a handful of cells, so almost all
 // atomics stay in LDS and only the touched bins go to memory.
 constexpr int LDS_CELLS = 8192;
 constexpr int SLOTS_PER_WG = 4096;
 
-__global__ __launch_bounds__(1024) void k_hist_lds(const int *__restrict__ cell, int *__restrict__ cell_count,
-                                                    int container, int num_cells)
+__global__ __launch_bounds__(1024) void k_hist_lds(DevParams P, const int *__restrict__ cell, int *__restrict__ cell_count,
+                                                    FrameScalars *fs)
 {
     __shared__ int h[LDS_CELLS];
-    const int tid = threadIdx.x, base = blockIdx.x * SLOTS_PER_WG;
-    for (int c = tid; c < num_cells; c += 1024) h[c] = 0;
+    const int tid = threadIdx.x, base = blockIdx.x * SLOTS_PER_WG, ncell = P.n_own_cells;
+    for (int c = tid; c < ncell; c += 1024) h[c] = 0;
     __syncthreads();
     for (int i = tid; i < SLOTS_PER_WG; i += 1024) {
-        const int slot = base + i;
-        if (slot < container) {
-            const int c = cell[slot];
-            if (c >= 0 && c < num_cells) atomicAdd(&h[c], 1);
+        const int si = base + i;
+        if (si < P.slots_total) {
+            const int c = own_local_cell(P, cell[si], fs);
+            if (c >= 0) atomicAdd(&h[c], 1);
         }
     }
     __syncthreads();
-    for (int c = tid; c < num_cells; c += 1024) {
+    for (int c = tid; c < ncell; c += 1024) {
         const int v = h[c];
         if (v) atomicAdd(&cell_count[c], v);
     }
 }
 
-__global__ __launch_bounds__(1024) void k_scatter_lds(const int *__restrict__ cell, int *__restrict__ cursor,
-                                                       int *__restrict__ sorted_id, int container, int num_cells)
+__global__ __launch_bounds__(1024) void k_scatter_lds(DevParams P, const int *__restrict__ cell, int *__restrict__ cursor,
+                                                       int *__restrict__ sorted_id)
 {
     __shared__ int h[LDS_CELLS];
-    const int tid = threadIdx.x, base = blockIdx.x * SLOTS_PER_WG;
-    for (int c = tid; c < num_cells; c += 1024) h[c] = 0;
+    const int tid = threadIdx.x, base = blockIdx.x * SLOTS_PER_WG, ncell = P.n_own_cells;
+    for (int c = tid; c < ncell; c += 1024) h[c] = 0;
     __syncthreads();
     int mine[SLOTS_PER_WG / 1024];
 #pragma unroll
     for (int i = 0; i < SLOTS_PER_WG / 1024; i++) {
-        const int slot = base + i * 1024 + tid;
+        const int si = base + i * 1024 + tid;
         int c = -1;
-        if (slot < container) { c = cell[slot]; if (c < 0 || c >= num_cells) c = -1; }
+        if (si < P.slots_total) {
+            c = cell[si];
+            c = (c < 0 || c >= P.num_cells_global) ? -1 : c - P.reg_first[0] * P.G * P.G;
+            if (c < 0 || c >= ncell) c = -1;          // foreign cells were flagged by the histogram pass
+        }
         mine[i] = c;
         if (c >= 0) atomicAdd(&h[c], 1);
     }
     __syncthreads();
-    for (int c = tid; c < num_cells; c += 1024) {      // reserve this workgroup's run in each touched cell
+    for (int c = tid; c < ncell; c += 1024) {      // reserve this workgroup's run in each touched cell
         const int v = h[c];
         if (v) h[c] = atomicAdd(&cursor[c], v);
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < SLOTS_PER_WG / 1024; i++)
-        if (mine[i] >= 0) sorted_id[atomicAdd(&h[mine[i]], 1)] = base + i * 1024 + tid;
+        if (mine[i] >= 0) sorted_id[atomicAdd(&h[mine[i]], 1)] = slot_of_index(P, base + i * 1024 + tid);
 }
 
-// One workgroup: exclusive prefix of the cell counts, the scatter cursors, the chunk
+// One workgroup: exclusive prefix of the own cells' counts, the scatter cursors, the chunk
 // totals and hostGridMax (ps.cpp:1504-1516: maxima are of stored entries, so capped).
 __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restrict__ cell_count,
                                                 int *__restrict__ cell_start, int *__restrict__ cursor,
@@ -239,28 +259,33 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
                                                 const CellInfo *__restrict__ celltab, FrameScalars *fs)
 {
     // Two prefix sums at once, packed in 64 bits: particles per cell (low word) and
-    // 64-particle pair-kernel tasks per cell (high word).  Each thread owns a contiguous run
-    // of cells, so the whole scan needs one pass and two barriers.
+    // 64-particle pair-kernel tasks per cell (high word; only the cells this rank computes).
+    // Each thread owns a contiguous run of cells, so the whole scan needs one pass and two barriers.
     constexpr int LDS_CHUNKS = 4096;
     __shared__ long long wave_tot[16];
     __shared__ int maxcell_s;
     __shared__ int chunk_s[LDS_CHUNKS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool chunks_in_lds = P.num_chunks <= LDS_CHUNKS;
+    const int ncell = P.n_own_cells, cell_off = P.reg_first[0] * P.G * P.G;
     if (tid == 0) maxcell_s = 0;
     if (chunks_in_lds) for (int ch = tid; ch < P.num_chunks; ch += 1024) chunk_s[ch] = 0;
     __syncthreads();
-    const int per = (P.num_cells + 1023) / 1024;
-    const int c0 = min(P.num_cells, tid * per), c1 = min(P.num_cells, c0 + per);
+    const int per = (ncell + 1023) / 1024;
+    const int c0 = min(ncell, tid * per), c1 = min(ncell, c0 + per);
+    auto word = [&](int c, int v) {
+        const bool computed = c >= P.comp_b0 && c < P.comp_b1;
+        return ((long long)(computed ? (min(v, P.max_per_cell) + 63) >> 6 : 0) << 32) | (long long)v;
+    };
     long long mine = 0;
     int mymax = 0;
     for (int c = c0; c < c1; c++) {
         const int v = cell_count[c];
         mymax = max(mymax, min(v, P.max_per_cell));
-        mine += ((long long)((min(v, P.max_per_cell) + 63) >> 6) << 32) | (long long)v;
+        mine += word(c, v);
         if (v > 0) {
-            if (chunks_in_lds) atomicAdd(&chunk_s[celltab[c].chunk], v);
-            else atomicAdd(&chunk_count[celltab[c].chunk], v);
+            if (chunks_in_lds) atomicAdd(&chunk_s[celltab[c + cell_off].chunk], v);
+            else atomicAdd(&chunk_count[celltab[c + cell_off].chunk], v);
         }
     }
     long long incl = mine;
@@ -279,59 +304,65 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
         cell_start[c] = excl;
         cursor[c] = excl;
         task_start[c] = (int)(run >> 32);
-        run += ((long long)((min(v, P.max_per_cell) + 63) >> 6) << 32) | (long long)v;
+        run += word(c, v);
     }
     if (tid == 0) {
-        cell_start[P.num_cells] = (int)(total & 0xffffffffll);
-        task_start[P.num_cells] = (int)(total >> 32);
+        cell_start[ncell] = (int)(total & 0xffffffffll);     // the gap cell after region 0: end of the own bodies
+        task_start[ncell] = (int)(total >> 32);
         fs->live = (int)(total & 0xffffffffll);
         fs->n_tasks = (int)(total >> 32);
         fs->gridmax[1] = maxcell_s;
     }
     // chunk totals: complete after the barrier above (every thread added its cells before it)
     int cm = 0;
+    bool over = false;
     if (chunks_in_lds) {
         for (int ch = tid; ch < P.num_chunks; ch += 1024) {
             const int v = chunk_s[ch];
             chunk_count[ch] = v;
+            over |= v > P.max_per_chunk;
             cm = max(cm, min(v, P.max_per_chunk));
         }
     } else {
         __threadfence();
         __syncthreads();
-        for (int ch = tid; ch < P.num_chunks; ch += 1024) cm = max(cm, min(chunk_count[ch], P.max_per_chunk));
+        for (int ch = tid; ch < P.num_chunks; ch += 1024) { const int v = chunk_count[ch]; over |= v > P.max_per_chunk; cm = max(cm, min(v, P.max_per_chunk)); }
     }
     if (cm > 0) atomicMax(&fs->gridmax[0], cm);
+    // The reference stores only MAX_PARTICLES_PER_CHUNK ids per chunk and calc_forces walks the
+    // stored list (ps.cpp:1502-1508): past that (only possible while cells overflow, the count
+    // includes the killed) its tail would be skipped.  Not reproduced: refuse loudly instead.
+    if (over) atomicOr(&fs->error, ERR_CHUNK_CAP);
 }
 
-__global__ void k_scatter(const int *__restrict__ cell, int *__restrict__ cursor, int *__restrict__ sorted_id,
-                          int container, int num_cells)
+__global__ void k_scatter(DevParams P, const int *__restrict__ cell, int *__restrict__ cursor, int *__restrict__ sorted_id)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = gridDim.x * blockDim.x;
-    for (; i < container; i += stride) {
-        const int c = cell[i];
-        if (c >= 0 && c < num_cells) sorted_id[atomicAdd(&cursor[c], 1)] = i;
+    for (; i < P.slots_total; i += stride) {
+        int c = cell[i];
+        c = (c < 0 || c >= P.num_cells_global) ? -1 : c - P.reg_first[0] * P.G * P.G;
+        if (c >= 0 && c < P.n_own_cells) sorted_id[atomicAdd(&cursor[c], 1)] = slot_of_index(P, i);
     }
 }
 
-// the pair kernel's work list: one entry per non-empty (cell, 64-particle slice)
+// the pair kernel's work list: one entry per non-empty (cell, 64-particle slice) of the own
+// computed cells (the lent ones are appended when their snapshot has arrived, k_remote_cells)
 __global__ void k_build_tasks(DevParams P, const int *__restrict__ task_start, int *__restrict__ task_list)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= P.num_cells) return;
+    const int c = P.comp_b0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.comp_b1) return;
     const int t0 = task_start[c], n = task_start[c + 1] - t0;
     for (int s = 0; s < n; s++) task_list[t0 + s] = c * P.slices + s;
 }
 
 // Halo bookkeeping of the two-pass pair stage.  Cell axes: i2 ~ +x, i1 ~ -y, i3 ~ -z
 // (set_pos_t, app.cu:117-158).  halo_dirs packs, two bits per axis (i2, i1, i3), whether a
-// body lies within P.halo_reach of the low (1) or high (2) face of cell c on that axis; an
-// axis whose neighbour would be outside the grid reports 0 (the stencil is not periodic).
-__device__ __forceinline__ int halo_dirs(const DevParams &P, int c, float x, float y, float z)
+// body lies within P.halo_reach of the low (1) or high (2) face of cell (i1, i2, i3) on that
+// axis; an axis whose neighbour would be outside the grid reports 0 (the stencil is not periodic).
+__device__ __forceinline__ int halo_dirs(const DevParams &P, int i1, int i2, int i3, float x, float y, float z)
 {
     const int G = P.G;
-    const int i3 = c / (G * G), rem = c - i3 * G * G, i1 = rem / G, i2 = rem - i1 * G;
     const float cs = (float)P.cell_size, half = (float)(G / 2), reach = P.halo_reach;
     const float u2 = (x / cs + half - (float)i2) * cs, u1 = (-y / cs + half - (float)i1) * cs,
                 u3 = (-z / cs + half - (float)i3) * cs;                         // offsets inside the cell, [0, cs)
@@ -355,14 +386,75 @@ __device__ __forceinline__ int halo_dir_of_subset(int dirs, int m)
     return (d3 + 1) * 9 + (d1 + 1) * 3 + (d2 + 1);
 }
 
-__device__ __forceinline__ int halo_neighbour(const DevParams &P, int c, int dir)
+// local index of the neighbour in direction `dir`, -1 if this rank does not hold it
+__device__ __forceinline__ int halo_neighbour(const DevParams &P, int i1, int i2, int i3, int dir)
 {
-    const int G = P.G;
     const int d3 = dir / 9 - 1, d1 = (dir / 3) % 3 - 1, d2 = dir % 3 - 1;
-    return c + d3 * G * G + d1 * G + d2;
+    return local_cell(P, i3 + d3, i1 + d1, i2 + d2);
 }
 
-// One workgroup per cell.  The scatter left the cell's ids in arrival order; the
+// Collision candidates of the neighbour cells (k_collide): a body within HALO_REACH of a
+// face, edge or corner of its cell is listed in the halo of the cell(s) beyond it.  Two
+// bodies in different cells can only collide (distance <= COLLISION_RADIUS < HALO_REACH) if
+// each is in the other's halo.  Called by all threads of a workgroup for one cell whose `kept`
+// bodies start at sorted index `start` (snap4 / snap_cid / sorted_id already written): count the
+// cell's contributions per direction, reserve the room with one global atomic per direction,
+// then write the bodies.  s_halo / s_halo_base: 27 ints of LDS each.
+__device__ __forceinline__ void list_in_neighbour_halos(const DevParams &P, int lc, int start, int kept,
+                                                        const float4 *__restrict__ snap4, const int *__restrict__ snap_cid,
+                                                        int *__restrict__ halo_count, float *__restrict__ halo_f,
+                                                        int *__restrict__ halo_id, int *s_halo, int *s_halo_base,
+                                                        bool counted)
+{
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    int i1, i2, i3;
+    cell_coords(P, lc, i1, i2, i3);
+    if (!counted) {                      // else the caller counted while it had the bodies in hand
+        if (tid < 27) s_halo[tid] = 0;
+        __syncthreads();
+        for (int e = tid; e < kept; e += nthr) {
+            if (snap_cid[start + e] < 0) continue;
+            const float4 q = snap4[start + e];
+            const int m3 = halo_dirs(P, i1, i2, i3, q.x, q.y, q.z);
+            if (!m3) continue;
+            for (int m = 1; m < 8; m++) {
+                const int dir = halo_dir_of_subset(m3, m);
+                if (dir >= 0) atomicAdd(&s_halo[dir], 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 27) {
+        int base = -1;
+        const int cnt = s_halo[tid];
+        if (cnt > 0) {
+            const int nc = halo_neighbour(P, i1, i2, i3, tid);
+            if (nc >= 0) base = atomicAdd(&halo_count[nc], cnt);
+        }
+        s_halo_base[tid] = base;
+        s_halo[tid] = 0;
+    }
+    __syncthreads();
+    for (int e = tid; e < kept; e += nthr) {
+        const int id = snap_cid[start + e];
+        if (id < 0) continue;
+        const float4 q = snap4[start + e];
+        const int m3 = halo_dirs(P, i1, i2, i3, q.x, q.y, q.z);
+        if (!m3) continue;
+        for (int m = 1; m < 8; m++) {
+            const int dir = halo_dir_of_subset(m3, m);
+            if (dir < 0 || s_halo_base[dir] < 0) continue;
+            const int k = s_halo_base[dir] + atomicAdd(&s_halo[dir], 1);
+            if (k < HALO_CAP) {
+                const size_t at = (size_t)halo_neighbour(P, i1, i2, i3, dir) * HALO_CAP + k, plane = (size_t)P.n_local_cells * HALO_CAP;
+                halo_f[at] = q.x; halo_f[plane + at] = q.y; halo_f[2 * plane + at] = q.z;
+                halo_id[at] = id;
+            }
+        }
+    }
+}
+
+// One workgroup per own cell.  The scatter left the cell's ids in arrival order; the
 // reference's list is in slot order (build_grid walks slots 0..CONTAINER_SIZE-1), so
 // rank each id among the cell's ids.  Then gather the snapshot the pair kernel reads
 // (T_DATA_TYPE role, ps.cpp:1495-1500) in that order: x,y,z and the mass, the mass
@@ -390,6 +482,8 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
     const int start = cell_start[c];
     int n = cell_start[c + 1] - start;
     if (n == 0) return;
+    int ci1, ci2, ci3;
+    cell_coords(P, c, ci1, ci2, ci3);
     if (n > SORT_MAX) {
         if (tid == 0) atomicOr(&fs->error, ERR_CELL_TOO_BIG);
         n = SORT_MAX;
@@ -412,83 +506,51 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
     }
     __syncthreads();
     for (int e = tid; e < n; e += 256) {
-        const int id = ordered[e];
-        const float4 p = pos4[id];
-        const float age = vel4[id].w;
+        const int id = ordered[e], si = slot_index(P, id);
+        const float4 p = pos4[si];
+        const float age = vel4[si].w;
         // the snapshot row is written before the overflow check, as in ps.cpp:1495-1500
-        uint32_t *t = tdata + (size_t)6 * id;
+        uint32_t *t = tdata + (size_t)6 * si;
         t[0] = (uint32_t)id; t[1] = __float_as_uint(p.x); t[2] = __float_as_uint(p.y);
         t[3] = __float_as_uint(p.z); t[4] = __float_as_uint(p.w); t[5] = __float_as_uint(age);
         if (e < P.max_per_cell) {
             sorted_id[start + e] = id;
-            rank_of_slot[id] = start + e;
-            snap4[start + e] = make_float4(p.x, p.y, p.z, (age < P.kid_thr) ? 0.0f : p.w);
+            rank_of_slot[si] = start + e;
+            const float w_eff = (age < P.kid_thr) ? 0.0f : p.w;
+            snap4[start + e] = make_float4(p.x, p.y, p.z, w_eff);
             {   // the same four values as separate arrays: what the pair kernel streams
-                const size_t cap = (size_t)P.container;
-                const float w_eff = (age < P.kid_thr) ? 0.0f : p.w;
+                const size_t cap = (size_t)P.sorted_cap;
                 snap_soa[start + e] = p.x; snap_soa[cap + start + e] = p.y;
                 snap_soa[2 * cap + start + e] = p.z; snap_soa[3 * cap + start + e] = w_eff;
             }
             snap_age[start + e] = age;
-            if (halo_count) {
-                // collision id: the slot id, or -1 for a body that can never collide (kid, over age)
-                const bool collides = !(age < P.kid_thr) && !(age > P.life_thr);
-                snap_cid[start + e] = collides ? id : -1;
-                const int m3 = collides ? halo_dirs(P, c, p.x, p.y, p.z) : 0;
-                if (m3) {
-                    for (int m = 1; m < 8; m++) {
-                        const int dir = halo_dir_of_subset(m3, m);
-                        if (dir >= 0) atomicAdd(&s_halo[dir], 1);
-                    }
+            // collision id: the slot id, or -1 for a body that can never collide (kid, over age)
+            const bool collides = !(age < P.kid_thr) && !(age > P.life_thr);
+            snap_cid[start + e] = collides ? id : -1;
+            const int m3 = (halo_count && collides) ? halo_dirs(P, ci1, ci2, ci3, p.x, p.y, p.z) : 0;
+            if (m3) {
+                for (int m = 1; m < 8; m++) {
+                    const int dir = halo_dir_of_subset(m3, m);
+                    if (dir >= 0) atomicAdd(&s_halo[dir], 1);
                 }
             }
         } else {
             sorted_id[start + e] = -1;
-            cell_arr[id] = -1; pflags[id] = 0;
-            pos4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
-            vel4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
-            acc4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+            cell_arr[si] = -1; pflags[si] = 0;
+            pos4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vel4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
+            acc4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
             atomicAdd(&(ctr + (blockIdx.x % COUNTER_COPIES))->cell_overflow_kills, 1ull);
             // freed with the already-reset segment (-1,-1): queue record 0 (ps.cpp:1523-1526)
+            if (!owns_record(P, 0)) atomicOr(&fs->error, ERR_REMOTE_RECORD0);
             const int k = atomicAdd(&fs->n_ops, 1);
             if (k < ops_cap) { op_keys[k] = ((uint64_t)(uint32_t)id << 2) | 2ull; op_args[k] = id; }
             else atomicOr(&fs->error, ERR_OPS_OVERFLOW);
         }
     }
     if (!halo_count) return;
-    // Collision candidates of the neighbour cells (k_collide): a body within HALO_REACH of a
-    // face, edge or corner of its cell is listed in the halo of the cell(s) beyond it.  Two
-    // bodies in different cells can only collide (distance <= COLLISION_RADIUS < HALO_REACH) if
-    // each is in the other's halo.  The loop above counted this cell's contributions per
-    // direction; one global atomic per direction reserves the room, then the bodies are
-    // written (positions re-read from the snapshot row just stored).
-    __syncthreads();
-    if (tid < 27) {
-        int base = 0;
-        const int cnt = s_halo[tid];
-        if (cnt > 0) base = atomicAdd(&halo_count[halo_neighbour(P, c, tid)], cnt);
-        s_halo_base[tid] = base;
-        s_halo[tid] = 0;
-    }
-    __syncthreads();
-    const int kept = min(n, P.max_per_cell);
-    for (int e = tid; e < kept; e += 256) {
-        if (snap_cid[start + e] < 0) continue;
-        const float4 q = snap4[start + e];
-        const int m3 = halo_dirs(P, c, q.x, q.y, q.z);
-        if (!m3) continue;
-        const int id = ordered[e];
-        for (int m = 1; m < 8; m++) {
-            const int dir = halo_dir_of_subset(m3, m);
-            if (dir < 0) continue;
-            const int k = s_halo_base[dir] + atomicAdd(&s_halo[dir], 1);
-            if (k < HALO_CAP) {
-                const size_t at = (size_t)halo_neighbour(P, c, dir) * HALO_CAP + k, plane = (size_t)P.num_cells * HALO_CAP;
-                halo_f[at] = q.x; halo_f[plane + at] = q.y; halo_f[2 * plane + at] = q.z;
-                halo_id[at] = id;
-            }
-        }
-    }
+    __syncthreads();                                     // the snapshot rows of this cell are in memory
+    list_in_neighbour_halos(P, c, start, min(n, P.max_per_cell), snap4, snap_cid, halo_count, halo_f, halo_id, s_halo, s_halo_base, true);
 }
 
 // ------------------------------------------------------------------ pair kernel
@@ -730,27 +792,6 @@ __device__ __forceinline__ void pair1_exact_lean(const DevParams &P, const PairC
     ax += rx * s; ay += ry * s; az += rz * s;
 }
 
-// Which entries of the task list can hold a particle with sorted index in [lo, hi)?  The
-// list is cell-major, so it is the run belonging to the cells between the cell of `lo` and
-// the cell of `hi - 1`.  One tiny launch per step on a sharded rank.
-__global__ void k_shard_tasks(DevParams P, const int *__restrict__ cell_start, const int *__restrict__ task_start,
-                              int lo, int hi, FrameScalars *fs)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int total = cell_start[P.num_cells];
-    lo = min(lo, total); hi = min(hi, total);
-    if (hi <= lo) { fs->shard_task_lo = 0; fs->shard_task_n = 0; fs->shard_cell_lo = 0; fs->shard_cell_hi = -1; return; }
-    auto cell_of = [&](int gi) {          // largest c with cell_start[c] <= gi
-        int a = 0, b = P.num_cells - 1;
-        while (a < b) { const int m = (a + b + 1) >> 1; if (cell_start[m] <= gi) a = m; else b = m - 1; }
-        return a;
-    };
-    const int c_lo = cell_of(lo), c_hi = cell_of(hi - 1);
-    fs->shard_task_lo = task_start[c_lo];
-    fs->shard_task_n = task_start[c_hi + 1] - task_start[c_lo];
-    fs->shard_cell_lo = c_lo; fs->shard_cell_hi = c_hi;
-}
-
 // ------------------------------------------------------------------ two-pass pair stage
 // The reference scans a particle's neighbours for collisions first and runs the force loop
 // only if there was none (ps.cpp:1182-1263): a particle that dies or "survives" a collision
@@ -822,16 +863,13 @@ __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restr
                                                  const int *__restrict__ task_list,
                                                  const int *__restrict__ halo_count, const float *__restrict__ halo_f,
                                                  const int *__restrict__ halo_id, int *__restrict__ flag_out,
-                                                 float4 *__restrict__ force4, const FrameScalars *__restrict__ fs,
-                                                 int sharded, int lo, int hi)
+                                                 float4 *__restrict__ force4, const FrameScalars *__restrict__ fs)
 {
     // (readfirstlane: the wave index is uniform but the compiler cannot know; with uniform
     // ranges the body loads below become scalar loads)
-    // a rank of a sharded run settles the flags of its own share only (the others arrive with
-    // the all-gather of force4)
     const int slot = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (slot >= (sharded ? fs->shard_task_n : fs->n_tasks)) return;
-    const int task = task_list[(sharded ? fs->shard_task_lo : 0) + slot];
+    if (slot >= fs->n_tasks) return;
+    const int task = task_list[slot];
     const int c = task / P.slices, slice = task - c * P.slices;
     const int base = __builtin_amdgcn_readfirstlane(cell_start[c]);
     const int cnt = __builtin_amdgcn_readfirstlane(min(cell_start[c + 1] - base, P.max_per_cell));
@@ -840,7 +878,7 @@ __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restr
     const int lane = threadIdx.x & 63;
     const bool valid = lane < cnt - first;
     const int gi = base + first + (valid ? lane : 0);
-    const size_t cap = (size_t)P.container;
+    const size_t cap = (size_t)P.sorted_cap;
     const float xi = snap_soa[gi], yi = snap_soa[cap + gi], zi = snap_soa[2 * cap + gi];
     const float age_i = snap_age[gi];
     const int id_i = sorted_id[gi];
@@ -852,17 +890,17 @@ __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restr
                  snap_cid + base, cnt, met_higher, met_lower);
     const int nh = __builtin_amdgcn_readfirstlane(halo_count[c]);
     if (nh <= HALO_CAP) {
-        const size_t at = (size_t)c * HALO_CAP, plane = (size_t)P.num_cells * HALO_CAP;
+        const size_t at = (size_t)c * HALO_CAP, plane = (size_t)P.n_local_cells * HALO_CAP;
         collide_scan(P, xi, yi, zi, id_i, scan, halo_f + at, halo_f + plane + at, halo_f + 2 * plane + at, halo_id + at, nh,
                      met_higher, met_lower);
     } else {
         // the halo list overflowed (denser than the container admits in steady state): whole stencil
-        const int G = P.G;
-        const int i3 = c / (G * G), rem = c - i3 * G * G, i1 = rem / G, i2 = rem - i1 * G;
+        int i1, i2, i3;
+        cell_coords(P, c, i1, i2, i3);
         for (int k = 1; k < 27; k++) {
-            const int n2 = i2 + c_stencil[k][0], n1 = i1 + c_stencil[k][1], n3 = i3 + c_stencil[k][2];
-            if (n1 < 0 || n1 >= G || n2 < 0 || n2 >= G || n3 < 0 || n3 >= G) continue;
-            const int nc = n3 * G * G + n1 * G + n2, nb = __builtin_amdgcn_readfirstlane(cell_start[nc]);
+            const int nc = __builtin_amdgcn_readfirstlane(local_cell(P, i3 + c_stencil[k][2], i1 + c_stencil[k][1], i2 + c_stencil[k][0]));
+            if (nc < 0) continue;
+            const int nb = __builtin_amdgcn_readfirstlane(cell_start[nc]);
             const int n = __builtin_amdgcn_readfirstlane(min(cell_start[nc + 1] - nb, P.max_per_cell));
             collide_scan(P, xi, yi, zi, id_i, scan, snap_soa + nb, snap_soa + cap + nb, snap_soa + 2 * cap + nb, snap_cid + nb, n,
                          met_higher, met_lower);
@@ -870,32 +908,27 @@ __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restr
     }
     int flag = met_higher ? 2 : met_lower ? 1 : 0;
     if (dead) flag = 2;                                          // ps.cpp:1183
-    if (valid && gi >= lo && gi < hi) {
+    if (valid) {
         flag_out[gi] = (flag == 0 && kid) ? -1 : flag;           // -1: moves, but every force term is skipped
         force4[gi] = make_float4(0.f, 0.f, 0.f, __int_as_float(flag));   // final unless the force pass overwrites it
     }
 }
 
-// One workgroup per cell: the sorted indices of the particles the force pass has to visit
-// (flag 0 and not a kid), packed at active_list[cell_start[c] ...], and their number.
+// One workgroup per computed cell: the sorted indices of the particles the force pass has to
+// visit (flag 0 and not a kid), packed at active_list[cell_start[c] ...], and their number.
 __global__ __launch_bounds__(256) void k_build_active(DevParams P, const int *__restrict__ cell_start,
                                                       const int *__restrict__ flag_in, int *__restrict__ active_list,
-                                                      int *__restrict__ active_count, const FrameScalars *__restrict__ fs,
-                                                      int sharded, int lo, int hi)
+                                                      int *__restrict__ active_count)
 {
     __shared__ int s_n;
-    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    if (sharded && (c < fs->shard_cell_lo || c > fs->shard_cell_hi)) {       // another rank's cells
-        if (tid == 0) active_count[c] = 0;
-        return;
-    }
+    const int c = comp_cell(P, blockIdx.x), tid = threadIdx.x, lane = tid & 63;
     const int base = cell_start[c];
     const int cnt = min(cell_start[c + 1] - base, P.max_per_cell);
     if (tid == 0) s_n = 0;
     __syncthreads();
     for (int e0 = 0; e0 < cnt; e0 += 256) {
         const int e = e0 + tid;
-        const bool on = e < cnt && base + e >= lo && base + e < hi && flag_in[base + e] == 0;
+        const bool on = e < cnt && flag_in[base + e] == 0;
         const unsigned long long m = __ballot(on);
         int wbase = 0;
         if (lane == 0 && m) wbase = atomicAdd(&s_n, __popcll(m));
@@ -906,27 +939,30 @@ __global__ __launch_bounds__(256) void k_build_active(DevParams P, const int *__
     if (tid == 0) active_count[c] = s_n;
 }
 
-// One workgroup: prefix of the active lists' 64-slices over the cells and the task list of
+// One workgroup: prefix of the active lists' 64-slices over the computed cells (the lent ones
+// first: their results travel back to the rank that owns them) and the task list of
 // the force pass.  With `merge`, only full slices become ordinary tasks; the leftovers (a cell's
 // last, partly filled slice: 20 of 64 lanes on average once the collided particles are gone)
 // are packed, up to four cells to a wave, into the merged tasks of k_pairs_merged.
 __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *__restrict__ active_count,
-                                                       int *__restrict__ task_start2, int *__restrict__ task_list2,
-                                                       int4 *__restrict__ merged_tasks, FrameScalars *fs, int sharded,
+                                                       int *__restrict__ task_list2,
+                                                       int4 *__restrict__ merged_tasks, FrameScalars *fs,
                                                        int merge)
 {
     __shared__ long long wave_tot[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int per = (P.num_cells + 1023) / 1024;
-    const int c0 = min(P.num_cells, tid * per), c1 = min(P.num_cells, c0 + per);
+    const int ncomp = comp_count(P);
+    const int per = (ncomp + 1023) / 1024;
+    const int c0 = min(ncomp, tid * per), c1 = min(ncomp, c0 + per);
     // the first 256 threads each pack the leftovers of a longer run of cells greedily, in
     // cell order (longer runs leave fewer half-empty packs at their ends)
-    const int pper = (P.num_cells + 255) / 256;
-    const int p0 = tid < 256 ? min(P.num_cells, tid * pper) : 0, p1 = tid < 256 ? min(P.num_cells, p0 + pper) : 0;
+    const int pper = (ncomp + 255) / 256;
+    const int p0 = tid < 256 ? min(ncomp, tid * pper) : 0, p1 = tid < 256 ? min(ncomp, p0 + pper) : 0;
     auto pack = [&](int4 *out) -> int {
         int npack = 0, used = 0, ng = 0;
         int4 cur = make_int4(-1, -1, -1, -1);
-        for (int c = p0; c < p1; c++) {
+        for (int j = p0; j < p1; j++) {
+            const int c = comp_cell(P, j);
             const int r = active_count[c] & 63;
             if (r == 0) continue;
             if (ng == 4 || used + r > 64) { if (out) out[npack] = cur; npack++; cur = make_int4(-1, -1, -1, -1); used = 0; ng = 0; }
@@ -937,7 +973,7 @@ __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *_
         return npack;
     };
     long long mine = 0;                       // tasks (low word) and merged tasks (high word)
-    for (int c = c0; c < c1; c++) mine += merge ? (active_count[c] >> 6) : ((active_count[c] + 63) >> 6);
+    for (int j = c0; j < c1; j++) { const int n = active_count[comp_cell(P, j)]; mine += merge ? (n >> 6) : ((n + 63) >> 6); }
     if (merge) mine |= (long long)pack(nullptr) << 32;
     long long incl = mine;
     for (int d = 1; d < 64; d <<= 1) {
@@ -950,26 +986,14 @@ __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *_
     for (int k = 0; k < 16; k++) { if (k < wv) run2 += wave_tot[k]; total2 += wave_tot[k]; }
     int run = (int)(run2 & 0xffffffffll);
     const int total = (int)(total2 & 0xffffffffll);
-    for (int c = c0; c < c1; c++) {
+    for (int j = c0; j < c1; j++) {
+        const int c = comp_cell(P, j);
         const int n = merge ? (active_count[c] >> 6) : ((active_count[c] + 63) >> 6);
-        task_start2[c] = run;
         for (int sl = 0; sl < n; sl++) task_list2[run + sl] = c * P.slices + sl;
         run += n;
     }
     if (merge) pack(merged_tasks + (int)(run2 >> 32));
-    if (tid == 0) { task_start2[P.num_cells] = total; fs->n_tasks2 = total; fs->n_merged = (int)(total2 >> 32); }
-    if (sharded) {                       // the force pass's run of this list: the share's cells
-        __syncthreads();
-        if (tid == 0) {
-            const int c_lo = fs->shard_cell_lo, c_hi = fs->shard_cell_hi;
-            if (c_hi < c_lo) { fs->shard_task_lo = 0; fs->shard_task_n = 0; }
-            else {
-                const int end = c_hi + 1 < P.num_cells ? task_start2[c_hi + 1] : total;
-                fs->shard_task_lo = task_start2[c_lo];
-                fs->shard_task_n = end - task_start2[c_lo];
-            }
-        }
-    }
+    if (tid == 0) { fs->n_tasks2 = total; fs->n_merged = (int)(total2 >> 32); }
 }
 
 // One wave = 64 consecutive particles of one cell (four independent waves per workgroup).
@@ -1010,7 +1034,7 @@ template <int MODE, int NQ>
 __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__restrict__ cell_start,
                                            const float4 *__restrict__ snap4, const float *__restrict__ snap_soa,
                                            const float *__restrict__ snap_age, const int *__restrict__ sorted_id,
-                                           float4 *__restrict__ force4, int lo, int hi, int task,
+                                           float4 *__restrict__ force4, int task,
                                            float4 *tile, unsigned long long *trace,
                                            const int *__restrict__ active_list = nullptr,
                                            const int *__restrict__ active_count = nullptr)
@@ -1026,7 +1050,6 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
     const int lane = threadIdx.x & 63;
     const bool valid = lane < nvalid;
     const int gi = active_list ? active_list[base + first + (valid ? lane : 0)] : base + first + (valid ? lane : 0);
-    if (!__any(valid && gi >= lo && gi < hi)) return;   // another rank's share
     const float4 me = snap4[gi];
     const float age_i = snap_age[gi];
     const int id_i = sorted_id[gi];
@@ -1034,27 +1057,25 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
     const bool kid = age_i < P.kid_thr;
     const bool scan = valid && !dead && !kid && !active_list;   // two-pass mode: flags are settled already
 
-    const int G = P.G;
-    const int i3 = c / (G * G), rem = c - i3 * G * G, i1 = rem / G, i2 = rem - i1 * G;
+    int i1, i2, i3;
+    cell_coords(P, c, i1, i2, i3);
     float ax = 0.f, ay = 0.f, az = 0.f;
     int flag = 0;
     const float eps2f = (float)P.eps2;
-    const bool mine = valid && gi >= lo && gi < hi;
 
     // Lane k (< 27) looks up neighbour cell k of the stencil once: its range in the
     // sorted order, or an empty range if it lies outside the grid.
     int my_nb = 0, my_cnt = 0;
     if (lane < 27) {
-        const int n2 = i2 + c_stencil[lane][0], n1 = i1 + c_stencil[lane][1], n3 = i3 + c_stencil[lane][2];
-        if (n1 >= 0 && n1 < G && n2 >= 0 && n2 < G && n3 >= 0 && n3 < G) {
-            const int nc = n3 * G * G + n1 * G + n2;
+        const int nc = local_cell(P, i3 + c_stencil[lane][2], i1 + c_stencil[lane][1], i2 + c_stencil[lane][0]);
+        if (nc >= 0) {
             my_nb = cell_start[nc];
             my_cnt = min(cell_start[nc + 1] - my_nb, P.max_per_cell);
         }
     }
     if (MODE != 0) {
         const PairCtx ctx = {me.x, me.y, me.z, age_i, id_i, gi, scan};
-        const size_t cap = (size_t)P.container;
+        const size_t cap = (size_t)P.sorted_cap;
         for (int k = 0; k < 27; k++) {
             const int nb = __builtin_amdgcn_readlane(my_nb, k), n = __builtin_amdgcn_readlane(my_cnt, k);
             const float *sx = snap_soa + nb, *sy = sx + cap, *sz = sy + cap, *sw = sz + cap;   // wave-uniform
@@ -1105,7 +1126,8 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
         // modes let a particle meet itself (r = 0 adds +0, exactly nothing) because
         // 1/sqrt(eps2^3) is finite on the range they are allowed on; this one also serves
         // softening lengths where it is not, so it skips the self pair explicitly, as the
-        // reference does by id (ps.cpp:1258).
+        // reference does by id (ps.cpp:1258), and a kid neighbour too (app_common.cu:240: ai
+        // comes back unchanged; its zeroed mass times an infinite 1/r^3 would be a NaN).
         int k = 0, t0 = 0;
         int nb = __shfl(my_nb, 0), ncnt = __shfl(my_cnt, 0);
         while (ncnt == 0 && ++k < 27) { nb = __shfl(my_nb, k); ncnt = __shfl(my_cnt, k); }
@@ -1129,7 +1151,13 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
 #pragma unroll 4
             for (int jj = 0; jj < n; jj++) {
                 if (c_nb + c_t0 + jj == gi) continue;
-                dmin = fminf(dmin, pair_exact(me.x, me.y, me.z, tile[jj], P.eps2, ax, ay, az));
+                const float4 q = tile[jj];
+                if (q.w == 0.0f) {                     // kid (or massless) neighbour: no force term, still a distance
+                    const float rx = q.x - me.x, ry = q.y - me.y, rz = q.z - me.z;
+                    dmin = fminf(dmin, rx * rx + ry * ry + rz * rz);
+                    continue;
+                }
+                dmin = fminf(dmin, pair_exact(me.x, me.y, me.z, q, P.eps2, ax, ay, az));
             }
             // rare: someone in this tile is within the collision gate of one of my lanes
             if (__any(scan && !(dmin > P.coll_d2_gate))) {
@@ -1148,18 +1176,18 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
     }
     if (dead) flag = 2;
     if (kid) { ax = 0.f; ay = 0.f; az = 0.f; }   // every term is skipped for a kid (app_common.cu:240)
-    if (mine) force4[gi] = make_float4(ax, ay, az, __int_as_float(flag));
+    if (valid) force4[gi] = make_float4(ax, ay, az, __int_as_float(flag));
     PS_TRACE_END();
 }
 
-template <int MODE, bool SHARDED, int NQ>
+template <int MODE, int NQ>
 __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restrict__ cell_start,
                                                const float4 *__restrict__ snap4,
                                                const float *__restrict__ snap_soa,
                                                const float *__restrict__ snap_age,
                                                const int *__restrict__ sorted_id,
                                                const int *__restrict__ task_list,
-                                               float4 *__restrict__ force4, int lo, int hi, int covered,
+                                               float4 *__restrict__ force4,
                                                FrameScalars *fs, unsigned long long *trace,
                                                const int *__restrict__ active_list, const int *__restrict__ active_count)
 {
@@ -1168,31 +1196,20 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
     // CUs, which keeps even a small share (a few waves per CU) evenly spread.
     __shared__ float4 tiles[MODE == 0 ? 4 : 1][MODE == 0 ? 64 : 1];   // mode 0 only
     const int wave = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && cell_start[P.num_cells] > covered) atomicOr(&fs->error, ERR_SHARD_BOUND);
-    // The work list holds only non-empty (cell, slice) tasks, cell-major (a sharded launch
-    // covers this rank's run of it).  Workgroups are dealt round-robin over the eight XCDs
-    // (b and b + 8 share an L2), so workgroup b takes its four tasks from XCD (b & 7)'s
-    // contiguous eighth of the list: neighbouring cells' snapshots then sit in that XCD's L2.
+    // The work list holds only non-empty (cell, slice) tasks, cell-major.  Workgroups are dealt
+    // round-robin over the eight XCDs (b and b + 8 share an L2), so workgroup b takes its four
+    // tasks from XCD (b & 7)'s contiguous eighth of the list: neighbouring cells' snapshots then
+    // sit in that XCD's L2.
     // (Eighths of equal WORK instead of equal length -- the outer planes of the grid have
     // fewer neighbours, so the two XCDs holding them go idle for the last sixth of the
     // launch -- were tried: the XCDs then finish together, yet the launch was only 1 %
     // shorter and the extra prefix sum cost k_scan 10 us.)
-    if (SHARDED) {
-        // this rank's run of the list, cut into eight contiguous runs like the whole list below
-        const int ntask = fs->shard_task_n, nwg = (ntask + 3) >> 2;
-        if ((int)blockIdx.x >= nwg) return;
-        const int slot = xcd_contiguous(blockIdx.x, nwg) * 4 + wave;
-        if (slot >= ntask) return;
-        pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, lo, hi,
-                             task_list[fs->shard_task_lo + slot], tiles[MODE == 0 ? wave : 0], trace, active_list, active_count);
-        return;
-    }
     const int ntask = active_list ? fs->n_tasks2 : fs->n_tasks;
     const int nwg = (ntask + 3) >> 2;
     if ((int)blockIdx.x >= nwg) return;
     const int slot = xcd_contiguous(blockIdx.x, nwg) * 4 + wave;
     if (slot >= ntask) return;
-    pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, lo, hi,
+    pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4,
                          task_list[slot], tiles[MODE == 0 ? wave : 0], trace, active_list, active_count);
 }
 
@@ -1239,17 +1256,16 @@ __global__ __launch_bounds__(256) void k_pairs_merged(DevParams P, const int *__
     const float eps2f = (float)P.eps2;
 
     // neighbour ranges of all groups: entry e = group * 27 + stencil step, held by lane e % 64
-    const int G = P.G;
     int tab_nb[2] = {0, 0}, tab_cnt[2] = {0, 0};
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         const int e = lane + 64 * r, eg = e / 27, ek = e - eg * 27;
         const int ec = eg == 0 ? cells[0] : eg == 1 ? cells[1] : eg == 2 ? cells[2] : eg == 3 ? cells[3] : -1;
         if (ec >= 0) {
-            const int i3 = ec / (G * G), rem = ec - i3 * G * G, i1 = rem / G, i2 = rem - i1 * G;
-            const int n2 = i2 + c_stencil[ek][0], n1 = i1 + c_stencil[ek][1], n3 = i3 + c_stencil[ek][2];
-            if (n1 >= 0 && n1 < G && n2 >= 0 && n2 < G && n3 >= 0 && n3 < G) {
-                const int nc = n3 * G * G + n1 * G + n2;
+            int i1, i2, i3;
+            cell_coords(P, ec, i1, i2, i3);
+            const int nc = local_cell(P, i3 + c_stencil[ek][2], i1 + c_stencil[ek][1], i2 + c_stencil[ek][0]);
+            if (nc >= 0) {
                 tab_nb[r] = cell_start[nc];
                 tab_cnt[r] = min(cell_start[nc + 1] - tab_nb[r], P.max_per_cell);
             }
@@ -1336,11 +1352,13 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 
 
 // Death, survival, integration, wrap and re-hash for every particle of the frame
-// (ps.cpp:1182-1242, 1261-1302), one thread per SLOT so that the particle arrays stream
+// (ps.cpp:1182-1242, 1261-1302), one thread per owned SLOT so that the particle arrays stream
 // through coalesced (live slots are dense at the head of every segment); only the
 // force record is gathered through the slot's rank in the sorted order.  Lifecycle side
 // effects that depend on the reference's serial order (free-slot queues) are emitted
-// as (key, arg) queue operations and MoveRec records and replayed afterwards.
+// as (key, arg) queue operations and MoveRec records and replayed afterwards.  A particle
+// (or a child) whose new segment belongs to a neighbour rank leaves through the outbox:
+// that rank's queue hands out its slot, in the same serial order.
 __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int step,
                                                 const int *__restrict__ rank_of_slot,
                                                 const float4 *__restrict__ force4,
@@ -1349,18 +1367,20 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
                                                 const CellInfo *__restrict__ celltab,
                                                 uint64_t *op_keys, int *op_args, int ops_cap,
                                                 MoveRec *moves, int moves_cap,
+                                                XferRec *out_down, XferRec *out_up,
                                                 FrameScalars *fs, DevCounters *ctr)
 {
     __shared__ int s_ops, s_moves, s_base_ops, s_base_moves;
     __shared__ unsigned int s_cnt[4];
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;       // slot == particle id
+    const int si = blockIdx.x * blockDim.x + threadIdx.x;       // storage index of the slot
     if (threadIdx.x == 0) { s_ops = 0; s_moves = 0; s_cnt[0] = s_cnt[1] = s_cnt[2] = s_cnt[3] = 0; }
     int old_cell = -1;
-    if (id < P.container) old_cell = cell_arr[id];
+    if (si < P.slots_total) old_cell = cell_arr[si];
     // free slots (and the ones the cell-overflow rule just killed) have cell == -1
-    const bool active = old_cell >= 0 && old_cell < P.num_cells;
+    const bool active = old_cell >= 0 && old_cell < P.num_cells_global;
     if (!__syncthreads_or(active)) return;                        // nothing alive in this workgroup
-    const int gi = active ? rank_of_slot[id] : 0;
+    const int id = active ? slot_of_index(P, si) : 0;             // slot == particle id
+    const int gi = active ? rank_of_slot[si] : 0;
 
     int flag = 0, new_cell = 0;
     float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1373,20 +1393,20 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
     int new_rec = 0;
 
     if (killed) {                                        // kill, ps.cpp:1211-1235
-        died_of_age = vel4[id].w > P.life_thr;
-        cell_arr[id] = -1; pflags[id] = 0;
-        pos4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
-        vel4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
-        acc4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+        died_of_age = vel4[si].w > P.life_thr;
+        cell_arr[si] = -1; pflags[si] = 0;
+        pos4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
+        vel4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else if (survived) {                               // survive_particle, app.cu:271-283
-        const float fert = acc4[id].w;
-        vel4[id] = make_float4(0.f, 0.f, 0.f, 0.f);
-        acc4[id] = make_float4(0.f, 0.f, 0.f, fert);
-        pflags[id] = 0;
+        const float fert = acc4[si].w;
+        vel4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc4[si] = make_float4(0.f, 0.f, 0.f, fert);
+        pflags[si] = 0;
     } else if (moved) {
-        const float4 p = pos4[id];
-        const float4 v = vel4[id];
-        const float fert = acc4[id].w;
+        const float4 p = pos4[si];
+        const float4 v = vel4[si];
+        const float fert = acc4[si].w;
         const float axv = f.x, ayv = f.y, azv = f.z;
         const float t = P.t;
         // dx = v*t (fp32) + 0.5*a*t*t (double, left to right), rounded once (ps.cpp:1274-1276)
@@ -1414,7 +1434,7 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
         float vx = v.x + axv * t, vy = v.y + ayv * t, vz = v.z + azv * t;   // ps.cpp:1289-1296
         vx = clamp_mag(vx, P.vmax); vy = clamp_mag(vy, P.vmax); vz = clamp_mag(vz, P.vmax);
         const float age = v.w + t;                                         // ps.cpp:1302
-        uint8_t pf = pflags[id];
+        uint8_t pf = pflags[si];
         const CellInfo new_ci = celltab[new_cell];
         new_rec = segment_record(S, new_ci.seg_type, new_ci.seg_tid);
 
@@ -1434,21 +1454,29 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
             pf |= 1;
             born = true;
         }
-        pos4[id] = make_float4(rx, ry, rz, p.w);
-        vel4[id] = make_float4(vx, vy, vz, age);
-        acc4[id] = make_float4(axv, ayv, azv, fert);
-        cell_arr[id] = new_cell;
-        pflags[id] = pf;
+        pos4[si] = make_float4(rx, ry, rz, p.w);
+        vel4[si] = make_float4(vx, vy, vz, age);
+        acc4[si] = make_float4(axv, ayv, azv, fert);
+        cell_arr[si] = new_cell;
+        pflags[si] = pf;
         // segment change => the particle must move to a slot of the new segment
         // (set_pos_x raises seg_fault, app.cu:178-185; handled at ps.cpp:1335-1374)
         relocate = (new_ci.seg_type != old_ci.seg_type || new_ci.seg_tid != old_ci.seg_tid);
     }
 
+    // Does the new segment's queue live on a neighbour rank?  Its layer is then the one above
+    // or below the old one (a step moves a particle by at most one cell, MAX_DX = CELL_SIZE;
+    // the box is periodic, so "above" the top layer is layer 0 on the ring's next rank).
+    const bool remote = (born || relocate) && P.world > 1 && !owns_record(P, new_rec);
+    const int GG = P.G * P.G;
+    const bool up = remote && (new_cell / GG) == ((old_cell / GG) + 1) % P.G;
+
     // Event counters and list space: wave -> workgroup (LDS) -> one global atomic per
     // workgroup.  Queue operations: kill -> insert; birth -> remove; relocation ->
-    // remove + insert.  Moves: one record per birth / relocation.
+    // remove + insert.  Moves: one record per birth / relocation.  A remove on a neighbour's
+    // queue is not a local operation: it travels in the outbox.
     const int lane = (int)__lane_id();
-    const int n_op = (killed ? 1 : 0) + (born ? 1 : 0) + (relocate ? 2 : 0);
+    const int n_op = (killed ? 1 : 0) + ((born && !remote) ? 1 : 0) + (relocate ? (remote ? 1 : 2) : 0);
     const int n_mv = (born ? 1 : 0) + (relocate ? 1 : 0);
     const int op_incl = wave_incl_scan(n_op), mv_incl = wave_incl_scan(n_mv);
     const unsigned long long b0 = __ballot(moved), b1 = __ballot(survived),
@@ -1479,22 +1507,38 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
         }
     }
     __syncthreads();
-    if (n_op == 0) return;
+    if (n_op == 0 && n_mv == 0) return;
     int k = s_base_ops + wave_ops + op_incl - n_op;
     int m = s_base_moves + wave_moves + mv_incl - n_mv;
     if (k + n_op > ops_cap || m + n_mv > moves_cap) { atomicOr(&fs->error, ERR_OPS_OVERFLOW); return; }
     const uint64_t own_rec = (uint64_t)(uint32_t)segment_record_of_slot(S, id) << P.key_rec_shift;
     const uint64_t dst_rec = (uint64_t)(uint32_t)new_rec << P.key_rec_shift;
+    // a departure: reserve its outbox entry and put the key there; k_moves_stage adds the state
+    auto depart = [&](int kind, uint64_t sub) -> int {
+        const int o = atomicAdd(&fs->n_out[up ? 1 : 0], 1);
+        if (o >= P.xfer_cap) { atomicOr(&fs->error, ERR_HALO_OVERFLOW); return -1; }
+        XferRec *x = (up ? out_up : out_down) + o;
+        x->key = dst_rec | key | sub; x->new_cell = new_cell; x->kind = kind;
+        return o;
+    };
     if (killed) { op_keys[k] = own_rec | key | 2ull; op_args[k] = id; }
     if (born) {
-        moves[m] = {id, -1, 1, new_cell};
-        op_keys[k] = dst_rec | key | 0ull; op_args[k] = m;
-        k++; m++;
+        if (remote) moves[m] = {id, depart(1, 0ull), 1 | MOVE_OUT | (up ? MOVE_UP : 0), new_cell};
+        else {
+            moves[m] = {id, -1, 1, new_cell};
+            op_keys[k] = dst_rec | key | 0ull; op_args[k] = m;
+            k++;
+        }
+        m++;
     }
     if (relocate) {
-        moves[m] = {id, -1, 0, new_cell};
-        op_keys[k] = dst_rec | key | 1ull; op_args[k] = m;
-        op_keys[k + 1] = own_rec | key | 2ull; op_args[k + 1] = id;
+        if (remote) moves[m] = {id, depart(0, 1ull), 0 | MOVE_OUT | (up ? MOVE_UP : 0), new_cell};
+        else {
+            moves[m] = {id, -1, 0, new_cell};
+            op_keys[k] = dst_rec | key | 1ull; op_args[k] = m;
+            k++;
+        }
+        op_keys[k] = own_rec | key | 2ull; op_args[k] = id;
     }
 }
 
@@ -1524,6 +1568,8 @@ __global__ __launch_bounds__(256) void k_replay(DevParams P, int n_ops,
 
     QueueInfo q = qinfo[rec];
     const bool in_lds = q.seg_size <= QUEUE_WINDOW;
+    // the queue array is stored like the slots: only the owned segments, back to back
+    queue += slot_index(P, q.rloc) - q.rloc;
     if (in_lds) for (int e = tid; e < q.seg_size; e += 256) window[e] = queue[q.rloc + e];
     unsigned long long lost = 0, reloc = 0, births = 0, births_failed = 0;
 
@@ -1676,7 +1722,7 @@ __global__ __launch_bounds__(1024) void k_ops_scatter(const uint64_t *__restrict
 // k-th insert becomes logical element count0 + k -- and all of them are applied at once;
 // otherwise one lane walks the list exactly as q_insert / q_remove do.
 constexpr int REPLAY_THREADS = 512;
-__global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(const int *__restrict__ rec_start,
+__global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, const int *__restrict__ rec_start,
                                                         const uint64_t *__restrict__ keys,
                                                         const int *__restrict__ args,
                                                         QueueInfo *qinfo, int *queue, MoveRec *moves,
@@ -1710,6 +1756,7 @@ __global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(const int *__r
     if (n == 0) return;
     QueueInfo q = qinfo[rec];
     const bool in_lds = q.seg_size <= QUEUE_WINDOW;
+    queue += slot_index(P, q.rloc) - q.rloc;           // owned segments only, back to back
     for (int e = tid; e < n; e += NT) { kbuf[e] = keys[start + e]; abuf[e] = args[start + e]; }
     if (tid == 0) s_bad = 0;
     __syncthreads();
@@ -1849,23 +1896,37 @@ __global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(const int *__r
 
 // Relocation phase 1a: read every moving particle (copy_particle, ps.cpp:1363) and
 // every parent of a child to be born.  Read-only on the particle arrays, so a
-// parent that also relocates this step is seen intact by both of its records.
-__global__ void k_moves_stage(MoveRec *moves, int n_host, const FrameScalars *__restrict__ fs,
+// parent that also relocates this step is seen intact by both of its records.  A record
+// that leaves for a neighbour rank (MOVE_OUT) gets its state written into the outbox entry
+// k_apply reserved; one that arrived from a neighbour (MOVE_IN) was staged on arrival.
+__global__ void k_moves_stage(DevParams P, MoveRec *moves, int n_host, const FrameScalars *__restrict__ fs,
                               const float4 *pos4, const float4 *vel4, const float4 *acc4,
-                              const uint8_t *pflags, float4 *stage)
+                              const uint8_t *pflags, float4 *stage, XferRec *out_down, XferRec *out_up)
 {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (n_host < 0 && lifecycle_deferred(fs)) return;
     const int n = n_host < 0 ? fs->n_moves : n_host;
     if (m >= n) return;
     const MoveRec r = moves[m];
+    if (r.kind & MOVE_IN) return;
+    const int si = slot_index(P, r.src);
+    if (r.kind & MOVE_OUT) {
+        if (r.dst < 0) return;                          // the outbox was full (error already raised)
+        XferRec *x = ((r.kind & MOVE_UP) ? out_up : out_down) + r.dst;
+        const float4 p = pos4[si], v = vel4[si], a = acc4[si];
+        x->pos[0] = p.x; x->pos[1] = p.y; x->pos[2] = p.z; x->pos[3] = p.w;
+        x->vel[0] = v.x; x->vel[1] = v.y; x->vel[2] = v.z; x->vel[3] = v.w;
+        x->acc[0] = a.x; x->acc[1] = a.y; x->acc[2] = a.z; x->acc[3] = a.w;
+        if ((r.kind & 0xff) == 0 && pflags[si]) x->kind |= MOVE_PARENT;
+        return;
+    }
     float4 *s = stage + (size_t)3 * m;
-    s[0] = pos4[r.src]; s[1] = vel4[r.src]; s[2] = acc4[r.src];
-    if (r.kind == 0 && pflags[r.src]) moves[m].kind = 0x100;  // is_parent travels in bit 8
+    s[0] = pos4[si]; s[1] = vel4[si]; s[2] = acc4[si];
+    if (r.kind == 0 && pflags[si]) moves[m].kind = MOVE_PARENT;  // is_parent travels in bit 8
 }
 
 // Relocation phase 1b: reset_particle on the vacated slots (ps.cpp:1367).
-__global__ void k_moves_reset(const MoveRec *__restrict__ moves, int n_host, const FrameScalars *__restrict__ fs,
+__global__ void k_moves_reset(DevParams P, const MoveRec *__restrict__ moves, int n_host, const FrameScalars *__restrict__ fs,
                               float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr, uint8_t *pflags)
 {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1873,11 +1934,12 @@ __global__ void k_moves_reset(const MoveRec *__restrict__ moves, int n_host, con
     const int n = n_host < 0 ? fs->n_moves : n_host;
     if (m >= n) return;
     const MoveRec r = moves[m];
-    if ((r.kind & 0xff) != 0) return;
-    cell_arr[r.src] = -1; pflags[r.src] = 0;
-    pos4[r.src] = make_float4(0.f, 0.f, 0.f, 0.f);
-    vel4[r.src] = make_float4(0.f, 0.f, 0.f, 0.f);
-    acc4[r.src] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((r.kind & 0xff) != 0 || (r.kind & MOVE_IN)) return;     // births and arrivals vacate nothing here
+    const int si = slot_index(P, r.src);
+    cell_arr[si] = -1; pflags[si] = 0;
+    pos4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
+    vel4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
+    acc4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // Relocation phase 2: drop each particle into the slot the queue replay assigned.
@@ -1890,12 +1952,13 @@ __global__ void k_moves_commit(DevParams P, int step, const MoveRec *__restrict_
     const int n = n_host < 0 ? fs->n_moves : n_host;
     if (m >= n) return;
     const MoveRec r = moves[m];
-    if (r.dst < 0) return;
+    if (r.dst < 0 || (r.kind & MOVE_OUT)) return;
     const float4 *s = stage + (size_t)3 * m;
+    const int di = slot_index(P, r.dst);
     if ((r.kind & 0xff) == 0) {
-        pos4[r.dst] = s[0]; vel4[r.dst] = s[1]; acc4[r.dst] = s[2];
-        cell_arr[r.dst] = r.new_cell;
-        pflags[r.dst] = (r.kind & 0x100) ? 1 : 0;
+        pos4[di] = s[0]; vel4[di] = s[1]; acc4[di] = s[2];
+        cell_arr[di] = r.new_cell;
+        pflags[di] = (r.kind & MOVE_PARENT) ? 1 : 0;
     } else {
         // create_particle_s (app.cu:189-208): child at the parent's position, opposite
         // velocity, age 0, fresh fertility age from the counter-based RNG
@@ -1904,12 +1967,224 @@ __global__ void k_moves_commit(DevParams P, int step, const MoveRec *__restrict_
         const double u = (double)(h3 >> 11) * (1.0 / 9007199254740992.0);
         const float fert = (float)((double)P.fert_lo + u * (double)(P.fert_hi - P.fert_lo));
         const float4 pp = s[0], pv = s[1];
-        pos4[r.dst] = make_float4(pp.x, pp.y, pp.z, P.w_default);
-        vel4[r.dst] = make_float4((float)(-1.0 * (double)pv.x), (float)(-1.0 * (double)pv.y),
+        pos4[di] = make_float4(pp.x, pp.y, pp.z, P.w_default);
+        vel4[di] = make_float4((float)(-1.0 * (double)pv.x), (float)(-1.0 * (double)pv.y),
                                   (float)(-1.0 * (double)pv.z), 0.0f);
-        acc4[r.dst] = make_float4(0.f, 0.f, 0.f, fert);
-        cell_arr[r.dst] = r.new_cell;
-        pflags[r.dst] = 0;
+        acc4[di] = make_float4(0.f, 0.f, 0.f, fert);
+        cell_arr[di] = r.new_cell;
+        pflags[di] = 0;
+    }
+}
+
+// ------------------------------------------------------------------ slab exchange
+// Messages are arrays of 32-bit words that start with MSG_HEADER_WORDS ints: [0] cells or
+// records carried, [1] bodies carried, [2] sticky error bits of the sender.  Their sizes are
+// fixed when the context is created (halo_cap_cell bodies per cell, xfer_cap records), so
+// the transport never has to negotiate a length.
+//
+// Snapshot of own cell layers for a neighbour (its halo layer and the layers it computes for
+// this rank): header, one count per cell, then x[], y[], z[], w_eff[], age[], id[] of
+// `cap` = cells * halo_cap_cell words each, bodies packed cell-major in list order.
+//
+// Exclusive prefix of min(count(c0 + j), limit) over j < ncell by one workgroup of 1024
+// threads: off[j], off[ncell] = total.  `count` is a callable.
+template <typename F>
+__device__ __forceinline__ void block_prefix_1024(int ncell, F count, int *__restrict__ off, int *wave_tot, int *carry)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) *carry = 0;
+    __syncthreads();
+    for (int b = 0; b < ncell; b += 1024) {
+        const int j = b + tid;
+        const int n = j < ncell ? count(j) : 0;
+        const int incl = wave_incl_scan(n);
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        int o = *carry;
+        for (int k = 0; k < wv; k++) o += wave_tot[k];
+        if (j < ncell) off[j] = o + incl - n;
+        __syncthreads();
+        if (tid == 1023) *carry = o + incl;
+        __syncthreads();
+    }
+    if (tid == 0) off[ncell] = *carry;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_halo_prefix_out(DevParams P, int c0, int ncell, const int *__restrict__ cell_start,
+                                                           int *__restrict__ msg, int *__restrict__ pack_off, FrameScalars *fs)
+{
+    __shared__ int wave_tot[16];
+    __shared__ int carry;
+    int *counts = msg + MSG_HEADER_WORDS;
+    const int lim = min(P.max_per_cell, P.halo_cap_cell);
+    bool over = false;
+    block_prefix_1024(ncell, [&](int j) {
+        const int n = min(cell_start[c0 + j + 1] - cell_start[c0 + j], P.max_per_cell);
+        over |= n > lim;
+        counts[j] = min(n, lim);
+        return min(n, lim); }, pack_off, wave_tot, &carry);
+    if (over) atomicOr(&fs->error, ERR_HALO_OVERFLOW);
+    __syncthreads();
+    if (threadIdx.x == 0) { msg[0] = ncell; msg[1] = pack_off[ncell]; msg[2] = fs->error; }
+}
+
+// one workgroup per cell of the message
+__global__ __launch_bounds__(256) void k_halo_bodies_out(DevParams P, int c0, int ncell, const int *__restrict__ cell_start,
+                                                          const int *__restrict__ pack_off, const float4 *__restrict__ snap4,
+                                                          const float *__restrict__ snap_age, const int *__restrict__ sorted_id,
+                                                          int *__restrict__ msg)
+{
+    const int j = blockIdx.x;
+    const size_t cap = (size_t)ncell * P.halo_cap_cell;
+    float *body = reinterpret_cast<float *>(msg + MSG_HEADER_WORDS + ncell);
+    const int src = cell_start[c0 + j], dst = pack_off[j], n = pack_off[j + 1] - dst;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const float4 q = snap4[src + e];
+        body[dst + e] = q.x; body[cap + dst + e] = q.y; body[2 * cap + dst + e] = q.z; body[3 * cap + dst + e] = q.w;
+        body[4 * cap + dst + e] = snap_age[src + e];
+        reinterpret_cast<int *>(body)[5 * cap + dst + e] = sorted_id[src + e];
+    }
+}
+
+// The other end: the message's cells become the local cells of one or two remote regions:
+// the first `split` cells those of region r0 (local cells from c0), the rest those of region
+// r1 (from c1; absent when split == ncell).  Writes cell_start for those cells and the gap
+// cell after each region, and -- when r1 holds lent layers, which this rank computes --
+// appends their slices to the collide work list.  One workgroup.
+__global__ __launch_bounds__(1024) void k_halo_prefix_in(DevParams P, int c0, int c1, int ncell, int split, int s0, int s1,
+                                                          int lent, const int *__restrict__ msg, int *__restrict__ unpack_off,
+                                                          int *__restrict__ cell_start, int *__restrict__ task_list,
+                                                          FrameScalars *fs)
+{
+    __shared__ int wave_tot[16];
+    __shared__ int carry, task_s;
+    const int tid = threadIdx.x;
+    const int *counts = msg + MSG_HEADER_WORDS;
+    if (msg[0] != ncell) {                      // not the message this rank was planned to get: leave the regions empty
+        if (tid == 0) atomicOr(&fs->error, ERR_SLAB_MISMATCH);
+        for (int j = tid; j <= ncell; j += 1024) unpack_off[j] = 0;
+        for (int j = tid; j <= split; j += 1024) cell_start[c0 + j] = s0;
+        for (int j = tid; j <= ncell - split && split < ncell; j += 1024) cell_start[c1 + j] = s1;
+        return;
+    }
+    if (tid == 0) { task_s = fs->n_tasks; if (msg[2]) atomicOr(&fs->error, msg[2]); }
+    const int lim = min(P.max_per_cell, P.halo_cap_cell);
+    block_prefix_1024(ncell, [&](int j) { return min(max(counts[j], 0), lim); }, unpack_off, wave_tot, &carry);
+    const int nfirst = unpack_off[split], total = unpack_off[ncell];
+    for (int j = tid; j < ncell; j += 1024) {
+        const int lc = j < split ? c0 + j : c1 + (j - split);
+        cell_start[lc] = j < split ? s0 + unpack_off[j] : s1 + unpack_off[j] - nfirst;
+        const int n = unpack_off[j + 1] - unpack_off[j];
+        if (lent && j >= split && n > 0) {            // the lent cells' slices join the collide work list
+            const int ns = (n + 63) >> 6;
+            const int t0 = atomicAdd(&task_s, ns);
+            for (int sl = 0; sl < ns; sl++) task_list[t0 + sl] = lc * P.slices + sl;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        cell_start[c0 + split] = s0 + nfirst;                                // gap cell after the first region
+        if (split < ncell) cell_start[c1 + (ncell - split)] = s1 + total - nfirst;   // ... and after the second
+        if (lent) { fs->n_tasks = task_s; fs->n_lent = total - nfirst; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_halo_bodies_in(DevParams P, int c0, int c1, int ncell, int split,
+                                                         const int *__restrict__ msg, const int *__restrict__ unpack_off,
+                                                         const int *__restrict__ cell_start, float4 *__restrict__ snap4,
+                                                         float *__restrict__ snap_soa, float *__restrict__ snap_age,
+                                                         int *__restrict__ sorted_id, int *__restrict__ snap_cid)
+{
+    const int j = blockIdx.x;
+    const size_t cap = (size_t)ncell * P.halo_cap_cell, sc = (size_t)P.sorted_cap;
+    const float *body = reinterpret_cast<const float *>(msg + MSG_HEADER_WORDS + ncell);
+    const int lc = j < split ? c0 + j : c1 + (j - split);
+    const int src = unpack_off[j], n = unpack_off[j + 1] - src, dst = cell_start[lc];
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const float x = body[src + e], y = body[cap + src + e], z = body[2 * cap + src + e], w = body[3 * cap + src + e],
+                    age = body[4 * cap + src + e];
+        const int id = reinterpret_cast<const int *>(body)[5 * cap + src + e];
+        snap4[dst + e] = make_float4(x, y, z, w);
+        snap_soa[dst + e] = x; snap_soa[sc + dst + e] = y; snap_soa[2 * sc + dst + e] = z; snap_soa[3 * sc + dst + e] = w;
+        snap_age[dst + e] = age;
+        sorted_id[dst + e] = id;
+        snap_cid[dst + e] = (!(age < P.kid_thr) && !(age > P.life_thr)) ? id : -1;
+    }
+}
+
+// Remote cells list their bodies in the halos of the cells around them, like k_sort_cells
+// does for the own cells.  One workgroup per remote cell (local cells [c0, c1)).
+__global__ __launch_bounds__(256) void k_remote_halo_lists(DevParams P, int c0, int c1, const int *__restrict__ cell_start,
+                                                           const float4 *__restrict__ snap4, const int *__restrict__ snap_cid,
+                                                           int *__restrict__ halo_count, float *__restrict__ halo_f,
+                                                           int *__restrict__ halo_id)
+{
+    __shared__ int s_halo[27], s_halo_base[27];
+    const int c = c0 + blockIdx.x;
+    if (c >= c1) return;
+    const int start = cell_start[c], n = min(cell_start[c + 1] - start, P.max_per_cell);
+    list_in_neighbour_halos(P, c, start, max(n, 0), snap4, snap_cid, halo_count, halo_f, halo_id, s_halo, s_halo_base, false);
+}
+
+// The force records of the lent layers go back as header + float4[bodies], in the order their
+// snapshot came.  Sender: the lent region's block of force4 is contiguous, copy it.
+__global__ void k_pack_force(DevParams P, const float4 *__restrict__ force4, int *__restrict__ msg, const FrameScalars *__restrict__ fs)
+{
+    const int n = fs->n_lent;
+    float4 *dst = reinterpret_cast<float4 *>(msg + MSG_HEADER_WORDS);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { msg[0] = n; msg[1] = n; msg[2] = fs->error; }
+    if (i < n) dst[i] = force4[P.reg_sorted[2] + i];
+}
+
+// Receiver (the owner): message cell j0 + b is own local cell lentout_c0 + b; its stored bodies
+// sit at pack_off[j0 + b] - pack_off[j0] in the message.  One workgroup per lent-out cell.
+__global__ __launch_bounds__(256) void k_unpack_force(DevParams P, int j0, const int *__restrict__ msg, const int *__restrict__ pack_off,
+                                                       const int *__restrict__ cell_start, float4 *__restrict__ force4,
+                                                       FrameScalars *fs)
+{
+    const int b = blockIdx.x, c = P.lentout_c0 + b;
+    const int ncell = P.lentout_c1 - P.lentout_c0;
+    const float4 *src = reinterpret_cast<const float4 *>(msg + MSG_HEADER_WORDS);
+    if (b == 0 && threadIdx.x == 0) {
+        if (msg[2]) atomicOr(&fs->error, msg[2]);
+        if (msg[1] != pack_off[j0 + ncell] - pack_off[j0]) atomicOr(&fs->error, ERR_SLAB_MISMATCH);
+    }
+    if (msg[1] != pack_off[j0 + ncell] - pack_off[j0]) return;
+    const int rel = pack_off[j0 + b] - pack_off[j0], n = pack_off[j0 + b + 1] - pack_off[j0 + b], dst = cell_start[c];
+    for (int e = threadIdx.x; e < n; e += 256) force4[dst + e] = src[rel + e];
+}
+
+// Arrivals: every record a neighbour sent becomes a MoveRec whose state is staged already,
+// plus the remove operation on this rank's queue, keyed as the sender keyed it.
+__global__ void k_inbox_merge(DevParams P, const int *__restrict__ msg, uint64_t *op_keys, int *op_args, int ops_cap,
+                              MoveRec *moves, int moves_cap, float4 *stage, FrameScalars *fs)
+{
+    const int n = min(msg[0], P.xfer_cap);
+    const XferRec *in = reinterpret_cast<const XferRec *>(msg + MSG_HEADER_WORDS);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && msg[2]) atomicOr(&fs->error, msg[2]);
+    if (i >= n) return;
+    const XferRec x = in[i];
+    const unsigned long long old = atomicAdd((unsigned long long *)&fs->n_ops, (1ull << 32) | 1ull);
+    const int k = (int)(old & 0xffffffffull), m = (int)(old >> 32);
+    if (k >= ops_cap || m >= moves_cap) { atomicOr(&fs->error, ERR_OPS_OVERFLOW); return; }
+    const int src = (int)((x.key >> 2) & ((1ull << (P.key_chunk_shift - 2)) - 1ull));     // the sender's slot (parent id for births)
+    moves[m] = {src, -1, (x.kind & (0xff | MOVE_PARENT)) | MOVE_IN, x.new_cell};
+    float4 *s = stage + (size_t)3 * m;
+    s[0] = make_float4(x.pos[0], x.pos[1], x.pos[2], x.pos[3]);
+    s[1] = make_float4(x.vel[0], x.vel[1], x.vel[2], x.vel[3]);
+    s[2] = make_float4(x.acc[0], x.acc[1], x.acc[2], x.acc[3]);
+    op_keys[k] = x.key; op_args[k] = m;
+}
+
+// close an outbox: header of the relocation message
+__global__ void k_outbox_header(int *__restrict__ msg_down, int *__restrict__ msg_up, const FrameScalars *__restrict__ fs, int cap)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        msg_down[0] = min(fs->n_out[0], cap); msg_down[1] = 0; msg_down[2] = fs->error;
+        msg_up[0] = min(fs->n_out[1], cap); msg_up[1] = 0; msg_up[2] = fs->error;
     }
 }
 
@@ -1982,31 +2257,30 @@ static inline int blocks_for(size_t n, int threads, int cap = 4096)
     return b < 1 ? 1 : (int)b;
 }
 
-hipError_t launch_unpack_aos(hipStream_t st, const void *aos, int first, int count, int num_cells, float half_box,
+hipError_t launch_unpack_aos(hipStream_t st, const DevParams &P, const void *aos, int first, int count, float half_box,
                              const DeviceState &d)
 {
     if (count <= 0) return hipSuccess;
-    k_unpack_aos<<<(count + 255) / 256, 256, 0, st>>>((const uint32_t *)aos, first, count, num_cells, half_box,
-                                                      d.pos4, d.vel4, d.acc4,
-                                                      d.cell, d.pflags, d.fs);
+    k_unpack_aos<<<(count + 255) / 256, 256, 0, st>>>(P, (const uint32_t *)aos, first, count, half_box,
+                                                      d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.fs);
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }
 
-hipError_t launch_pack_aos(hipStream_t st, void *aos, int first, int count, int num_cells, const DeviceState &d)
+hipError_t launch_pack_aos(hipStream_t st, const DevParams &P, void *aos, int first, int count, const DeviceState &d)
 {
     if (count <= 0) return hipSuccess;
-    k_pack_aos<<<(count + 255) / 256, 256, 0, st>>>((uint32_t *)aos, first, count, num_cells, d.pos4, d.vel4,
+    k_pack_aos<<<(count + 255) / 256, 256, 0, st>>>(P, (uint32_t *)aos, first, count, d.pos4, d.vel4,
                                                     d.acc4, d.cell, d.pflags, d.celltab);
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }
 
-hipError_t launch_place(hipStream_t st, int n, const int *ids, const float4 *p, const float4 *v, const float4 *a,
+hipError_t launch_place(hipStream_t st, const DevParams &P, int n, const int *ids, const float4 *p, const float4 *v, const float4 *a,
                         const int *cells, const DeviceState &d)
 {
     if (n <= 0) return hipSuccess;
-    k_place<<<(n + 255) / 256, 256, 0, st>>>(n, ids, p, v, a, cells, d.pos4, d.vel4, d.acc4, d.cell, d.pflags);
+    k_place<<<(n + 255) / 256, 256, 0, st>>>(P, n, ids, p, v, a, cells, d.pos4, d.vel4, d.acc4, d.cell, d.pflags);
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -2038,33 +2312,34 @@ hipError_t launch_fill_int(hipStream_t st, int *p, int v, size_t n)
     return hipSuccess;
 }
 
-hipError_t launch_init_tdata(hipStream_t st, const DeviceState &d, int n)
+hipError_t launch_init_tdata(hipStream_t st, const DevParams &P, const DeviceState &d)
 {
-    k_init_tdata<<<(n + 255) / 256, 256, 0, st>>>(d.tdata, n);
+    if (P.slots_total <= 0) return hipSuccess;
+    k_init_tdata<<<(P.slots_total + 255) / 256, 256, 0, st>>>(P, d.tdata);
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }
 
 hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev)
 {
-    const int nb = blocks_for((size_t)P.container, 256, 2048);
-    const bool lds = P.num_cells <= LDS_CELLS;
-    const int nwg = (P.container + SLOTS_PER_WG - 1) / SLOTS_PER_WG;
+    const int nb = blocks_for((size_t)P.slots_total, 256, 2048);
+    const bool lds = P.n_own_cells <= LDS_CELLS;
+    const int nwg = std::max(1, (P.slots_total + SLOTS_PER_WG - 1) / SLOTS_PER_WG);
     if (ev) (void)hipEventRecord(ev[0], st);
-    if (lds) k_hist_lds<<<nwg, 1024, 0, st>>>(d.cell, d.cell_count, P.container, P.num_cells);
-    else k_hist<<<nb, 256, 0, st>>>(d.cell, d.cell_count, P.container, P.num_cells);
+    if (lds) k_hist_lds<<<nwg, 1024, 0, st>>>(P, d.cell, d.cell_count, d.fs);
+    else k_hist<<<nb, 256, 0, st>>>(P, d.cell, d.cell_count, d.fs);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[1], st);
     k_scan<<<1, 1024, 0, st>>>(P, d.cell_count, d.cell_start, d.cursor, d.task_start, d.chunk_count, d.celltab, d.fs);
     PS_LAUNCH_CHECK();
-    k_build_tasks<<<(P.num_cells + 255) / 256, 256, 0, st>>>(P, d.task_start, d.task_list);
+    if (P.comp_b1 > P.comp_b0) k_build_tasks<<<(P.comp_b1 - P.comp_b0 + 255) / 256, 256, 0, st>>>(P, d.task_start, d.task_list);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[2], st);
-    if (lds) k_scatter_lds<<<nwg, 1024, 0, st>>>(d.cell, d.cursor, d.sorted_id, P.container, P.num_cells);
-    else k_scatter<<<nb, 256, 0, st>>>(d.cell, d.cursor, d.sorted_id, P.container, P.num_cells);
+    if (lds) k_scatter_lds<<<nwg, 1024, 0, st>>>(P, d.cell, d.cursor, d.sorted_id);
+    else k_scatter<<<nb, 256, 0, st>>>(P, d.cell, d.cursor, d.sorted_id);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[3], st);
-    k_sort_cells<<<P.num_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
+    k_sort_cells<<<P.n_own_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
                                                d.pflags, d.snap4, d.snap_soa, d.snap_age, d.tdata, d.rank_of_slot, d.op_keys, d.op_args, d.ops_cap,
                                                P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.snap_cid, d.fs, d.ctr);
     PS_LAUNCH_CHECK();
@@ -2072,82 +2347,130 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     return hipSuccess;
 }
 
-template <int MODE, int NQ>
-static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi,
-                                    int covered, bool sharded, hipEvent_t ev_force)
+// ---- slab exchange ----
+hipError_t launch_pack_halo(hipStream_t st, const DevParams &P, const DeviceState &d, int c0, int ncell, int *msg, int *pack_off)
 {
-    const int tasks = P.num_cells * P.slices;
+    if (ncell <= 0) return hipSuccess;
+    k_halo_prefix_out<<<1, 1024, 0, st>>>(P, c0, ncell, d.cell_start, msg, pack_off, d.fs);
+    PS_LAUNCH_CHECK();
+    k_halo_bodies_out<<<ncell, 256, 0, st>>>(P, c0, ncell, d.cell_start, pack_off, d.snap4, d.snap_age, d.sorted_id, msg);
+    PS_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// message cells: the first `split` become region r0's cells, the rest region r1's
+hipError_t launch_unpack_halo(hipStream_t st, const DevParams &P, const DeviceState &d, int r0, int r1, int ncell, int split,
+                              bool lent, const int *msg, int *unpack_off)
+{
+    if (ncell <= 0) return hipSuccess;
+    const int c0 = P.reg_base[r0], c1 = r1 >= 0 ? P.reg_base[r1] : 0, s0 = P.reg_sorted[r0], s1 = r1 >= 0 ? P.reg_sorted[r1] : 0;
+    k_halo_prefix_in<<<1, 1024, 0, st>>>(P, c0, c1, ncell, split, s0, s1, lent ? 1 : 0, msg, unpack_off, d.cell_start, d.task_list, d.fs);
+    PS_LAUNCH_CHECK();
+    k_halo_bodies_in<<<ncell, 256, 0, st>>>(P, c0, c1, ncell, split, msg, unpack_off, d.cell_start, d.snap4, d.snap_soa, d.snap_age,
+                                            d.sorted_id, d.snap_cid);
+    PS_LAUNCH_CHECK();
+    if (P.two_pass) {
+        if (split > 0) k_remote_halo_lists<<<split, 256, 0, st>>>(P, c0, c0 + split, d.cell_start, d.snap4, d.snap_cid, d.halo_count, d.halo_f, d.halo_id);
+        if (ncell > split) k_remote_halo_lists<<<ncell - split, 256, 0, st>>>(P, c1, c1 + ncell - split, d.cell_start, d.snap4, d.snap_cid, d.halo_count, d.halo_f, d.halo_id);
+        PS_LAUNCH_CHECK();
+    }
+    return hipSuccess;
+}
+
+// a region that no message fills this frame (e.g. world == 1 never has any): nothing to do, its cells keep zero counts
+hipError_t launch_pack_force(hipStream_t st, const DevParams &P, const DeviceState &d, int *msg, int cap_bodies)
+{
+    if (cap_bodies <= 0) return hipSuccess;
+    k_pack_force<<<(cap_bodies + 255) / 256, 256, 0, st>>>(P, d.force4, msg, d.fs);
+    PS_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_unpack_force(hipStream_t st, const DevParams &P, const DeviceState &d, int j0, const int *msg, const int *pack_off)
+{
+    const int ncell = P.lentout_c1 - P.lentout_c0;
+    if (ncell <= 0) return hipSuccess;
+    k_unpack_force<<<ncell, 256, 0, st>>>(P, j0, msg, pack_off, d.cell_start, d.force4, d.fs);
+    PS_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *msg)
+{
+    if (P.xfer_cap <= 0) return hipSuccess;
+    k_inbox_merge<<<(P.xfer_cap + 255) / 256, 256, 0, st>>>(P, msg, d.op_keys, d.op_args, d.ops_cap, d.moves, d.moves_cap, d.stage, d.fs);
+    PS_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <int MODE, int NQ>
+static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force)
+{
+    const int ncomp = comp_count(P);
+    if (ncomp <= 0) return hipSuccess;
+    const int tasks = ncomp * P.slices;
     const bool two = MODE != 0 && P.two_pass;
-    // leftover slices of several cells in one wave (k_pairs_merged).
-    // A rank's share: only while it is big (half the cloud: 1.46 -> 1.41 ms).  A merged wave is
-    // long and stalls on its tile loads; with a 1/4 or 1/8 share there is too little other
-    // work to cover that and it becomes the critical path (measured 0.86 -> 0.92, 0.64 -> 0.74 ms).
+    // leftover slices of several cells in one wave (k_pairs_merged).  A merged wave is long and
+    // stalls on its tile loads; a small share (a slab of a multi-GPU run) has too little other
+    // work to cover that and it becomes the critical path (measured on 1/4 and 1/8 shares).
     static const bool merge_off = std::getenv("PSAMD_NO_MERGE") != nullptr;
-    const bool merge = two && !merge_off && (!sharded || (std::min(hi, covered) - lo) / 57 >= 8192);
+    const bool merge = two && !merge_off && (P.world == 1 || ncomp >= 2048);
     if (two) {
-        // collision flags (a rank of a sharded run: of its own share), then the per-cell lists
-        // and the tasks of the particles that need a force
-        if (sharded) k_shard_tasks<<<1, 64, 0, st>>>(P, d.cell_start, d.task_start, lo, hi, d.fs);
+        // collision flags, then the per-cell lists and the tasks of the particles that need a force
         k_collide<<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.snap_cid, d.task_list,
-                                                   d.halo_count, d.halo_f, d.halo_id, d.pair_flag, d.force4, d.fs,
-                                                   sharded ? 1 : 0, lo, hi);
-        k_build_active<<<P.num_cells, 256, 0, st>>>(P, d.cell_start, d.pair_flag, d.active_list, d.active_count, d.fs,
-                                                    sharded ? 1 : 0, lo, hi);
-        k_active_tasks<<<1, 1024, 0, st>>>(P, d.active_count, d.task_start2, d.task_list2, d.merged_tasks, d.fs, sharded ? 1 : 0,
-                                           merge ? 1 : 0);
+                                                   d.halo_count, d.halo_f, d.halo_id, d.pair_flag, d.force4, d.fs);
+        k_build_active<<<ncomp, 256, 0, st>>>(P, d.cell_start, d.pair_flag, d.active_list, d.active_count);
+        k_active_tasks<<<1, 1024, 0, st>>>(P, d.active_count, d.task_list2, d.merged_tasks, d.fs, merge ? 1 : 0);
     }
     if (ev_force) (void)hipEventRecord(ev_force, st);      // timing: the force pass proper starts here
-    const int *task_start = two ? d.task_start2 : d.task_start, *task_list = two ? d.task_list2 : d.task_list;
+    const int *task_list = two ? d.task_list2 : d.task_list;
     const int *active_list = two ? d.active_list : nullptr, *active_count = two ? d.active_count : nullptr;
-    if (sharded) {
-        // slices of the share: at most one partial slice per cell on top of the full ones
-        const long long share_tasks = std::min<long long>(tasks, (long long)std::max(0, std::min(hi, covered) - lo) / 64 + P.num_cells + 8);
-        if (!two) k_shard_tasks<<<1, 64, 0, st>>>(P, d.cell_start, task_start, lo, hi, d.fs);   // two-pass: done above
-        if (merge) {
-            (void)hipEventRecord(d.ev_fork, st);
-            (void)hipStreamWaitEvent(d.side_stream, d.ev_fork, 0);
-            k_pairs_merged<MODE == 0 ? 1 : MODE, NQ><<<(P.num_cells + 3) / 4, 256, 0, d.side_stream>>>(
-                P, d.cell_start, d.snap4, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
-            (void)hipEventRecord(d.ev_join, d.side_stream);
-        }
-        k_pairs<MODE, true, NQ><<<(int)((share_tasks + 3) / 4), 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
-                                                   lo, hi, covered, d.fs, d.trace, active_list, active_count);
-        if (merge) (void)hipStreamWaitEvent(st, d.ev_join, 0);
-    } else {
-        if (merge) {
-            // fork: the merged tasks run beside the ordinary ones (their waves stall on tile loads
-            // that the ordinary waves' arithmetic covers); the join below puts everything that
-            // follows on `st` after both
-            (void)hipEventRecord(d.ev_fork, st);
-            (void)hipStreamWaitEvent(d.side_stream, d.ev_fork, 0);
-            k_pairs_merged<MODE == 0 ? 1 : MODE, NQ><<<(P.num_cells + 3) / 4, 256, 0, d.side_stream>>>(
-                P, d.cell_start, d.snap4, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
-            (void)hipEventRecord(d.ev_join, d.side_stream);
-        }
-        k_pairs<MODE, false, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
-                                                    lo, hi, covered, d.fs, d.trace, active_list, active_count);
-        if (merge) (void)hipStreamWaitEvent(st, d.ev_join, 0);
+    if (merge) {
+        // fork: the merged tasks run beside the ordinary ones (their waves stall on tile loads
+        // that the ordinary waves' arithmetic covers); the join below puts everything that
+        // follows on `st` after both
+        (void)hipEventRecord(d.ev_fork, st);
+        (void)hipStreamWaitEvent(d.side_stream, d.ev_fork, 0);
+        k_pairs_merged<MODE == 0 ? 1 : MODE, NQ><<<(ncomp + 3) / 4, 256, 0, d.side_stream>>>(
+            P, d.cell_start, d.snap4, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
+        (void)hipEventRecord(d.ev_join, d.side_stream);
     }
+    k_pairs<MODE, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
+                                                d.fs, d.trace, active_list, active_count);
+    if (merge) (void)hipStreamWaitEvent(st, d.ev_join, 0);
     return hipGetLastError();
 }
 
-hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, int lo, int hi, int covered,
-                        bool sharded, hipEvent_t ev_force)
+hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force)
 {
     // fast math shares the lean modes' validity range (finite 1/sqrt(eps2^3))
-    if ((P.flags & PSAMD_FLAG_FAST_MATH) && P.lean_math) return launch_pairs_mode<2, 8>(st, P, d, lo, hi, covered, sharded, ev_force);
+    if ((P.flags & PSAMD_FLAG_FAST_MATH) && P.lean_math) return launch_pairs_mode<2, 8>(st, P, d, ev_force);
     // 8 pairs per slow-branch test: measured 3 % (full GPU) to 5 % (a 1/8 share) faster than 4
-    if (P.lean_math) return launch_pairs_mode<1, 8>(st, P, d, lo, hi, covered, sharded, ev_force);
-    return launch_pairs_mode<0, 4>(st, P, d, lo, hi, covered, sharded, ev_force);
+    if (P.lean_math) return launch_pairs_mode<1, 8>(st, P, d, ev_force);
+    return launch_pairs_mode<0, 4>(st, P, d, ev_force);
 }
 
-hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step,
-                        int live_bound)
+hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step)
 {
-    if (live_bound <= 0) return hipSuccess;
-    k_apply<<<(live_bound + 1023) / 1024, 1024, 0, st>>>(P, S, step, d.rank_of_slot, d.force4, d.pos4,
+    if (P.slots_total <= 0) return hipSuccess;
+    k_apply<<<(P.slots_total + 1023) / 1024, 1024, 0, st>>>(P, S, step, d.rank_of_slot, d.force4, d.pos4,
                                                       d.vel4, d.acc4, d.cell, d.pflags, d.celltab, d.op_keys, d.op_args, d.ops_cap,
-                                                      d.moves, d.moves_cap, d.fs, d.ctr);
+                                                      d.moves, d.moves_cap, d.xfer_out[0], d.xfer_out[1], d.fs, d.ctr);
+    PS_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// slab mode, right after apply: the state of the departing particles goes into the outboxes
+// (the rest of the staging waits for the queue replay) and the two messages get their headers
+hipError_t launch_outbox_close(hipStream_t st, const DevParams &P, const DeviceState &d, int64_t live_bound, int *msg_down, int *msg_up)
+{
+    const int64_t max_moves = std::min<int64_t>(d.moves_cap, 2 * live_bound);
+    const int nb = (int)((max_moves + 255) / 256);
+    if (nb > 0) {
+        k_moves_stage<<<nb, 256, 0, st>>>(P, d.moves, -2, d.fs, d.pos4, d.vel4, d.acc4, d.pflags, d.stage, d.xfer_out[0], d.xfer_out[1]);
+        PS_LAUNCH_CHECK();
+    }
+    k_outbox_header<<<1, 64, 0, st>>>(msg_down, msg_up, d.fs, P.xfer_cap);
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -2162,8 +2485,8 @@ hipError_t launch_ops_census(hipStream_t st, const DevParams &P, const DeviceSta
 }
 
 // Usual case, enqueued without waiting for the host: every queue's operations fit one
-// workgroup's LDS.  `live_bound` >= live particles of the step: at most 3 queue operations
-// and 2 move records each.
+// workgroup's LDS.  `live_bound` >= live particles of the step (arrivals from the neighbour
+// ranks included): at most 3 queue operations and 2 move records each.
 hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
                             int64_t live_bound)
 {
@@ -2172,14 +2495,15 @@ hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceStat
     k_ops_scatter<<<(int)((max_ops + SLOTS_PER_WG - 1) / SLOTS_PER_WG), 1024, 0, st>>>(
         d.op_keys, d.op_args, d.fs, P.key_rec_shift, nrec, d.rec_cursor, d.op_keys_sorted, d.op_args_sorted);
     PS_LAUNCH_CHECK();
-    k_replay_bucket<<<nrec, REPLAY_THREADS, 0, st>>>(d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
+    k_replay_bucket<<<nrec, REPLAY_THREADS, 0, st>>>(P, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
                                           d.moves, d.ctr, d.fs, d.trace);
     PS_LAUNCH_CHECK();
     const int nb = (int)((max_moves + 255) / 256);
     if (nb > 0) {
-        k_moves_stage<<<nb, 256, 0, st>>>(d.moves, -1, d.fs, d.pos4, d.vel4, d.acc4, d.pflags, d.stage);
+        // slab mode staged every local record when it closed the outboxes (launch_outbox_close)
+        if (P.world == 1) k_moves_stage<<<nb, 256, 0, st>>>(P, d.moves, -1, d.fs, d.pos4, d.vel4, d.acc4, d.pflags, d.stage, d.xfer_out[0], d.xfer_out[1]);
         PS_LAUNCH_CHECK();
-        k_moves_reset<<<nb, 256, 0, st>>>(d.moves, -1, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags);
+        k_moves_reset<<<nb, 256, 0, st>>>(P, d.moves, -1, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags);
         PS_LAUNCH_CHECK();
         k_moves_commit<<<nb, 256, 0, st>>>(P, step, d.moves, -1, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
         PS_LAUNCH_CHECK();
@@ -2200,9 +2524,9 @@ hipError_t launch_lifecycle_sorted(hipStream_t st, const DevParams &P, const Dev
     }
     if (n_moves > 0) {
         const int nb = (n_moves + 255) / 256;
-        k_moves_stage<<<nb, 256, 0, st>>>(d.moves, n_moves, d.fs, d.pos4, d.vel4, d.acc4, d.pflags, d.stage);
+        k_moves_stage<<<nb, 256, 0, st>>>(P, d.moves, n_moves, d.fs, d.pos4, d.vel4, d.acc4, d.pflags, d.stage, d.xfer_out[0], d.xfer_out[1]);
         PS_LAUNCH_CHECK();
-        k_moves_reset<<<nb, 256, 0, st>>>(d.moves, n_moves, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags);
+        k_moves_reset<<<nb, 256, 0, st>>>(P, d.moves, n_moves, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags);
         PS_LAUNCH_CHECK();
         k_moves_commit<<<nb, 256, 0, st>>>(P, step, d.moves, n_moves, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
         PS_LAUNCH_CHECK();

@@ -1,0 +1,179 @@
+"""Stepping a slab-partitioned system: the message exchange around the four stage calls.
+
+Every rank holds one slab of the system (include/psamd.h, "slab partition": the segments of
+its cell layers, their slots, particles and free-slot queues) and talks to its two neighbours
+only.  One step is
+
+    slab_build   ->  halo:  snapshot of boundary layers to the rank below / above
+    slab_pairs   ->  force: (ax, ay, az, flag) of lent layers back to the rank below
+    slab_apply   ->  xfer:  particles whose new segment a neighbour owns (ring: periodic box)
+    slab_finish
+
+with fixed-size messages, so the transport never negotiates a length.  This module is the
+host-side plumbing only; it computes nothing.  Three transports:
+
+  * ``DeviceRing``  torch.distributed P2P (RCCL over xGMI) directly on the contexts' device
+    buffers; the halo travels on a side stream while the main stream is free for other work.
+  * ``HostRing``    torch.distributed P2P (gloo) through host copies of the messages: for tests,
+    and for several processes that share one GPU.
+  * ``step_local``  all ranks live in one process (tests): messages are copied rank to rank.
+
+A "rank" is anything with the stage calls and ``msg_bytes / msg_download / msg_upload``
+(``particlesystem_amd.ParticleSystem``; the CPU tests drive a host stand-in the same way).
+"""
+import numpy as np
+
+# message slots, as in psamd_slab_msg_download: out/in x below/above
+HALO_OUT, HALO_IN, FORCE_OUT, FORCE_IN, XFER_OUT, XFER_IN = 0, 2, 4, 5, 6, 8
+BELOW, ABOVE = 0, 1
+
+
+def routes(rank, world, periodic_ring=True):
+    """(phase, out slot of this rank, peer rank, in slot of the peer) for every message this
+    rank may send.  Which of them exist is decided by the sizes (0 bytes = no such message)."""
+    r = []
+    if rank > 0:
+        r.append(("halo", HALO_OUT + BELOW, rank - 1, HALO_IN + ABOVE))
+        r.append(("force", FORCE_OUT, rank - 1, FORCE_IN))
+    if rank + 1 < world:
+        r.append(("halo", HALO_OUT + ABOVE, rank + 1, HALO_IN + BELOW))
+    if world > 1:
+        r.append(("xfer", XFER_OUT + BELOW, (rank - 1) % world, XFER_IN + ABOVE))
+        r.append(("xfer", XFER_OUT + ABOVE, (rank + 1) % world, XFER_IN + BELOW))
+    return r
+
+
+def step_local(ranks):
+    """One step of a whole system whose ranks all live in this process (tests)."""
+    world = len(ranks)
+
+    def deliver(phase):
+        for r, sysr in enumerate(ranks):
+            for ph, out_slot, peer, in_slot in routes(r, world):
+                n = sysr.msg_bytes(out_slot)
+                if ph != phase or n == 0:
+                    continue
+                assert ranks[peer].msg_bytes(in_slot) == n, (phase, r, peer, n, ranks[peer].msg_bytes(in_slot))
+                ranks[peer].msg_upload(in_slot, sysr.msg_download(out_slot))
+
+    for s in ranks:
+        s.slab_build()
+    deliver("halo")
+    for s in ranks:
+        s.slab_pairs()
+    deliver("force")
+    for s in ranks:
+        s.slab_apply()
+    deliver("xfer")
+    for s in ranks:
+        s.slab_finish()
+
+
+class _Ring:
+    """Pairs every message this rank sends with the one it receives in the same phase."""
+
+    def __init__(self, sysr, dist, rank, world):
+        self.s, self.dist, self.rank, self.world = sysr, dist, rank, world
+        self.sends = {}      # phase -> [(out slot, peer)]
+        self.recvs = {}      # phase -> [(in slot, peer)]
+        for ph, out_slot, peer, _ in routes(rank, world):
+            if sysr.msg_bytes(out_slot):
+                self.sends.setdefault(ph, []).append((out_slot, peer))
+        # what the neighbours send here: their routes, seen from this side
+        for peer in sorted({(rank - 1) % world, (rank + 1) % world}):
+            for ph, _, dst, in_slot in routes(peer, world):
+                if dst == rank and sysr.msg_bytes(in_slot):
+                    self.recvs.setdefault(ph, []).append((in_slot, peer))
+        # both sides must post the operations between one pair of ranks in the same order
+        # (RCCL matches sends and receives of a pair by order, there are no tags): order every
+        # list by (peer, direction of travel)
+        for d in (self.sends, self.recvs):
+            for ph in d:
+                d[ph].sort(key=lambda e: (e[1], e[0] & 1) if d is self.sends else (e[1], 1 - (e[0] & 1)))
+
+    def _ops(self, phase, tensor_of):
+        P2POp = self.dist.P2POp
+        ops = []
+        for slot, peer in self.sends.get(phase, []):
+            ops.append(P2POp(self.dist.isend, tensor_of(slot), peer))
+        for slot, peer in self.recvs.get(phase, []):
+            ops.append(P2POp(self.dist.irecv, tensor_of(slot), peer))
+        return ops
+
+
+class HostRing(_Ring):
+    """Messages travel as CPU tensors (gloo, or any backend that takes host memory)."""
+
+    def exchange(self, phase):
+        import torch
+        out = {slot: torch.from_numpy(self.s.msg_download(slot)) for slot, _ in self.sends.get(phase, [])}
+        inn = {slot: torch.empty(self.s.msg_bytes(slot) // 4, dtype=torch.int32) for slot, _ in self.recvs.get(phase, [])}
+        ops = self._ops(phase, lambda slot: out[slot] if slot in out else inn[slot])
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+        for slot, t in inn.items():
+            self.s.msg_upload(slot, t.numpy())
+
+    def step(self):
+        s = self.s
+        s.slab_build()
+        self.exchange("halo")
+        s.slab_pairs()
+        self.exchange("force")
+        s.slab_apply()
+        self.exchange("xfer")
+        s.slab_finish()
+
+
+class _DevPtr:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+
+
+class DeviceRing(_Ring):
+    """RCCL send/recv straight out of / into the contexts' message buffers (no copies).
+    Stage kernels and collectives are ordered by ONE stream: torch's current stream, which the
+    context is switched to (psamd_set_stream)."""
+
+    def __init__(self, sysr, dist, rank, world, torch_stream):
+        super().__init__(sysr, dist, rank, world)
+        import torch
+        b = sysr.slab_buffers()
+        ptrs = {HALO_OUT + 0: (b.halo_out[0], b.halo_out_bytes[0]), HALO_OUT + 1: (b.halo_out[1], b.halo_out_bytes[1]),
+                HALO_IN + 0: (b.halo_in[0], b.halo_in_bytes[0]), HALO_IN + 1: (b.halo_in[1], b.halo_in_bytes[1]),
+                FORCE_OUT: (b.force_out, b.force_out_bytes), FORCE_IN: (b.force_in, b.force_in_bytes),
+                XFER_OUT + 0: (b.xfer_out[0], b.xfer_bytes), XFER_OUT + 1: (b.xfer_out[1], b.xfer_bytes),
+                XFER_IN + 0: (b.xfer_in[0], b.xfer_bytes), XFER_IN + 1: (b.xfer_in[1], b.xfer_bytes)}
+        self.t = {slot: torch.as_tensor(_DevPtr(p, n), device="cuda") for slot, (p, n) in ptrs.items() if p and n}
+        self.stream = torch_stream
+        sysr.set_stream(torch_stream.cuda_stream)
+
+    def exchange(self, phase):
+        ops = self._ops(phase, lambda slot: self.t[slot])
+        if ops:
+            # enqueued on the current stream; later kernels on it wait for the transfers
+            self.dist.batch_isend_irecv(ops)
+
+    def step(self):
+        import torch
+        s = self.s
+        with torch.cuda.stream(self.stream):
+            s.slab_build()
+            self.exchange("halo")
+            s.slab_pairs()
+            self.exchange("force")
+            s.slab_apply()
+            self.exchange("xfer")
+            s.slab_finish()
+
+
+def merge_owned(arrays, plans, kind="slots"):
+    """Assemble a whole-container array from the ranks' downloads: every slot (or QUEUE_INFO
+    record, kind="records") is taken from the rank that owns it."""
+    out = np.array(arrays[0], copy=True)
+    for a, p in zip(arrays, plans):
+        lo, hi = (p.slot_lo, p.slot_hi) if kind == "slots" else (p.rec_lo, p.rec_hi)
+        for t in range(4):
+            out[lo[t]:hi[t]] = a[lo[t]:hi[t]]
+    return out

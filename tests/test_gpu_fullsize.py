@@ -85,7 +85,7 @@ def test_pair_pass_sample_matches_oracle_bitwise(big):
     o.close()
 
 
-def test_step_is_deterministic_and_shard_invariant(big):
+def test_step_is_deterministic_and_slab_invariant(big):
     g, xyz, age, fert, ids = big
     digests = []
     for _ in range(2):
@@ -95,18 +95,22 @@ def test_step_is_deterministic_and_shard_invariant(big):
     assert digests[0] == digests[1]
     c = g.counters
     assert c["particles_processed"] % N == 0
-    # the same step with the pair pass cut in two halves computed separately
-    g.snapshot_restore()
-    g.init_iframe(); g.build_grid(); g.calc_forces_pairs()
-    total = int(g.download_cellgrid()[:, 0].sum())
-    whole = g.download_force4(0, total)
+    whole = g.download_particles()
+    qi_w, q_w = g.download_queues()
+    # the same step on two slabs (each holds half of the system; halo, force and transfer
+    # messages copied between them): the union is the same state
+    from particlesystem_amd.slab import merge_owned, step_local
     halves = [ps.ParticleSystem(ps.default_config(rank=r, world=2)) for r in range(2)]
     for h in halves:
         h.fill_particles(xyz, age=age, fert_age=fert)
-        h.init_iframe(); h.build_grid()
-        lo, hi, share = h.force_shard()
-        h.calc_forces_pairs()
-        assert np.array_equal(h.download_force4(lo, hi - lo).view(np.uint32), whole[lo:hi].view(np.uint32))
+    step_local(halves)
+    plans = [h.slab_plan() for h in halves]
+    assert merge_owned([h.download_particles() for h in halves], plans).tobytes() == whole.tobytes()
+    qs = [h.download_queues() for h in halves]
+    assert merge_owned([q[0] for q in qs], plans, "records").tobytes() == qi_w.tobytes()
+    assert np.array_equal(merge_owned([q[1] for q in qs], plans), q_w)
+    assert sum(int(h.msg_download(ps.MSG_XFER_OUT + k)[0]) for h in halves for k in (0, 1)) > 0
+    for h in halves:
         h.close()
 
 

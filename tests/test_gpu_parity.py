@@ -241,38 +241,6 @@ def test_errors_are_statuses():
     g.upload_particles(p)               # a valid upload afterwards is accepted
 
 
-def test_two_rank_contexts_share_the_pair_loop():
-    """world=2 on one GPU: two contexts each evaluate half of the sorted particles,
-    swap their force4 shards through host memory, and both must stay bit-identical
-    to the single-context run and to the oracle."""
-    n = 30000
-    xyz = cloud(n, 61)
-    rng = np.random.default_rng(61)
-    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
-    ranks = [ps.ParticleSystem(ps.default_config(rank=r, world=2)) for r in range(2)]
-    for g in ranks:
-        g.fill_particles(xyz, age=age, fert_age=1e6)
-    single, o = make_pair(xyz, age=age, fert=1e6)
-    for step in range(4):
-        shards = []
-        for g in ranks:
-            g.init_iframe(); g.build_grid()
-            lo, hi, share = g.force_shard()
-            g.calc_forces_pairs()
-            shards.append((lo, g.download_force4(lo, hi - lo)))
-        assert shards[0][0] == 0 and shards[1][0] == len(shards[0][1])
-        for g in ranks:
-            for lo, arr in shards:
-                g.upload_force4(arr, lo)
-            g.calc_forces_apply()
-        single.step(1); o.step(1)
-        for r, g in enumerate(ranks):
-            compare_all(g, o, "rank %d of 2, step %d" % (r, step + 1))
-        compare_all(single, o, "single context step %d" % (step + 1))
-    with pytest.raises(ps.PsamdError):
-        ranks[0].init_iframe(); ranks[0].build_grid(); ranks[0].calc_forces()   # world > 1 needs the split calls
-
-
 def test_large_grid_uses_the_global_atomic_build():
     """BASELINE config 4's grid (40^3 = 64000 cells, more than fit an LDS histogram): the
     fallback hist/scatter kernels and the 1000-chunk scan, against the oracle."""
@@ -301,47 +269,6 @@ def test_snapshot_restore_is_exact():
     assert qi.tobytes() == o.queue_info.tobytes() and np.array_equal(q, o.queue)
     g.step(1); o.step(1)
     assert_same_particles(g.download_particles(), o.particles, "step after restore")
-
-
-def test_sharded_step_ordered_by_a_shared_torch_stream():
-    """The bench's multi-GPU plumbing minus RCCL: two rank contexts enqueue on one torch
-    stream, their force4 arrays are caller-owned torch tensors, and the exchange is a pair
-    of device copies on that stream.  Nothing synchronises except stream order, so a
-    context that ignored psamd_set_stream / psamd_bind_force4 would read stale forces."""
-    import torch
-    n = 60000
-    xyz = cloud(n, 91)
-    rng = np.random.default_rng(91)
-    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
-    ranks, forces = [], []
-    for r in range(2):
-        g = ps.ParticleSystem(ps.default_config(rank=r, world=2))
-        g.fill_particles(xyz, age=age, fert_age=1e6)
-        f = torch.full((g.sizes.container_size + 2, 4), float("nan"), device="cuda")
-        torch.cuda.synchronize()
-        g.bind_force4(f.data_ptr(), len(f))
-        g.set_stream(stream.cuda_stream)
-        ranks.append(g); forces.append(f)
-    o = O.System(oracle_cfg_from(ranks[0].cfg))
-    o.fill(xyz, age=age, fert_age=1e6)
-    for step in range(3):
-        shares = []
-        for g in ranks:
-            g.init_iframe(); g.build_grid()
-            shares.append(g.force_shard())
-            g.calc_forces_pairs()
-        (lo0, hi0, sh), (lo1, hi1, _) = shares
-        forces[0][lo1:hi1].copy_(forces[1][lo1:hi1], non_blocking=True)   # "all-gather"
-        forces[1][lo0:hi0].copy_(forces[0][lo0:hi0], non_blocking=True)
-        for g in ranks:
-            g.calc_forces_apply()
-        o.step(1)
-        for r, g in enumerate(ranks):
-            compare_all(g, o, "stream-ordered rank %d step %d" % (r, step + 1))
-    torch.cuda.set_stream(torch.cuda.default_stream())
 
 
 @pytest.mark.parametrize("eps2", [1e-20, 0.01, 0.37, 1.0, 3.0])

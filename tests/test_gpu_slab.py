@@ -1,0 +1,208 @@
+"""The slab-partitioned (multi-GPU) path on ONE GPU: `world` contexts in one process, each
+holding only its slab -- the segments of its cell layers with their slots, particles and
+free-slot queues -- stepped through the four psamd_slab_* stage calls with the halo / force /
+transfer messages copied rank to rank (particlesystem_amd.slab.step_local; the transport is
+the only thing that differs from an RCCL run).  The union of the ranks' states must equal the
+single-system oracle byte for byte, every step, including the particles that change owner
+and the slot ids the neighbours' queues hand out to them."""
+import numpy as np
+import pytest
+
+import oracle_py as O
+import particlesystem_amd as ps
+from particlesystem_amd.slab import merge_owned, step_local
+from util import assert_same_particles, cloud, explosion_rng, g2_cloud, oracle_cfg_from
+
+pytestmark = pytest.mark.gpu
+
+COUNTERS = ("deaths_age", "deaths_collision", "survives", "integrated", "relocations",
+            "relocations_lost", "births", "births_failed", "cell_overflow_kills")
+
+
+def make_world(world, xyz, age, fert, flags=0, cuts=None, **over):
+    ranks = []
+    for r in range(world):
+        kw = dict(rank=r, world=world, flags=flags, **over)
+        if cuts is not None:
+            kw["cuts"] = cuts
+        ranks.append(ps.ParticleSystem(ps.default_config(**kw)))
+    o = O.System(oracle_cfg_from(ranks[0].cfg))
+    ids_o = o.fill(xyz, age=age, fert_age=fert)
+    ids = np.stack([g.fill_particles(xyz, age=age, fert_age=fert) for g in ranks])
+    # every particle was placed by exactly one rank, in the slot the oracle gave it
+    assert ((ids >= 0).sum(0) == 1).all()
+    assert np.array_equal(ids.max(0), ids_o)
+    return ranks, o
+
+
+def compare_world(ranks, o, what):
+    plans = [g.slab_plan() for g in ranks]
+    p = merge_owned([g.download_particles() for g in ranks], plans)
+    assert_same_particles(p, o.particles, what)
+    qs = [g.download_queues() for g in ranks]
+    qi = merge_owned([q[0] for q in qs], plans, "records")
+    q = merge_owned([q[1] for q in qs], plans)
+    assert qi.tobytes() == o.queue_info.tobytes(), what + ": QUEUE_INFO differs"
+    assert np.array_equal(q, o.queue), what + ": queue array differs"
+    cs = [g.counters for g in ranks]
+    for k in COUNTERS:
+        assert sum(c[k] for c in cs) == o.counters[k], (what, k, [c[k] for c in cs], o.counters[k])
+    return cs
+
+
+def changed_owner(ranks):
+    """particles that arrived from a neighbour so far = relocations + births whose slot the
+    neighbour's queue handed out: visible as xfer records sent"""
+    return sum(int(g.msg_download(ps.MSG_XFER_OUT + k)[0]) for g in ranks for k in (0, 1))
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+def test_slab_world_matches_oracle_every_step(world):
+    n = 60000
+    xyz = cloud(n, 300 + world)
+    rng = np.random.default_rng(world)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    fert = (1e6 + np.arange(n)).astype(np.float32)
+    ranks, o = make_world(world, xyz, age, fert)
+    moved = 0
+    for step in range(12):
+        step_local(ranks)
+        o.step(1)
+        moved += changed_owner(ranks)
+        compare_world(ranks, o, "world %d step %d" % (world, step + 1))
+    assert moved > 0 and o.counters["relocations"] > 0 and o.counters["deaths_collision"] > 0
+    for g in ranks:
+        g.close()
+
+
+def test_slab_wraps_around_the_periodic_box():
+    """fast particles: |v| up to 90 => every particle moves a whole cell per step (MAX_DX clamp),
+    so the top and bottom layers trade particles through the wrap, rank world-1 <-> rank 0."""
+    n, world = 30000, 4
+    xyz = cloud(n, 41)
+    rng = np.random.default_rng(41)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    ranks = [ps.ParticleSystem(ps.default_config(rank=r, world=world)) for r in range(world)]
+    o = O.System(oracle_cfg_from(ranks[0].cfg))
+    v = rng.uniform(-90, 90, (n, 3)).astype(np.float32)
+    ids_o = o.fill(xyz, age=age, fert_age=np.float32(1e6))
+    pp = o.particles
+    pp["vx"][ids_o], pp["vy"][ids_o], pp["vz"][ids_o] = v.T
+    for g in ranks:
+        g.fill_particles(xyz, age=age, fert_age=np.float32(1e6), vxyz=v)
+    for step in range(6):
+        step_local(ranks); o.step(1)
+        compare_world(ranks, o, "wrap step %d" % (step + 1))
+    sent_down_by_rank0 = int(ranks[0].msg_download(ps.MSG_XFER_OUT + 0)[0])
+    sent_up_by_last = int(ranks[-1].msg_download(ps.MSG_XFER_OUT + 1)[0])
+    assert sent_down_by_rank0 > 0 and sent_up_by_last > 0
+    for g in ranks:
+        g.close()
+
+
+def test_slab_births_cross_ranks():
+    """explosions on: a child is born into the parent's NEW segment, which may be a
+    neighbour's; the counter-based RNG is keyed by the parent's id, so the child is the same
+    whoever places it."""
+    n, world, seed = 40000, 4, 777
+    xyz = cloud(n, 51)
+    rng = np.random.default_rng(51)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    fert = rng.uniform(2.5, 8.0, n).astype(np.float32)
+    ranks, o = make_world(world, xyz, age, fert, flags=ps.FLAG_EXPLOSIONS, seed=seed)
+    o.set_rng(explosion_rng(seed))
+    for step in range(10):
+        step_local(ranks); o.step(1)
+        compare_world(ranks, o, "births step %d" % (step + 1))
+    assert o.counters["births"] > 100
+    for g in ranks:
+        g.close()
+
+
+@pytest.mark.parametrize("cuts", [[0, 7, 16], [0, 9, 16], [0, 3, 16], [0, 4, 7, 11, 16], [0, 2, 5, 8, 10, 13, 16]])
+def test_slab_uneven_and_group_aligned_cuts(cuts):
+    """cuts at 7|: aligned with a segment group (a halo layer travels DOWN as well, nothing is
+    lent); 9|, 3|: the other parity; mixed."""
+    world = len(cuts) - 1
+    n = 30000
+    xyz = cloud(n, 61)
+    rng = np.random.default_rng(61)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    ranks, o = make_world(world, xyz, age, np.float32(1e6), cuts=cuts)
+    for step in range(6):
+        step_local(ranks); o.step(1)
+        compare_world(ranks, o, "cuts %r step %d" % (cuts, step + 1))
+    for g in ranks:
+        g.close()
+
+
+def test_slab_g2_cloud_100_steps():
+    """BASELINE config 0's cloud, 100 steps on three slabs: the reference's own life-cycle
+    counts come out of the union."""
+    xyz = g2_cloud()
+    fert = (1e6 + np.arange(len(xyz))).astype(np.float32)
+    ranks, o = make_world(3, xyz, np.float32(40 * 0.01), fert, dt=0.01)
+    for step in range(100):
+        step_local(ranks)
+    o.step(100)
+    cs = compare_world(ranks, o, "G2 on 3 slabs after 100 steps")
+    assert sum(g.live_count() for g in ranks) == 2724 and sum(c["relocations"] for c in cs) == 1537
+    for g in ranks:
+        g.close()
+
+
+def test_slab_other_grid_and_one_pass_mode():
+    """chunk_dim 5 (three-layer inner groups) and an EPS2 that forces the generic one-pass
+    pair kernel (collision flags come from the force walk, remote ids and ages are used)."""
+    over = {"chunk_factor": 3, "chunk_dim": 5, "max_particles_num": 20000}
+    n = 15000
+    xyz = cloud(n, 71, 34.9)              # the odd grid is not centred: x in [-35, 40), y and z in (-40, 35]
+    rng = np.random.default_rng(71)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    for eps2 in (0.2, 1e-20):
+        ranks, o = make_world(3, xyz, age, np.float32(1e6), eps2=eps2, **over)
+        for step in range(4):
+            step_local(ranks); o.step(1)
+            compare_world(ranks, o, "15^3 grid eps2=%g step %d" % (eps2, step + 1))
+        for g in ranks:
+            g.close()
+
+
+def test_world_one_slab_calls_are_the_plain_step():
+    xyz = cloud(20000, 81)
+    g = ps.ParticleSystem(ps.default_config())
+    o = O.System(oracle_cfg_from(g.cfg))
+    g.fill_particles(xyz, age=np.float32(3.0), fert_age=np.float32(1e6))
+    o.fill(xyz, age=np.float32(3.0), fert_age=np.float32(1e6))
+    for step in range(3):
+        step_local([g]); o.step(1)
+        assert_same_particles(g.download_particles(), o.particles, "world 1 step %d" % (step + 1))
+    assert all(g.msg_bytes(k) == 0 for k in range(10))
+    with pytest.raises(ps.PsamdError):
+        g.slab_pairs()                      # out of order
+    g.close()
+
+
+def test_slab_context_refuses_the_plain_stage_calls_and_bad_worlds():
+    g = ps.ParticleSystem(ps.default_config(rank=0, world=2))
+    with pytest.raises(ps.PsamdError):
+        g.step(1)
+    g.close()
+    with pytest.raises(ps.PsamdError):
+        ps.ParticleSystem(ps.default_config(rank=0, world=16))      # 16 layers: one per rank is not enough
+
+
+def test_slab_message_overflow_is_loud():
+    """halo_cap_cell too small for the densest boundary cell => a sticky error on the ranks
+    involved, not a silent truncation."""
+    n = 60000
+    xyz = cloud(n, 91)
+    ranks = [ps.ParticleSystem(ps.default_config(rank=r, world=2, halo_cap_cell=8)) for r in range(2)]
+    for g in ranks:
+        g.fill_particles(xyz, age=np.float32(3.0), fert_age=np.float32(1e6))
+    with pytest.raises(ps.PsamdError):
+        step_local(ranks)
+        for g in ranks:
+            g.synchronize()
+    for g in ranks:
+        g.close()

@@ -13,21 +13,22 @@ surface implode (a ~ 3000 in the outer cell layer) and collisions, cell overflow
 full segments remove half the particles within a few steps.  So each timed step is
 one pass over the SAME batch: the N = 2^20 cloud is restored from a device-side
 snapshot (an HBM-to-HBM copy, inside the timed region) and advanced by one step --
-exactly the work the CPU baseline samples.  --evolve runs free instead and counts the
-live particles of every step.
+exactly the work the CPU baseline samples.  The line's `evolve` key reports a
+free-running stretch beside it (--evolve makes that the timed loop).
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
 
-N > 1: every rank keeps the whole (bit-identical) container; the pair loop -- 99.9 % of
-the step -- is sharded by sorted-particle range, and one RCCL all-gather per step
-exchanges the float4 (ax, ay, az, flag) results (16 B per particle, the size of the
-position all-gather it replaces); integrate + lifecycle are replicated streaming work.
-Total work is fixed at N = 2^20 as the GPU count grows => "scaling": "strong".
+N > 1 starts one process per GPU (python -m torch.distributed.run; or is started that way by
+the caller) and runs the SLAB-PARTITIONED path: every rank holds only the segments of its
+cell layers -- slots, particles, free-slot queues -- and exchanges, with its two ring
+neighbours over RCCL send/recv, the snapshot of its boundary layers, the force records of
+lent layers and the particles that change owner (particlesystem_amd/slab.py).  Total work is
+fixed at N = 2^20 as the GPU count grows => "scaling": "strong".
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -40,9 +41,56 @@ VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector (spec)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FLOP_PER_PAIR = 20           # the usual N-body convention
 APPLY_BYTES_PER_UPDATE = 64  # read pos4+vel4, write pos4+vel4
+TRAFFIC_FILE = os.path.join("profiles", "r2_traffic.json")
+XGMI_LINK_GBS = 153.0        # MI355X_MICROARCH.md: one xGMI link, one direction (model only)
 
 
-def make_inputs(ps, sysobj, n, seed):
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=1 << 20)
+    ap.add_argument("--fast-math", action="store_true", help="FMA/rsq pair arithmetic (not bit-exact)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-threads", type=int, default=64, help="cap on host threads for the all-core CPU figure")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--kernel-times", action="store_true", help="HIP events between all stage kernels, not only around the "
+                    "pair pass / apply / life cycle (costs ~40 us of idle GPU per step)")
+    ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--chunk-factor", type=int, default=4, help="grid = (chunk_factor*chunk_dim)^3 cells (reference: 4)")
+    ap.add_argument("--chunk-dim", type=int, default=4)
+    ap.add_argument("--evolve", action="store_true", help="free-running steps instead of one pass per step over the same cloud")
+    ap.add_argument("--evolve-steps", type=int, default=10, help="length of the free-running stretch reported beside the headline")
+    ap.add_argument("--halo-cap-cell", type=int, default=0, help="bodies per cell a halo message has room for (0: the cell capacity)")
+    ap.add_argument("--settle-seconds", type=float, default=0.5, help="untimed steps before the warmup until the clocks have settled")
+    ap.add_argument("--sim-world", type=int, default=0, help="projection on ONE GPU: all ranks of an N-rank slab run live in this "
+                    "process and run one after the other; reports every rank's stage times and the modelled step")
+    ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL; gloo: messages staged "
+                    "through host memory, for rehearsals on one GPU)")
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """--gpus N without a launcher: start the ranks (fresh processes, nothing here has touched
+    the GPU), relay rank 0's JSON line, exit with the job's status."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, PSAMD_BENCH_CHILD="1")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    if lines:
+        print(lines[-1])
+    else:
+        sys.stderr.write(p.stdout)
+    sys.exit(p.returncode if p.returncode else (0 if lines else 1))
+
+
+def make_inputs(sysobj, n, seed):
     xyz = sysobj.uniform_cloud(n, seed)
     rng = np.random.default_rng(seed)
     life = 300.0 * sysobj.cfg.dt
@@ -51,10 +99,14 @@ def make_inputs(ps, sysobj, n, seed):
     return xyz, age, fert
 
 
-def measured_traffic(kernel_prefix):
-    """HBM bytes per launch from the committed rocprofv3 PMC capture (profiles/), or None."""
+def measured_traffic(kernel_prefix, args, world):
+    """HBM bytes per launch from the committed rocprofv3 PMC capture -- only for the very
+    configuration it was captured with (bench.py defaults on one GPU); else None."""
+    if world != 1 or args.n != (1 << 20) or args.chunk_factor != 4 or args.chunk_dim != 4 or args.evolve or args.fast_math \
+            or args.sim_world:
+        return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
             kernels = json.load(f)["kernels"]
         for name, rec in kernels.items():
             if name.startswith(kernel_prefix):
@@ -83,7 +135,7 @@ def cpu_baseline(args, xyz, age, fert, cfg_over):
     """The oracle (CPU port of the reference `_host` path) on bounded samples of the SAME
     workload.  `cpu_baseline`: one thread, whole chunks of calc_forces until ~args.cpu_seconds
     have passed.  `cpu_baseline_all_cores`: the read-only pair pass (collision scan + force
-    loop, >99.9 % of the CPU step) on every usable host core, contiguous shares per thread."""
+    loop, >99.9 % of the CPU step) on up to --cpu-threads host threads, contiguous shares per thread."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     o = O.System(O.default_config(**cfg_over))
@@ -109,7 +161,8 @@ def cpu_baseline(args, xyz, age, fert, cfg_over):
         tm = time.perf_counter() - t0
         many = {"value": seg * segs / tm, "unit": "particle-updates/s", "cores": cores, "kind": "port",
                 "sample": "pair pass (collision scan + force loop) of %d particles (%d runs of cells spread over the "
-                          "box) of the same N=%d cloud on %d host threads, %.1f s" % (seg * segs, segs, len(xyz), cores, tm)}
+                          "box) of the same N=%d cloud on %d host threads, %.1f s" % (seg * segs, segs, len(xyz), cores, tm),
+                "host_cpus": os.cpu_count()}
         del f
     gm = int(o.gridmax[0])
     counts = o.chunkgrid[:, 0].copy()
@@ -129,82 +182,140 @@ def cpu_baseline(args, xyz, age, fert, cfg_over):
     return one, many
 
 
-def fast_math_rate(ps, cfg_over, device, xyz, age, fert, steps=5):
-    """For the record, never the headline: the same timed loop with PSAMD_FLAG_FAST_MATH
-    (FMA + v_rsq pair arithmetic: accelerations within 1e-5 relative of the oracle,
-    tests/test_gpu_fast.py; the headline runs the bit-exact arithmetic)."""
-    g = ps.ParticleSystem(ps.default_config(device=device, flags=ps.FLAG_FAST_MATH, **cfg_over))
+def side_run(ps, cfg_over, device, xyz, age, fert, flags, steps, restore):
+    """A second, short measurement on a fresh context: the same timed loop with other flags
+    (fast math) or free-running (restore=False).  Never the headline."""
+    g = ps.ParticleSystem(ps.default_config(device=device, flags=flags, **cfg_over))
     g.fill_particles(xyz, age=age, fert_age=fert)
     g.snapshot_save()
-    for _ in range(2):
-        g.snapshot_restore(); g.step(1)
+    live = []
+    if restore:
+        for _ in range(2):
+            g.snapshot_restore(); g.step(1)
     g.synchronize()
     p0 = g.counters["particles_processed"]
     t0 = time.perf_counter()
     for _ in range(steps):
-        g.snapshot_restore(); g.step(1)
+        if restore:
+            g.snapshot_restore()
+        g.step(1)
+        if not restore:
+            live.append(int(g.device_view().live))      # particles that step processed (host copy, no sync)
     g.synchronize()
     dt = time.perf_counter() - t0
     done = g.counters["particles_processed"] - p0
     g.close()
-    return {"arithmetic": "PSAMD_FLAG_FAST_MATH (FMA + v_rsq), within 1e-5 relative of the oracle; not the headline",
-            "value": done / dt, "unit": "particle-updates/s", "ms_per_step": 1e3 * dt / steps, "steps": steps}
+    return done, dt, live
+
+
+def sim_world(args, ps, cfg_over, flags):
+    """All ranks of a world-`W` slab run in this process, on this one GPU, one after the other
+    on one stream: every rank's stage then takes what it would take with a GPU to itself.
+    Messages are copied device to device; their transfer is modelled from their sizes."""
+    import torch
+    from particlesystem_amd.slab import DeviceRing, routes
+    W = args.sim_world
+    stream = torch.cuda.Stream()
+    ranks = [ps.ParticleSystem(ps.default_config(device=0, rank=r, world=W, flags=flags, halo_cap_cell=args.halo_cap_cell, **cfg_over))
+             for r in range(W)]
+    xyz, age, fert = make_inputs(ranks[0], args.n, args.seed)
+    for g in ranks:
+        g.fill_particles(xyz, age=age, fert_age=fert)
+        g.snapshot_save()
+    rings = [DeviceRing(g, None, r, W, stream) for r, g in enumerate(ranks)]
+    stages = ("build", "pairs", "apply", "finish")
+    ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in stages] for _ in range(W)]
+    tot = np.zeros((W, len(stages)))
+
+    def deliver(phase):
+        for r in range(W):
+            for ph, out_slot, peer, in_slot in routes(r, W):
+                if ph == phase and out_slot in rings[r].t:
+                    rings[peer].t[in_slot].copy_(rings[r].t[out_slot], non_blocking=True)
+
+    def one_step(timed):
+        with torch.cuda.stream(stream):
+            for g in ranks:
+                if not args.evolve:
+                    g.snapshot_restore()
+            for k, (name, phase) in enumerate(zip(stages, ("halo", "force", "xfer", None))):
+                for r, g in enumerate(ranks):
+                    ev[r][k][0].record(stream)
+                    getattr(g, "slab_" + name)()
+                    ev[r][k][1].record(stream)
+                if phase:
+                    deliver(phase)
+        if timed:
+            torch.cuda.synchronize()
+            for r in range(W):
+                for k in range(len(stages)):
+                    tot[r, k] += ev[r][k][0].elapsed_time(ev[r][k][1])
+
+    for _ in range(args.warmup):
+        one_step(False)
+    p0 = [g.counters["particles_processed"] for g in ranks]
+    for _ in range(args.steps):
+        one_step(True)
+    tot /= args.steps
+    updates = sum(g.counters["particles_processed"] - a for g, a in zip(ranks, p0)) / args.steps
+    msg = {}
+    for r, g in enumerate(ranks):
+        msg[r] = {ph: sum(g.msg_bytes(s) for p2, s, _, _ in routes(r, W) if p2 == ph) for ph in ("halo", "force", "xfer")}
+    # model: a message costs 10 us + bytes / one xGMI link; halo, force and xfer are on the
+    # critical path once each (nothing overlapped in this estimate)
+    comm_ms = [sum(1e-2 + 1e3 * b / (XGMI_LINK_GBS * 1e9) for b in msg[r].values() if b) for r in range(W)]
+    per_rank = tot.sum(1)
+    step_ms = float((per_rank + np.array(comm_ms)).max())
+    out = {"sim_world": W, "n": args.n, "stage_ms_per_rank": {name: [round(float(x), 4) for x in tot[:, k]] for k, name in enumerate(stages)},
+           "compute_ms_per_rank": [round(float(x), 4) for x in per_rank], "modelled_comm_ms_per_rank": [round(x, 4) for x in comm_ms],
+           "message_bytes_rank1": msg[min(1, W - 1)], "modelled_step_ms": step_ms,
+           "modelled_updates_per_s": updates / (step_ms * 1e-3), "updates_per_step": updates,
+           "note": "one GPU runs the ranks one after the other; compute times are measured (HIP events), transfers are "
+                   "modelled as 10 us + bytes / %.0f GB/s per message and not overlapped" % XGMI_LINK_GBS}
+    for g in ranks:
+        g.close()
+    return out
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1 << 20)
-    ap.add_argument("--fast-math", action="store_true", help="FMA/rsq pair arithmetic (not bit-exact)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--cpu-threads", type=int, default=64, help="cap on host threads for the all-core CPU figure")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--kernel-times", action="store_true", help="HIP events between all stage kernels, not only around the "
-                    "pair pass / apply / life cycle (costs ~40 us of idle GPU per step)")
-    ap.add_argument("--seed", type=int, default=2026)
-    ap.add_argument("--chunk-factor", type=int, default=4, help="grid = (chunk_factor*chunk_dim)^3 cells (reference: 4)")
-    ap.add_argument("--chunk-dim", type=int, default=4)
-    ap.add_argument("--evolve", action="store_true", help="free-running steps instead of one pass per step over the same cloud")
-    ap.add_argument("--force-dist", action="store_true", help="take the collective code path even with one rank (rehearsal)")
-    ap.add_argument("--sim-world", type=int, default=0, help="diagnostic: time ONE rank's work of an N-rank run on one GPU "
-                    "(its pair shard + the replicated stages; no collective, results are not valid physics)")
-    ap.add_argument("--sim-rank", type=int, default=0)
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
+    args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "PSAMD_BENCH_CHILD" not in os.environ:
+        launch_ranks(args)          # does not return
+    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
-    import torch
     import particlesystem_amd as ps
-    if not os.path.exists(ps.LIB_PATH):
-        if rank == 0:
-            ps.build()
-    from particlesystem_amd.sharded import step_sharded
+    # build before anything touches the GPU or the process group; only one process compiles
+    if rank == 0:
+        ps.build()                   # no-op when the library is newer than its sources
+    else:
+        for _ in range(600):
+            if not ps._build.needs_build():
+                break
+            time.sleep(0.5)
+    import torch
     dist = None
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
+    if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if world == 1 and "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", RANK="0", WORLD_SIZE="1")
+        gpu_backend = args.backend == "nccl"
+        if gpu_backend:
+            torch.cuda.set_device(local_rank)
         # librccl prints a version banner on stdout when the first communicator comes up;
         # the driver wants exactly one JSON line there, so park fd 1 on stderr meanwhile
         sys.stdout.flush()
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            if gpu_backend:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                warm = torch.zeros(8, device="cuda")
+                dist.all_reduce(warm)
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group(args.backend)
             dist.barrier()
-            warm = torch.zeros(world * 4, device="cuda")
-            dist.all_gather_into_tensor(warm, warm[rank * 4:(rank + 1) * 4])
-            torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
             os.dup2(saved, 1)
@@ -213,71 +324,96 @@ def main():
     cfg_over = dict(chunk_factor=args.chunk_factor, chunk_dim=args.chunk_dim,
                     max_particles_num=max(args.n, 1 << 20))
     flags = ps.FLAG_FAST_MATH if args.fast_math else 0
-    cfg = ps.default_config(device=local_rank, rank=args.sim_rank if args.sim_world else rank,
-                            world=args.sim_world if args.sim_world else world, flags=flags, **cfg_over)
+    if args.sim_world:
+        print(json.dumps(sim_world(args, ps, cfg_over, flags)))
+        return
+    device = local_rank if (world == 1 or args.backend == "nccl") else 0
+    cfg = ps.default_config(device=device, rank=rank, world=world, flags=flags, halo_cap_cell=args.halo_cap_cell, **cfg_over)
     g = ps.ParticleSystem(cfg)
-    xyz, age, fert = make_inputs(ps, g, args.n, args.seed)
-    g.fill_particles(xyz, age=age, fert_age=fert)
+    xyz, age, fert = make_inputs(g, args.n, args.seed)
+    g.fill_particles(xyz, age=age, fert_age=fert)       # a slab rank keeps the particles of its own segments
     G = g.sizes.grid_dim
 
-    force = None
-    if use_dist:
-        # One explicit (non-default) stream carries the stage kernels AND is the stream
-        # RCCL orders its collectives against, so pair pass -> all-gather -> apply are
-        # ordered by the stream alone.  (The legacy default stream has handle 0, which
-        # psamd_set_stream reads as "use the context's own stream": never pass it.)
-        torch.cuda.set_device(local_rank)
-        stream = torch.cuda.Stream(device=local_rank)
-        torch.cuda.set_stream(stream)
-        assert stream.cuda_stream != 0
-        cap = g.sizes.container_size + world
-        force = torch.zeros((cap, 4), dtype=torch.float32, device="cuda")
-        torch.cuda.synchronize()
-        g.bind_force4(force.data_ptr(), cap)
-        g.set_stream(stream.cuda_stream)
+    ring = None
+    if world > 1:
+        from particlesystem_amd.slab import DeviceRing, HostRing
+        if args.backend == "nccl":
+            # One explicit (non-default) stream carries the stage kernels AND is the stream
+            # RCCL orders its transfers against, so pack -> send/recv -> unpack are ordered by
+            # the stream alone.  (The legacy default stream has handle 0, which psamd_set_stream
+            # reads as "use the context's own stream": never pass it.)
+            stream = torch.cuda.Stream(device=local_rank)
+            assert stream.cuda_stream != 0
+            ring = DeviceRing(g, dist, rank, world, stream)
+        else:
+            ring = HostRing(g, dist, rank, world)
 
     g.snapshot_save()
 
     def one_step():
         if not args.evolve:
             g.snapshot_restore()
-        if args.sim_world:
-            g.init_iframe(); g.build_grid(); g.force_shard(); g.calc_forces_pairs(); g.calc_forces_apply()
-            return
-        if not use_dist:
+        if ring is None:
             g.step(1)
-            return
-        step_sharded(g, force, dist, rank, world, always_gather=True)
+        else:
+            ring.step()
 
     def sync():
         g.synchronize()
-        if use_dist:
-            torch.cuda.synchronize()
+        if world > 1:
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
 
+    def allsum(a):
+        if world == 1:
+            return a
+        t = torch.from_numpy(np.ascontiguousarray(a, np.int64))
+        if args.backend == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t)
+        return t.cpu().numpy()
+
+    # untimed: let the clocks settle (the first launches of a process run at a lower clock)
+    settle = 0
+    t_end = time.perf_counter() + args.settle_seconds
+    while time.perf_counter() < t_end and not args.evolve:
+        one_step()
+        settle += 1
     for _ in range(args.warmup):
         one_step()
     sync()
-    # pairs per launch, measured on the state the timed steps start from
-    if not args.evolve:
-        g.snapshot_restore()
-    def frame_counts():
-        g.init_iframe(); g.build_grid()
-        n = g.download_cellgrid()[:, 0].copy()
-        if world > 1 or args.sim_world:
-            g.force_shard()
-        g.calc_forces_pairs()
-        f = g.download_force_counts()
-        if use_dist and world > 1:        # a rank lists only its own share's particles
-            t = torch.from_numpy(f.astype(np.int64)).cuda()
-            dist.all_reduce(t)
-            f = t.cpu().numpy()
-        elif args.sim_world:              # one rank's share timed alone: scale to the whole for the rate below
-            f = f * args.sim_world
-        return n, f
 
-    counts0, fcounts0 = frame_counts()
+    def frame_counts():
+        """particles per cell and particles the force pass visits per cell, whole system"""
+        if not args.evolve:
+            g.snapshot_restore()
+        if ring is None:
+            g.init_iframe(); g.build_grid()
+            n = g.download_cellgrid()[:, 0].copy()
+            g.calc_forces_pairs()
+            f = g.download_force_counts()
+            mine = f
+            g.calc_forces_apply()
+        else:
+            g.slab_build()
+            n = g.download_cellgrid()[:, 0].copy()
+            ring.exchange("halo")
+            g.slab_pairs()
+            mine = g.download_force_counts()
+            ring.exchange("force")
+            g.slab_apply()
+            ring.exchange("xfer")
+            g.slab_finish()
+            n, f = allsum(n), allsum(mine)
+        return n, f, mine
+
+    if args.evolve:
+        counts0 = fcounts0 = mine0 = None
+    else:
+        counts0, fcounts0, mine0 = frame_counts()
     g.set_timing(True, every_stage=args.kernel_times)
     sync()
     processed0 = g.counters["particles_processed"]
@@ -289,27 +425,31 @@ def main():
     tim, launches = g.timing()
     g.set_timing(False)
     ctr = g.counters
-    if not args.evolve:
-        g.snapshot_restore()
-    counts1, fcounts1 = frame_counts()
+    own_updates = float(ctr["particles_processed"] - processed0)
+    counts1, fcounts1, mine1 = frame_counts()
+    if counts0 is None:
+        counts0, fcounts0, mine0 = counts1, fcounts1, mine1
     live = int(counts1.sum())
-
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    updates = float(allsum(np.array([int(own_updates)]))[0])
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        if args.backend == "nccl":
+            t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
         # a particle-update = one live particle taken through one step; the population is
         # not constant (cell-overflow and full-segment losses as the cloud collapses)
-        updates = float(g.counters["particles_processed"] - processed0)
         value = updates / elapsed
-        pairs = 0.5 * (pair_count(counts0, fcounts0, G) + pair_count(counts1, fcounts1, G))
-        pairs_rank = pairs / world
+        # the force kernel of THIS rank: its own share of the pairs against its own launch time
+        pairs_rank = 0.5 * (pair_count(counts0, mine0, G) + pair_count(counts1, mine1, G))
         us_pairs = tim["pairs"] / max(launches, 1)
         us_apply = tim["apply"] / max(launches, 1)
         ach_tflops = pairs_rank * FLOP_PER_PAIR / (us_pairs * 1e-6) / 1e12 if us_pairs > 0 else 0.0
-        ach_gbs = updates / args.steps * APPLY_BYTES_PER_UPDATE / (us_apply * 1e-6) / 1e9 if us_apply > 0 else 0.0
+        ach_gbs = own_updates / args.steps * APPLY_BYTES_PER_UPDATE / (us_apply * 1e-6) / 1e9 if us_apply > 0 else 0.0
+        traffic_pairs = measured_traffic("k_pairs<1", args, world)
+        traffic_apply = measured_traffic("k_apply", args, world)
         out = {
             "metric": "particle-updates/sec at N=2^20", "value": value, "unit": "particle-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -320,29 +460,44 @@ def main():
                                    "+ reference collisions/integrate/wrap/relocation, all constants at reference defaults, "
                                    "%s" % (args.n, G, "free-running" if args.evolve else "each step = one pass over the same cloud (restored in HBM)"),
                        "arithmetic": "fast-math" if args.fast_math else "reference-exact fp32 (bitwise parity mode)",
-                       "parallelism": "pair loop sharded x%d + RCCL all-gather of float4 results" % world if world > 1 else "single GPU",
-                       "updates_in_timed_region": updates, "live_after": live,
+                       "parallelism": ("%d slabs of cell layers, one per GPU (state partitioned by segment); halo / force / "
+                                       "transfer messages between ring neighbours over %s" % (world, "RCCL send/recv" if args.backend == "nccl" else args.backend))
+                                      if world > 1 else "single GPU",
+                       "updates_in_timed_region": updates, "live_after": live, "settle_steps_before_warmup": settle,
                        "particles_with_a_force_term": int(fcounts1.sum()),
                        "relocations": ctr["relocations"], "relocations_lost": ctr["relocations_lost"],
                        "cell_overflow_kills": ctr["cell_overflow_kills"]},
             "roofline": {"kernel": "k_pairs", "bound": "valu", "achieved": ach_tflops, "peak": VALU_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach_tflops / VALU_PEAK_TFLOPS,
-                         "traffic": measured_traffic("k_pairs<1") if world == 1 and not args.fast_math else None,
+                         "unit": "TFLOP/s", "frac": ach_tflops / VALU_PEAK_TFLOPS, "traffic": traffic_pairs,
+                         "traffic_source": TRAFFIC_FILE if traffic_pairs is not None else None,
                          "pairs_per_launch": pairs_rank, "flop_per_pair": FLOP_PER_PAIR, "us_per_launch": us_pairs},
             "roofline_streaming": {"kernel": "k_apply", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS, "traffic": measured_traffic("k_apply"),
+                                   "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic_apply,
+                                   "traffic_source": TRAFFIC_FILE if traffic_apply is not None else None,
                                    "bytes_per_update": APPLY_BYTES_PER_UPDATE, "us_per_launch": us_apply},
             "kernel_us_per_step": {k: v / max(launches, 1) for k, v in tim.items() if v > 0},
         }
+        if world > 1:
+            out["config"]["message_bytes_rank0"] = {name: int(g.msg_bytes(k)) for name, k in
+                                                    (("halo_up", 1), ("halo_down", 0), ("force_in", 5), ("xfer_each", 6))}
         if world == 1 and not args.no_cpu:
-            if not args.fast_math and not args.evolve and not args.sim_world:
-                out["within_tolerance_mode"] = fast_math_rate(ps, cfg_over, local_rank, xyz, age, fert)
+            if not args.fast_math and not args.evolve:
+                d, t, _ = side_run(ps, cfg_over, local_rank, xyz, age, fert, ps.FLAG_FAST_MATH, 5, True)
+                out["within_tolerance_mode"] = {
+                    "arithmetic": "PSAMD_FLAG_FAST_MATH (FMA + v_rsq): accelerations deviate from the oracle's by the amounts "
+                                  "tests/test_gpu_fast.py measures and bounds (also at this density); not the headline",
+                    "value": d / t, "unit": "particle-updates/s", "ms_per_step": 1e3 * t / 5, "steps": 5}
+                d, t, lv = side_run(ps, cfg_over, local_rank, xyz, age, fert, flags, args.evolve_steps, False)
+                out["evolve"] = {"what": "%d free-running steps from the same cloud (the population collapses: surface implosion, "
+                                         "collisions), exact arithmetic" % args.evolve_steps,
+                                 "value": d / t, "unit": "particle-updates/s", "ms_per_step": 1e3 * t / args.evolve_steps,
+                                 "live_per_step": lv}
             out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(args, xyz, age, fert, cfg_over)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
     g.close()
-    if use_dist:
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,4 +1,4 @@
-"""Diagnostic: per-wave timeline of the pair kernel for one simulated rank.
+"""Diagnostic: per-wave timeline of the pair kernel (single GPU; argv kept for old notes).
 Build first with PSAMD_EXTRA_FLAGS=-DPSAMD_WAVE_TRACE python particlesystem_amd/build.py --force"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,14 +6,13 @@ import numpy as np
 import particlesystem_amd as ps
 world, rank = int(sys.argv[1]), int(sys.argv[2])
 n = 1 << 20
-g = ps.ParticleSystem(ps.default_config(rank=rank, world=world))
+g = ps.ParticleSystem(ps.default_config())
 xyz = g.uniform_cloud(n, 2026)
 age = np.random.default_rng(2026).uniform(15 / 7, 7.5, n).astype(np.float32)
 g.fill_particles(xyz, age=age, fert_age=np.full(n, 1e6, np.float32))
 g.snapshot_save()
 for _ in range(3):
     g.snapshot_restore(); g.init_iframe(); g.build_grid()
-    if world > 1: g.force_shard()
     g.calc_forces_pairs(); g.calc_forces_apply()
 g.synchronize()
 t = g.wave_trace()

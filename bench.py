@@ -376,12 +376,14 @@ def main():
         dist.all_reduce(t)
         return t.cpu().numpy()
 
-    # untimed: let the clocks settle (the first launches of a process run at a lower clock)
+    # untimed: let the clocks settle (the first launches of a process run at a lower clock).
+    # All ranks must take the same number of steps: they decide together, ten steps at a time.
     settle = 0
     t_end = time.perf_counter() + args.settle_seconds
-    while time.perf_counter() < t_end and not args.evolve:
-        one_step()
-        settle += 1
+    while not args.evolve and int(allsum(np.array([1 if time.perf_counter() < t_end else 0]))[0]) == world:
+        for _ in range(10):
+            one_step()
+        settle += 10
     for _ in range(args.warmup):
         one_step()
     sync()

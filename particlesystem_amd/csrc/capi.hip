@@ -379,7 +379,8 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     d.ops_cap = (int)std::min<size_t>(3 * C + 2 * xf + 64, (size_t)INT32_MAX / 2);
     d.moves_cap = (int)std::min<size_t>(2 * C + 2 * xf + 64, (size_t)INT32_MAX / 2);
     int *frame = nullptr;
-    const size_t frame_ints = LC + g.num_chunks + g.queue_infos + LC;   // cell counts, chunk counts, record counts, halo counts
+    // cell counts, chunk counts, record counts, halo counts, hand-off flags of the force pass
+    const size_t frame_ints = LC + g.num_chunks + g.queue_infos + LC + LC * P.slices;
     PS_HIP(c, dev_alloc(c, &d.pos4, C));
     PS_HIP(c, dev_alloc(c, &d.vel4, C));
     PS_HIP(c, dev_alloc(c, &d.acc4, C));
@@ -391,6 +392,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &frame, frame_ints));
     d.cell_count = frame; d.chunk_count = frame + LC; d.rec_count = d.chunk_count + g.num_chunks;
     d.halo_count = d.rec_count + g.queue_infos;
+    d.task_ready = d.halo_count + LC;
     c->frame_ints = frame_ints;
     PS_HIP(c, dev_alloc(c, &d.halo_f, (size_t)3 * LC * HALO_CAP + 64));   // + slack: scalar loads fetch whole groups
     PS_HIP(c, dev_alloc(c, &d.halo_id, LC * HALO_CAP + 64));
@@ -400,6 +402,10 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.active_count, LC));
     PS_HIP(c, dev_alloc(c, &d.task_list2, LC * P.slices));
     PS_HIP(c, dev_alloc(c, &d.merged_tasks, LC));
+    PS_HIP(c, dev_alloc(c, &d.task_cost, LC));
+    PS_HIP(c, dev_alloc(c, &d.ctask_start, LC + 1));
+    PS_HIP(c, dev_alloc(c, &d.cost_start, LC + 1));
+    PS_HIP(c, dev_alloc(c, &d.wave_pos, (size_t)MAX_PAIR_WAVES + 1));
     PS_HIP(c, dev_alloc(c, &d.rec_start, (size_t)g.queue_infos + 1));
     PS_HIP(c, dev_alloc(c, &d.rec_cursor, (size_t)g.queue_infos));
     PS_HIP(c, dev_alloc(c, &d.fs, 1));
@@ -874,7 +880,8 @@ static int do_pairs(psamd_ctx *c)
 {
     if (!c->grid_built) return fail(c, PSAMD_ERR_STATE, "calc_forces needs build_grid first");
     if (c->timing) (void)hipEventRecord(c->ev[5], c->stream);
-    PS_HIP(c, launch_pairs(c->stream, c->P, c->d, c->timing ? c->ev[13] : nullptr));
+    PS_HIP(c, launch_pairs(c->stream, c->P, c->d, c->timing ? c->ev[13] : nullptr,
+                           c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total));
     if (c->timing) (void)hipEventRecord(c->ev[6], c->stream);
     c->pairs_done = true;
     return PSAMD_OK;

@@ -163,6 +163,7 @@ struct FrameScalars {
     int32_t n_out[2];       // slab mode: relocation / birth records leaving for the rank below [0] / above [1]
     int32_t n_lent;         // slab mode: bodies in the lent-in region this frame
     int32_t pad_i;
+    long long cost_total;   // two-pass mode: sum over the force pass's tasks of the bodies each walks (its stencil's population)
 };
 
 // Cumulative event counters, mirrors psamd_counters.  Kept in COUNTER_COPIES copies on
@@ -184,6 +185,7 @@ enum : int32_t {
     ERR_SLAB_MISMATCH = 128,// slab mode: a message disagrees with the receiver's own counts
     ERR_REMOTE_RECORD0 = 256,// slab mode: a cell-overflow kill on a rank that does not own queue record 0
     ERR_CHUNK_CAP = 512,    // a chunk list passed MAX_PARTICLES_PER_CHUNK (the reference would skip its tail)
+    ERR_HANDOFF_TIMEOUT = 1024, // force pass: a wave never saw the partial sums of the task it continues (should be impossible)
 };
 
 // A free-slot-queue operation produced by calc_forces is a (key, arg) pair kept in
@@ -217,6 +219,8 @@ constexpr int SORT_MAX = 4096;   // ids one cell may hold for the in-LDS ranking
 constexpr int REPLAY_CHUNK = 2048;   // queue ops staged through LDS at a time
 constexpr int QUEUE_WINDOW = 6144;   // largest segment (slots) whose queue is replayed in LDS
 constexpr int BUCKET_MAX = 2048;     // ops per segment the one-workgroup fast replay sorts in LDS
+constexpr int MAX_PAIR_WAVES = 6144;    // wave slots of the balanced force pass: 256 CUs x 4 SIMDs x 6 resident waves (78 VGPRs)
+constexpr int STENCIL = 27;          // cells a particle's force walk visits, in the reference's order (app.cu:370-409)
 constexpr int HALO_CAP = 768;        // collision candidates one cell can list from its neighbours (else: full stencil)
 
 }  // namespace psamd

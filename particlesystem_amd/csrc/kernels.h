@@ -44,6 +44,12 @@ struct DeviceState {
     int *active_list = nullptr;   // [container] per cell (at cell_start[c]): sorted indices of the particles that need a force
     int *active_count = nullptr;  // [num_cells]
     int *task_list2 = nullptr;    // [num_cells * slices]
+    // balanced force pass: every wave walks the same number of bodies; a task may be cut at a stencil-cell boundary
+    int *task_cost = nullptr;     // [local cells] bodies in the cell's stencil = what one task of the cell walks
+    int *ctask_start = nullptr;   // [computed cells + 1] first entry of task_list2 of the j-th computed cell
+    long long *cost_start = nullptr;  // [computed cells + 1] cost of all tasks before the j-th computed cell
+    int *wave_pos = nullptr;      // [waves + 1] first (task, stencil step) unit of every wave: task index * 27 + step
+    int *task_ready = nullptr;    // [num_cells * slices] hand-off flags, zeroed with the frame
     int4 *merged_tasks = nullptr; // [num_cells] cells whose leftover slices share one wave (-1: unused)
     // the merged tasks run beside k_pairs on a stream of their own (fork / join by events)
     hipStream_t side_stream = nullptr;
@@ -86,7 +92,8 @@ hipError_t launch_selftest_math(hipStream_t st, uint32_t lo_bits, uint32_t hi_bi
 hipError_t launch_init_tdata(hipStream_t st, const DevParams &P, const DeviceState &d);
 // ev (optional) = 5 events recorded before hist, scan, scatter, sort and after sort
 hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev);
-hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force);
+// live_bound: the host's upper bound of the live particles (sizes the balanced force pass)
+hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t live_bound);
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step);
 // after apply, before the per-step read-back: ops per queue record, their prefix and maximum
 hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints);

@@ -918,13 +918,25 @@ __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restr
 // visit (flag 0 and not a kid), packed at active_list[cell_start[c] ...], and their number.
 __global__ __launch_bounds__(256) void k_build_active(DevParams P, const int *__restrict__ cell_start,
                                                       const int *__restrict__ flag_in, int *__restrict__ active_list,
-                                                      int *__restrict__ active_count)
+                                                      int *__restrict__ active_count, int *__restrict__ task_cost)
 {
     __shared__ int s_n;
     const int c = comp_cell(P, blockIdx.x), tid = threadIdx.x, lane = tid & 63;
     const int base = cell_start[c];
     const int cnt = min(cell_start[c + 1] - base, P.max_per_cell);
     if (tid == 0) s_n = 0;
+    if (tid < 64) {
+        // what one force task of this cell walks: the population of its stencil
+        int n = 0;
+        if (lane < STENCIL) {
+            int i1, i2, i3;
+            cell_coords(P, c, i1, i2, i3);
+            const int nc = local_cell(P, i3 + c_stencil[lane][2], i1 + c_stencil[lane][1], i2 + c_stencil[lane][0]);
+            if (nc >= 0) n = min(cell_start[nc + 1] - cell_start[nc], P.max_per_cell);
+        }
+        n = wave_incl_scan(n);
+        if (lane == 63) task_cost[c] = n;
+    }
     __syncthreads();
     for (int e0 = 0; e0 < cnt; e0 += 256) {
         const int e = e0 + tid;
@@ -945,11 +957,13 @@ __global__ __launch_bounds__(256) void k_build_active(DevParams P, const int *__
 // last, partly filled slice: 20 of 64 lanes on average once the collided particles are gone)
 // are packed, up to four cells to a wave, into the merged tasks of k_pairs_merged.
 __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *__restrict__ active_count,
-                                                       int *__restrict__ task_list2,
+                                                       const int *__restrict__ task_cost,
+                                                       int *__restrict__ task_list2, int *__restrict__ ctask_start,
+                                                       long long *__restrict__ cost_start,
                                                        int4 *__restrict__ merged_tasks, FrameScalars *fs,
                                                        int merge)
 {
-    __shared__ long long wave_tot[16];
+    __shared__ long long wave_tot[16], wave_cost[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ncomp = comp_count(P);
     const int per = (ncomp + 1023) / 1024;
@@ -972,28 +986,95 @@ __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *_
         if (ng) { if (out) out[npack] = cur; npack++; }
         return npack;
     };
-    long long mine = 0;                       // tasks (low word) and merged tasks (high word)
-    for (int j = c0; j < c1; j++) { const int n = active_count[comp_cell(P, j)]; mine += merge ? (n >> 6) : ((n + 63) >> 6); }
-    if (merge) mine |= (long long)pack(nullptr) << 32;
-    long long incl = mine;
-    for (int d = 1; d < 64; d <<= 1) {
-        const long long o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
+    long long mine = 0, mycost = 0;           // tasks (low word) and merged tasks (high word); bodies the tasks walk
+    for (int j = c0; j < c1; j++) {
+        const int c = comp_cell(P, j), n = active_count[c], nt = merge ? (n >> 6) : ((n + 63) >> 6);
+        mine += nt;
+        mycost += (long long)nt * task_cost[c];
     }
-    if (lane == 63) wave_tot[wv] = incl;
+    if (merge) mine |= (long long)pack(nullptr) << 32;
+    long long incl = mine, cincl = mycost;
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long o = __shfl_up(incl, d), oc = __shfl_up(cincl, d);
+        if (lane >= d) { incl += o; cincl += oc; }
+    }
+    if (lane == 63) { wave_tot[wv] = incl; wave_cost[wv] = cincl; }
     __syncthreads();
-    long long run2 = incl - mine, total2 = 0;
-    for (int k = 0; k < 16; k++) { if (k < wv) run2 += wave_tot[k]; total2 += wave_tot[k]; }
+    long long run2 = incl - mine, total2 = 0, crun = cincl - mycost, ctotal = 0;
+    for (int k = 0; k < 16; k++) { if (k < wv) { run2 += wave_tot[k]; crun += wave_cost[k]; } total2 += wave_tot[k]; ctotal += wave_cost[k]; }
     int run = (int)(run2 & 0xffffffffll);
     const int total = (int)(total2 & 0xffffffffll);
     for (int j = c0; j < c1; j++) {
         const int c = comp_cell(P, j);
         const int n = merge ? (active_count[c] >> 6) : ((active_count[c] + 63) >> 6);
+        ctask_start[j] = run; cost_start[j] = crun;
         for (int sl = 0; sl < n; sl++) task_list2[run + sl] = c * P.slices + sl;
         run += n;
+        crun += (long long)n * task_cost[c];
     }
     if (merge) pack(merged_tasks + (int)(run2 >> 32));
-    if (tid == 0) { fs->n_tasks2 = total; fs->n_merged = (int)(total2 >> 32); }
+    if (tid == 0) {
+        ctask_start[ncomp] = total; cost_start[ncomp] = ctotal;
+        fs->n_tasks2 = total; fs->n_merged = (int)(total2 >> 32); fs->cost_total = ctotal;
+    }
+}
+
+// Where does every wave of the balanced force pass start?  The pass's work is the list of
+// (task, stencil step) units -- task-major, 27 steps per task -- and a unit costs the bodies
+// of the neighbour cell it visits.  Wave s of `nw` takes the units from wave_pos[s] up to
+// wave_pos[s + 1]: equal shares of the total cost, cut at unit boundaries.  The eight runs of
+// waves that share an XCD (wave slots are dealt XCD by XCD, see k_pairs) start at whole tasks,
+// so a task that is cut is always continued by a workgroup of the same run.
+// One thread per boundary.
+__global__ void k_split_tasks(DevParams P, int nw, const int *__restrict__ cell_start, const int *__restrict__ task_cost,
+                              const int *__restrict__ ctask_start, const long long *__restrict__ cost_start,
+                              int *__restrict__ wave_pos, const FrameScalars *__restrict__ fs)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > nw) return;
+    const int ncomp = comp_count(P), ntask = fs->n_tasks2;
+    const long long T = fs->cost_total;
+    // unit (task index * 27 + step) at which the cumulative cost reaches x; whole = round up to the next task start
+    auto unit_at = [&](long long x, bool whole) -> int {
+        if (x >= T) return ntask * STENCIL;
+        int a = 0, b = ncomp - 1;                         // last computed cell whose tasks start at or before x
+        while (a < b) { const int m = (a + b + 1) >> 1; if (cost_start[m] <= x) a = m; else b = m - 1; }
+        const int c = comp_cell(P, a), S = task_cost[c];
+        const int nt = ctask_start[a + 1] - ctask_start[a];
+        if (nt == 0 || S <= 0) return ctask_start[a + 1] * STENCIL;     // (x < T: cannot be the last cell)
+        const long long off = x - cost_start[a];
+        const int q = (int)min((long long)(nt - 1), off / S);
+        int r = (int)(off - (long long)q * S), k = 0;
+        int i1, i2, i3;
+        cell_coords(P, c, i1, i2, i3);
+        for (; k < STENCIL - 1; k++) {
+            const int nc = local_cell(P, i3 + c_stencil[k][2], i1 + c_stencil[k][1], i2 + c_stencil[k][0]);
+            const int n = nc >= 0 ? min(cell_start[nc + 1] - cell_start[nc], P.max_per_cell) : 0;
+            if (r < n) break;
+            r -= n;
+        }
+        const int t = ctask_start[a] + q;
+        if (whole) return (t + ((k > 0 || r > 0) ? 1 : 0)) * STENCIL;
+        return t * STENCIL + k;
+    };
+    const int m = nw >> 3;                                // wave slots per XCD run (nw is a multiple of 32)
+    const int x = min(s / m, 8), j = s - x * m;
+    const int run_lo = unit_at(T * x / 8, true);
+    int pos = run_lo;
+    if (j > 0) {
+        // equal shares of the run's own cost range, which starts and ends at whole tasks
+        const int run_hi = unit_at(T * (x + 1) / 8, true);
+        auto cost_of_task_start = [&](int unit) -> long long {
+            const int t = unit / STENCIL;
+            if (t >= ntask) return T;
+            int a = 0, b = ncomp - 1;
+            while (a < b) { const int mm = (a + b + 1) >> 1; if (ctask_start[mm] <= t) a = mm; else b = mm - 1; }
+            return cost_start[a] + (long long)(t - ctask_start[a]) * task_cost[comp_cell(P, a)];
+        };
+        const long long lo = cost_of_task_start(run_lo), hi = cost_of_task_start(run_hi);
+        pos = max(run_lo, min(run_hi, unit_at(lo + (hi - lo) * j / m, false)));
+    }
+    wave_pos[s] = pos;
 }
 
 // One wave = 64 consecutive particles of one cell (four independent waves per workgroup).
@@ -1030,6 +1111,52 @@ __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *_
 #endif
 
 // One task: 64 consecutive particles of one cell against the cell's stencil.
+// Hand-off of a task's partial sums between the wave that walked the first stencil steps and
+// the one that continues (balanced force pass).  Follows the guide's inter-workgroup recipe
+// (cdna_hip_programming.md, Guideline 16): the payload is stored write-through with agent-scope
+// atomic stores, the storing wave drains its stores, ONE lane raises the flag with an agent-scope
+// atomic store; the consumer polls that one word relaxed and reads the payload with agent-scope
+// atomic loads (they bypass the CU's L1, so no acquire fence is needed).  The flags are zeroed
+// with the frame, before the launch.
+typedef __attribute__((address_space(1))) unsigned int gu32;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+__device__ __forceinline__ void handoff_publish(float4 *slot, float ax, float ay, float az, int flag, bool valid, int *ready)
+{
+    if (valid) {
+        gu64 *p = (gu64 *)(unsigned long long *)slot;
+        __hip_atomic_store(p, ((unsigned long long)__float_as_uint(ay) << 32) | __float_as_uint(ax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 1, ((unsigned long long)(unsigned)flag << 32) | __float_as_uint(az), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store((gu32 *)(unsigned int *)ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// false: the flag never came (bounded spin; the caller raises a sticky error)
+__device__ __forceinline__ bool handoff_consume(const float4 *slot, float &ax, float &ay, float &az, int &flag, bool valid, const int *ready)
+{
+    int ok = 0;
+    if ((threadIdx.x & 63) == 0) {
+        for (unsigned spins = 0; spins < (1u << 22); spins++) {
+            if (__hip_atomic_load((gu32 *)(unsigned int *)ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    ok = __builtin_amdgcn_readfirstlane(ok);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // compiler-only: the loads below stay below the poll
+    if (ok && valid) {
+        gu64 *p = (gu64 *)(unsigned long long *)slot;
+        const unsigned long long a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ax = __uint_as_float((unsigned)a); ay = __uint_as_float((unsigned)(a >> 32));
+        az = __uint_as_float((unsigned)b); flag = (int)(unsigned)(b >> 32);
+    }
+    return ok != 0;
+}
+
+// Stencil steps [k0, k1) of a task.  resume: the sums of steps < k0 come from the wave that
+// walked them (ready != nullptr); a walk that stops before step 27 publishes its sums instead
+// of finishing the particle.  The whole task is k0 = 0, k1 = 27, ready = nullptr.
 template <int MODE, int NQ>
 __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__restrict__ cell_start,
                                            const float4 *__restrict__ snap4, const float *__restrict__ snap_soa,
@@ -1037,7 +1164,8 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
                                            float4 *__restrict__ force4, int task,
                                            float4 *tile, unsigned long long *trace,
                                            const int *__restrict__ active_list = nullptr,
-                                           const int *__restrict__ active_count = nullptr)
+                                           const int *__restrict__ active_count = nullptr,
+                                           int k0 = 0, int k1 = STENCIL, int *ready = nullptr, FrameScalars *fs = nullptr)
 {
     PS_TRACE_BEGIN();
     const int c = task / P.slices, slice = task - c * P.slices;
@@ -1076,7 +1204,10 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
     if (MODE != 0) {
         const PairCtx ctx = {me.x, me.y, me.z, age_i, id_i, gi, scan};
         const size_t cap = (size_t)P.sorted_cap;
-        for (int k = 0; k < 27; k++) {
+        if (k0 > 0 && !handoff_consume(force4 + gi, ax, ay, az, flag, valid, ready)) {
+            if (lane == 0) atomicOr(&fs->error, ERR_HANDOFF_TIMEOUT);
+        }
+        for (int k = k0; k < k1; k++) {
             const int nb = __builtin_amdgcn_readlane(my_nb, k), n = __builtin_amdgcn_readlane(my_cnt, k);
             const float *sx = snap_soa + nb, *sy = sx + cap, *sz = sy + cap, *sw = sz + cap;   // wave-uniform
             float dmin = 3.0e38f;
@@ -1174,6 +1305,11 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
             }
         }
     }
+    if (MODE != 0 && k1 < STENCIL) {             // not the end of the walk: hand the sums on
+        handoff_publish(force4 + gi, ax, ay, az, flag, valid, ready);
+        PS_TRACE_END();
+        return;
+    }
     if (dead) flag = 2;
     if (kid) { ax = 0.f; ay = 0.f; az = 0.f; }   // every term is skipped for a kid (app_common.cu:240)
     if (valid) force4[gi] = make_float4(ax, ay, az, __int_as_float(flag));
@@ -1211,6 +1347,52 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
     if (slot >= ntask) return;
     pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4,
                          task_list[slot], tiles[MODE == 0 ? wave : 0], trace, active_list, active_count);
+}
+
+// The force pass, balanced: `nw` waves (all resident), wave slot s walks the (task, stencil step)
+// units from wave_pos[s] up to wave_pos[s + 1] -- the same number of bodies for every wave
+// (k_split_tasks).  Most of a wave's share is whole tasks; the task its share ends in is started
+// FIRST (steps 0 .. k-1, sums published), then the whole tasks, and LAST the task its share
+// begins in is finished from the sums the previous wave slot published at the very start of its
+// own work -- so nobody waits in practice, and a particle's sum is still one serial chain of
+// fp32 additions in the reference's order.  A share that lies inside one task (few tasks, many
+// waves) is one middle piece: consume, walk, publish.
+// Wave slots are dealt XCD by XCD like the tasks of k_pairs; k_split_tasks starts every XCD's
+// run at a whole task, so the wave that continues a task runs in a workgroup that was
+// dispatched no later (block b - 8) or is the same workgroup.
+template <int MODE, int NQ>
+__global__ __launch_bounds__(256) void k_pairs_balanced(DevParams P, const int *__restrict__ cell_start,
+                                                        const float4 *__restrict__ snap4,
+                                                        const float *__restrict__ snap_soa,
+                                                        const float *__restrict__ snap_age,
+                                                        const int *__restrict__ sorted_id,
+                                                        const int *__restrict__ task_list,
+                                                        float4 *__restrict__ force4,
+                                                        FrameScalars *fs, unsigned long long *trace,
+                                                        const int *__restrict__ active_list, const int *__restrict__ active_count,
+                                                        const int *__restrict__ wave_pos, int *__restrict__ task_ready)
+{
+    const int wave = threadIdx.x >> 6;
+    const int slot = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave;
+    const int ub = __builtin_amdgcn_readfirstlane(wave_pos[slot]), ue = __builtin_amdgcn_readfirstlane(wave_pos[slot + 1]);
+    if (ue <= ub) return;
+    const int tb = ub / STENCIL, lb = ub - tb * STENCIL;            // first unit: task tb, step lb
+    const int tl = (ue - 1) / STENCIL, le = ue - tl * STENCIL;      // last task tl, its steps [.., le)
+    // one call site, so one copy of the walk: the pieces in the order they are done
+    const bool single = tb == tl;
+    const int has_head = (!single && le < STENCIL) ? 1 : 0, has_tail = (!single && lb > 0) ? 1 : 0;
+    const int first_whole = tb + has_tail, last_whole = tl + (has_head ? 0 : 1);      // tasks walked whole: [first, last)
+    const int nwhole = single ? 0 : last_whole - first_whole;
+    const int pieces = single ? 1 : has_head + nwhole + has_tail;
+    for (int i = 0; i < pieces; i++) {
+        int t, k0 = 0, k1 = STENCIL;
+        if (single) { t = tb; k0 = lb; k1 = le; }
+        else if (has_head && i == 0) { t = tl; k1 = le; }                 // the head of the last task first: publish early
+        else if (i - has_head < nwhole) t = first_whole + (i - has_head);
+        else { t = tb; k0 = lb; }                                         // the tail of the first task last: its head was published long ago
+        pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, task_list[t], nullptr, trace,
+                             active_list, active_count, k0, k1, task_ready + t, fs);
+    }
 }
 
 // Merged task of the two-pass force pass: the partly filled last slices of up to four cells
@@ -2404,7 +2586,7 @@ hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceSt
 }
 
 template <int MODE, int NQ>
-static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force)
+static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t live_bound)
 {
     const int ncomp = comp_count(P);
     if (ncomp <= 0) return hipSuccess;
@@ -2414,13 +2596,27 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     // stalls on its tile loads; a small share (a slab of a multi-GPU run) has too little other
     // work to cover that and it becomes the critical path (measured on 1/4 and 1/8 shares).
     static const bool merge_off = std::getenv("PSAMD_NO_MERGE") != nullptr;
+    static const bool balance_off = std::getenv("PSAMD_NO_BALANCE") != nullptr;
+    static const int waves_env = std::getenv("PSAMD_WAVES") ? std::atoi(std::getenv("PSAMD_WAVES")) : 0;
     const bool merge = two && !merge_off && (P.world == 1 || ncomp >= 2048);
+    const bool balanced = two && !balance_off;
+    // Balanced pass: a fixed number of waves, all resident, each walking the same number of
+    // bodies.  Enough of them that a SIMD has several to switch between, but not many more
+    // than there are tasks (a task cut in more pieces only adds hand-offs): from the host's
+    // bound of the live count, 1024 (one per SIMD) to 6144.
+    int nw = 0;
+    if (balanced) {
+        const int64_t est = live_bound / 64 + ncomp;                 // tasks, at most
+        nw = 1024 * (int)std::min<int64_t>(6, std::max<int64_t>(1, (est + 1024) / 2048));
+        if (waves_env >= 32) nw = std::min(waves_env & ~31, MAX_PAIR_WAVES);
+    }
     if (two) {
         // collision flags, then the per-cell lists and the tasks of the particles that need a force
         k_collide<<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.snap_cid, d.task_list,
                                                    d.halo_count, d.halo_f, d.halo_id, d.pair_flag, d.force4, d.fs);
-        k_build_active<<<ncomp, 256, 0, st>>>(P, d.cell_start, d.pair_flag, d.active_list, d.active_count);
-        k_active_tasks<<<1, 1024, 0, st>>>(P, d.active_count, d.task_list2, d.merged_tasks, d.fs, merge ? 1 : 0);
+        k_build_active<<<ncomp, 256, 0, st>>>(P, d.cell_start, d.pair_flag, d.active_list, d.active_count, d.task_cost);
+        k_active_tasks<<<1, 1024, 0, st>>>(P, d.active_count, d.task_cost, d.task_list2, d.ctask_start, d.cost_start, d.merged_tasks, d.fs, merge ? 1 : 0);
+        if (balanced) k_split_tasks<<<(nw + 1 + 63) / 64, 64, 0, st>>>(P, nw, d.cell_start, d.task_cost, d.ctask_start, d.cost_start, d.wave_pos, d.fs);
     }
     if (ev_force) (void)hipEventRecord(ev_force, st);      // timing: the force pass proper starts here
     const int *task_list = two ? d.task_list2 : d.task_list;
@@ -2435,19 +2631,23 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
             P, d.cell_start, d.snap4, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
         (void)hipEventRecord(d.ev_join, d.side_stream);
     }
-    k_pairs<MODE, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
-                                                d.fs, d.trace, active_list, active_count);
+    if (balanced)
+        k_pairs_balanced<MODE == 0 ? 1 : MODE, NQ><<<nw / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list,
+                                                                        d.force4, d.fs, d.trace, active_list, active_count, d.wave_pos, d.task_ready);
+    else
+        k_pairs<MODE, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
+                                                    d.fs, d.trace, active_list, active_count);
     if (merge) (void)hipStreamWaitEvent(st, d.ev_join, 0);
     return hipGetLastError();
 }
 
-hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force)
+hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t live_bound)
 {
     // fast math shares the lean modes' validity range (finite 1/sqrt(eps2^3))
-    if ((P.flags & PSAMD_FLAG_FAST_MATH) && P.lean_math) return launch_pairs_mode<2, 8>(st, P, d, ev_force);
+    if ((P.flags & PSAMD_FLAG_FAST_MATH) && P.lean_math) return launch_pairs_mode<2, 8>(st, P, d, ev_force, live_bound);
     // 8 pairs per slow-branch test: measured 3 % (full GPU) to 5 % (a 1/8 share) faster than 4
-    if (P.lean_math) return launch_pairs_mode<1, 8>(st, P, d, ev_force);
-    return launch_pairs_mode<0, 4>(st, P, d, ev_force);
+    if (P.lean_math) return launch_pairs_mode<1, 8>(st, P, d, ev_force, live_bound);
+    return launch_pairs_mode<0, 4>(st, P, d, ev_force, live_bound);
 }
 
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step)

@@ -1,0 +1,116 @@
+"""BASELINE.json configs[3] and configs[4] on the GPU (configs[0] and [2]: test_gpu_parity,
+test_gpu_fullsize; configs[1], all-pairs: test_gpu_allpairs).  At these sizes the oracle cannot
+run whole steps in seconds, so: size-independent properties (sorted partition, determinism,
+slab invariance) plus windows of the sorted order against the oracle's pair pass, bit for bit."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+import particlesystem_amd as ps
+from particlesystem_amd.slab import merge_owned, step_local
+from util import oracle_cfg_from
+
+pytestmark = pytest.mark.gpu
+
+
+def digest(p, qi, q):
+    h = hashlib.sha256()
+    h.update(p.tobytes()); h.update(qi.tobytes()); h.update(q.tobytes())
+    return h.hexdigest()
+
+
+def windows_match_oracle(g, o, windows, min_free=500):
+    """force4 of the GPU's pair pass vs the oracle's on [lo, hi) windows of the sorted order"""
+    total = o.sorted_count()
+    f = np.zeros((total, 4), np.float32)
+    for lo, hi in windows:
+        o.calc_pairs(lo, hi, f)
+        got = g.download_force4(lo, hi - lo).view(np.uint32)
+        want = f[lo:hi].view(np.uint32)
+        assert np.array_equal(got[:, 3], want[:, 3]), "collision flags differ at %d" % lo
+        keep = want[:, 3] == 0                       # a flagged particle's force is never looked at
+        assert keep.sum() >= min_free and np.array_equal(got[keep, :3], want[keep, :3]), lo
+
+
+@pytest.mark.timeout(1500)
+def test_config3_n22_two_slabs_on_one_gpu():
+    """configs[3]: N = 2^22 (1024 per cell in the default 16^3 box).  One context vs two slabs
+    of the same system: identical union after a whole step; windows of the pair pass against
+    the oracle (each particle there sums ~27600 terms)."""
+    n = 1 << 22
+    over = dict(max_particles_num=n)
+    g = ps.ParticleSystem(ps.default_config(**over))
+    xyz = g.uniform_cloud(n, 11)
+    rng = np.random.default_rng(11)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    fert = np.full(n, 1e6, np.float32)
+    ids = g.fill_particles(xyz, age=age, fert_age=fert)
+    g.snapshot_save()
+    g.init_iframe(); g.build_grid()
+    cg = g.download_cellgrid()
+    assert cg[:, 0].sum() == n and cg[:, 0].max() <= g.sizes.max_per_cell
+    g.calc_forces_pairs()
+    o = O.System(oracle_cfg_from(g.cfg))
+    assert np.array_equal(o.fill(xyz, age=age, fert_age=fert), ids)
+    o.init_iframe(); o.build_grid()
+    assert np.array_equal(cg, o.cellgrid)
+    total = o.sorted_count()
+    windows_match_oracle(g, o, [(0, 1500), (total // 2 + 333, total // 2 + 1833), (total - 1500, total)], min_free=50)
+    o.close()
+    g.calc_forces_apply()
+    whole = (g.download_particles(), *g.download_queues())
+    c1 = g.counters
+    g.snapshot_restore(); g.step(1)
+    assert digest(*whole) == digest(g.download_particles(), *g.download_queues())          # deterministic
+    g.close()
+    halves = [ps.ParticleSystem(ps.default_config(rank=r, world=2, **over)) for r in range(2)]
+    for h in halves:
+        h.fill_particles(xyz, age=age, fert_age=fert)
+    step_local(halves)
+    plans = [h.slab_plan() for h in halves]
+    qs = [h.download_queues() for h in halves]
+    union = (merge_owned([h.download_particles() for h in halves], plans), merge_owned([q[0] for q in qs], plans, "records"),
+             merge_owned([q[1] for q in qs], plans))
+    assert digest(*union) == digest(*whole)
+    assert sum(h.counters["relocations"] for h in halves) == c1["relocations"] > 0
+    for h in halves:
+        h.close()
+
+
+@pytest.mark.timeout(1500)
+def test_config4_n24_in_40_cubed_cells():
+    """configs[4]: N = 2^24, grid scaled to the reference's density (40^3 cells, 262 per cell):
+    sorted partition, windows of the pair pass vs the oracle, determinism of a whole step."""
+    n = 1 << 24
+    over = dict(max_particles_num=n, chunk_factor=10)
+    g = ps.ParticleSystem(ps.default_config(**over))
+    assert g.sizes.num_cells == 64000
+    xyz = g.uniform_cloud(n, 12)
+    rng = np.random.default_rng(12)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    fert = np.full(n, 1e6, np.float32)
+    ids = g.fill_particles(xyz, age=age, fert_age=fert)
+    g.snapshot_save()
+    g.init_iframe(); g.build_grid()
+    cg = g.download_cellgrid()
+    counts = cg[:, 0]
+    assert counts.sum() == n and counts.max() <= g.sizes.max_per_cell
+    for c in range(0, g.sizes.num_cells, 997):
+        row = cg[c, 1:1 + counts[c]]
+        assert (np.diff(row) > 0).all()
+    g.calc_forces_pairs()
+    o = O.System(oracle_cfg_from(g.cfg))
+    assert np.array_equal(o.fill(xyz, age=age, fert_age=fert), ids)
+    o.init_iframe(); o.build_grid()
+    assert np.array_equal(cg, o.cellgrid)
+    total = o.sorted_count()
+    windows_match_oracle(g, o, [(0, 4000), (total // 2 + 777, total // 2 + 4777), (total - 4000, total)])
+    o.close()
+    g.calc_forces_apply()
+    a = digest(g.download_particles(), *g.download_queues())
+    g.snapshot_restore(); g.step(1)
+    assert a == digest(g.download_particles(), *g.download_queues())
+    assert g.counters["relocations"] > 0
+    g.close()

@@ -48,6 +48,12 @@ typedef enum psamd_status {
 /* config.flags */
 #define PSAMD_FLAG_EXPLOSIONS   0x1u  /* births enabled (ps.cpp:1306-1333) with the counter-based RNG below */
 #define PSAMD_FLAG_FAST_MATH    0x2u  /* FMA/rsq pair arithmetic: NOT bit-identical to the reference, see DESIGN.md */
+#define PSAMD_FLAG_ALL_PAIRS    0x4u  /* force walk over EVERY cell, not only the 27-cell stencil (the reference has only the
+                                         cutoff, app.cu:352-452): the stencil first, in the reference's order, then the other
+                                         cells in index order -- so a cloud that fits a 2x2x2 block of cells gets the cutoff
+                                         result bit for bit.  Collisions stay short-range.  One GPU only (world == 1). */
+#define PSAMD_FLAG_EULER        0x8u  /* position update x += v*dt (explicit Euler) instead of the reference's
+                                         x += v*dt + 0.5*a*dt*dt (ps.cpp:1274-1276); the velocity update is the same */
 
 /* Runtime form of the reference's compile-time configuration, common.h:12-70.
  * psamd_default_config() fills in the shipped values. */
@@ -77,6 +83,10 @@ typedef struct psamd_config {
     int32_t  halo_cap_cell;      /* bodies per cell a halo message has room for; 0 = MAX_PARTICLES_PER_CELL (never overflows) */
     int32_t  xfer_cap;           /* particles per step and direction that may change owner; 0 = 32 per cell of a layer */
     int32_t  cuts[PSAMD_MAX_RANKS + 1];
+    /* Not in the reference (BASELINE.json asks for them; nothing there can pin them): */
+    double   drag;               /* linear drag k >= 0: the acceleration that is integrated and stored is a - k*v; 0 = the
+                                    reference's arithmetic, untouched                                          */
+    double   force_sign;         /* +1 gravity (reference), -1 repulsion: multiplies every mass in the force term; 0 reads as +1 */
 } psamd_config;
 
 /* Sizes DoInit derives (ps.cpp:2204-2222), in elements. */

@@ -23,6 +23,8 @@ LIB_PATH = os.path.join(HERE, "libpsamd.so")
 MAX_RANKS = 64
 FLAG_EXPLOSIONS = 0x1
 FLAG_FAST_MATH = 0x2
+FLAG_ALL_PAIRS = 0x4
+FLAG_EULER = 0x8
 NUM_TIMERS = 9
 TIMER_NAMES = ("hist", "scan", "scatter", "sort_cells", "pairs", "apply", "lifecycle", "init_iframe", "collide")
 
@@ -48,7 +50,8 @@ class Config(C.Structure):
                 ("device", C.c_int32), ("flags", C.c_uint32), ("seed", C.c_uint64),
                 ("rank", C.c_int32), ("world", C.c_int32),
                 ("halo_cap_cell", C.c_int32), ("xfer_cap", C.c_int32),
-                ("cuts", C.c_int32 * (MAX_RANKS + 1))]
+                ("cuts", C.c_int32 * (MAX_RANKS + 1)),
+                ("drag", C.c_double), ("force_sign", C.c_double)]
 
 
 class Sizes(C.Structure):

@@ -257,6 +257,8 @@ int psamd_default_config(psamd_config *cfg)
     cfg->seed = 1;                         // RAND_SEED, common.h:56
     cfg->rank = 0;
     cfg->world = 1;
+    cfg->drag = 0.0;
+    cfg->force_sign = 1.0;
     return PSAMD_OK;
 }
 
@@ -340,6 +342,10 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     P.cell_size = cfg->cell_size; P.eps2 = cfg->eps2; P.coll_radius = cfg->collision_radius;
     P.kid_age = g.kid_age; P.life = g.particle_life; P.expl_speed = cfg->explosion_speed;
     P.seed = cfg->seed;
+    P.drag = (float)cfg->drag;
+    P.force_sign = cfg->force_sign < 0 ? -1.0f : 1.0f;
+    if (cfg->drag < 0) return fail(c, PSAMD_ERR_INVALID_ARG, "drag must be >= 0");
+    if ((cfg->flags & PSAMD_FLAG_ALL_PAIRS) && cfg->world > 1) return fail(c, PSAMD_ERR_UNSUPPORTED, "all-pairs forces need every body on one GPU (world == 1)");
     fill_slab_params(g, c->plan, *cfg, P);
     auto bits_for = [](int64_t n) { int b = 1; while (((int64_t)1 << b) < n) b++; return b; };
     P.key_chunk_shift = 2 + bits_for(g.container);
@@ -368,6 +374,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
         P.two_pass = (P.lean_math && P.halo_reach < 0.25 * cfg->cell_size && !std::getenv("PSAMD_ONE_PASS")) ? 1 : 0;
     }
     if (P.key_bits > 63) return fail(c, PSAMD_ERR_UNSUPPORTED, "queue-op key does not fit 64 bits for this configuration");
+    if ((cfg->flags & PSAMD_FLAG_ALL_PAIRS) && !P.lean_math) return fail(c, PSAMD_ERR_UNSUPPORTED, "all-pairs forces are built for the lean pair arithmetic only (EPS2 in its validated range)");
     for (int k = 0; k < 5; k++) { c->S.seg_base[k] = g.seg_base[k]; c->S.info_base[k] = g.info_base[k]; }
     for (int k = 0; k < 4; k++) c->S.seg_size_t[k] = g.seg_size_t[k];
 

@@ -67,6 +67,8 @@ struct DevParams {
     int32_t xfer_cap;        // relocation records per direction and step
     int32_t lentout_c0, lentout_c1;  // own local cells computed by the rank above (their force records come back)
     int32_t num_cells_global;
+    float drag;              // linear drag coefficient (0: the reference's arithmetic)
+    float force_sign;        // +1 gravity, -1 repulsion
 };
 
 // Which cells / slots / records a rank holds.  All device code goes through these.

@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
         if (e < P.max_per_cell) {
             sorted_id[start + e] = id;
             rank_of_slot[si] = start + e;
-            const float w_eff = (age < P.kid_thr) ? 0.0f : p.w;
+            const float w_eff = (age < P.kid_thr) ? 0.0f : (P.force_sign < 0.f ? -p.w : p.w);
             snap4[start + e] = make_float4(p.x, p.y, p.z, w_eff);
             {   // the same four values as separate arrays: what the pair kernel streams
                 const size_t cap = (size_t)P.sorted_cap;
@@ -1207,8 +1207,19 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
         if (k0 > 0 && !handoff_consume(force4 + gi, ax, ay, az, flag, valid, ready)) {
             if (lane == 0) atomicOr(&fs->error, ERR_HANDOFF_TIMEOUT);
         }
-        for (int k = k0; k < k1; k++) {
-            const int nb = __builtin_amdgcn_readlane(my_nb, k), n = __builtin_amdgcn_readlane(my_cnt, k);
+        // all-pairs mode (not in the reference): after the stencil, every other cell in index order
+        const int kend = ((P.flags & PSAMD_FLAG_ALL_PAIRS) && k1 == STENCIL) ? STENCIL + P.n_own_cells : k1;
+        for (int k = k0; k < kend; k++) {
+            int nb, n;
+            if (k < STENCIL) { nb = __builtin_amdgcn_readlane(my_nb, k); n = __builtin_amdgcn_readlane(my_cnt, k); }
+            else {
+                const int c2 = k - STENCIL;
+                int j1, j2, j3;
+                cell_coords(P, c2, j1, j2, j3);
+                if (abs(j1 - i1) <= 1 && abs(j2 - i2) <= 1 && abs(j3 - i3) <= 1) continue;      // a stencil cell: done above
+                nb = __builtin_amdgcn_readfirstlane(cell_start[c2]);
+                n = __builtin_amdgcn_readfirstlane(min(cell_start[c2 + 1] - nb, P.max_per_cell));
+            }
             const float *sx = snap_soa + nb, *sy = sx + cap, *sz = sy + cap, *sw = sz + cap;   // wave-uniform
             float dmin = 3.0e38f;
             int jj = 0;
@@ -1589,12 +1600,14 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
         const float4 p = pos4[si];
         const float4 v = vel4[si];
         const float fert = acc4[si].w;
-        const float axv = f.x, ayv = f.y, azv = f.z;
+        float axv = f.x, ayv = f.y, azv = f.z;
         const float t = P.t;
+        if (P.drag > 0.f) { axv -= P.drag * v.x; ayv -= P.drag * v.y; azv -= P.drag * v.z; }    // not in the reference
         // dx = v*t (fp32) + 0.5*a*t*t (double, left to right), rounded once (ps.cpp:1274-1276)
         float dx = (float)((double)(v.x * t) + ((0.5 * (double)axv) * (double)t) * (double)t);
         float dy = (float)((double)(v.y * t) + ((0.5 * (double)ayv) * (double)t) * (double)t);
         float dz = (float)((double)(v.z * t) + ((0.5 * (double)azv) * (double)t) * (double)t);
+        if (P.flags & PSAMD_FLAG_EULER) { dx = v.x * t; dy = v.y * t; dz = v.z * t; }           // not in the reference
         dx = clamp_mag(dx, P.dmax); dy = clamp_mag(dy, P.dmax); dz = clamp_mag(dz, P.dmax);
         float rx = p.x + dx, ry = p.y + dy, rz = p.z + dz;
 
@@ -2599,7 +2612,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     static const bool balance_off = std::getenv("PSAMD_NO_BALANCE") != nullptr;
     static const int waves_env = std::getenv("PSAMD_WAVES") ? std::atoi(std::getenv("PSAMD_WAVES")) : 0;
     const bool merge = two && !merge_off && (P.world == 1 || ncomp >= 2048);
-    const bool balanced = two && !balance_off;
+    const bool balanced = two && !balance_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS);
     // Balanced pass: a fixed number of waves, all resident, each walking the same number of
     // bodies.  Enough of them that a SIMD has several to switch between, but not many more
     // than there are tasks (a task cut in more pieces only adds hand-offs): from the host's

@@ -1,0 +1,156 @@
+"""What BASELINE.json names and the reference does not contain ("parity
+unpinned"): all-pairs forces (configs[1]), a drag term, an explicit-Euler position update,
+repulsion.  Nothing in the reference can pin them, so the checks are: the limit in which they
+must coincide with the pinned cutoff path (bit for bit), an fp64 direct sum (1e-5 relative,
+BASELINE's bar), and closed forms."""
+import numpy as np
+import pytest
+
+import oracle_py as O
+import particlesystem_amd as ps
+from util import assert_same_particles, cloud, oracle_cfg_from
+
+pytestmark = pytest.mark.gpu
+
+
+def force_of(g, n):
+    g.init_iframe(); g.build_grid(); g.calc_forces_pairs()
+    f = g.download_force4(0, n)
+    ids = g.download_cellgrid()
+    order = np.concatenate([row[1:1 + row[0]] for row in ids])
+    g.calc_forces_apply()
+    return order, f
+
+
+def test_all_pairs_is_the_cutoff_result_when_everything_is_within_one_stencil():
+    """a cloud inside a 2x2x2 block of cells: every cell of the block is in every other's
+    stencil, so the all-pairs walk (stencil first, in the reference's order, then the rest --
+    empty) must reproduce the reference's cutoff sums bit for bit, and the whole step too."""
+    n = 3000
+    rng = np.random.default_rng(7)
+    xyz = rng.uniform(-4.99, 4.99, (n, 3)).astype(np.float32)           # cells 7..8 on every axis
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    a = ps.ParticleSystem(ps.default_config(flags=ps.FLAG_ALL_PAIRS))
+    b = ps.ParticleSystem(ps.default_config())
+    o = O.System(oracle_cfg_from(b.cfg))
+    for s in (a, b):
+        s.fill_particles(xyz, age=age, fert_age=np.float32(1e6))
+    o.fill(xyz, age=age, fert_age=np.float32(1e6))
+    oa, fa = force_of(a, n)
+    ob, fb = force_of(b, n)
+    assert np.array_equal(oa, ob) and fa.tobytes() == fb.tobytes()
+    o.step(1)
+    assert_same_particles(a.download_particles(), o.particles, "all-pairs step on a confined cloud")
+    a.close(); b.close(); o.close()
+
+
+def test_all_pairs_against_an_fp64_direct_sum():
+    """a cloud spread over the whole box: every particle feels every other (softened gravity,
+    kids excluded as in bodyBodyInteraction); |a| within 1e-5 relative of the fp64 direct sum"""
+    n = 6000
+    xyz = cloud(n, 8)
+    rng = np.random.default_rng(8)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    age[::17] = 0.5                                                       # some kids: exert and feel nothing
+    g = ps.ParticleSystem(ps.default_config(flags=ps.FLAG_ALL_PAIRS, collision_radius=1e-6))
+    g.fill_particles(xyz, age=age, fert_age=np.float32(1e6))
+    order, f = force_of(g, n)
+    p = g.download_particles()
+    live = np.nonzero(p["cell"] >= 0)[0]
+    # the positions of the frame the forces were computed in = the fill (apply ran afterwards)
+    pos = xyz.astype(np.float64)
+    kid = age < 1.5
+    d = pos[None, :, :] - pos[:, None, :]
+    r2 = (d * d).sum(2) + 0.2
+    s = np.where(kid[None, :], 0.0, 60.0 / (r2 * np.sqrt(r2)))
+    np.fill_diagonal(s, 0.0)
+    exact = (d * s[:, :, None]).sum(1)
+    exact[kid] = 0.0
+    # map sorted order -> input order through the slot ids the fill returned
+    g2 = ps.ParticleSystem(ps.default_config(flags=ps.FLAG_ALL_PAIRS, collision_radius=1e-6))
+    ids = g2.fill_particles(xyz, age=age, fert_age=np.float32(1e6))
+    g2.close()
+    where = {int(s_): i for i, s_ in enumerate(ids)}
+    idx = np.array([where[int(s_)] for s_ in order])
+    got = f[:, :3].astype(np.float64)
+    want = exact[idx]
+    assert (f[:, 3].view(np.int32) == 0).all()
+    adults = ~kid[idx]
+    rel = np.linalg.norm(got[adults] - want[adults], axis=1) / np.linalg.norm(want[adults], axis=1)
+    print("all-pairs vs fp64 direct sum, N=%d: max relative deviation %.3g" % (n, rel.max()))
+    assert rel.max() < 1e-5 and not got[~adults].any() and len(live) == n
+    g.close()
+
+
+def lone_particles(v0, **over):
+    """particles far apart (no neighbour within a stencil): no force, no collision"""
+    xyz = np.array([[-30.0, -30.0, -30.0], [0.0, 0.0, 0.0], [30.0, 30.0, 30.0]], np.float32)
+    g = ps.ParticleSystem(ps.default_config(**over))
+    ids = g.fill_particles(xyz, age=np.float32(3.0), fert_age=np.float32(1e6), vxyz=np.asarray(v0, np.float32))
+    return g, ids, xyz
+
+
+def test_drag_decays_like_v0_exp_minus_kt():
+    k, dt, steps = 0.8, 0.01, 100
+    v0 = np.array([[1.0, -2.0, 0.5], [0.3, 0.2, -0.1], [-1.5, 0.0, 2.0]], np.float32)
+    g, ids, _ = lone_particles(v0, drag=k, dt=dt)
+    v = v0.copy()
+    for _ in range(steps):
+        g.step(1)
+        a = np.float32(-k) * v if False else -(np.float32(k) * v)      # a = 0 - k*v, fp32
+        v = v + a * np.float32(dt)
+    p = g.download_particles()
+    # the relocated slots: find the three live particles by their ages
+    live = np.nonzero(p["cell"] >= 0)[0]
+    assert len(live) == 3
+    got = np.stack([p["vx"][live], p["vy"][live], p["vz"][live]], 1)
+    model = v[np.lexsort(v.T[::-1])]
+    assert np.array_equal(np.sort(got, axis=0), np.sort(v, axis=0)), "explicit update v += (a - k v) dt, fp32"
+    exact = v0 * np.exp(-k * dt * steps)
+    assert np.abs(np.sort(got, axis=0) - np.sort(exact, axis=0)).max() < 2 * k * k * dt * steps * dt * np.abs(v0).max()
+    g.close()
+
+
+def test_euler_switch_and_default_position_update():
+    v0 = np.array([[1.0, -2.0, 0.5], [0.3, 0.2, -0.1], [-1.5, 0.0, 2.0]], np.float32)
+    for flags in (0, ps.FLAG_EULER):
+        g, ids, xyz = lone_particles(v0, flags=flags)
+        g.step(1)
+        p = g.download_particles()
+        live = np.nonzero(p["cell"] >= 0)[0]
+        got = np.stack([p["x"][live], p["y"][live], p["z"][live]], 1)
+        want = xyz + v0 * np.float32(0.05)                                # a = 0: both forms coincide
+        assert np.array_equal(np.sort(got, axis=0), np.sort(want, axis=0))
+        g.close()
+    # with a force: two bodies 8 apart; Euler leaves out 0.5*a*dt^2
+    two = np.array([[-4.0, 0, 0], [4.0, 0, 0]], np.float32)
+    xs = {}
+    for flags in (0, ps.FLAG_EULER):
+        g = ps.ParticleSystem(ps.default_config(flags=flags))
+        g.fill_particles(two, age=np.float32(2.0), fert_age=np.float32(1e6))
+        g.step(1)
+        p = g.download_particles()
+        live = np.nonzero(p["cell"] >= 0)[0]
+        xs[flags] = (np.sort(p["x"][live]), np.sort(p["vx"][live]), np.sort(p["ax"][live]))
+        g.close()
+    assert np.float32(xs[0][0][0]) == np.float32(-3.99883366)            # the reference's own number
+    assert np.array_equal(xs[ps.FLAG_EULER][0], np.array([-4.0, 4.0], np.float32))
+    assert np.array_equal(xs[0][1], xs[ps.FLAG_EULER][1]) and np.array_equal(xs[0][2], xs[ps.FLAG_EULER][2])
+
+
+def test_repulsion_is_gravity_with_the_sign_flipped():
+    n = 20000
+    xyz = cloud(n, 9)
+    rng = np.random.default_rng(9)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    f = {}
+    for sign in (1.0, -1.0):
+        g = ps.ParticleSystem(ps.default_config(force_sign=sign))
+        g.fill_particles(xyz, age=age, fert_age=np.float32(1e6))
+        f[sign] = force_of(g, n)[1]
+        g.close()
+    assert np.array_equal(f[1.0][:, 3].view(np.int32), f[-1.0][:, 3].view(np.int32))
+    keep = f[1.0][:, 3].view(np.int32) == 0
+    a, b = f[1.0][keep, :3], f[-1.0][keep, :3]
+    assert np.array_equal(a.view(np.uint32) ^ np.uint32(0x80000000), b.view(np.uint32)) or np.array_equal(-a, b)
+    assert np.abs(a).max() > 0

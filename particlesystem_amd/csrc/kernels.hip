@@ -2,8 +2,8 @@
 //
 // Step pipeline (all on the context's stream):
 //   k_hist_lds / k_scatter_lds   counting sort of the live slots by cell, histogram
-//               private to a workgroup in LDS (k_hist / k_scatter with global atomics
-//               for grids of more than 8192 cells)                     (streaming, HBM)
+//               private to a workgroup in LDS (a window of 8192 cells from the first
+//               cell the workgroup meets)                               (streaming, HBM)
 //   k_scan, k_build_tasks   prefix over cells, hostGridMax, the pair kernel's work list
 //   k_sort_cells   rank ids inside each cell (ascending = the reference's cell-list
 //               order, ps.cpp:1510-1516), gather the T_DATA snapshot in that order
@@ -182,41 +182,57 @@ __device__ __forceinline__ int own_local_cell(const DevParams &P, int gc, FrameS
     return lc;
 }
 
-__global__ void k_hist(DevParams P, const int *__restrict__ cell, int *__restrict__ cell_count, FrameScalars *fs)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int stride = gridDim.x * blockDim.x;
-    for (; i < P.slots_total; i += stride) {
-        const int c = own_local_cell(P, cell[i], fs);
-        if (c >= 0) atomicAdd(&cell_count[c], 1);
-    }
-}
-
-// Same two kernels with a workgroup-private histogram in LDS (at most LDS_CELLS own
-// cells): a workgroup owns SLOTS_PER_WG consecutive slots, which by the container's
-// construction belong to one or two segments, i.e. a handful of cells, so almost all
-// atomics stay in LDS and only the touched bins go to memory.
+// Same two kernels with a workgroup-private histogram in LDS: a workgroup owns SLOTS_PER_WG
+// consecutive slots, which by the container's construction belong to one or two segments,
+// i.e. a handful of cells a few grid planes apart, so almost all atomics stay in LDS and only
+// the touched bins go to memory.  The LDS histogram is a WINDOW of LDS_CELLS cells starting at
+// the smallest cell the workgroup meets (grids of up to LDS_CELLS cells: the whole grid); the
+// rare slot outside it (a workgroup straddling two distant segments) goes to memory directly.
 constexpr int LDS_CELLS = 8192;
 constexpr int SLOTS_PER_WG = 4096;
+
+// first cell of the workgroup's window; s_min: one int of LDS
+__device__ __forceinline__ int hist_window(const DevParams &P, const int (&mine)[SLOTS_PER_WG / 1024], int *s_min)
+{
+    if (P.n_own_cells <= LDS_CELLS) return 0;
+    if (threadIdx.x == 0) *s_min = 0x7fffffff;
+    __syncthreads();
+    int m = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < SLOTS_PER_WG / 1024; i++) if (mine[i] >= 0) m = min(m, mine[i]);
+    for (int d = 32; d > 0; d >>= 1) m = min(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0 && m != 0x7fffffff) atomicMin(s_min, m);
+    __syncthreads();
+    return *s_min;
+}
 
 __global__ __launch_bounds__(1024) void k_hist_lds(DevParams P, const int *__restrict__ cell, int *__restrict__ cell_count,
                                                     FrameScalars *fs)
 {
     __shared__ int h[LDS_CELLS];
+    __shared__ int s_min;
     const int tid = threadIdx.x, base = blockIdx.x * SLOTS_PER_WG, ncell = P.n_own_cells;
-    for (int c = tid; c < ncell; c += 1024) h[c] = 0;
+    int mine[SLOTS_PER_WG / 1024];
+#pragma unroll
+    for (int i = 0; i < SLOTS_PER_WG / 1024; i++) {
+        const int si = base + i * 1024 + tid;
+        mine[i] = si < P.slots_total ? own_local_cell(P, cell[si], fs) : -1;
+    }
+    const int w0 = hist_window(P, mine, &s_min);
+    if (w0 == 0x7fffffff) return;                              // nothing alive in these slots
+    const int span = min(ncell - w0, LDS_CELLS);
+    for (int c = tid; c < span; c += 1024) h[c] = 0;
     __syncthreads();
-    for (int i = tid; i < SLOTS_PER_WG; i += 1024) {
-        const int si = base + i;
-        if (si < P.slots_total) {
-            const int c = own_local_cell(P, cell[si], fs);
-            if (c >= 0) atomicAdd(&h[c], 1);
-        }
+#pragma unroll
+    for (int i = 0; i < SLOTS_PER_WG / 1024; i++) {
+        const int c = mine[i];
+        if (c < 0) continue;
+        if (c - w0 < LDS_CELLS) atomicAdd(&h[c - w0], 1); else atomicAdd(&cell_count[c], 1);
     }
     __syncthreads();
-    for (int c = tid; c < ncell; c += 1024) {
+    for (int c = tid; c < span; c += 1024) {
         const int v = h[c];
-        if (v) atomicAdd(&cell_count[c], v);
+        if (v) atomicAdd(&cell_count[w0 + c], v);
     }
 }
 
@@ -224,9 +240,8 @@ __global__ __launch_bounds__(1024) void k_scatter_lds(DevParams P, const int *__
                                                        int *__restrict__ sorted_id)
 {
     __shared__ int h[LDS_CELLS];
+    __shared__ int s_min;
     const int tid = threadIdx.x, base = blockIdx.x * SLOTS_PER_WG, ncell = P.n_own_cells;
-    for (int c = tid; c < ncell; c += 1024) h[c] = 0;
-    __syncthreads();
     int mine[SLOTS_PER_WG / 1024];
 #pragma unroll
     for (int i = 0; i < SLOTS_PER_WG / 1024; i++) {
@@ -238,17 +253,28 @@ __global__ __launch_bounds__(1024) void k_scatter_lds(DevParams P, const int *__
             if (c < 0 || c >= ncell) c = -1;          // foreign cells were flagged by the histogram pass
         }
         mine[i] = c;
-        if (c >= 0) atomicAdd(&h[c], 1);
     }
+    const int w0 = hist_window(P, mine, &s_min);
+    if (w0 == 0x7fffffff) return;
+    const int span = min(ncell - w0, LDS_CELLS);
+    for (int c = tid; c < span; c += 1024) h[c] = 0;
     __syncthreads();
-    for (int c = tid; c < ncell; c += 1024) {      // reserve this workgroup's run in each touched cell
+#pragma unroll
+    for (int i = 0; i < SLOTS_PER_WG / 1024; i++)
+        if (mine[i] >= 0 && mine[i] - w0 < LDS_CELLS) atomicAdd(&h[mine[i] - w0], 1);
+    __syncthreads();
+    for (int c = tid; c < span; c += 1024) {      // reserve this workgroup's run in each touched cell
         const int v = h[c];
-        if (v) h[c] = atomicAdd(&cursor[c], v);
+        if (v) h[c] = atomicAdd(&cursor[w0 + c], v);
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < SLOTS_PER_WG / 1024; i++)
-        if (mine[i] >= 0) sorted_id[atomicAdd(&h[mine[i]], 1)] = slot_of_index(P, base + i * 1024 + tid);
+        if (mine[i] >= 0) {
+            const int c = mine[i];
+            const int pos = c - w0 < LDS_CELLS ? atomicAdd(&h[c - w0], 1) : atomicAdd(&cursor[c], 1);
+            sorted_id[pos] = slot_of_index(P, base + i * 1024 + tid);
+        }
 }
 
 // One workgroup: exclusive prefix of the own cells' counts, the scatter cursors, the chunk
@@ -333,17 +359,6 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
     // stored list (ps.cpp:1502-1508): past that (only possible while cells overflow, the count
     // includes the killed) its tail would be skipped.  Not reproduced: refuse loudly instead.
     if (over) atomicOr(&fs->error, ERR_CHUNK_CAP);
-}
-
-__global__ void k_scatter(DevParams P, const int *__restrict__ cell, int *__restrict__ cursor, int *__restrict__ sorted_id)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int stride = gridDim.x * blockDim.x;
-    for (; i < P.slots_total; i += stride) {
-        int c = cell[i];
-        c = (c < 0 || c >= P.num_cells_global) ? -1 : c - P.reg_first[0] * P.G * P.G;
-        if (c >= 0 && c < P.n_own_cells) sorted_id[atomicAdd(&cursor[c], 1)] = slot_of_index(P, i);
-    }
 }
 
 // the pair kernel's work list: one entry per non-empty (cell, 64-particle slice) of the own
@@ -1121,7 +1136,9 @@ __global__ void k_split_tasks(DevParams P, int nw, const int *__restrict__ cell_
 typedef __attribute__((address_space(1))) unsigned int gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 
-__device__ __forceinline__ void handoff_publish(float4 *slot, float ax, float ay, float az, int flag, bool valid, int *ready)
+// The flag word carries the stencil step the published sums stand at, so that a task cut in
+// three or more pieces hands on correctly at every cut (each consumer waits for ITS step).
+__device__ __forceinline__ void handoff_publish(float4 *slot, float ax, float ay, float az, int flag, bool valid, int *ready, int step)
 {
     if (valid) {
         gu64 *p = (gu64 *)(unsigned long long *)slot;
@@ -1129,16 +1146,16 @@ __device__ __forceinline__ void handoff_publish(float4 *slot, float ax, float ay
         __hip_atomic_store(p + 1, ((unsigned long long)(unsigned)flag << 32) | __float_as_uint(az), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if ((threadIdx.x & 63) == 0) __hip_atomic_store((gu32 *)(unsigned int *)ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store((gu32 *)(unsigned int *)ready, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // false: the flag never came (bounded spin; the caller raises a sticky error)
-__device__ __forceinline__ bool handoff_consume(const float4 *slot, float &ax, float &ay, float &az, int &flag, bool valid, const int *ready)
+__device__ __forceinline__ bool handoff_consume(const float4 *slot, float &ax, float &ay, float &az, int &flag, bool valid, const int *ready, int step)
 {
     int ok = 0;
     if ((threadIdx.x & 63) == 0) {
         for (unsigned spins = 0; spins < (1u << 22); spins++) {
-            if (__hip_atomic_load((gu32 *)(unsigned int *)ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 1; break; }
+            if (__hip_atomic_load((gu32 *)(unsigned int *)ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)step) { ok = 1; break; }
             __builtin_amdgcn_s_sleep(16);
         }
     }
@@ -1204,7 +1221,7 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
     if (MODE != 0) {
         const PairCtx ctx = {me.x, me.y, me.z, age_i, id_i, gi, scan};
         const size_t cap = (size_t)P.sorted_cap;
-        if (k0 > 0 && !handoff_consume(force4 + gi, ax, ay, az, flag, valid, ready)) {
+        if (k0 > 0 && !handoff_consume(force4 + gi, ax, ay, az, flag, valid, ready, k0)) {
             if (lane == 0) atomicOr(&fs->error, ERR_HANDOFF_TIMEOUT);
         }
         // all-pairs mode (not in the reference): after the stencil, every other cell in index order
@@ -1317,7 +1334,7 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
         }
     }
     if (MODE != 0 && k1 < STENCIL) {             // not the end of the walk: hand the sums on
-        handoff_publish(force4 + gi, ax, ay, az, flag, valid, ready);
+        handoff_publish(force4 + gi, ax, ay, az, flag, valid, ready, k1);
         PS_TRACE_END();
         return;
     }
@@ -2517,12 +2534,9 @@ hipError_t launch_init_tdata(hipStream_t st, const DevParams &P, const DeviceSta
 
 hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev)
 {
-    const int nb = blocks_for((size_t)P.slots_total, 256, 2048);
-    const bool lds = P.n_own_cells <= LDS_CELLS;
     const int nwg = std::max(1, (P.slots_total + SLOTS_PER_WG - 1) / SLOTS_PER_WG);
     if (ev) (void)hipEventRecord(ev[0], st);
-    if (lds) k_hist_lds<<<nwg, 1024, 0, st>>>(P, d.cell, d.cell_count, d.fs);
-    else k_hist<<<nb, 256, 0, st>>>(P, d.cell, d.cell_count, d.fs);
+    k_hist_lds<<<nwg, 1024, 0, st>>>(P, d.cell, d.cell_count, d.fs);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[1], st);
     k_scan<<<1, 1024, 0, st>>>(P, d.cell_count, d.cell_start, d.cursor, d.task_start, d.chunk_count, d.celltab, d.fs);
@@ -2530,8 +2544,7 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     if (P.comp_b1 > P.comp_b0) k_build_tasks<<<(P.comp_b1 - P.comp_b0 + 255) / 256, 256, 0, st>>>(P, d.task_start, d.task_list);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[2], st);
-    if (lds) k_scatter_lds<<<nwg, 1024, 0, st>>>(P, d.cell, d.cursor, d.sorted_id);
-    else k_scatter<<<nb, 256, 0, st>>>(P, d.cell, d.cursor, d.sorted_id);
+    k_scatter_lds<<<nwg, 1024, 0, st>>>(P, d.cell, d.cursor, d.sorted_id);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[3], st);
     k_sort_cells<<<P.n_own_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
@@ -2611,7 +2624,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     static const bool merge_off = std::getenv("PSAMD_NO_MERGE") != nullptr;
     static const bool balance_off = std::getenv("PSAMD_NO_BALANCE") != nullptr;
     static const int waves_env = std::getenv("PSAMD_WAVES") ? std::atoi(std::getenv("PSAMD_WAVES")) : 0;
-    const bool merge = two && !merge_off && (P.world == 1 || ncomp >= 2048);
+    const bool merge = two && !merge_off && (P.world == 1 || ncomp >= 2048) && !(P.flags & PSAMD_FLAG_ALL_PAIRS);   // (the merged kernel walks the stencil only)
     const bool balanced = two && !balance_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS);
     // Balanced pass: a fixed number of waves, all resident, each walking the same number of
     // bodies.  Enough of them that a SIMD has several to switch between, but not many more

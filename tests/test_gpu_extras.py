@@ -47,13 +47,13 @@ def test_all_pairs_is_the_cutoff_result_when_everything_is_within_one_stencil():
 def test_all_pairs_against_an_fp64_direct_sum():
     """a cloud spread over the whole box: every particle feels every other (softened gravity,
     kids excluded as in bodyBodyInteraction); |a| within 1e-5 relative of the fp64 direct sum"""
-    n = 6000
+    n = 4000
     xyz = cloud(n, 8)
     rng = np.random.default_rng(8)
     age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
     age[::17] = 0.5                                                       # some kids: exert and feel nothing
     g = ps.ParticleSystem(ps.default_config(flags=ps.FLAG_ALL_PAIRS, collision_radius=1e-6))
-    g.fill_particles(xyz, age=age, fert_age=np.float32(1e6))
+    ids = g.fill_particles(xyz, age=age, fert_age=np.float32(1e6))
     order, f = force_of(g, n)
     p = g.download_particles()
     live = np.nonzero(p["cell"] >= 0)[0]
@@ -67,9 +67,6 @@ def test_all_pairs_against_an_fp64_direct_sum():
     exact = (d * s[:, :, None]).sum(1)
     exact[kid] = 0.0
     # map sorted order -> input order through the slot ids the fill returned
-    g2 = ps.ParticleSystem(ps.default_config(flags=ps.FLAG_ALL_PAIRS, collision_radius=1e-6))
-    ids = g2.fill_particles(xyz, age=age, fert_age=np.float32(1e6))
-    g2.close()
     where = {int(s_): i for i, s_ in enumerate(ids)}
     idx = np.array([where[int(s_)] for s_ in order])
     got = f[:, :3].astype(np.float64)
@@ -86,7 +83,7 @@ def lone_particles(v0, **over):
     """particles far apart (no neighbour within a stencil): no force, no collision"""
     xyz = np.array([[-30.0, -30.0, -30.0], [0.0, 0.0, 0.0], [30.0, 30.0, 30.0]], np.float32)
     g = ps.ParticleSystem(ps.default_config(**over))
-    ids = g.fill_particles(xyz, age=np.float32(3.0), fert_age=np.float32(1e6), vxyz=np.asarray(v0, np.float32))
+    ids = g.fill_particles(xyz, age=np.float32(1.0), fert_age=np.float32(1e6), vxyz=np.asarray(v0, np.float32))
     return g, ids, xyz
 
 
@@ -97,14 +94,13 @@ def test_drag_decays_like_v0_exp_minus_kt():
     v = v0.copy()
     for _ in range(steps):
         g.step(1)
-        a = np.float32(-k) * v if False else -(np.float32(k) * v)      # a = 0 - k*v, fp32
+        a = -(np.float32(k) * v)                                        # a = 0 - k*v, fp32
         v = v + a * np.float32(dt)
     p = g.download_particles()
     # the relocated slots: find the three live particles by their ages
     live = np.nonzero(p["cell"] >= 0)[0]
     assert len(live) == 3
     got = np.stack([p["vx"][live], p["vy"][live], p["vz"][live]], 1)
-    model = v[np.lexsort(v.T[::-1])]
     assert np.array_equal(np.sort(got, axis=0), np.sort(v, axis=0)), "explicit update v += (a - k v) dt, fp32"
     exact = v0 * np.exp(-k * dt * steps)
     assert np.abs(np.sort(got, axis=0) - np.sort(exact, axis=0)).max() < 2 * k * k * dt * steps * dt * np.abs(v0).max()

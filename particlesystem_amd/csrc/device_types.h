@@ -215,6 +215,8 @@ struct XferRec {
     int32_t kind;           // 0 relocation (| MOVE_PARENT), 1 birth
     float pos[4], vel[4], acc[4];   // relocation: the particle; birth: the parent's position and velocity
 };
+constexpr int STATUS_KILL_CAP = 4080;   // cell-overflow kills one rank can report per step (status message: 16 + 4080 words)
+constexpr int STATUS_WORDS = 16 + STATUS_KILL_CAP;
 constexpr int MSG_HEADER_WORDS = 16;   // every message starts with 16 ints: [0] count, [1] bodies, [2] error bits
 
 constexpr int SORT_MAX = 4096;   // ids one cell may hold for the in-LDS ranking

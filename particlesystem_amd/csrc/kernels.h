@@ -74,6 +74,7 @@ struct DeviceState {
     int moves_cap = 0;
     float4 *stage = nullptr;      // 3 float4 per move
     XferRec *xfer_out[2] = {nullptr, nullptr};   // slab mode: records leaving for the rank below / above (inside the messages)
+    int *status_out = nullptr;    // slab mode: [0] cell-overflow kills this frame, [1] error bits, [2] live, [16..] the killed slot ids
     DevCounters *ctr = nullptr;
     unsigned long long *trace = nullptr;  // 3 words per pair-kernel wave slot (diagnostic builds only)
 };
@@ -96,7 +97,7 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
 hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t live_bound);
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step);
 // after apply, before the per-step read-back: ops per queue record, their prefix and maximum
-hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints);
+hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints);   // also clears the status message's header
 hipError_t launch_ops_census(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec);
 // n_ops / n_moves / max_bucket are the counts read back from FrameScalars
 hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
@@ -111,6 +112,8 @@ hipError_t launch_pack_force(hipStream_t st, const DevParams &P, const DeviceSta
 hipError_t launch_unpack_force(hipStream_t st, const DevParams &P, const DeviceState &d, int j0, const int *msg, const int *pack_off);
 hipError_t launch_outbox_close(hipStream_t st, const DevParams &P, const DeviceState &d, int64_t live_bound, int *msg_down, int *msg_up);
 hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *msg);
+hipError_t launch_status_close(hipStream_t st, const DeviceState &d);
+hipError_t launch_status_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *status_all);
 // lifecycle_sort.hip (rocPRIM radix sort of the op keys; library code, not a hot path)
 hipError_t sort_ops_tmp_bytes(size_t n, int key_bits, size_t *bytes);
 hipError_t sort_ops(hipStream_t st, const DeviceState &d, int n, int key_bits);

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
                                                      uint64_t *op_keys, int *op_args, int ops_cap,
                                                      int *__restrict__ halo_count, float *__restrict__ halo_f,
                                                      int *__restrict__ halo_id, int *__restrict__ snap_cid,
-                                                     FrameScalars *fs, DevCounters *ctr)
+                                                     int *__restrict__ status_out, FrameScalars *fs, DevCounters *ctr)
 {
     __shared__ __attribute__((aligned(16))) int ids[SORT_MAX + 4];
     __shared__ int ordered[SORT_MAX];
@@ -556,11 +556,17 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
             vel4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
             acc4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
             atomicAdd(&(ctr + (blockIdx.x % COUNTER_COPIES))->cell_overflow_kills, 1ull);
-            // freed with the already-reset segment (-1,-1): queue record 0 (ps.cpp:1523-1526)
-            if (!owns_record(P, 0)) atomicOr(&fs->error, ERR_REMOTE_RECORD0);
-            const int k = atomicAdd(&fs->n_ops, 1);
-            if (k < ops_cap) { op_keys[k] = ((uint64_t)(uint32_t)id << 2) | 2ull; op_args[k] = id; }
-            else atomicOr(&fs->error, ERR_OPS_OVERFLOW);
+            // freed with the already-reset segment (-1,-1): queue record 0 (ps.cpp:1523-1526).  On a
+            // slab that does not hold that queue the slot id travels to its owner in the status message.
+            if (owns_record(P, 0)) {
+                const int k = atomicAdd(&fs->n_ops, 1);
+                if (k < ops_cap) { op_keys[k] = ((uint64_t)(uint32_t)id << 2) | 2ull; op_args[k] = id; }
+                else atomicOr(&fs->error, ERR_OPS_OVERFLOW);
+            } else {
+                const int k = atomicAdd(&status_out[0], 1);
+                if (k < STATUS_KILL_CAP) status_out[MSG_HEADER_WORDS + k] = id;
+                else atomicOr(&fs->error, ERR_REMOTE_RECORD0);
+            }
         }
     }
     if (!halo_count) return;
@@ -1040,15 +1046,25 @@ __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *_
 // wave_pos[s + 1]: equal shares of the total cost, cut at unit boundaries.  The eight runs of
 // waves that share an XCD (wave slots are dealt XCD by XCD, see k_pairs) start at whole tasks,
 // so a task that is cut is always continued by a workgroup of the same run.
-// One thread per boundary.
-__global__ void k_split_tasks(DevParams P, int nw, const int *__restrict__ cell_start, const int *__restrict__ task_cost,
-                              const int *__restrict__ ctask_start, const long long *__restrict__ cost_start,
-                              int *__restrict__ wave_pos, const FrameScalars *__restrict__ fs)
+// One workgroup per run; the two prefix arrays are searched in LDS when they fit.
+constexpr int SPLIT_LDS_CELLS = 4096;
+__global__ __launch_bounds__(256) void k_split_tasks(DevParams P, int nw, const int *__restrict__ cell_start, const int *__restrict__ task_cost,
+                                                      const int *__restrict__ ctask_start_g, const long long *__restrict__ cost_start_g,
+                                                      int *__restrict__ wave_pos, const FrameScalars *__restrict__ fs)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s > nw) return;
-    const int ncomp = comp_count(P), ntask = fs->n_tasks2;
+    __shared__ long long s_cost[SPLIT_LDS_CELLS + 1];
+    __shared__ int s_task[SPLIT_LDS_CELLS + 1];
+    __shared__ int s_run[2];
+    __shared__ long long s_runcost[2];
+    const int ncomp = comp_count(P), ntask = fs->n_tasks2, tid = threadIdx.x;
     const long long T = fs->cost_total;
+    const bool in_lds = ncomp <= SPLIT_LDS_CELLS;
+    if (in_lds) {
+        for (int j = tid; j <= ncomp; j += 256) { s_cost[j] = cost_start_g[j]; s_task[j] = ctask_start_g[j]; }
+        __syncthreads();
+    }
+    const long long *cost_start = in_lds ? s_cost : cost_start_g;
+    const int *ctask_start = in_lds ? s_task : ctask_start_g;
     // unit (task index * 27 + step) at which the cumulative cost reaches x; whole = round up to the next task start
     auto unit_at = [&](long long x, bool whole) -> int {
         if (x >= T) return ntask * STENCIL;
@@ -1072,24 +1088,25 @@ __global__ void k_split_tasks(DevParams P, int nw, const int *__restrict__ cell_
         if (whole) return (t + ((k > 0 || r > 0) ? 1 : 0)) * STENCIL;
         return t * STENCIL + k;
     };
+    auto cost_of_task_start = [&](int unit) -> long long {
+        const int t = unit / STENCIL;
+        if (t >= ntask) return T;
+        int a = 0, b = ncomp - 1;
+        while (a < b) { const int mm = (a + b + 1) >> 1; if (ctask_start[mm] <= t) a = mm; else b = mm - 1; }
+        return cost_start[a] + (long long)(t - ctask_start[a]) * task_cost[comp_cell(P, a)];
+    };
     const int m = nw >> 3;                                // wave slots per XCD run (nw is a multiple of 32)
-    const int x = min(s / m, 8), j = s - x * m;
-    const int run_lo = unit_at(T * x / 8, true);
-    int pos = run_lo;
-    if (j > 0) {
-        // equal shares of the run's own cost range, which starts and ends at whole tasks
-        const int run_hi = unit_at(T * (x + 1) / 8, true);
-        auto cost_of_task_start = [&](int unit) -> long long {
-            const int t = unit / STENCIL;
-            if (t >= ntask) return T;
-            int a = 0, b = ncomp - 1;
-            while (a < b) { const int mm = (a + b + 1) >> 1; if (ctask_start[mm] <= t) a = mm; else b = mm - 1; }
-            return cost_start[a] + (long long)(t - ctask_start[a]) * task_cost[comp_cell(P, a)];
-        };
-        const long long lo = cost_of_task_start(run_lo), hi = cost_of_task_start(run_hi);
-        pos = max(run_lo, min(run_hi, unit_at(lo + (hi - lo) * j / m, false)));
+    const int x = blockIdx.x;                             // this workgroup's run
+    if (tid < 2) {
+        s_run[tid] = unit_at(T * (x + tid) / 8, true);
+        s_runcost[tid] = cost_of_task_start(s_run[tid]);
     }
-    wave_pos[s] = pos;
+    __syncthreads();
+    const int run_lo = s_run[0], run_hi = s_run[1];
+    const long long lo = s_runcost[0], hi = s_runcost[1];
+    for (int j = tid; j < m; j += 256)                    // equal shares of the run's own cost range
+        wave_pos[x * m + j] = j == 0 ? run_lo : max(run_lo, min(run_hi, unit_at(lo + (hi - lo) * j / m, false)));
+    if (x == 7 && tid == 0) wave_pos[nw] = run_hi;        // = ntask * 27
 }
 
 // One wave = 64 consecutive particles of one cell (four independent waves per workgroup).
@@ -1377,6 +1394,92 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
                          task_list[slot], tiles[MODE == 0 ? wave : 0], trace, active_list, active_count);
 }
 
+// The same walk for a wave that has its SIMD (almost) to itself -- a slab of a multi-GPU run has
+// about 1.5 force tasks per SIMD.  There the scalar-load walk of pairs_task is latency-bound (one
+// wave cannot cover its own s_load round trips: 1.6x slower per task, PSAMD_WAVES sweep in
+// DESIGN.md), so the bodies come as 64-body tiles instead: one vector load per lane, issued a
+// whole tile ahead (vector loads retire in order, so they pipeline), through 1 KiB of LDS per
+// wave (SoA, no barrier: a wave reads only its own tile and its LDS operations complete in
+// order), read back as broadcast 16-byte rows.  Same arithmetic, same order: short last tiles
+// are padded with massless bodies far outside the box (r * 0 = +-0 added to a sum that started
+// at +0 changes nothing, as for kids).  Two-pass mode only (flags are settled), lean arithmetic.
+template <int MODE, int NQ>
+__device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *__restrict__ cell_start,
+                                                const float4 *__restrict__ snap4, float4 *__restrict__ force4, int task,
+                                                float *tile, const int *__restrict__ active_list,
+                                                const int *__restrict__ active_count,
+                                                int k0, int k1, int *ready, FrameScalars *fs)
+{
+    const int c = task / P.slices, slice = task - c * P.slices;
+    const int base = cell_start[c];
+    const int cnt = active_count[c];
+    const int first = slice * 64;
+    if (first >= cnt) return;
+    const int lane = threadIdx.x & 63;
+    const bool valid = lane < min(64, cnt - first);
+    const int gi = active_list[base + first + (valid ? lane : 0)];
+    const float4 me = snap4[gi];
+    int i1, i2, i3;
+    cell_coords(P, c, i1, i2, i3);
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    int flag = 0;
+    const float eps2f = (float)P.eps2;
+    int my_nb = 0, my_cnt = 0;
+    if (lane < STENCIL) {
+        const int nc = local_cell(P, i3 + c_stencil[lane][2], i1 + c_stencil[lane][1], i2 + c_stencil[lane][0]);
+        if (nc >= 0) { my_nb = cell_start[nc]; my_cnt = min(cell_start[nc + 1] - my_nb, P.max_per_cell); }
+    }
+    const PairCtx ctx = {me.x, me.y, me.z, 0.f, 0, gi, false};
+    if (k0 > 0 && !handoff_consume(force4 + gi, ax, ay, az, flag, valid, ready, k0)) {
+        if (lane == 0) atomicOr(&fs->error, ERR_HANDOFF_TIMEOUT);
+    }
+    const float far = 1.0e6f;                                       // padding body, mass 0
+    const float *tx = tile, *ty = tile + 64, *tz = tile + 128, *tw = tile + 192;
+    // first non-empty tile from step k0 on, fetched ahead
+    int k = k0, t0 = 0;
+    int nb = 0, ncnt = 0;
+    while (k < k1) { nb = __builtin_amdgcn_readlane(my_nb, k); ncnt = __builtin_amdgcn_readlane(my_cnt, k); if (ncnt > 0) break; k++; }
+    bool have = k < k1;
+    float4 pre = make_float4(far, far, far, 0.f);
+    if (have && lane < ncnt) pre = snap4[nb + lane];
+    while (have) {
+        const int n = (min(64, ncnt - t0) + NQ - 1) & ~(NQ - 1);
+        PS_WAVE_SYNC();                               // previous tile fully consumed
+        tile[lane] = pre.x; tile[64 + lane] = pre.y; tile[128 + lane] = pre.z; tile[192 + lane] = pre.w;
+        PS_WAVE_SYNC();
+        t0 += 64;                                     // advance to the next non-empty tile
+        if (t0 >= ncnt) {
+            t0 = 0; ncnt = 0; k++;
+            while (k < k1) { nb = __builtin_amdgcn_readlane(my_nb, k); ncnt = __builtin_amdgcn_readlane(my_cnt, k); if (ncnt > 0) break; k++; }
+        }
+        have = k < k1;
+        // issued after the fences (they drain outstanding loads), consumed a tile later
+        pre = make_float4(far, far, far, 0.f);
+        if (have && lane < ncnt - t0) pre = snap4[nb + t0 + lane];
+        float dmin = 3.0e38f;
+        for (int jj = 0; jj < n; jj += NQ) {
+            v2f qx[NQ / 2], qy[NQ / 2], qz[NQ / 2], qw[NQ / 2];   // 16-byte LDS reads, NQ is a multiple of 4
+#pragma unroll
+            for (int i = 0; i < NQ / 2; i += 2) {
+                const float4 vx = *reinterpret_cast<const float4 *>(tx + jj + 2 * i);
+                const float4 vy = *reinterpret_cast<const float4 *>(ty + jj + 2 * i);
+                const float4 vz = *reinterpret_cast<const float4 *>(tz + jj + 2 * i);
+                const float4 vw = *reinterpret_cast<const float4 *>(tw + jj + 2 * i);
+                qx[i] = v2f{vx.x, vx.y}; qx[i + 1] = v2f{vx.z, vx.w};
+                qy[i] = v2f{vy.x, vy.y}; qy[i + 1] = v2f{vy.z, vy.w};
+                qz[i] = v2f{vz.x, vz.y}; qz[i + 1] = v2f{vz.z, vz.w};
+                qw[i] = v2f{vw.x, vw.y}; qw[i + 1] = v2f{vw.z, vw.w};
+            }
+            if (MODE == 1)
+                pairsN_exact_lean<NQ>(P, ctx, qx, qy, qz, qw, 0, nullptr, nullptr, ax, ay, az, flag);
+            else
+                dmin = fminf(dmin, pairsN_fast<NQ>(ctx, qx, qy, qz, qw, eps2f, ax, ay, az));
+        }
+    }
+    if (k1 < STENCIL) { handoff_publish(force4 + gi, ax, ay, az, flag, valid, ready, k1); return; }
+    if (valid) force4[gi] = make_float4(ax, ay, az, __int_as_float(flag));
+}
+
 // The force pass, balanced: `nw` waves (all resident), wave slot s walks the (task, stencil step)
 // units from wave_pos[s] up to wave_pos[s + 1] -- the same number of bodies for every wave
 // (k_split_tasks).  Most of a wave's share is whole tasks; the task its share ends in is started
@@ -1388,7 +1491,7 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
 // Wave slots are dealt XCD by XCD like the tasks of k_pairs; k_split_tasks starts every XCD's
 // run at a whole task, so the wave that continues a task runs in a workgroup that was
 // dispatched no later (block b - 8) or is the same workgroup.
-template <int MODE, int NQ>
+template <int MODE, int NQ, bool TILE>
 __global__ __launch_bounds__(256) void k_pairs_balanced(DevParams P, const int *__restrict__ cell_start,
                                                         const float4 *__restrict__ snap4,
                                                         const float *__restrict__ snap_soa,
@@ -1400,6 +1503,7 @@ __global__ __launch_bounds__(256) void k_pairs_balanced(DevParams P, const int *
                                                         const int *__restrict__ active_list, const int *__restrict__ active_count,
                                                         const int *__restrict__ wave_pos, int *__restrict__ task_ready)
 {
+    __shared__ __attribute__((aligned(16))) float tiles[TILE ? 4 : 1][TILE ? 256 : 4];   // TILE: 1 KiB per wave
     const int wave = threadIdx.x >> 6;
     const int slot = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave;
     const int ub = __builtin_amdgcn_readfirstlane(wave_pos[slot]), ue = __builtin_amdgcn_readfirstlane(wave_pos[slot + 1]);
@@ -1418,8 +1522,12 @@ __global__ __launch_bounds__(256) void k_pairs_balanced(DevParams P, const int *
         else if (has_head && i == 0) { t = tl; k1 = le; }                 // the head of the last task first: publish early
         else if (i - has_head < nwhole) t = first_whole + (i - has_head);
         else { t = tb; k0 = lb; }                                         // the tail of the first task last: its head was published long ago
-        pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, task_list[t], nullptr, trace,
-                             active_list, active_count, k0, k1, task_ready + t, fs);
+        if (TILE)
+            pairs_task_tile<MODE, NQ>(P, cell_start, snap4, force4, task_list[t], tiles[TILE ? wave : 0], active_list, active_count,
+                                      k0, k1, task_ready + t, fs);
+        else
+            pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, task_list[t], nullptr, trace,
+                                 active_list, active_count, k0, k1, task_ready + t, fs);
     }
 }
 
@@ -2499,7 +2607,7 @@ hipError_t launch_place(hipStream_t st, const DevParams &P, int n, const int *id
 
 // init_iframe: zero the per-frame counts (cells, chunks, queue records: one array) and the
 // per-frame scalars; the sticky error word survives
-__global__ void k_frame_reset(int *frame, size_t n, FrameScalars *fs)
+__global__ void k_frame_reset(int *frame, size_t n, FrameScalars *fs, int *status_out)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) frame[i] = 0;
@@ -2508,11 +2616,54 @@ __global__ void k_frame_reset(int *frame, size_t n, FrameScalars *fs)
         *fs = FrameScalars{};
         fs->error = err;
     }
+    if (status_out && i < (size_t)MSG_HEADER_WORDS) status_out[i] = 0;
 }
 
 hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints)
 {
-    k_frame_reset<<<(unsigned)((frame_ints + 1023) / 1024), 1024, 0, st>>>(d.cell_count, frame_ints, d.fs);
+    k_frame_reset<<<(unsigned)((frame_ints + 1023) / 1024), 1024, 0, st>>>(d.cell_count, frame_ints, d.fs, d.status_out);
+    return hipGetLastError();
+}
+
+// Status message of a slab (all-gathered once per step, off the critical path): what the build
+// stage has to tell the other ranks -- sticky error bits, so that every rank stops in the same
+// step, and the slots the cell-overflow rule killed, for the owner of queue record 0.
+__global__ void k_status_close(int *status_out, const FrameScalars *fs)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { status_out[1] = fs->error; status_out[2] = fs->live; }
+}
+
+hipError_t launch_status_close(hipStream_t st, const DeviceState &d)
+{
+    if (!d.status_out) return hipSuccess;
+    k_status_close<<<1, 64, 0, st>>>(d.status_out, d.fs);
+    return hipGetLastError();
+}
+
+// one workgroup per rank's status record: adopt its error bits; the owner of queue record 0
+// queues the reported kills as the inserts build_grid would have made (ps.cpp:1523-1526): key =
+// chunk field 0 | slot | insert, i.e. before every calc_forces operation and in slot order.
+__global__ __launch_bounds__(256) void k_status_merge(DevParams P, const int *__restrict__ status_all, uint64_t *op_keys, int *op_args,
+                                                       int ops_cap, FrameScalars *fs)
+{
+    const int r = blockIdx.x;
+    if (r == P.rank) return;
+    const int *st = status_all + (size_t)r * STATUS_WORDS;
+    if (threadIdx.x == 0 && st[1]) atomicOr(&fs->error, st[1]);
+    if (!owns_record(P, 0)) return;
+    const int n = min(st[0], STATUS_KILL_CAP);
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int id = st[MSG_HEADER_WORDS + e];
+        const int k = atomicAdd(&fs->n_ops, 1);
+        if (k < ops_cap) { op_keys[k] = ((uint64_t)(uint32_t)id << 2) | 2ull; op_args[k] = id; }
+        else atomicOr(&fs->error, ERR_OPS_OVERFLOW);
+    }
+}
+
+hipError_t launch_status_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *status_all)
+{
+    if (!status_all || P.world <= 1) return hipSuccess;
+    k_status_merge<<<P.world, 256, 0, st>>>(P, status_all, d.op_keys, d.op_args, d.ops_cap, d.fs);
     return hipGetLastError();
 }
 
@@ -2549,7 +2700,7 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     if (ev) (void)hipEventRecord(ev[3], st);
     k_sort_cells<<<P.n_own_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
                                                d.pflags, d.snap4, d.snap_soa, d.snap_age, d.tdata, d.rank_of_slot, d.op_keys, d.op_args, d.ops_cap,
-                                               P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.snap_cid, d.fs, d.ctr);
+                                               P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.snap_cid, d.status_out, d.fs, d.ctr);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[4], st);
     return hipSuccess;
@@ -2642,7 +2793,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
                                                    d.halo_count, d.halo_f, d.halo_id, d.pair_flag, d.force4, d.fs);
         k_build_active<<<ncomp, 256, 0, st>>>(P, d.cell_start, d.pair_flag, d.active_list, d.active_count, d.task_cost);
         k_active_tasks<<<1, 1024, 0, st>>>(P, d.active_count, d.task_cost, d.task_list2, d.ctask_start, d.cost_start, d.merged_tasks, d.fs, merge ? 1 : 0);
-        if (balanced) k_split_tasks<<<(nw + 1 + 63) / 64, 64, 0, st>>>(P, nw, d.cell_start, d.task_cost, d.ctask_start, d.cost_start, d.wave_pos, d.fs);
+        if (balanced) k_split_tasks<<<8, 256, 0, st>>>(P, nw, d.cell_start, d.task_cost, d.ctask_start, d.cost_start, d.wave_pos, d.fs);
     }
     if (ev_force) (void)hipEventRecord(ev_force, st);      // timing: the force pass proper starts here
     const int *task_list = two ? d.task_list2 : d.task_list;
@@ -2657,9 +2808,16 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
             P, d.cell_start, d.snap4, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
         (void)hipEventRecord(d.ev_join, d.side_stream);
     }
-    if (balanced)
-        k_pairs_balanced<MODE == 0 ? 1 : MODE, NQ><<<nw / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list,
-                                                                        d.force4, d.fs, d.trace, active_list, active_count, d.wave_pos, d.task_ready);
+    // few waves per SIMD (a slab of a multi-GPU run): the scalar-load walk cannot cover its own
+    // load latency, bodies come through LDS tiles fetched a tile ahead instead
+    static const int tile_env = std::getenv("PSAMD_TILE") ? std::atoi(std::getenv("PSAMD_TILE")) : -1;
+    const bool tile = tile_env >= 0 ? tile_env != 0 : nw <= 2048;
+    if (balanced && tile)
+        k_pairs_balanced<MODE == 0 ? 1 : MODE, NQ, true><<<nw / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list,
+                                                                              d.force4, d.fs, d.trace, active_list, active_count, d.wave_pos, d.task_ready);
+    else if (balanced)
+        k_pairs_balanced<MODE == 0 ? 1 : MODE, NQ, false><<<nw / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list,
+                                                                               d.force4, d.fs, d.trace, active_list, active_count, d.wave_pos, d.task_ready);
     else
         k_pairs<MODE, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
                                                     d.fs, d.trace, active_list, active_count);

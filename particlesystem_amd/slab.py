@@ -23,8 +23,8 @@ A "rank" is anything with the stage calls and ``msg_bytes / msg_download / msg_u
 """
 import numpy as np
 
-# message slots, as in psamd_slab_msg_download: out/in x below/above
-HALO_OUT, HALO_IN, FORCE_OUT, FORCE_IN, XFER_OUT, XFER_IN = 0, 2, 4, 5, 6, 8
+# message slots, as in psamd_slab_msg_download: out/in x below/above; the status record is all-gathered
+HALO_OUT, HALO_IN, FORCE_OUT, FORCE_IN, XFER_OUT, XFER_IN, STATUS_OUT, STATUS_IN = 0, 2, 4, 5, 6, 8, 10, 11
 BELOW, ABOVE = 0, 1
 
 
@@ -59,6 +59,10 @@ def step_local(ranks):
     for s in ranks:
         s.slab_build()
     deliver("halo")
+    if world > 1 and ranks[0].msg_bytes(STATUS_OUT):          # the "all-gather" of the status records
+        every = np.concatenate([s.msg_download(STATUS_OUT) for s in ranks])
+        for s in ranks:
+            s.msg_upload(STATUS_IN, every)
     for s in ranks:
         s.slab_pairs()
     deliver("force")
@@ -115,10 +119,21 @@ class HostRing(_Ring):
         for slot, t in inn.items():
             self.s.msg_upload(slot, t.numpy())
 
+    def gather_status(self):
+        import torch
+        n = self.s.msg_bytes(STATUS_OUT)
+        if not n or self.world == 1:
+            return
+        mine = torch.from_numpy(self.s.msg_download(STATUS_OUT))
+        every = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(every, mine)
+        self.s.msg_upload(STATUS_IN, torch.cat(every).numpy())
+
     def step(self):
         s = self.s
         s.slab_build()
         self.exchange("halo")
+        self.gather_status()
         s.slab_pairs()
         self.exchange("force")
         s.slab_apply()
@@ -144,7 +159,8 @@ class DeviceRing(_Ring):
                 HALO_IN + 0: (b.halo_in[0], b.halo_in_bytes[0]), HALO_IN + 1: (b.halo_in[1], b.halo_in_bytes[1]),
                 FORCE_OUT: (b.force_out, b.force_out_bytes), FORCE_IN: (b.force_in, b.force_in_bytes),
                 XFER_OUT + 0: (b.xfer_out[0], b.xfer_bytes), XFER_OUT + 1: (b.xfer_out[1], b.xfer_bytes),
-                XFER_IN + 0: (b.xfer_in[0], b.xfer_bytes), XFER_IN + 1: (b.xfer_in[1], b.xfer_bytes)}
+                XFER_IN + 0: (b.xfer_in[0], b.xfer_bytes), XFER_IN + 1: (b.xfer_in[1], b.xfer_bytes),
+                STATUS_OUT: (b.status_out, b.status_bytes), STATUS_IN: (b.status_in, b.status_bytes * world)}
         self.t = {slot: torch.as_tensor(_DevPtr(p, n), device="cuda") for slot, (p, n) in ptrs.items() if p and n}
         self.stream = torch_stream
         sysr.set_stream(torch_stream.cuda_stream)
@@ -161,10 +177,17 @@ class DeviceRing(_Ring):
         with torch.cuda.stream(self.stream):
             s.slab_build()
             self.exchange("halo")
+            # the status records travel on RCCL's own stream beside the pair pass (async_op: this
+            # stream is not held up); they are needed only by slab_finish
+            status = None
+            if self.dist is not None and STATUS_OUT in self.t and self.world > 1:
+                status = self.dist.all_gather_into_tensor(self.t[STATUS_IN], self.t[STATUS_OUT], async_op=True)
             s.slab_pairs()
             self.exchange("force")
             s.slab_apply()
             self.exchange("xfer")
+            if status is not None:
+                status.wait()
             s.slab_finish()
 
 

@@ -45,7 +45,8 @@ class OracleSlabRank:
         self.sizes = {HALO_OUT + 0: halo_words(lay(p.send_down_lo, p.send_down_hi)), HALO_OUT + 1: halo_words(lay(p.send_up_lo, p.send_up_hi)),
                       HALO_IN + 0: halo_words(lay(p.below_lo, p.below_hi)), HALO_IN + 1: halo_words(lay(p.above_lo, p.above_hi)),
                       FORCE_OUT: force_words(lay(p.lentin_lo, p.lentin_hi)), FORCE_IN: force_words(lay(p.lentout_lo, p.lentout_hi)),
-                      XFER_OUT + 0: xfer_words, XFER_OUT + 1: xfer_words, XFER_IN + 0: xfer_words, XFER_IN + 1: xfer_words}
+                      XFER_OUT + 0: xfer_words, XFER_OUT + 1: xfer_words, XFER_IN + 0: xfer_words, XFER_IN + 1: xfer_words,
+                      10: 0, 11: 0}        # no status record: this stand-in neither overflows cells nor fails
         self.msgs = {k: np.zeros(n, np.int32) for k, n in self.sizes.items()}
         self.sent = 0
 

@@ -895,8 +895,11 @@ static int do_pairs(psamd_ctx *c)
 {
     if (!c->grid_built) return fail(c, PSAMD_ERR_STATE, "calc_forces needs build_grid first");
     if (c->timing) (void)hipEventRecord(c->ev[5], c->stream);
-    PS_HIP(c, launch_pairs(c->stream, c->P, c->d, c->timing ? c->ev[13] : nullptr,
-                           c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total));
+    // size of the balanced force pass: the tasks of the last step this context ran (the
+    // read-back of its scalars is on the host already), else the bound of the live count
+    const int64_t tasks_hint = (c->steps_total > 0 && c->h_fs->n_tasks2 > 0) ? (int64_t)c->h_fs->n_tasks2
+                               : (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) / 64 + comp_count(c->P);
+    PS_HIP(c, launch_pairs(c->stream, c->P, c->d, c->timing ? c->ev[13] : nullptr, tasks_hint));
     if (c->timing) (void)hipEventRecord(c->ev[6], c->stream);
     c->pairs_done = true;
     return PSAMD_OK;

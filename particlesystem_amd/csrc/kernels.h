@@ -93,8 +93,8 @@ hipError_t launch_selftest_math(hipStream_t st, uint32_t lo_bits, uint32_t hi_bi
 hipError_t launch_init_tdata(hipStream_t st, const DevParams &P, const DeviceState &d);
 // ev (optional) = 5 events recorded before hist, scan, scatter, sort and after sort
 hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev);
-// live_bound: the host's upper bound of the live particles (sizes the balanced force pass)
-hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t live_bound);
+// tasks_hint: about how many force tasks the pass will have (sizes the balanced force pass)
+hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint);
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step);
 // after apply, before the per-step read-back: ops per queue record, their prefix and maximum
 hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints);   // also clears the status message's header

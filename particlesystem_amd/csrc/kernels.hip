@@ -2763,7 +2763,7 @@ hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceSt
 }
 
 template <int MODE, int NQ>
-static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t live_bound)
+static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint)
 {
     const int ncomp = comp_count(P);
     if (ncomp <= 0) return hipSuccess;
@@ -2778,13 +2778,13 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     const bool merge = two && !merge_off && (P.world == 1 || ncomp >= 2048) && !(P.flags & PSAMD_FLAG_ALL_PAIRS);   // (the merged kernel walks the stencil only)
     const bool balanced = two && !balance_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS);
     // Balanced pass: a fixed number of waves, all resident, each walking the same number of
-    // bodies.  Enough of them that a SIMD has several to switch between, but not many more
-    // than there are tasks (a task cut in more pieces only adds hand-offs): from the host's
-    // bound of the live count, 1024 (one per SIMD) to 6144.
+    // bodies.  At least four per SIMD when there are that many tasks (fewer cannot cover their
+    // scalar-load latency: 1024 / 2048 / 4096 / 6144 waves took 3.73 / 2.54 / 2.27 / 2.29 ms on
+    // the N = 2^20 cloud), but not more waves than tasks (a task cut in three or more pieces is
+    // a chain of waves that wait for each other).
     int nw = 0;
     if (balanced) {
-        const int64_t est = live_bound / 64 + ncomp;                 // tasks, at most
-        nw = 1024 * (int)std::min<int64_t>(6, std::max<int64_t>(1, (est + 1024) / 2048));
+        nw = 1024 * (int)std::min<int64_t>(6, std::max<int64_t>(1, tasks_hint / 1024));
         if (waves_env >= 32) nw = std::min(waves_env & ~31, MAX_PAIR_WAVES);
     }
     if (two) {
@@ -2825,13 +2825,13 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     return hipGetLastError();
 }
 
-hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t live_bound)
+hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint)
 {
     // fast math shares the lean modes' validity range (finite 1/sqrt(eps2^3))
-    if ((P.flags & PSAMD_FLAG_FAST_MATH) && P.lean_math) return launch_pairs_mode<2, 8>(st, P, d, ev_force, live_bound);
+    if ((P.flags & PSAMD_FLAG_FAST_MATH) && P.lean_math) return launch_pairs_mode<2, 8>(st, P, d, ev_force, tasks_hint);
     // 8 pairs per slow-branch test: measured 3 % (full GPU) to 5 % (a 1/8 share) faster than 4
-    if (P.lean_math) return launch_pairs_mode<1, 8>(st, P, d, ev_force, live_bound);
-    return launch_pairs_mode<0, 4>(st, P, d, ev_force, live_bound);
+    if (P.lean_math) return launch_pairs_mode<1, 8>(st, P, d, ev_force, tasks_hint);
+    return launch_pairs_mode<0, 4>(st, P, d, ev_force, tasks_hint);
 }
 
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step)

@@ -59,4 +59,8 @@ def assert_same_particles(gpu_p, ora_p, what=""):
             k = bad[0]
             raise AssertionError("%s field %s differs at %d slots, first slot %d: gpu %r oracle %r" %
                                  (what, f, len(bad), k, gpu_p[f][k], ora_p[f][k]))
-    raise AssertionError(what + " records differ only in padding bytes")
+    ga = np.frombuffer(gpu_p.tobytes(), np.uint8).reshape(-1, 72)
+    oa = np.frombuffer(ora_p.tobytes(), np.uint8).reshape(-1, 72)
+    rows, cols = np.nonzero(ga != oa)
+    raise AssertionError("%s records differ only in padding bytes: %d slots, first slot %d byte %d gpu %d oracle %d, cell there %d" %
+                         (what, len(set(rows.tolist())), rows[0], cols[0], ga[rows[0], cols[0]], oa[rows[0], cols[0]], gpu_p["cell"][rows[0]]))

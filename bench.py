@@ -66,6 +66,8 @@ def parse_args():
     ap.add_argument("--settle-seconds", type=float, default=0.5, help="untimed steps before the warmup until the clocks have settled")
     ap.add_argument("--sim-world", type=int, default=0, help="projection on ONE GPU: all ranks of an N-rank slab run live in this "
                     "process and run one after the other; reports every rank's stage times and the modelled step")
+    ap.add_argument("--launch-check", action="store_true", help="only start the ranks, form the process group, reduce one number and "
+                    "print the line's skeleton (no GPU work): proves the --gpus N launcher on a machine without GPUs")
     ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL; gloo: messages staged "
                     "through host memory, for rehearsals on one GPU)")
     return ap.parse_args()
@@ -291,6 +293,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
 
+    if args.launch_check:
+        import torch.distributed as dist
+        dist.init_process_group(args.backend if args.backend != "nccl" else "gloo")
+        import torch
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"metric": "particle-updates/sec at N=2^20", "launch_check": True, "n_gpus": int(t.item()),
+                              "steps": args.steps, "warmup": args.warmup}))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     import particlesystem_amd as ps
     # build before anything touches the GPU or the process group; only one process compiles
     if rank == 0:

@@ -274,7 +274,9 @@ int psamd_slab_buffers_get(psamd_ctx *ctx, psamd_slab_buffers *out);
  * context's stream except finish, which ends with the per-step read-back.  With world == 1
  * the four calls are psamd_step(1) cut in four and no message exists. */
 int psamd_slab_build(psamd_ctx *ctx);   /* init_iframe + build_grid of the own layers; packs halo_out   */
-int psamd_slab_pairs(psamd_ctx *ctx);   /* unpacks halo_in; collision flags + forces; packs force_out   */
+int psamd_slab_pairs_interior(psamd_ctx *ctx);  /* optional, while the halo travels: the pair stage of the cells whose
+                                                    stencil lies in the rank's own layers (needs no message)          */
+int psamd_slab_pairs(psamd_ctx *ctx);   /* unpacks halo_in; collision flags + forces (of the remaining cells); packs force_out */
 int psamd_slab_apply(psamd_ctx *ctx);   /* unpacks force_in; integrate ... (calc_forces' tail); closes xfer_out */
 int psamd_slab_finish(psamd_ctx *ctx);  /* merges xfer_in; queue replay and relocation                  */
 /* Transport through host memory (tests, two processes sharing one GPU): copy message buffer

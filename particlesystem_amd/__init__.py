@@ -147,6 +147,7 @@ ABI = [
     ("psamd_get_slab_plan", C.c_int, [_vp, C.POINTER(SlabPlan)]),
     ("psamd_slab_buffers_get", C.c_int, [_vp, C.POINTER(SlabBuffers)]),
     ("psamd_slab_build", C.c_int, [_vp]),
+    ("psamd_slab_pairs_interior", C.c_int, [_vp]),
     ("psamd_slab_pairs", C.c_int, [_vp]),
     ("psamd_slab_apply", C.c_int, [_vp]),
     ("psamd_slab_finish", C.c_int, [_vp]),
@@ -374,6 +375,9 @@ class ParticleSystem:
 
     def slab_build(self):
         self._ck(self.lib.psamd_slab_build(self.h))
+
+    def slab_pairs_interior(self):
+        self._ck(self.lib.psamd_slab_pairs_interior(self.h))
 
     def slab_pairs(self):
         self._ck(self.lib.psamd_slab_pairs(self.h))

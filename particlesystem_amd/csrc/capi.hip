@@ -28,6 +28,8 @@ using namespace psamd;
 struct psamd_ctx {
     Geometry geo;
     DevParams P{};
+    DevParams P_int{}, P_rest{};      // the pair stage cut in two: interior own cells (no halo needed), the rest
+    bool have_interior = false, interior_done = false;
     SegLayout S{};
     DeviceState d;
     hipStream_t stream = nullptr;       // stream in use
@@ -65,6 +67,8 @@ struct psamd_ctx {
     int step = 0;
     int64_t steps_total = 0;
     int live_at_build = -1;           // host copy of fs->live (valid after a sync)
+    bool interior_ran = false;        // this step's pair stage ran in two passes (the scalars hold the second pass's task count)
+    int64_t tasks_last = 0;           // force tasks of the last step (all passes), sizes the next step's balanced pass
     // upper bound of the live count at the next build_grid, kept on the host so that the
     // life-cycle kernels can be sized without a read-back (-1 = unknown)
     int64_t live_bound = 0, snapshot_live_bound = 0;
@@ -294,10 +298,13 @@ static void fill_slab_params(const Geometry &g, const SlabPlan &pl, const psamd_
     }
     P.n_local_cells = base; P.n_own_cells = layers[0] * GG;
     P.sorted_cap = (int)sorted;
-    P.comp_a0 = P.reg_base[2]; P.comp_a1 = P.reg_base[2] + layers[2] * GG;
-    P.comp_b0 = (std::max(pl.cut_lo, pl.state_lo) - pl.state_lo) * GG;
-    P.comp_b1 = (std::min(pl.cut_hi, pl.state_hi) - pl.state_lo) * GG;
-    if (P.comp_b1 < P.comp_b0) P.comp_b1 = P.comp_b0;
+    P.own_comp0 = (std::max(pl.cut_lo, pl.state_lo) - pl.state_lo) * GG;
+    P.own_comp1 = (std::min(pl.cut_hi, pl.state_hi) - pl.state_lo) * GG;
+    if (P.own_comp1 < P.own_comp0) P.own_comp1 = P.own_comp0;
+    // the whole pair stage in one pass: the lent cells, then the own ones
+    P.comp_lo[0] = P.reg_base[2]; P.comp_hi[0] = P.reg_base[2] + layers[2] * GG;
+    P.comp_lo[1] = P.own_comp0; P.comp_hi[1] = P.own_comp1;
+    P.comp_lo[2] = P.comp_hi[2] = 0;
     P.lentout_c0 = (pl.lentout_lo - pl.state_lo) * GG; P.lentout_c1 = (pl.lentout_hi - pl.state_lo) * GG;
 }
 
@@ -516,6 +523,24 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     }
 
     P.slow_below = std::max(P.eps_f32_from, std::nextafterf(P.coll_d2_gate, INFINITY));
+    {   // Interior own cells: computed layers whose neighbour layers are both own state (or outside
+        // the grid): their collision flags and forces need nothing from another rank, so that
+        // pass can run while the halo messages travel (two-pass mode; slab_pairs_interior).
+        const SlabPlan &pl = c->plan;
+        const int GG = g.G * g.G, lo = std::max(pl.cut_lo, pl.state_lo), hi = std::min(pl.cut_hi, pl.state_hi);
+        auto own = [&](int l) { return l < 0 || l >= g.G || (l >= pl.state_lo && l < pl.state_hi); };
+        int i0 = lo, i1 = lo;
+        for (int l = lo; l < hi; l++) if (own(l - 1) && own(l + 1)) { if (i1 == i0) i0 = l; i1 = l + 1; } else if (i1 > i0) break;
+        c->P_int = P; c->P_rest = P;
+        c->have_interior = P.world > 1 && P.two_pass && P.lean_math && i1 > i0 && (i1 - i0) < (hi - lo) + (pl.lentin_hi - pl.lentin_lo);
+        if (c->have_interior) {
+            const int a = (i0 - pl.state_lo) * GG, b = (i1 - pl.state_lo) * GG;
+            c->P_int.comp_lo[0] = a; c->P_int.comp_hi[0] = b;
+            c->P_int.comp_lo[1] = c->P_int.comp_hi[1] = c->P_int.comp_lo[2] = c->P_int.comp_hi[2] = 0;
+            c->P_rest.comp_lo[1] = P.own_comp0; c->P_rest.comp_hi[1] = a;
+            c->P_rest.comp_lo[2] = b; c->P_rest.comp_hi[2] = P.own_comp1;
+        }
+    }
 
     // init_particles (ps.cpp:722-753): every slot reset, cell = -1
     PS_HIP(c, hipMemsetAsync(d.pos4, 0, std::max<size_t>(C, 1) * sizeof(float4), c->stream));
@@ -891,17 +916,19 @@ static int do_build_grid(psamd_ctx *c)
     return PSAMD_OK;
 }
 
-static int do_pairs(psamd_ctx *c)
+static int do_pairs(psamd_ctx *c, const DevParams &P, bool last = true, bool first = true)
 {
     if (!c->grid_built) return fail(c, PSAMD_ERR_STATE, "calc_forces needs build_grid first");
-    if (c->timing) (void)hipEventRecord(c->ev[5], c->stream);
+    if (c->timing && first) (void)hipEventRecord(c->ev[5], c->stream);
     // size of the balanced force pass: the tasks of the last step this context ran (the
     // read-back of its scalars is on the host already), else the bound of the live count
-    const int64_t tasks_hint = (c->steps_total > 0 && c->h_fs->n_tasks2 > 0) ? (int64_t)c->h_fs->n_tasks2
-                               : (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) / 64 + comp_count(c->P);
-    PS_HIP(c, launch_pairs(c->stream, c->P, c->d, c->timing ? c->ev[13] : nullptr, tasks_hint));
-    if (c->timing) (void)hipEventRecord(c->ev[6], c->stream);
-    c->pairs_done = true;
+    // (a pass over part of the cells gets its share of the hint)
+    int64_t tasks_hint = (c->steps_total > 0 && c->tasks_last > 0) ? c->tasks_last
+                         : (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) / 64 + comp_count(c->P);
+    tasks_hint = tasks_hint * comp_count(P) / std::max(1, comp_count(c->P));
+    PS_HIP(c, launch_pairs(c->stream, P, c->d, (c->timing && first) ? c->ev[13] : nullptr, tasks_hint));
+    if (c->timing && last) (void)hipEventRecord(c->ev[6], c->stream);
+    c->pairs_done = last;
     return PSAMD_OK;
 }
 
@@ -940,6 +967,8 @@ static int do_lifecycle(psamd_ctx *c)
     c->host_queues_valid = false;
     PS_HIP(c, hipEventSynchronize(c->ev_scalars));
     c->live_at_build = c->h_fs->live;
+    c->tasks_last = c->interior_ran ? (int64_t)c->h_fs->n_tasks2 * comp_count(c->P) / std::max(1, comp_count(c->P_rest)) : c->h_fs->n_tasks2;
+    c->interior_ran = false;
     c->live_bound = std::min<int64_t>(c->P.slots_total, (int64_t)c->h_fs->live + c->h_fs->n_moves);   // births and arrivals <= moves
     c->processed_total += c->h_fs->live;
     c->max_bucket_seen = std::max<int64_t>(c->max_bucket_seen, c->h_fs->max_bucket);
@@ -984,7 +1013,7 @@ int psamd_calc_forces_pairs(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
     if (c->P.world > 1) return slab_only(c, "calc_forces");
-    return do_pairs(c);
+    return do_pairs(c, c->P);
 }
 
 int psamd_calc_forces_apply(psamd_ctx *c)
@@ -1032,6 +1061,19 @@ int psamd_slab_build(psamd_ctx *c)
     return PSAMD_OK;
 }
 
+// optional, between slab_build and the arrival of the halo: the pair stage of the cells whose
+// stencil lies inside this rank's own layers
+int psamd_slab_pairs_interior(psamd_ctx *c)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (c->slab_stage != 1) return fail(c, PSAMD_ERR_STATE, "slab_pairs_interior belongs between slab_build and slab_pairs");
+    if (!c->have_interior || c->interior_done) return PSAMD_OK;
+    int rc = do_pairs(c, c->P_int, false, true);
+    if (rc != PSAMD_OK) return rc;
+    c->interior_done = true; c->interior_ran = true;
+    return PSAMD_OK;
+}
+
 int psamd_slab_pairs(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
@@ -1044,7 +1086,8 @@ int psamd_slab_pairs(psamd_ctx *c)
     if (c->halo_in_cells[1] > 0)      // from the rank above: halo layer (region 3)
         PS_HIP(c, launch_unpack_halo(c->stream, P, c->d, 3, -1, c->halo_in_cells[1], c->halo_in_cells[1], false,
                                      c->halo_in[1], c->unpack_off[1]));
-    int rc = do_pairs(c);
+    int rc = do_pairs(c, c->interior_done ? c->P_rest : c->P, true, !c->interior_done);
+    c->interior_done = false;
     if (rc != PSAMD_OK) return rc;
     if (c->force_out) PS_HIP(c, launch_pack_force(c->stream, P, c->d, c->force_out, P.reg_layers[2] * GG * P.halo_cap_cell));
     c->slab_stage = 2;

@@ -57,8 +57,12 @@ struct DevParams {
     int32_t n_local_cells;   // all regions and their gap cells
     int32_t n_own_cells;     // cells of region 0
     int32_t sorted_cap;      // capacity of the sorted-order arrays = plane stride of snap_soa
-    int32_t comp_a0, comp_a1;   // local cells this rank computes collisions / forces for: the lent ones ...
-    int32_t comp_b0, comp_b1;   // ... and its own (in this order in the work lists)
+    int32_t own_comp0, own_comp1;   // own local cells this rank computes collisions / forces for (a contiguous run of region 0)
+    // the cell ranges ONE pass of the pair stage works on, in work-list order (lent cells first:
+    // their results travel back).  The whole stage: {lent, own computed, -}; cut in two to overlap
+    // the halo exchange: {interior own cells} before the halo has arrived, then {lent, own cells
+    // below the interior, own cells above it}.
+    int32_t comp_lo[3], comp_hi[3];
     int32_t slot_lo[4], slot_n[4];   // owned slot range per segment type; storage index = position in their concatenation
     int32_t slots_total;
     int32_t rec_lo[4], rec_hi[4];    // owned QUEUE_INFO records per segment type
@@ -115,13 +119,16 @@ PS_HD int global_of_local(const DevParams &P, int lc)
     return (i3 * P.G + i1) * P.G + i2;
 }
 
-// j-th computed cell (lent ones first)
+// j-th cell of the pass's ranges
 PS_HD int comp_cell(const DevParams &P, int j)
 {
-    const int na = P.comp_a1 - P.comp_a0;
-    return j < na ? P.comp_a0 + j : P.comp_b0 + (j - na);
+    const int n0 = P.comp_hi[0] - P.comp_lo[0], n1 = P.comp_hi[1] - P.comp_lo[1];
+    return j < n0 ? P.comp_lo[0] + j : j < n0 + n1 ? P.comp_lo[1] + (j - n0) : P.comp_lo[2] + (j - n0 - n1);
 }
-PS_HD int comp_count(const DevParams &P) { return (P.comp_a1 - P.comp_a0) + (P.comp_b1 - P.comp_b0); }
+PS_HD int comp_count(const DevParams &P)
+{
+    return (P.comp_hi[0] - P.comp_lo[0]) + (P.comp_hi[1] - P.comp_lo[1]) + (P.comp_hi[2] - P.comp_lo[2]);
+}
 
 // storage index of an owned slot (position in the concatenation of the four owned ranges), -1 if not owned
 PS_HD int slot_index(const DevParams &P, int slot)

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
     const int per = (ncell + 1023) / 1024;
     const int c0 = min(ncell, tid * per), c1 = min(ncell, c0 + per);
     auto word = [&](int c, int v) {
-        const bool computed = c >= P.comp_b0 && c < P.comp_b1;
+        const bool computed = c >= P.own_comp0 && c < P.own_comp1;
         return ((long long)(computed ? (min(v, P.max_per_cell) + 63) >> 6 : 0) << 32) | (long long)v;
     };
     long long mine = 0;
@@ -365,8 +365,8 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
 // computed cells (the lent ones are appended when their snapshot has arrived, k_remote_cells)
 __global__ void k_build_tasks(DevParams P, const int *__restrict__ task_start, int *__restrict__ task_list)
 {
-    const int c = P.comp_b0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= P.comp_b1) return;
+    const int c = P.own_comp0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.own_comp1) return;
     const int t0 = task_start[c], n = task_start[c + 1] - t0;
     for (int s = 0; s < n; s++) task_list[t0 + s] = c * P.slices + s;
 }
@@ -881,16 +881,27 @@ __device__ __forceinline__ void collide_scan(const DevParams &P, float xi, float
 __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restrict__ cell_start,
                                                  const float *__restrict__ snap_soa, const float *__restrict__ snap_age,
                                                  const int *__restrict__ sorted_id, const int *__restrict__ snap_cid,
-                                                 const int *__restrict__ task_list,
+                                                 const int *__restrict__ task_list, const int *__restrict__ task_start,
                                                  const int *__restrict__ halo_count, const float *__restrict__ halo_f,
                                                  const int *__restrict__ halo_id, int *__restrict__ flag_out,
                                                  float4 *__restrict__ force4, const FrameScalars *__restrict__ fs)
 {
     // (readfirstlane: the wave index is uniform but the compiler cannot know; with uniform
     // ranges the body loads below become scalar loads)
-    const int slot = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (slot >= fs->n_tasks) return;
-    const int task = task_list[slot];
+    int slot = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // the collide work list: own cells' slices cell-major (prefix task_start), then the lent
+    // cells' slices (appended when their snapshot arrived); this pass takes its ranges' part
+    int at = -1;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        if (at >= 0 || P.comp_hi[r] <= P.comp_lo[r]) continue;
+        const bool lent = P.comp_lo[r] >= P.n_own_cells;
+        const int t0 = lent ? task_start[P.n_own_cells] : task_start[P.comp_lo[r]];
+        const int t1 = lent ? fs->n_tasks : task_start[P.comp_hi[r]];
+        if (slot < t1 - t0) at = t0 + slot; else slot -= t1 - t0;
+    }
+    if (at < 0) return;
+    const int task = task_list[at];
     const int c = task / P.slices, slice = task - c * P.slices;
     const int base = __builtin_amdgcn_readfirstlane(cell_start[c]);
     const int cnt = __builtin_amdgcn_readfirstlane(min(cell_start[c + 1] - base, P.max_per_cell));
@@ -1078,12 +1089,15 @@ __global__ __launch_bounds__(256) void k_split_tasks(DevParams P, int nw, const 
         int r = (int)(off - (long long)q * S), k = 0;
         int i1, i2, i3;
         cell_coords(P, c, i1, i2, i3);
-        for (; k < STENCIL - 1; k++) {
-            const int nc = local_cell(P, i3 + c_stencil[k][2], i1 + c_stencil[k][1], i2 + c_stencil[k][0]);
-            const int n = nc >= 0 ? min(cell_start[nc + 1] - cell_start[nc], P.max_per_cell) : 0;
-            if (r < n) break;
-            r -= n;
+        int cnts[STENCIL];                               // all 27 loads go out together, then the walk is in registers
+#pragma unroll
+        for (int kk = 0; kk < STENCIL; kk++) {
+            const int nc = local_cell(P, i3 + c_stencil[kk][2], i1 + c_stencil[kk][1], i2 + c_stencil[kk][0]);
+            cnts[kk] = nc >= 0 ? min(cell_start[nc + 1] - cell_start[nc], P.max_per_cell) : 0;
         }
+#pragma unroll
+        for (int kk = 0; kk < STENCIL - 1; kk++)
+            if (k == kk && r >= cnts[kk]) { r -= cnts[kk]; k = kk + 1; }
         const int t = ctask_start[a] + q;
         if (whole) return (t + ((k > 0 || r > 0) ? 1 : 0)) * STENCIL;
         return t * STENCIL + k;
@@ -2692,7 +2706,7 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     if (ev) (void)hipEventRecord(ev[1], st);
     k_scan<<<1, 1024, 0, st>>>(P, d.cell_count, d.cell_start, d.cursor, d.task_start, d.chunk_count, d.celltab, d.fs);
     PS_LAUNCH_CHECK();
-    if (P.comp_b1 > P.comp_b0) k_build_tasks<<<(P.comp_b1 - P.comp_b0 + 255) / 256, 256, 0, st>>>(P, d.task_start, d.task_list);
+    if (P.own_comp1 > P.own_comp0) k_build_tasks<<<(P.own_comp1 - P.own_comp0 + 255) / 256, 256, 0, st>>>(P, d.task_start, d.task_list);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[2], st);
     k_scatter_lds<<<nwg, 1024, 0, st>>>(P, d.cell, d.cursor, d.sorted_id);
@@ -2789,7 +2803,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     }
     if (two) {
         // collision flags, then the per-cell lists and the tasks of the particles that need a force
-        k_collide<<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.snap_cid, d.task_list,
+        k_collide<<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.snap_cid, d.task_list, d.task_start,
                                                    d.halo_count, d.halo_f, d.halo_id, d.pair_flag, d.force4, d.fs);
         k_build_active<<<ncomp, 256, 0, st>>>(P, d.cell_start, d.pair_flag, d.active_list, d.active_count, d.task_cost);
         k_active_tasks<<<1, 1024, 0, st>>>(P, d.active_count, d.task_cost, d.task_list2, d.ctask_start, d.cost_start, d.merged_tasks, d.fs, merge ? 1 : 0);

@@ -13,7 +13,8 @@ with fixed-size messages, so the transport never negotiates a length.  This modu
 host-side plumbing only; it computes nothing.  Three transports:
 
   * ``DeviceRing``  torch.distributed P2P (RCCL over xGMI) directly on the contexts' device
-    buffers; the halo travels on a side stream while the main stream is free for other work.
+    buffers; the halo travels on RCCL's stream while the context's stream works on the cells
+    that need no halo (slab_pairs_interior), the status records beside the whole pair pass.
   * ``HostRing``    torch.distributed P2P (gloo) through host copies of the messages: for tests,
     and for several processes that share one GPU.
   * ``step_local``  all ranks live in one process (tests): messages are copied rank to rank.
@@ -58,6 +59,8 @@ def step_local(ranks):
 
     for s in ranks:
         s.slab_build()
+    for s in ranks:
+        s.slab_pairs_interior()       # (in a real run: while the halo travels)
     deliver("halo")
     if world > 1 and ranks[0].msg_bytes(STATUS_OUT):          # the "all-gather" of the status records
         every = np.concatenate([s.msg_download(STATUS_OUT) for s in ranks])
@@ -132,6 +135,7 @@ class HostRing(_Ring):
     def step(self):
         s = self.s
         s.slab_build()
+        s.slab_pairs_interior()
         self.exchange("halo")
         self.gather_status()
         s.slab_pairs()
@@ -165,23 +169,34 @@ class DeviceRing(_Ring):
         self.stream = torch_stream
         sysr.set_stream(torch_stream.cuda_stream)
 
-    def exchange(self, phase):
+    def start(self, phase):
+        """Post the phase's sends and receives.  RCCL runs them on its own stream once the work
+        already enqueued on this context's stream is done (what was packed is complete); this
+        stream is NOT held up -- whatever is enqueued next runs beside the transfer -- until
+        finish() makes it wait for the arrivals."""
         ops = self._ops(phase, lambda slot: self.t[slot])
-        if ops:
-            # enqueued on the current stream; later kernels on it wait for the transfers
-            self.dist.batch_isend_irecv(ops)
+        return self.dist.batch_isend_irecv(ops) if ops else []
+
+    @staticmethod
+    def finish(works):
+        for w in works:
+            w.wait()            # a stream-side wait (the host goes on)
+
+    def exchange(self, phase):
+        self.finish(self.start(phase))
 
     def step(self):
         import torch
         s = self.s
         with torch.cuda.stream(self.stream):
             s.slab_build()
-            self.exchange("halo")
-            # the status records travel on RCCL's own stream beside the pair pass (async_op: this
-            # stream is not held up); they are needed only by slab_finish
+            halo = self.start("halo")
+            # the status records travel beside the pair pass; they are needed only by slab_finish
             status = None
             if self.dist is not None and STATUS_OUT in self.t and self.world > 1:
                 status = self.dist.all_gather_into_tensor(self.t[STATUS_IN], self.t[STATUS_OUT], async_op=True)
+            s.slab_pairs_interior()          # cells whose stencil lies in the own layers: no halo needed
+            self.finish(halo)
             s.slab_pairs()
             self.exchange("force")
             s.slab_apply()

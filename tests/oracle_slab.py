@@ -133,6 +133,9 @@ class OracleSlabRank:
         if self.sizes[HALO_OUT + 1]:
             self._pack_layers(p.send_up_lo, p.send_up_hi, HALO_OUT + 1)
 
+    def slab_pairs_interior(self):
+        pass                                   # an optimisation of the product (overlap); nothing to model
+
     def slab_pairs(self):
         p = self.plan
         self.borrowed = []

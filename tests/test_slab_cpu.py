@@ -179,3 +179,18 @@ def test_world_size_2_gloo_matches_serial(tmp_path):
 
 if __name__ == "__main__" and "--worker" in sys.argv:
     _worker()
+
+
+@pytest.mark.timeout(300)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts the ranks itself
+    (torch.distributed.run, fresh processes), relays rank 0's single JSON line and exits 0."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check", "--steps", "7", "--warmup", "3"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["launch_check"] and d["steps"] == 7 and d["warmup"] == 3

@@ -396,7 +396,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     d.moves_cap = (int)std::min<size_t>(2 * C + 2 * xf + 64, (size_t)INT32_MAX / 2);
     int *frame = nullptr;
     // cell counts, chunk counts, record counts, halo counts, hand-off flags of the force pass
-    const size_t frame_ints = LC + g.num_chunks + g.queue_infos + LC + LC * P.slices;
+    const size_t frame_ints = LC + g.num_chunks + g.queue_infos + LC + 2 * LC * P.slices;   // (flags: one block per pass of the pair stage)
     PS_HIP(c, dev_alloc(c, &d.pos4, C));
     PS_HIP(c, dev_alloc(c, &d.vel4, C));
     PS_HIP(c, dev_alloc(c, &d.acc4, C));
@@ -926,7 +926,7 @@ static int do_pairs(psamd_ctx *c, const DevParams &P, bool last = true, bool fir
     int64_t tasks_hint = (c->steps_total > 0 && c->tasks_last > 0) ? c->tasks_last
                          : (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) / 64 + comp_count(c->P);
     tasks_hint = tasks_hint * comp_count(P) / std::max(1, comp_count(c->P));
-    PS_HIP(c, launch_pairs(c->stream, P, c->d, (c->timing && first) ? c->ev[13] : nullptr, tasks_hint));
+    PS_HIP(c, launch_pairs(c->stream, P, c->d, (c->timing && first) ? c->ev[13] : nullptr, tasks_hint, first ? 0 : 1));
     if (c->timing && last) (void)hipEventRecord(c->ev[6], c->stream);
     c->pairs_done = last;
     return PSAMD_OK;

@@ -94,7 +94,8 @@ hipError_t launch_init_tdata(hipStream_t st, const DevParams &P, const DeviceSta
 // ev (optional) = 5 events recorded before hist, scan, scatter, sort and after sort
 hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev);
 // tasks_hint: about how many force tasks the pass will have (sizes the balanced force pass)
-hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint);
+// pass: 0 or 1, which of a frame's (up to two) passes of the pair stage this is
+hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint, int pass);
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step);
 // after apply, before the per-step read-back: ops per queue record, their prefix and maximum
 hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints);   // also clears the status message's header

@@ -2777,19 +2777,20 @@ hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceSt
 }
 
 template <int MODE, int NQ>
-static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint)
+static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint, int pass)
 {
     const int ncomp = comp_count(P);
     if (ncomp <= 0) return hipSuccess;
     const int tasks = ncomp * P.slices;
     const bool two = MODE != 0 && P.two_pass;
     // leftover slices of several cells in one wave (k_pairs_merged).  A merged wave is long and
-    // stalls on its tile loads; a small share (a slab of a multi-GPU run) has too little other
-    // work to cover that and it becomes the critical path (measured on 1/4 and 1/8 shares).
+    // stalls on its tile loads; a small share (a slab with fewer than ~3 tasks per SIMD) has too
+    // little other work to cover that and it becomes the critical path (measured on 1/4 and 1/8
+    // shares of the N = 2^20 cloud).
     static const bool merge_off = std::getenv("PSAMD_NO_MERGE") != nullptr;
     static const bool balance_off = std::getenv("PSAMD_NO_BALANCE") != nullptr;
     static const int waves_env = std::getenv("PSAMD_WAVES") ? std::atoi(std::getenv("PSAMD_WAVES")) : 0;
-    const bool merge = two && !merge_off && (P.world == 1 || ncomp >= 2048) && !(P.flags & PSAMD_FLAG_ALL_PAIRS);   // (the merged kernel walks the stencil only)
+    const bool merge = two && !merge_off && (P.world == 1 || tasks_hint >= 3000) && !(P.flags & PSAMD_FLAG_ALL_PAIRS);   // (the merged kernel walks the stencil only)
     const bool balanced = two && !balance_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS);
     // Balanced pass: a fixed number of waves, all resident, each walking the same number of
     // bodies.  At least four per SIMD when there are that many tasks (fewer cannot cover their
@@ -2826,12 +2827,15 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     // load latency, bodies come through LDS tiles fetched a tile ahead instead
     static const int tile_env = std::getenv("PSAMD_TILE") ? std::atoi(std::getenv("PSAMD_TILE")) : -1;
     const bool tile = tile_env >= 0 ? tile_env != 0 : nw <= 2048;
+    // the hand-off flags are indexed by task number, which starts at 0 in every pass of a frame:
+    // each pass has its own block of them (both zeroed with the frame)
+    int *task_ready = d.task_ready + (size_t)pass * P.n_local_cells * P.slices;
     if (balanced && tile)
         k_pairs_balanced<MODE == 0 ? 1 : MODE, NQ, true><<<nw / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list,
-                                                                              d.force4, d.fs, d.trace, active_list, active_count, d.wave_pos, d.task_ready);
+                                                                              d.force4, d.fs, d.trace, active_list, active_count, d.wave_pos, task_ready);
     else if (balanced)
         k_pairs_balanced<MODE == 0 ? 1 : MODE, NQ, false><<<nw / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list,
-                                                                               d.force4, d.fs, d.trace, active_list, active_count, d.wave_pos, d.task_ready);
+                                                                               d.force4, d.fs, d.trace, active_list, active_count, d.wave_pos, task_ready);
     else
         k_pairs<MODE, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
                                                     d.fs, d.trace, active_list, active_count);
@@ -2839,13 +2843,13 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     return hipGetLastError();
 }
 
-hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint)
+hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint, int pass)
 {
     // fast math shares the lean modes' validity range (finite 1/sqrt(eps2^3))
-    if ((P.flags & PSAMD_FLAG_FAST_MATH) && P.lean_math) return launch_pairs_mode<2, 8>(st, P, d, ev_force, tasks_hint);
+    if ((P.flags & PSAMD_FLAG_FAST_MATH) && P.lean_math) return launch_pairs_mode<2, 8>(st, P, d, ev_force, tasks_hint, pass);
     // 8 pairs per slow-branch test: measured 3 % (full GPU) to 5 % (a 1/8 share) faster than 4
-    if (P.lean_math) return launch_pairs_mode<1, 8>(st, P, d, ev_force, tasks_hint);
-    return launch_pairs_mode<0, 4>(st, P, d, ev_force, tasks_hint);
+    if (P.lean_math) return launch_pairs_mode<1, 8>(st, P, d, ev_force, tasks_hint, pass);
+    return launch_pairs_mode<0, 4>(st, P, d, ev_force, tasks_hint, pass);
 }
 
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step)

@@ -469,7 +469,7 @@ def main():
         us_apply = tim["apply"] / max(launches, 1)
         ach_tflops = pairs_rank * FLOP_PER_PAIR / (us_pairs * 1e-6) / 1e12 if us_pairs > 0 else 0.0
         ach_gbs = own_updates / args.steps * APPLY_BYTES_PER_UPDATE / (us_apply * 1e-6) / 1e9 if us_apply > 0 else 0.0
-        traffic_pairs = measured_traffic("k_pairs<1", args, world)
+        traffic_pairs = measured_traffic("k_pairs_balanced", args, world)
         traffic_apply = measured_traffic("k_apply", args, world)
         out = {
             "metric": "particle-updates/sec at N=2^20", "value": value, "unit": "particle-updates/s",

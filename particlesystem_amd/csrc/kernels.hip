@@ -1057,9 +1057,11 @@ __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *_
 // wave_pos[s + 1]: equal shares of the total cost, cut at unit boundaries.  The eight runs of
 // waves that share an XCD (wave slots are dealt XCD by XCD, see k_pairs) start at whole tasks,
 // so a task that is cut is always continued by a workgroup of the same run.
-// One workgroup per run; the two prefix arrays are searched in LDS when they fit.
+// SPLIT_SUB workgroups per run (everything here is latency: many threads, few steps each);
+// the two prefix arrays are searched in LDS when they fit.
 constexpr int SPLIT_LDS_CELLS = 4096;
-__global__ __launch_bounds__(256) void k_split_tasks(DevParams P, int nw, const int *__restrict__ cell_start, const int *__restrict__ task_cost,
+constexpr int SPLIT_SUB = 1;     // (a run has at most 768 wave slots: one workgroup of 1024 threads covers it)
+__global__ __launch_bounds__(1024) void k_split_tasks(DevParams P, int nw, const int *__restrict__ cell_start, const int *__restrict__ task_cost,
                                                       const int *__restrict__ ctask_start_g, const long long *__restrict__ cost_start_g,
                                                       int *__restrict__ wave_pos, const FrameScalars *__restrict__ fs)
 {
@@ -1071,7 +1073,7 @@ __global__ __launch_bounds__(256) void k_split_tasks(DevParams P, int nw, const 
     const long long T = fs->cost_total;
     const bool in_lds = ncomp <= SPLIT_LDS_CELLS;
     if (in_lds) {
-        for (int j = tid; j <= ncomp; j += 256) { s_cost[j] = cost_start_g[j]; s_task[j] = ctask_start_g[j]; }
+        for (int j = tid; j <= ncomp; j += 1024) { s_cost[j] = cost_start_g[j]; s_task[j] = ctask_start_g[j]; }
         __syncthreads();
     }
     const long long *cost_start = in_lds ? s_cost : cost_start_g;
@@ -1110,7 +1112,7 @@ __global__ __launch_bounds__(256) void k_split_tasks(DevParams P, int nw, const 
         return cost_start[a] + (long long)(t - ctask_start[a]) * task_cost[comp_cell(P, a)];
     };
     const int m = nw >> 3;                                // wave slots per XCD run (nw is a multiple of 32)
-    const int x = blockIdx.x;                             // this workgroup's run
+    const int x = blockIdx.x / SPLIT_SUB, sub = blockIdx.x % SPLIT_SUB;   // this workgroup's run, and its part of the run's slots
     if (tid < 2) {
         s_run[tid] = unit_at(T * (x + tid) / 8, true);
         s_runcost[tid] = cost_of_task_start(s_run[tid]);
@@ -1118,9 +1120,9 @@ __global__ __launch_bounds__(256) void k_split_tasks(DevParams P, int nw, const 
     __syncthreads();
     const int run_lo = s_run[0], run_hi = s_run[1];
     const long long lo = s_runcost[0], hi = s_runcost[1];
-    for (int j = tid; j < m; j += 256)                    // equal shares of the run's own cost range
+    for (int j = sub * 1024 + tid; j < m; j += SPLIT_SUB * 1024)     // equal shares of the run's own cost range
         wave_pos[x * m + j] = j == 0 ? run_lo : max(run_lo, min(run_hi, unit_at(lo + (hi - lo) * j / m, false)));
-    if (x == 7 && tid == 0) wave_pos[nw] = run_hi;        // = ntask * 27
+    if (x == 7 && sub == 0 && tid == 0) wave_pos[nw] = run_hi;       // = ntask * 27
 }
 
 // One wave = 64 consecutive particles of one cell (four independent waves per workgroup).
@@ -1568,6 +1570,10 @@ __global__ __launch_bounds__(256) void k_pairs_merged(DevParams P, const int *__
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slot = blockIdx.x * 4 + wave;
     if (slot >= fs->n_merged) return;
+    // These waves run beside the balanced pass (one per SIMD among its six) and each walks a whole
+    // stencil: at equal priority they got a seventh of the issue slots and ended 0.27 ms after
+    // everybody else.  Issue priority up: they finish early, the others fill what they leave.
+    __builtin_amdgcn_s_setprio(3);
     float *tile = tiles[wave];
     const int4 pk = merged_tasks[slot];
     const int cells[4] = {pk.x, pk.y, pk.z, pk.w};
@@ -2808,7 +2814,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
                                                    d.halo_count, d.halo_f, d.halo_id, d.pair_flag, d.force4, d.fs);
         k_build_active<<<ncomp, 256, 0, st>>>(P, d.cell_start, d.pair_flag, d.active_list, d.active_count, d.task_cost);
         k_active_tasks<<<1, 1024, 0, st>>>(P, d.active_count, d.task_cost, d.task_list2, d.ctask_start, d.cost_start, d.merged_tasks, d.fs, merge ? 1 : 0);
-        if (balanced) k_split_tasks<<<8, 256, 0, st>>>(P, nw, d.cell_start, d.task_cost, d.ctask_start, d.cost_start, d.wave_pos, d.fs);
+        if (balanced) k_split_tasks<<<8 * SPLIT_SUB, 1024, 0, st>>>(P, nw, d.cell_start, d.task_cost, d.ctask_start, d.cost_start, d.wave_pos, d.fs);
     }
     if (ev_force) (void)hipEventRecord(ev_force, st);      // timing: the force pass proper starts here
     const int *task_list = two ? d.task_list2 : d.task_list;

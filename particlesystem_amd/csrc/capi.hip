@@ -419,8 +419,8 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.task_list2, LC * P.slices));
     PS_HIP(c, dev_alloc(c, &d.merged_tasks, LC));
     PS_HIP(c, dev_alloc(c, &d.task_cost, LC));
-    PS_HIP(c, dev_alloc(c, &d.ctask_start, LC + 1));
-    PS_HIP(c, dev_alloc(c, &d.cost_start, LC + 1));
+    PS_HIP(c, dev_alloc(c, &d.ctask_start, 2 * LC + 2));     // (+ one virtual cell per merged pack)
+    PS_HIP(c, dev_alloc(c, &d.cost_start, 2 * LC + 2));
     PS_HIP(c, dev_alloc(c, &d.wave_pos, (size_t)MAX_PAIR_WAVES + 1));
     PS_HIP(c, dev_alloc(c, &d.rec_start, (size_t)g.queue_infos + 1));
     PS_HIP(c, dev_alloc(c, &d.rec_cursor, (size_t)g.queue_infos));
@@ -967,7 +967,8 @@ static int do_lifecycle(psamd_ctx *c)
     c->host_queues_valid = false;
     PS_HIP(c, hipEventSynchronize(c->ev_scalars));
     c->live_at_build = c->h_fs->live;
-    c->tasks_last = c->interior_ran ? (int64_t)c->h_fs->n_tasks2 * comp_count(c->P) / std::max(1, comp_count(c->P_rest)) : c->h_fs->n_tasks2;
+    const int64_t tasks_now = (int64_t)c->h_fs->n_tasks2 + c->h_fs->n_merged;       // ordinary tasks + packs of partial slices
+    c->tasks_last = c->interior_ran ? tasks_now * comp_count(c->P) / std::max(1, comp_count(c->P_rest)) : tasks_now;
     c->interior_ran = false;
     c->live_bound = std::min<int64_t>(c->P.slots_total, (int64_t)c->h_fs->live + c->h_fs->n_moves);   // births and arrivals <= moves
     c->processed_total += c->h_fs->live;

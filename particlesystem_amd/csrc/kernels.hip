@@ -995,7 +995,11 @@ __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *_
                                                        int4 *__restrict__ merged_tasks, FrameScalars *fs,
                                                        int merge)
 {
-    __shared__ long long wave_tot[16], wave_cost[16];
+    // merge: 0 every slice is an ordinary task; 1 partly filled last slices are packed, up to four
+    // cells to a wave, into merged tasks for k_pairs_merged (run beside the balanced pass);
+    // 2 the same packs, appended to the balanced pass's own task list (tile walk): pack m is task
+    // n_tasks2 + m, with one virtual "cell" ncomp + m in the cost prefix arrays
+    __shared__ long long wave_tot[16], wave_cost[16], wave_pcost[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ncomp = comp_count(P);
     const int per = (ncomp + 1023) / 1024;
@@ -1004,38 +1008,50 @@ __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *_
     // cell order (longer runs leave fewer half-empty packs at their ends)
     const int pper = (ncomp + 255) / 256;
     const int p0 = tid < 256 ? min(ncomp, tid * pper) : 0, p1 = tid < 256 ? min(ncomp, p0 + pper) : 0;
-    auto pack = [&](int4 *out) -> int {
-        int npack = 0, used = 0, ng = 0;
+    // out / cost_out (may be null): the packs and, per pack, what its wave walks (its longest stencil)
+    auto pack = [&](int4 *out, long long *cost_out, long long cost_base, long long *cost_sum) -> int {
+        int npack = 0, used = 0, ng = 0, pc = 0;
+        long long acc = 0;
         int4 cur = make_int4(-1, -1, -1, -1);
+        auto flush = [&]() {
+            if (out) out[npack] = cur;
+            if (cost_out) cost_out[npack] = cost_base + acc;
+            acc += pc; npack++;
+            cur = make_int4(-1, -1, -1, -1); used = 0; ng = 0; pc = 0;
+        };
         for (int j = p0; j < p1; j++) {
             const int c = comp_cell(P, j);
             const int r = active_count[c] & 63;
             if (r == 0) continue;
-            if (ng == 4 || used + r > 64) { if (out) out[npack] = cur; npack++; cur = make_int4(-1, -1, -1, -1); used = 0; ng = 0; }
+            if (ng == 4 || used + r > 64) flush();
             if (ng == 0) cur.x = c; else if (ng == 1) cur.y = c; else if (ng == 2) cur.z = c; else cur.w = c;
-            ng++; used += r;
+            ng++; used += r; pc = max(pc, task_cost[c]);
         }
-        if (ng) { if (out) out[npack] = cur; npack++; }
+        if (ng) flush();
+        if (cost_sum) *cost_sum = acc;
         return npack;
     };
-    long long mine = 0, mycost = 0;           // tasks (low word) and merged tasks (high word); bodies the tasks walk
+    long long mine = 0, mycost = 0, mypcost = 0;   // tasks (low word) and packs (high word); bodies the tasks walk; ... the packs walk
     for (int j = c0; j < c1; j++) {
         const int c = comp_cell(P, j), n = active_count[c], nt = merge ? (n >> 6) : ((n + 63) >> 6);
         mine += nt;
         mycost += (long long)nt * task_cost[c];
     }
-    if (merge) mine |= (long long)pack(nullptr) << 32;
-    long long incl = mine, cincl = mycost;
+    if (merge) mine |= (long long)pack(nullptr, nullptr, 0, &mypcost) << 32;
+    long long incl = mine, cincl = mycost, pincl = mypcost;
     for (int d = 1; d < 64; d <<= 1) {
-        const long long o = __shfl_up(incl, d), oc = __shfl_up(cincl, d);
-        if (lane >= d) { incl += o; cincl += oc; }
+        const long long o = __shfl_up(incl, d), oc = __shfl_up(cincl, d), op = __shfl_up(pincl, d);
+        if (lane >= d) { incl += o; cincl += oc; pincl += op; }
     }
-    if (lane == 63) { wave_tot[wv] = incl; wave_cost[wv] = cincl; }
+    if (lane == 63) { wave_tot[wv] = incl; wave_cost[wv] = cincl; wave_pcost[wv] = pincl; }
     __syncthreads();
-    long long run2 = incl - mine, total2 = 0, crun = cincl - mycost, ctotal = 0;
-    for (int k = 0; k < 16; k++) { if (k < wv) { run2 += wave_tot[k]; crun += wave_cost[k]; } total2 += wave_tot[k]; ctotal += wave_cost[k]; }
+    long long run2 = incl - mine, total2 = 0, crun = cincl - mycost, ctotal = 0, prun = pincl - mypcost, ptotal = 0;
+    for (int k = 0; k < 16; k++) {
+        if (k < wv) { run2 += wave_tot[k]; crun += wave_cost[k]; prun += wave_pcost[k]; }
+        total2 += wave_tot[k]; ctotal += wave_cost[k]; ptotal += wave_pcost[k];
+    }
     int run = (int)(run2 & 0xffffffffll);
-    const int total = (int)(total2 & 0xffffffffll);
+    const int total = (int)(total2 & 0xffffffffll), npacks = (int)(total2 >> 32);
     for (int j = c0; j < c1; j++) {
         const int c = comp_cell(P, j);
         const int n = merge ? (active_count[c] >> 6) : ((active_count[c] + 63) >> 6);
@@ -1044,10 +1060,16 @@ __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *_
         run += n;
         crun += (long long)n * task_cost[c];
     }
-    if (merge) pack(merged_tasks + (int)(run2 >> 32));
+    if (merge) {
+        const int m0 = (int)(run2 >> 32);
+        const int np = pack(merged_tasks + m0, merge == 2 ? cost_start + ncomp + m0 : nullptr, ctotal + prun, nullptr);
+        if (merge == 2) for (int m = 0; m < np; m++) ctask_start[ncomp + m0 + m] = total + m0 + m;
+    }
     if (tid == 0) {
-        ctask_start[ncomp] = total; cost_start[ncomp] = ctotal;
-        fs->n_tasks2 = total; fs->n_merged = (int)(total2 >> 32); fs->cost_total = ctotal;
+        const bool ext = merge == 2;
+        ctask_start[ncomp + (ext ? npacks : 0)] = total + (ext ? npacks : 0);
+        cost_start[ncomp + (ext ? npacks : 0)] = ctotal + (ext ? ptotal : 0);
+        fs->n_tasks2 = total; fs->n_merged = npacks; fs->cost_total = ctotal + (ext ? ptotal : 0);
     }
 }
 
@@ -1063,13 +1085,15 @@ constexpr int SPLIT_LDS_CELLS = 4096;
 constexpr int SPLIT_SUB = 1;     // (a run has at most 768 wave slots: one workgroup of 1024 threads covers it)
 __global__ __launch_bounds__(1024) void k_split_tasks(DevParams P, int nw, const int *__restrict__ cell_start, const int *__restrict__ task_cost,
                                                       const int *__restrict__ ctask_start_g, const long long *__restrict__ cost_start_g,
-                                                      int *__restrict__ wave_pos, const FrameScalars *__restrict__ fs)
+                                                      int *__restrict__ wave_pos, const FrameScalars *__restrict__ fs, int ext)
 {
     __shared__ long long s_cost[SPLIT_LDS_CELLS + 1];
     __shared__ int s_task[SPLIT_LDS_CELLS + 1];
     __shared__ int s_run[2];
     __shared__ long long s_runcost[2];
-    const int ncomp = comp_count(P), ntask = fs->n_tasks2, tid = threadIdx.x;
+    // ext: the merged packs are tasks of this pass too (one virtual cell each, after the real ones)
+    const int ncells = comp_count(P), ncomp = ncells + (ext ? fs->n_merged : 0), ntask = fs->n_tasks2 + (ext ? fs->n_merged : 0);
+    const int tid = threadIdx.x;
     const long long T = fs->cost_total;
     const bool in_lds = ncomp <= SPLIT_LDS_CELLS;
     if (in_lds) {
@@ -1083,8 +1107,14 @@ __global__ __launch_bounds__(1024) void k_split_tasks(DevParams P, int nw, const
         if (x >= T) return ntask * STENCIL;
         int a = 0, b = ncomp - 1;                         // last computed cell whose tasks start at or before x
         while (a < b) { const int m = (a + b + 1) >> 1; if (cost_start[m] <= x) a = m; else b = m - 1; }
-        const int c = comp_cell(P, a), S = task_cost[c];
         const int nt = ctask_start[a + 1] - ctask_start[a];
+        if (a >= ncells) {                                // a merged pack: one task, its steps taken as equally long
+            const long long S = cost_start[a + 1] - cost_start[a], off = x - cost_start[a];
+            const int k = S > 0 ? (int)min((long long)(STENCIL - 1), off * STENCIL / S) : 0;
+            if (whole) return (ctask_start[a] + (off > 0 ? 1 : 0)) * STENCIL;
+            return ctask_start[a] * STENCIL + k;
+        }
+        const int c = comp_cell(P, a), S = task_cost[c];
         if (nt == 0 || S <= 0) return ctask_start[a + 1] * STENCIL;     // (x < T: cannot be the last cell)
         const long long off = x - cost_start[a];
         const int q = (int)min((long long)(nt - 1), off / S);
@@ -1109,6 +1139,7 @@ __global__ __launch_bounds__(1024) void k_split_tasks(DevParams P, int nw, const
         if (t >= ntask) return T;
         int a = 0, b = ncomp - 1;
         while (a < b) { const int mm = (a + b + 1) >> 1; if (ctask_start[mm] <= t) a = mm; else b = mm - 1; }
+        if (a >= ncells) return cost_start[a];             // a merged pack is one task
         return cost_start[a] + (long long)(t - ctask_start[a]) * task_cost[comp_cell(P, a)];
     };
     const int m = nw >> 3;                                // wave slots per XCD run (nw is a multiple of 32)
@@ -1410,68 +1441,115 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
                          task_list[slot], tiles[MODE == 0 ? wave : 0], trace, active_list, active_count);
 }
 
+constexpr int MERGE_TILE = 4 * 64 + 4;          // floats per lane group: x[64] y[64] z[64] w[64] + skew
+
 // The same walk for a wave that has its SIMD (almost) to itself -- a slab of a multi-GPU run has
 // about 1.5 force tasks per SIMD.  There the scalar-load walk of pairs_task is latency-bound (one
 // wave cannot cover its own s_load round trips: 1.6x slower per task, PSAMD_WAVES sweep in
 // DESIGN.md), so the bodies come as 64-body tiles instead: one vector load per lane, issued a
-// whole tile ahead (vector loads retire in order, so they pipeline), through 1 KiB of LDS per
-// wave (SoA, no barrier: a wave reads only its own tile and its LDS operations complete in
-// order), read back as broadcast 16-byte rows.  Same arithmetic, same order: short last tiles
-// are padded with massless bodies far outside the box (r * 0 = +-0 added to a sum that started
-// at +0 changes nothing, as for kids).  Two-pass mode only (flags are settled), lean arithmetic.
+// whole tile ahead (vector loads retire in order, so they pipeline), through LDS (SoA, no
+// barrier: a wave reads only its own tiles and its LDS operations complete in order), read back
+// as broadcast 16-byte rows.  Same arithmetic, same order: short last tiles are padded with
+// massless bodies far outside the box (r * 0 = +-0 added to a sum that started at +0 changes
+// nothing, as for kids).  Two-pass mode only (flags are settled), lean arithmetic.
+//
+// A wave serves up to four lane GROUPS, each a run of one cell's particles with its own stencil
+// and its own tile (the groups' tiles skewed by 16 bytes onto different banks): one group of up
+// to 64 lanes = an ordinary (cell, slice) task; several = the partly filled last slices of up to
+// four cells packed into one wave (a cell's list of ~148 particles fills two slices and a third
+// of another).  All groups walk stencil step k together, tile by tile, for as many rows as the
+// longest of their lists.
+struct TileGroups {
+    int ng;
+    int cell[4], first[4], count[4];      // group g: particles active_list[cell_start[cell] + first ..][0 .. count)
+};
+
 template <int MODE, int NQ>
 __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *__restrict__ cell_start,
-                                                const float4 *__restrict__ snap4, float4 *__restrict__ force4, int task,
-                                                float *tile, const int *__restrict__ active_list,
-                                                const int *__restrict__ active_count,
+                                                const float4 *__restrict__ snap4, float4 *__restrict__ force4,
+                                                const TileGroups &G, float *tile, const int *__restrict__ active_list,
                                                 int k0, int k1, int *ready, FrameScalars *fs)
 {
-    const int c = task / P.slices, slice = task - c * P.slices;
-    const int base = cell_start[c];
-    const int cnt = active_count[c];
-    const int first = slice * 64;
-    if (first >= cnt) return;
     const int lane = threadIdx.x & 63;
-    const bool valid = lane < min(64, cnt - first);
-    const int gi = active_list[base + first + (valid ? lane : 0)];
+    int off[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < 4; g++) off[g + 1] = off[g] + (g < G.ng ? G.count[g] : 0);
+    const int g = (lane >= off[1]) + (lane >= off[2]) + (lane >= off[3]);       // a lane past the last group: 3, invalid
+    const bool valid = lane < off[4];
+    const int gc = valid ? (g == 0 ? G.cell[0] : g == 1 ? G.cell[1] : g == 2 ? G.cell[2] : G.cell[3]) : G.cell[0];
+    const int gf = valid ? (g == 0 ? G.first[0] : g == 1 ? G.first[1] : g == 2 ? G.first[2] : G.first[3]) : G.first[0];
+    const int l = valid ? lane - (g == 0 ? off[0] : g == 1 ? off[1] : g == 2 ? off[2] : off[3]) : 0;
+    const int gi = active_list[cell_start[gc] + gf + l];
     const float4 me = snap4[gi];
-    int i1, i2, i3;
-    cell_coords(P, c, i1, i2, i3);
+    const float eps2f = (float)P.eps2;
+    // neighbour ranges of all groups: entry e = group * 27 + stencil step, held by lane e % 64
+    int tab_nb[2] = {0, 0}, tab_cnt[2] = {0, 0};
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int e = lane + 64 * r, eg = e / STENCIL, ek = e - eg * STENCIL;
+        const int ec = (eg < G.ng) ? (eg == 0 ? G.cell[0] : eg == 1 ? G.cell[1] : eg == 2 ? G.cell[2] : G.cell[3]) : -1;
+        if (ec >= 0) {
+            int i1, i2, i3;
+            cell_coords(P, ec, i1, i2, i3);
+            const int nc = local_cell(P, i3 + c_stencil[ek][2], i1 + c_stencil[ek][1], i2 + c_stencil[ek][0]);
+            if (nc >= 0) {
+                tab_nb[r] = cell_start[nc];
+                tab_cnt[r] = min(cell_start[nc + 1] - tab_nb[r], P.max_per_cell);
+            }
+        }
+    }
     float ax = 0.f, ay = 0.f, az = 0.f;
     int flag = 0;
-    const float eps2f = (float)P.eps2;
-    int my_nb = 0, my_cnt = 0;
-    if (lane < STENCIL) {
-        const int nc = local_cell(P, i3 + c_stencil[lane][2], i1 + c_stencil[lane][1], i2 + c_stencil[lane][0]);
-        if (nc >= 0) { my_nb = cell_start[nc]; my_cnt = min(cell_start[nc + 1] - my_nb, P.max_per_cell); }
-    }
     const PairCtx ctx = {me.x, me.y, me.z, 0.f, 0, gi, false};
     if (k0 > 0 && !handoff_consume(force4 + gi, ax, ay, az, flag, valid, ready, k0)) {
         if (lane == 0) atomicOr(&fs->error, ERR_HANDOFF_TIMEOUT);
     }
     const float far = 1.0e6f;                                       // padding body, mass 0
-    const float *tx = tile, *ty = tile + 64, *tz = tile + 128, *tw = tile + 192;
-    // first non-empty tile from step k0 on, fetched ahead
-    int k = k0, t0 = 0;
-    int nb = 0, ncnt = 0;
-    while (k < k1) { nb = __builtin_amdgcn_readlane(my_nb, k); ncnt = __builtin_amdgcn_readlane(my_cnt, k); if (ncnt > 0) break; k++; }
+    const float *tx = tile + (valid ? g : 0) * MERGE_TILE, *ty = tx + 64, *tz = tx + 128, *tw = tx + 192;
+    int nbs[4] = {0, 0, 0, 0}, cnts[4] = {0, 0, 0, 0};
+    // ranges of stencil step k for every group; returns the longest list
+    auto step_ranges = [&](int k) -> int {
+        int longest = 0;
+#pragma unroll
+        for (int gg = 0; gg < 4; gg++) {
+            const int e = gg * STENCIL + k;
+            nbs[gg] = __builtin_amdgcn_readlane(e < 64 ? tab_nb[0] : tab_nb[1], e & 63);
+            cnts[gg] = gg < G.ng ? __builtin_amdgcn_readlane(e < 64 ? tab_cnt[0] : tab_cnt[1], e & 63) : 0;
+            longest = max(longest, cnts[gg]);
+        }
+        return longest;
+    };
+    float4 pre[4];
+    auto fetch = [&](int t0) {                                      // this lane's body of every group's tile at row t0
+#pragma unroll
+        for (int gg = 0; gg < 4; gg++) {
+            pre[gg] = make_float4(far, far, far, 0.f);
+            if (gg < G.ng && lane < cnts[gg] - t0) pre[gg] = snap4[nbs[gg] + t0 + lane];
+        }
+    };
+    // first non-empty step from k0 on, its first tiles fetched ahead
+    int k = k0, t0 = 0, longest = 0;
+    while (k < k1 && (longest = step_ranges(k)) == 0) k++;
     bool have = k < k1;
-    float4 pre = make_float4(far, far, far, 0.f);
-    if (have && lane < ncnt) pre = snap4[nb + lane];
+    if (have) fetch(0);
     while (have) {
-        const int n = (min(64, ncnt - t0) + NQ - 1) & ~(NQ - 1);
-        PS_WAVE_SYNC();                               // previous tile fully consumed
-        tile[lane] = pre.x; tile[64 + lane] = pre.y; tile[128 + lane] = pre.z; tile[192 + lane] = pre.w;
+        const int n = (min(64, longest - t0) + NQ - 1) & ~(NQ - 1);
+        PS_WAVE_SYNC();                               // previous tiles fully consumed
+#pragma unroll
+        for (int gg = 0; gg < 4; gg++)
+            if (gg < G.ng) {
+                float *t = tile + gg * MERGE_TILE + lane;
+                t[0] = pre[gg].x; t[64] = pre[gg].y; t[128] = pre[gg].z; t[192] = pre[gg].w;
+            }
         PS_WAVE_SYNC();
-        t0 += 64;                                     // advance to the next non-empty tile
-        if (t0 >= ncnt) {
-            t0 = 0; ncnt = 0; k++;
-            while (k < k1) { nb = __builtin_amdgcn_readlane(my_nb, k); ncnt = __builtin_amdgcn_readlane(my_cnt, k); if (ncnt > 0) break; k++; }
+        t0 += 64;                                     // advance to the next non-empty row of tiles
+        if (t0 >= longest) {
+            t0 = 0; longest = 0; k++;
+            while (k < k1 && (longest = step_ranges(k)) == 0) k++;
         }
         have = k < k1;
         // issued after the fences (they drain outstanding loads), consumed a tile later
-        pre = make_float4(far, far, far, 0.f);
-        if (have && lane < ncnt - t0) pre = snap4[nb + t0 + lane];
+        if (have) fetch(t0);
         float dmin = 3.0e38f;
         for (int jj = 0; jj < n; jj += NQ) {
             v2f qx[NQ / 2], qy[NQ / 2], qz[NQ / 2], qw[NQ / 2];   // 16-byte LDS reads, NQ is a multiple of 4
@@ -1507,7 +1585,10 @@ __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *_
 // Wave slots are dealt XCD by XCD like the tasks of k_pairs; k_split_tasks starts every XCD's
 // run at a whole task, so the wave that continues a task runs in a workgroup that was
 // dispatched no later (block b - 8) or is the same workgroup.
-template <int MODE, int NQ, bool TILE>
+// WALK 0: scalar-load walk, ordinary tasks only (packs, if any, run in k_pairs_merged beside it);
+//      1: tile walk for everything, packs of partial slices included (few waves per SIMD);
+//      2: scalar-load walk for the ordinary tasks, tile walk for the packs, all in one balanced list.
+template <int MODE, int NQ, int WALK>
 __global__ __launch_bounds__(256) void k_pairs_balanced(DevParams P, const int *__restrict__ cell_start,
                                                         const float4 *__restrict__ snap4,
                                                         const float *__restrict__ snap_soa,
@@ -1517,9 +1598,11 @@ __global__ __launch_bounds__(256) void k_pairs_balanced(DevParams P, const int *
                                                         float4 *__restrict__ force4,
                                                         FrameScalars *fs, unsigned long long *trace,
                                                         const int *__restrict__ active_list, const int *__restrict__ active_count,
-                                                        const int *__restrict__ wave_pos, int *__restrict__ task_ready)
+                                                        const int *__restrict__ wave_pos, int *__restrict__ task_ready,
+                                                        const int4 *__restrict__ merged_tasks)
 {
-    __shared__ __attribute__((aligned(16))) float tiles[TILE ? 4 : 1][TILE ? 256 : 4];   // TILE: 1 KiB per wave
+    constexpr bool TILES = WALK != 0;
+    __shared__ __attribute__((aligned(16))) float tiles[TILES ? 4 : 1][TILES ? 4 * MERGE_TILE : 4];   // up to four 1-KiB tiles per wave
     const int wave = threadIdx.x >> 6;
     const int slot = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave;
     const int ub = __builtin_amdgcn_readfirstlane(wave_pos[slot]), ue = __builtin_amdgcn_readfirstlane(wave_pos[slot + 1]);
@@ -1538,10 +1621,29 @@ __global__ __launch_bounds__(256) void k_pairs_balanced(DevParams P, const int *
         else if (has_head && i == 0) { t = tl; k1 = le; }                 // the head of the last task first: publish early
         else if (i - has_head < nwhole) t = first_whole + (i - has_head);
         else { t = tb; k0 = lb; }                                         // the tail of the first task last: its head was published long ago
-        if (TILE)
-            pairs_task_tile<MODE, NQ>(P, cell_start, snap4, force4, task_list[t], tiles[TILE ? wave : 0], active_list, active_count,
-                                      k0, k1, task_ready + t, fs);
-        else
+        const int nord = fs->n_tasks2;
+        if (WALK == 1 || (WALK == 2 && t >= nord)) {
+            // task t: an ordinary (cell, slice) task, or -- past them -- merged pack t - n_tasks2
+            TileGroups G;
+            if (t < nord) {
+                const int task = task_list[t], c = task / P.slices, slice = task - c * P.slices;
+                G.ng = 1; G.cell[0] = c; G.first[0] = slice * 64; G.count[0] = min(64, active_count[c] - slice * 64);
+                G.cell[1] = G.cell[2] = G.cell[3] = c; G.first[1] = G.first[2] = G.first[3] = 0; G.count[1] = G.count[2] = G.count[3] = 0;
+            } else {
+                const int4 pk = merged_tasks[t - nord];
+                const int cells[4] = {pk.x, pk.y, pk.z, pk.w};
+                G.ng = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const bool on = cells[q] >= 0;
+                    G.cell[q] = on ? cells[q] : pk.x;
+                    G.first[q] = on ? (active_count[cells[q]] & ~63) : 0;
+                    G.count[q] = on ? (active_count[cells[q]] & 63) : 0;
+                    if (on) G.ng = q + 1;
+                }
+            }
+            pairs_task_tile<MODE, NQ>(P, cell_start, snap4, force4, G, tiles[TILES ? wave : 0], active_list, k0, k1, task_ready + t, fs);
+        } else
             pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, task_list[t], nullptr, trace,
                                  active_list, active_count, k0, k1, task_ready + t, fs);
     }
@@ -1556,7 +1658,6 @@ __global__ __launch_bounds__(256) void k_pairs_balanced(DevParams P, const int *
 // their lists; shorter lists are padded with massless bodies far outside the box: such a
 // row adds r * 0 = +-0 to a sum that started at +0 (bit-identical, as for kids).  Launched
 // on its own (different register budget from k_pairs).
-constexpr int MERGE_TILE = 4 * 64 + 4;          // floats per lane group: x[64] y[64] z[64] w[64] + skew
 
 template <int MODE, int NQ>
 __global__ __launch_bounds__(256) void k_pairs_merged(DevParams P, const int *__restrict__ cell_start,
@@ -1570,10 +1671,9 @@ __global__ __launch_bounds__(256) void k_pairs_merged(DevParams P, const int *__
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slot = blockIdx.x * 4 + wave;
     if (slot >= fs->n_merged) return;
-    // These waves run beside the balanced pass (one per SIMD among its six) and each walks a whole
-    // stencil: at equal priority they got a seventh of the issue slots and ended 0.27 ms after
-    // everybody else.  Issue priority up: they finish early, the others fill what they leave.
-    __builtin_amdgcn_s_setprio(3);
+    // (Raising these waves' issue priority -- they run one per SIMD among six of the balanced
+    // pass and end 0.27 ms after it -- was tried: s_setprio(3) ended them 0.6 ms earlier and the
+    // balanced pass 0.5 ms later, 2.26 -> 2.48 ms for the stage.)
     float *tile = tiles[wave];
     const int4 pk = merged_tasks[slot];
     const int cells[4] = {pk.x, pk.y, pk.z, pk.w};
@@ -2796,7 +2896,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     static const bool merge_off = std::getenv("PSAMD_NO_MERGE") != nullptr;
     static const bool balance_off = std::getenv("PSAMD_NO_BALANCE") != nullptr;
     static const int waves_env = std::getenv("PSAMD_WAVES") ? std::atoi(std::getenv("PSAMD_WAVES")) : 0;
-    const bool merge = two && !merge_off && (P.world == 1 || tasks_hint >= 3000) && !(P.flags & PSAMD_FLAG_ALL_PAIRS);   // (the merged kernel walks the stencil only)
+    bool merge = two && !merge_off && (P.world == 1 || tasks_hint >= 3000) && !(P.flags & PSAMD_FLAG_ALL_PAIRS);   // (the merged kernel walks the stencil only)
     const bool balanced = two && !balance_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS);
     // Balanced pass: a fixed number of waves, all resident, each walking the same number of
     // bodies.  At least four per SIMD when there are that many tasks (fewer cannot cover their
@@ -2808,13 +2908,27 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
         nw = 1024 * (int)std::min<int64_t>(6, std::max<int64_t>(1, tasks_hint / 1024));
         if (waves_env >= 32) nw = std::min(waves_env & ~31, MAX_PAIR_WAVES);
     }
+    // few waves per SIMD (a slab of a multi-GPU run): the scalar-load walk cannot cover its own
+    // load latency, bodies come through LDS tiles fetched a tile ahead instead -- and the partly
+    // filled last slices are packed into tasks of the same pass
+    static const int tile_env = std::getenv("PSAMD_TILE") ? std::atoi(std::getenv("PSAMD_TILE")) : -1;
+    static const bool separate_merged = std::getenv("PSAMD_SEPARATE_MERGED") != nullptr;
+    const bool tile = balanced && (tile_env >= 0 ? tile_env != 0 : nw <= 2048);
+    // the packs of partly filled last slices as tasks of the balanced pass itself (tile walk): always
+    // with the tile walk; with the scalar walk when there are enough tasks to pay for them (as for
+    // the separate merged kernel, which this replaces: its waves ended 0.27 ms after the pass)
+    const bool packs_in_list = balanced && !merge_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS) && (tile || (merge && !separate_merged));
+    if (packs_in_list) { merge = false; nw = std::min(nw, 4096); }      // (98 VGPRs with the tile walk in: 4 resident waves per SIMD)
+    if (tile) merge = false;                  // no separate merged kernel beside a tile-walk pass
     if (two) {
         // collision flags, then the per-cell lists and the tasks of the particles that need a force
         k_collide<<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.snap_cid, d.task_list, d.task_start,
                                                    d.halo_count, d.halo_f, d.halo_id, d.pair_flag, d.force4, d.fs);
         k_build_active<<<ncomp, 256, 0, st>>>(P, d.cell_start, d.pair_flag, d.active_list, d.active_count, d.task_cost);
-        k_active_tasks<<<1, 1024, 0, st>>>(P, d.active_count, d.task_cost, d.task_list2, d.ctask_start, d.cost_start, d.merged_tasks, d.fs, merge ? 1 : 0);
-        if (balanced) k_split_tasks<<<8 * SPLIT_SUB, 1024, 0, st>>>(P, nw, d.cell_start, d.task_cost, d.ctask_start, d.cost_start, d.wave_pos, d.fs);
+        k_active_tasks<<<1, 1024, 0, st>>>(P, d.active_count, d.task_cost, d.task_list2, d.ctask_start, d.cost_start, d.merged_tasks, d.fs,
+                                           packs_in_list ? 2 : merge ? 1 : 0);
+        if (balanced) k_split_tasks<<<8 * SPLIT_SUB, 1024, 0, st>>>(P, nw, d.cell_start, d.task_cost, d.ctask_start, d.cost_start, d.wave_pos, d.fs,
+                                                                    packs_in_list ? 1 : 0);
     }
     if (ev_force) (void)hipEventRecord(ev_force, st);      // timing: the force pass proper starts here
     const int *task_list = two ? d.task_list2 : d.task_list;
@@ -2829,19 +2943,16 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
             P, d.cell_start, d.snap4, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
         (void)hipEventRecord(d.ev_join, d.side_stream);
     }
-    // few waves per SIMD (a slab of a multi-GPU run): the scalar-load walk cannot cover its own
-    // load latency, bodies come through LDS tiles fetched a tile ahead instead
-    static const int tile_env = std::getenv("PSAMD_TILE") ? std::atoi(std::getenv("PSAMD_TILE")) : -1;
-    const bool tile = tile_env >= 0 ? tile_env != 0 : nw <= 2048;
     // the hand-off flags are indexed by task number, which starts at 0 in every pass of a frame:
     // each pass has its own block of them (both zeroed with the frame)
     int *task_ready = d.task_ready + (size_t)pass * P.n_local_cells * P.slices;
-    if (balanced && tile)
-        k_pairs_balanced<MODE == 0 ? 1 : MODE, NQ, true><<<nw / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list,
-                                                                              d.force4, d.fs, d.trace, active_list, active_count, d.wave_pos, task_ready);
-    else if (balanced)
-        k_pairs_balanced<MODE == 0 ? 1 : MODE, NQ, false><<<nw / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list,
-                                                                               d.force4, d.fs, d.trace, active_list, active_count, d.wave_pos, task_ready);
+    if (balanced) {
+        constexpr int M = MODE == 0 ? 1 : MODE;
+#define PS_BALANCED(W) k_pairs_balanced<M, NQ, W><<<nw / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, \
+                                                                     d.force4, d.fs, d.trace, active_list, active_count, d.wave_pos, task_ready, d.merged_tasks)
+        if (tile) PS_BALANCED(1); else if (packs_in_list) PS_BALANCED(2); else PS_BALANCED(0);
+#undef PS_BALANCED
+    }
     else
         k_pairs<MODE, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
                                                     d.fs, d.trace, active_list, active_count);

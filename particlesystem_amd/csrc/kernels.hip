@@ -83,10 +83,26 @@ __global__ void k_unpack_aos(DevParams P, const uint32_t *__restrict__ aos, int 
     // the pair arithmetic is validated for in-box distances only
     if ((int)r[1] >= 0) {
         const float x = __uint_as_float(r[9]), y = __uint_as_float(r[10]), z = __uint_as_float(r[11]);
-        if ((int)r[1] >= P.num_cells_global || !(fabsf(x) <= half_box) || !(fabsf(y) <= half_box) || !(fabsf(z) <= half_box))
-            atomicOr(&fs->error, ERR_BAD_POS);
+        bool bad = (int)r[1] >= P.num_cells_global || !(fabsf(x) <= half_box) || !(fabsf(y) <= half_box) || !(fabsf(z) <= half_box);
+        if (!bad) {
+            // ... and inside the cell it claims (set_pos_t derives the cell from the position, app.cu:126-157;
+            // the two-pass collision stage relies on it).  A wrapped position is rounded to float after the
+            // cell was fixed, so allow it a sliver beyond the faces.
+            const int c = (int)r[1], G = P.G, i3 = c / (G * G), i1 = (c - i3 * G * G) / G, i2 = c - i3 * G * G - i1 * G;
+            const float cs = (float)P.cell_size, tol = 1e-4f * cs, h = (float)(G / 2);
+            const float u2 = x / cs + h - (float)i2, u1 = -y / cs + h - (float)i1, u3 = -z / cs + h - (float)i3;   // in [0, 1) inside
+            bad = !(u1 * cs >= -tol && u1 * cs <= cs + tol && u2 * cs >= -tol && u2 * cs <= cs + tol && u3 * cs >= -tol && u3 * cs <= cs + tol);
+        }
+        if (bad) atomicOr(&fs->error, ERR_BAD_POS);
     }
     cell[si] = (int)r[1];
+    if ((int)r[1] < 0) {
+        // a free slot holds a reset record (reset_particle, app.cu:239-264), whatever the caller sent:
+        // snapshot_restore relies on free slots being all-zero
+        pflags[si] = 0;
+        pos4[si] = vel4[si] = acc4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     pflags[si] = ((r[5] >> 8) & 0xffu) ? 1 : 0;
     pos4[si] = make_float4(__uint_as_float(r[9]), __uint_as_float(r[10]), __uint_as_float(r[11]), __uint_as_float(r[6]));
     vel4[si] = make_float4(__uint_as_float(r[12]), __uint_as_float(r[13]), __uint_as_float(r[14]), __uint_as_float(r[7]));

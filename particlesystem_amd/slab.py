@@ -209,7 +209,7 @@ class DeviceRing(_Ring):
 def merge_owned(arrays, plans, kind="slots"):
     """Assemble a whole-container array from the ranks' downloads: every slot (or QUEUE_INFO
     record, kind="records") is taken from the rank that owns it."""
-    out = np.zeros_like(arrays[0])          # (a copy of a record array would leave its pad bytes undefined)
+    out = np.zeros(arrays[0].shape, arrays[0].dtype)    # (copies / zeros_like of a record array leave its pad bytes undefined)
     out[...] = arrays[0]
     for a, p in zip(arrays, plans):
         lo, hi = (p.slot_lo, p.slot_hi) if kind == "slots" else (p.rec_lo, p.rec_hi)

@@ -238,12 +238,25 @@ def test_errors_are_statuses():
     with pytest.raises(ps.PsamdError) as e:
         g.upload_particles(bad)
     assert e.value.status == 1
+    # ... and inside the cell the record claims (the reference derives the cell from the position)
+    bad = p.copy(); bad["cell"][1] = 5; bad["x"][1] = 0.0; bad["y"][1] = 0.0; bad["z"][1] = 0.0
+    with pytest.raises(ps.PsamdError) as e:
+        g.upload_particles(bad)
+    assert e.value.status == 1
+    good = p.copy(); good["cell"][1] = 8 * 256 + 8 * 16 + 8; good["x"][1] = 0.5; good["y"][1] = -0.5; good["z"][1] = -0.5
+    good["w"][1] = 60.0
+    g.upload_particles(good)            # cell 2184 = (i3, i1, i2) = (8, 8, 8) holds (0.5, -0.5, -0.5)
+    # a free record is stored as a reset one, whatever else it carries
+    junk = p.copy(); junk["x"][3] = 7.0; junk["age"][3] = 3.0
+    g.upload_particles(junk)
+    back = g.download_particles(0, 4)
+    assert back["x"][3] == 0.0 and back["age"][3] == 0.0
     g.upload_particles(p)               # a valid upload afterwards is accepted
 
 
-def test_large_grid_uses_the_global_atomic_build():
-    """BASELINE config 4's grid (40^3 = 64000 cells, more than fit an LDS histogram): the
-    fallback hist/scatter kernels and the 1000-chunk scan, against the oracle."""
+def test_large_grid_windowed_histogram():
+    """BASELINE config 4's grid (40^3 = 64000 cells, more than one LDS histogram holds): the
+    windowed hist/scatter kernels and the 1000-chunk scan, against the oracle."""
     over = {"chunk_factor": 10, "chunk_dim": 4, "max_particles_num": 200000}
     n = 150000
     xyz = cloud(n, 71, 100.0)

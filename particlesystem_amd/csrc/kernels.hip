@@ -1480,7 +1480,8 @@ struct TileGroups {
     int cell[4], first[4], count[4];      // group g: particles active_list[cell_start[cell] + first ..][0 .. count)
 };
 
-template <int MODE, int NQ>
+// NG: how many groups the code is built for (1: an ordinary task, nothing per-group left in it; 4: a pack)
+template <int MODE, int NQ, int NG>
 __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *__restrict__ cell_start,
                                                 const float4 *__restrict__ snap4, float4 *__restrict__ force4,
                                                 const TileGroups &G, float *tile, const int *__restrict__ active_list,
@@ -1489,8 +1490,8 @@ __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *_
     const int lane = threadIdx.x & 63;
     int off[5] = {0, 0, 0, 0, 0};
 #pragma unroll
-    for (int g = 0; g < 4; g++) off[g + 1] = off[g] + (g < G.ng ? G.count[g] : 0);
-    const int g = (lane >= off[1]) + (lane >= off[2]) + (lane >= off[3]);       // a lane past the last group: 3, invalid
+    for (int g = 0; g < 4; g++) off[g + 1] = off[g] + ((g < NG && g < G.ng) ? G.count[g] : 0);
+    const int g = NG == 1 ? 0 : (lane >= off[1]) + (lane >= off[2]) + (lane >= off[3]);       // a lane past the last group: 3, invalid
     const bool valid = lane < off[4];
     const int gc = valid ? (g == 0 ? G.cell[0] : g == 1 ? G.cell[1] : g == 2 ? G.cell[2] : G.cell[3]) : G.cell[0];
     const int gf = valid ? (g == 0 ? G.first[0] : g == 1 ? G.first[1] : g == 2 ? G.first[2] : G.first[3]) : G.first[0];
@@ -1501,9 +1502,9 @@ __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *_
     // neighbour ranges of all groups: entry e = group * 27 + stencil step, held by lane e % 64
     int tab_nb[2] = {0, 0}, tab_cnt[2] = {0, 0};
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
+    for (int r = 0; r < (NG == 1 ? 1 : 2); r++) {
         const int e = lane + 64 * r, eg = e / STENCIL, ek = e - eg * STENCIL;
-        const int ec = (eg < G.ng) ? (eg == 0 ? G.cell[0] : eg == 1 ? G.cell[1] : eg == 2 ? G.cell[2] : G.cell[3]) : -1;
+        const int ec = (eg < NG && eg < G.ng) ? (eg == 0 ? G.cell[0] : eg == 1 ? G.cell[1] : eg == 2 ? G.cell[2] : G.cell[3]) : -1;
         if (ec >= 0) {
             int i1, i2, i3;
             cell_coords(P, ec, i1, i2, i3);
@@ -1527,7 +1528,7 @@ __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *_
     auto step_ranges = [&](int k) -> int {
         int longest = 0;
 #pragma unroll
-        for (int gg = 0; gg < 4; gg++) {
+        for (int gg = 0; gg < NG; gg++) {
             const int e = gg * STENCIL + k;
             nbs[gg] = __builtin_amdgcn_readlane(e < 64 ? tab_nb[0] : tab_nb[1], e & 63);
             cnts[gg] = gg < G.ng ? __builtin_amdgcn_readlane(e < 64 ? tab_cnt[0] : tab_cnt[1], e & 63) : 0;
@@ -1535,10 +1536,10 @@ __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *_
         }
         return longest;
     };
-    float4 pre[4];
+    float4 pre[NG];
     auto fetch = [&](int t0) {                                      // this lane's body of every group's tile at row t0
 #pragma unroll
-        for (int gg = 0; gg < 4; gg++) {
+        for (int gg = 0; gg < NG; gg++) {
             pre[gg] = make_float4(far, far, far, 0.f);
             if (gg < G.ng && lane < cnts[gg] - t0) pre[gg] = snap4[nbs[gg] + t0 + lane];
         }
@@ -1552,7 +1553,7 @@ __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *_
         const int n = (min(64, longest - t0) + NQ - 1) & ~(NQ - 1);
         PS_WAVE_SYNC();                               // previous tiles fully consumed
 #pragma unroll
-        for (int gg = 0; gg < 4; gg++)
+        for (int gg = 0; gg < NG; gg++)
             if (gg < G.ng) {
                 float *t = tile + gg * MERGE_TILE + lane;
                 t[0] = pre[gg].x; t[64] = pre[gg].y; t[128] = pre[gg].z; t[192] = pre[gg].w;
@@ -1658,7 +1659,8 @@ __global__ __launch_bounds__(256) void k_pairs_balanced(DevParams P, const int *
                     if (on) G.ng = q + 1;
                 }
             }
-            pairs_task_tile<MODE, NQ>(P, cell_start, snap4, force4, G, tiles[TILES ? wave : 0], active_list, k0, k1, task_ready + t, fs);
+            if (t < nord) pairs_task_tile<MODE, NQ, 1>(P, cell_start, snap4, force4, G, tiles[TILES ? wave : 0], active_list, k0, k1, task_ready + t, fs);
+            else pairs_task_tile<MODE, NQ, 4>(P, cell_start, snap4, force4, G, tiles[TILES ? wave : 0], active_list, k0, k1, task_ready + t, fs);
         } else
             pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, task_list[t], nullptr, trace,
                                  active_list, active_count, k0, k1, task_ready + t, fs);
@@ -2928,12 +2930,12 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     // load latency, bodies come through LDS tiles fetched a tile ahead instead -- and the partly
     // filled last slices are packed into tasks of the same pass
     static const int tile_env = std::getenv("PSAMD_TILE") ? std::atoi(std::getenv("PSAMD_TILE")) : -1;
-    static const bool separate_merged = std::getenv("PSAMD_SEPARATE_MERGED") != nullptr;
+    static const bool unified_packs = std::getenv("PSAMD_UNIFIED_PACKS") != nullptr;   // (measured slower on one GPU: 2.40 vs 2.31 ms)
     const bool tile = balanced && (tile_env >= 0 ? tile_env != 0 : nw <= 2048);
-    // the packs of partly filled last slices as tasks of the balanced pass itself (tile walk): always
-    // with the tile walk; with the scalar walk when there are enough tasks to pay for them (as for
-    // the separate merged kernel, which this replaces: its waves ended 0.27 ms after the pass)
-    const bool packs_in_list = balanced && !merge_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS) && (tile || (merge && !separate_merged));
+    // the packs of partly filled last slices as tasks of the balanced pass itself (tile walk): with
+    // the tile walk.  (With the scalar walk they stay in k_pairs_merged beside the pass: one kernel
+    // holding both walks needs 99 VGPRs -- 4 waves per SIMD instead of 6 -- and was 4 % slower.)
+    const bool packs_in_list = balanced && !merge_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS) && (tile || (merge && unified_packs));
     if (packs_in_list) { merge = false; nw = std::min(nw, 4096); }      // (98 VGPRs with the tile walk in: 4 resident waves per SIMD)
     if (tile) merge = false;                  // no separate merged kernel beside a tile-walk pass
     if (two) {

@@ -2202,7 +2202,9 @@ __global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, c
     uint64_t *kbuf = reinterpret_cast<uint64_t *>(raw);
     int *abuf = reinterpret_cast<int *>(raw + KEY_BYTES);
     int *window = reinterpret_cast<int *>(raw);
-    __shared__ int s_arg[BUCKET_MAX];
+    // (the sorted args stay where the sort left them, behind the keys: the segment copy of the serial
+    // walk and the insert list of the closed form both fit in the key area in front of them)
+    static_assert(QUEUE_WINDOW * 4 <= KEY_BYTES && BUCKET_MAX * 4 <= KEY_BYTES, "abuf must survive the reuse of the key area");
     __shared__ unsigned char s_sub[BUCKET_MAX];
     constexpr int NT = REPLAY_THREADS;
     __shared__ int wave_tot[NT / 64];
@@ -2246,7 +2248,8 @@ __global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, c
             else PS_WAVE_SYNC();
         }
     __syncthreads();
-    for (int e = tid; e < n; e += NT) { s_arg[e] = abuf[e]; s_sub[e] = (unsigned char)(kbuf[e] & 3ull); }
+    for (int e = tid; e < n; e += NT) s_sub[e] = (unsigned char)(kbuf[e] & 3ull);
+    const int *s_arg = abuf;
     __syncthreads();
     RT();
     int *ins_arg = (int *)kbuf;                        // keys no longer needed

@@ -2933,12 +2933,17 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     // load latency, bodies come through LDS tiles fetched a tile ahead instead -- and the partly
     // filled last slices are packed into tasks of the same pass
     static const int tile_env = std::getenv("PSAMD_TILE") ? std::atoi(std::getenv("PSAMD_TILE")) : -1;
-    static const bool unified_packs = std::getenv("PSAMD_UNIFIED_PACKS") != nullptr;   // (measured slower on one GPU: 2.40 vs 2.31 ms)
+    static const bool unified_packs = std::getenv("PSAMD_UNIFIED_PACKS") != nullptr;
+    static const bool tile_packs = std::getenv("PSAMD_TILE_PACKS") != nullptr;
     const bool tile = balanced && (tile_env >= 0 ? tile_env != 0 : nw <= 2048);
-    // the packs of partly filled last slices as tasks of the balanced pass itself (tile walk): with
-    // the tile walk.  (With the scalar walk they stay in k_pairs_merged beside the pass: one kernel
-    // holding both walks needs 99 VGPRs -- 4 waves per SIMD instead of 6 -- and was 4 % slower.)
-    const bool packs_in_list = balanced && !merge_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS) && (tile || (merge && unified_packs));
+    // The packs of partly filled last slices as tasks of the balanced pass itself (tile walk).
+    // Measured (pair stage, N = 2^20): one GPU, 8200 tasks: beside the pass in k_pairs_merged 2.31 ms,
+    // in the list 2.40 (one kernel holding both walks needs 99 VGPRs: 4 waves per SIMD, not 6);
+    // half the cloud (a slab of two): 1.67 vs 1.40 -- the separate kernel's 512 waves end long after
+    // a pass that has only 4 waves per SIMD; an eighth (tile walk): no packs 0.58, packs 0.60 -- a
+    // pack's four-group walk costs more than the two tasks it saves.  So: in the list for the slabs
+    // that use the scalar walk, beside the pass on one GPU, none with the tile walk.
+    const bool packs_in_list = balanced && !merge_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS) && (tile ? tile_packs : (merge && (unified_packs || P.world > 1)));
     if (packs_in_list) { merge = false; nw = std::min(nw, 4096); }      // (98 VGPRs with the tile walk in: 4 resident waves per SIMD)
     if (tile) merge = false;                  // no separate merged kernel beside a tile-walk pass
     if (two) {

@@ -429,6 +429,7 @@ def main():
             g.slab_build()
             n = g.download_cellgrid()[:, 0].copy()
             ring.exchange("halo")
+            ring.finish_status(ring.gather_status())
             g.slab_pairs()
             mine = g.download_force_counts()
             ring.exchange("force")

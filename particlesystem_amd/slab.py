@@ -122,6 +122,9 @@ class HostRing(_Ring):
         for slot, t in inn.items():
             self.s.msg_upload(slot, t.numpy())
 
+    def finish_status(self, work):
+        pass                                    # (gather_status is synchronous here)
+
     def gather_status(self):
         import torch
         n = self.s.msg_bytes(STATUS_OUT)
@@ -174,16 +177,35 @@ class DeviceRing(_Ring):
         already enqueued on this context's stream is done (what was packed is complete); this
         stream is NOT held up -- whatever is enqueued next runs beside the transfer -- until
         finish() makes it wait for the arrivals."""
+        import torch
         ops = self._ops(phase, lambda slot: self.t[slot])
-        return self.dist.batch_isend_irecv(ops) if ops else []
+        if not ops:
+            return []
+        with torch.cuda.stream(self.stream):       # RCCL orders against torch's CURRENT stream: make it the context's
+            return self.dist.batch_isend_irecv(ops)
 
-    @staticmethod
-    def finish(works):
-        for w in works:
-            w.wait()            # a stream-side wait (the host goes on)
+    def finish(self, works):
+        import torch
+        with torch.cuda.stream(self.stream):
+            for w in works:
+                w.wait()        # a stream-side wait (the host goes on)
 
     def exchange(self, phase):
         self.finish(self.start(phase))
+
+    def gather_status(self):
+        """start the all-gather of the status records (needed only by slab_finish); returns the work or None"""
+        import torch
+        if self.dist is None or STATUS_OUT not in self.t or self.world == 1:
+            return None
+        with torch.cuda.stream(self.stream):
+            return self.dist.all_gather_into_tensor(self.t[STATUS_IN], self.t[STATUS_OUT], async_op=True)
+
+    def finish_status(self, work):
+        import torch
+        if work is not None:
+            with torch.cuda.stream(self.stream):
+                work.wait()
 
     def step(self):
         import torch
@@ -191,18 +213,14 @@ class DeviceRing(_Ring):
         with torch.cuda.stream(self.stream):
             s.slab_build()
             halo = self.start("halo")
-            # the status records travel beside the pair pass; they are needed only by slab_finish
-            status = None
-            if self.dist is not None and STATUS_OUT in self.t and self.world > 1:
-                status = self.dist.all_gather_into_tensor(self.t[STATUS_IN], self.t[STATUS_OUT], async_op=True)
+            status = self.gather_status()      # travels beside the pair pass
             s.slab_pairs_interior()          # cells whose stencil lies in the own layers: no halo needed
             self.finish(halo)
             s.slab_pairs()
             self.exchange("force")
             s.slab_apply()
             self.exchange("xfer")
-            if status is not None:
-                status.wait()
+            self.finish_status(status)
             s.slab_finish()
 
 

@@ -68,6 +68,8 @@ def parse_args():
                     "process and run one after the other; reports every rank's stage times and the modelled step")
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, form the process group, reduce one number and "
                     "print the line's skeleton (no GPU work): proves the --gpus N launcher on a machine without GPUs")
+    ap.add_argument("--overlap-interior", action="store_true", help="multi-GPU: a pass of its own for the cells that need no halo, "
+                    "run while the halo travels (measured slower than the single pass it splits; see DESIGN.md)")
     ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL; gloo: messages staged "
                     "through host memory, for rehearsals on one GPU)")
     return ap.parse_args()
@@ -248,7 +250,8 @@ def sim_world(args, ps, cfg_over, flags):
             for k, (name, phase) in enumerate(zip(stages, (None, "halo", "force", "xfer", None))):
                 for r, g in enumerate(ranks):
                     ev[r][k][0].record(stream)
-                    getattr(g, "slab_" + name)()
+                    if name != "pairs_interior" or args.overlap_interior:
+                        getattr(g, "slab_" + name)()
                     ev[r][k][1].record(stream)
                 if phase:
                     deliver(phase)
@@ -370,7 +373,7 @@ def main():
             # reads as "use the context's own stream": never pass it.)
             stream = torch.cuda.Stream(device=local_rank)
             assert stream.cuda_stream != 0
-            ring = DeviceRing(g, dist, rank, world, stream)
+            ring = DeviceRing(g, dist, rank, world, stream, overlap_interior=args.overlap_interior)
         else:
             ring = HostRing(g, dist, rank, world)
 

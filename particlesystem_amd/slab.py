@@ -13,8 +13,8 @@ with fixed-size messages, so the transport never negotiates a length.  This modu
 host-side plumbing only; it computes nothing.  Three transports:
 
   * ``DeviceRing``  torch.distributed P2P (RCCL over xGMI) directly on the contexts' device
-    buffers; the halo travels on RCCL's stream while the context's stream works on the cells
-    that need no halo (slab_pairs_interior), the status records beside the whole pair pass.
+    buffers; the transfers run on RCCL's stream: the status records beside the whole pair pass,
+    the halo beside the interior pass if that is asked for (overlap_interior).
   * ``HostRing``    torch.distributed P2P (gloo) through host copies of the messages: for tests,
     and for several processes that share one GPU.
   * ``step_local``  all ranks live in one process (tests): messages are copied rank to rank.
@@ -44,7 +44,7 @@ def routes(rank, world, periodic_ring=True):
     return r
 
 
-def step_local(ranks):
+def step_local(ranks, overlap_interior=False):
     """One step of a whole system whose ranks all live in this process (tests)."""
     world = len(ranks)
 
@@ -59,8 +59,9 @@ def step_local(ranks):
 
     for s in ranks:
         s.slab_build()
-    for s in ranks:
-        s.slab_pairs_interior()       # (in a real run: while the halo travels)
+    if overlap_interior:
+        for s in ranks:
+            s.slab_pairs_interior()   # (in a real run: while the halo travels)
     deliver("halo")
     if world > 1 and ranks[0].msg_bytes(STATUS_OUT):          # the "all-gather" of the status records
         every = np.concatenate([s.msg_download(STATUS_OUT) for s in ranks])
@@ -138,7 +139,6 @@ class HostRing(_Ring):
     def step(self):
         s = self.s
         s.slab_build()
-        s.slab_pairs_interior()
         self.exchange("halo")
         self.gather_status()
         s.slab_pairs()
@@ -158,8 +158,13 @@ class DeviceRing(_Ring):
     Stage kernels and collectives are ordered by ONE stream: torch's current stream, which the
     context is switched to (psamd_set_stream)."""
 
-    def __init__(self, sysr, dist, rank, world, torch_stream):
+    def __init__(self, sysr, dist, rank, world, torch_stream, overlap_interior=False):
+        """overlap_interior: run the pair stage of the cells that need no halo as a pass of its own
+        while the halo travels.  Off by default: two passes are each less well filled than one --
+        measured on one MI355X (N = 2^20, half the cloud per rank) 1.68 ms for the two against
+        1.40 ms for the single pass, far more than the ~50 us of halo transfer they would hide."""
         super().__init__(sysr, dist, rank, world)
+        self.overlap_interior = overlap_interior
         import torch
         b = sysr.slab_buffers()
         ptrs = {HALO_OUT + 0: (b.halo_out[0], b.halo_out_bytes[0]), HALO_OUT + 1: (b.halo_out[1], b.halo_out_bytes[1]),
@@ -214,7 +219,8 @@ class DeviceRing(_Ring):
             s.slab_build()
             halo = self.start("halo")
             status = self.gather_status()      # travels beside the pair pass
-            s.slab_pairs_interior()          # cells whose stencil lies in the own layers: no halo needed
+            if self.overlap_interior:
+                s.slab_pairs_interior()      # cells whose stencil lies in the own layers: no halo needed
             self.finish(halo)
             s.slab_pairs()
             self.exchange("force")

@@ -136,6 +136,21 @@ def test_slab_uneven_and_group_aligned_cuts(cuts):
         g.close()
 
 
+def test_slab_interior_pass_while_the_halo_travels():
+    """the optional split of the pair stage -- interior cells first, the rest after the halo --
+    gives the same state (4 slabs of 4 layers: two interior layers each)"""
+    n = 60000
+    xyz = cloud(n, 66)
+    rng = np.random.default_rng(66)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    ranks, o = make_world(4, xyz, age, np.float32(1e6))
+    for step in range(6):
+        step_local(ranks, overlap_interior=True); o.step(1)
+        compare_world(ranks, o, "interior pass, step %d" % (step + 1))
+    for g in ranks:
+        g.close()
+
+
 def test_slab_g2_cloud_100_steps():
     """BASELINE config 0's cloud, 100 steps on three slabs: the reference's own life-cycle
     counts come out of the union."""

@@ -4,9 +4,10 @@
  * oracle/_ref/libref_l4.so (recipe: oracle/Makefile, target `ref`).
  *
  * TEST INFRASTRUCTURE ONLY: used to pin oracle/ps_oracle.c and to generate the
- * golden vectors under tests/golden/.  Never shipped, never measured, absent on
- * the GPU box (the .so travels there only as a prebuilt checker aid; nothing in
- * the gpu tests loads it).
+ * golden vectors under tests/golden/.  Never shipped, never measured.  The GPU box
+ * has no /root/reference, so nothing is built from this file there, and no `-m gpu`
+ * test, smoke() or bench.py loads the library (tests/test_oracle_vs_ref.py, which
+ * does, runs without a GPU and skips itself where the library is absent).
  *
  * What is built: common.h, app_common.cu, app.cu (the per-particle arithmetic,
  * cell/segment index math, free-slot queues).  hipcc's host-only pass supplies

@@ -150,3 +150,37 @@ def test_repulsion_is_gravity_with_the_sign_flipped():
     a, b = f[1.0][keep, :3], f[-1.0][keep, :3]
     assert np.array_equal(a.view(np.uint32) ^ np.uint32(0x80000000), b.view(np.uint32)) or np.array_equal(-a, b)
     assert np.abs(a).max() > 0
+
+
+@pytest.mark.timeout(900)
+def test_all_pairs_at_config1_size():
+    """BASELINE configs[1]: N = 2^18, all-pairs gravity.  No CPU can re-do 6.9e10 pairs in a test,
+    so: a size-independent property -- equal masses, so the accelerations of all adults sum to
+    zero (Newton's third law; each pair's two terms differ only by rounding) -- plus 200 particles
+    against an fp64 direct sum over all 2^18 bodies (1e-5 relative, BASELINE's bar)."""
+    n = 1 << 18
+    g = ps.ParticleSystem(ps.default_config(flags=ps.FLAG_ALL_PAIRS, collision_radius=1e-6))
+    xyz = g.uniform_cloud(n, 18)
+    rng = np.random.default_rng(18)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    ids = g.fill_particles(xyz, age=age, fert_age=np.float32(1e6))
+    order, f = force_of(g, n)
+    a = f[:, :3].astype(np.float64)
+    assert (f[:, 3].view(np.int32) == 0).all()
+    net = np.linalg.norm(a.sum(0)) / np.linalg.norm(a, axis=1).sum()
+    print("all-pairs N=2^18: |sum a| / sum |a| = %.3g" % net)
+    assert net < 1e-5
+    where = np.empty(g.sizes.container_size, np.int64)
+    where[ids] = np.arange(n)
+    idx = where[order]
+    pos = xyz.astype(np.float64)
+    pick = rng.choice(n, 200, replace=False)
+    d = pos[None, :, :] - pos[idx[pick], None, :]
+    r2 = (d * d).sum(2) + 0.2
+    s = 60.0 / (r2 * np.sqrt(r2))
+    s[np.arange(200), idx[pick]] = 0.0
+    exact = (d * s[:, :, None]).sum(1)
+    rel = np.linalg.norm(a[pick] - exact, axis=1) / np.linalg.norm(exact, axis=1)
+    print("all-pairs N=2^18 vs fp64 direct sum (200 particles): max relative deviation %.3g" % rel.max())
+    assert rel.max() < 1e-5
+    g.close()

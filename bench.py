@@ -76,22 +76,28 @@ def parse_args():
 
 
 def launch_ranks(args):
-    """--gpus N without a launcher: start the ranks (fresh processes, nothing here has touched
-    the GPU), relay rank 0's JSON line, exit with the job's status."""
+    """--gpus N without a launcher: start the N ranks as fresh child processes (nothing here has
+    touched the GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as
+    torch.distributed.run would set them), relay rank 0's JSON line, exit with the job's status."""
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, PSAMD_BENCH_CHILD="1")
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PSAMD_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out = procs[0].communicate()[0]
+    codes = [p.wait() for p in procs]
+    lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
     if lines:
         print(lines[-1])
     else:
-        sys.stderr.write(p.stdout)
-    sys.exit(p.returncode if p.returncode else (0 if lines else 1))
+        sys.stderr.write(out)
+    rc = max((abs(c) for c in codes), default=0)
+    sys.exit(rc if rc else (0 if lines else 1))
 
 
 def make_inputs(sysobj, n, seed):

@@ -1308,6 +1308,10 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
         const int kend = ((P.flags & PSAMD_FLAG_ALL_PAIRS) && k1 == STENCIL) ? STENCIL + P.n_own_cells : k1;
         for (int k = k0; k < kend; k++) {
             int nb, n;
+            // a far cell's bodies are summed on their own and the cell's sum added to the particle's:
+            // an fp32 sum of a quarter of a million terms in one chain would carry 4e-5 of rounding
+            // (measured at N = 2^18); the stencil's chain is the reference's and stays as it is
+            float near_x = 0.f, near_y = 0.f, near_z = 0.f;
             if (k < STENCIL) { nb = __builtin_amdgcn_readlane(my_nb, k); n = __builtin_amdgcn_readlane(my_cnt, k); }
             else {
                 const int c2 = k - STENCIL;
@@ -1316,6 +1320,7 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
                 if (abs(j1 - i1) <= 1 && abs(j2 - i2) <= 1 && abs(j3 - i3) <= 1) continue;      // a stencil cell: done above
                 nb = __builtin_amdgcn_readfirstlane(cell_start[c2]);
                 n = __builtin_amdgcn_readfirstlane(min(cell_start[c2 + 1] - nb, P.max_per_cell));
+                near_x = ax; near_y = ay; near_z = az; ax = 0.f; ay = 0.f; az = 0.f;
             }
             const float *sx = snap_soa + nb, *sy = sx + cap, *sz = sy + cap, *sw = sz + cap;   // wave-uniform
             float dmin = 3.0e38f;
@@ -1345,6 +1350,7 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
                 else
                     dmin = fminf(dmin, pair_fast(me.x, me.y, me.z, q, eps2f, ax, ay, az) + eps2f);
             }
+            if (k >= STENCIL) { ax = near_x + ax; ay = near_y + ay; az = near_z + az; }
             // fast math, rare: someone in this cell is within the (widened) collision gate of
             // one of my lanes; the exact rule is then evaluated on unfused distances
             const float gate_soft = (P.coll_d2_gate + eps2f) * 1.0001f;
@@ -2953,22 +2959,25 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
         k_build_active<<<ncomp, 256, 0, st>>>(P, d.cell_start, d.pair_flag, d.active_list, d.active_count, d.task_cost);
         k_active_tasks<<<1, 1024, 0, st>>>(P, d.active_count, d.task_cost, d.task_list2, d.ctask_start, d.cost_start, d.merged_tasks, d.fs,
                                            packs_in_list ? 2 : merge ? 1 : 0);
+        if (merge) {
+            // fork: the packs of partly filled slices run beside the ordinary tasks (their waves
+            // stall on tile loads that the ordinary waves' arithmetic covers); the join further
+            // down puts everything that follows on `st` after both.  They need only the lists, so
+            // they start while the balanced pass is still being cut up.
+            // (The packs through the balanced pass's own four-group tile walk, as a kernel of its own
+            // here, were slower than k_pairs_merged: 2.47 against 2.32 ms for the stage.)
+            (void)hipEventRecord(d.ev_fork, st);
+            (void)hipStreamWaitEvent(d.side_stream, d.ev_fork, 0);
+            k_pairs_merged<MODE == 0 ? 1 : MODE, NQ><<<(ncomp + 3) / 4, 256, 0, d.side_stream>>>(
+                P, d.cell_start, d.snap4, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
+            (void)hipEventRecord(d.ev_join, d.side_stream);
+        }
         if (balanced) k_split_tasks<<<8 * SPLIT_SUB, 1024, 0, st>>>(P, nw, d.cell_start, d.task_cost, d.ctask_start, d.cost_start, d.wave_pos, d.fs,
                                                                     packs_in_list ? 1 : 0);
     }
     if (ev_force) (void)hipEventRecord(ev_force, st);      // timing: the force pass proper starts here
     const int *task_list = two ? d.task_list2 : d.task_list;
     const int *active_list = two ? d.active_list : nullptr, *active_count = two ? d.active_count : nullptr;
-    if (merge) {
-        // fork: the merged tasks run beside the ordinary ones (their waves stall on tile loads
-        // that the ordinary waves' arithmetic covers); the join below puts everything that
-        // follows on `st` after both
-        (void)hipEventRecord(d.ev_fork, st);
-        (void)hipStreamWaitEvent(d.side_stream, d.ev_fork, 0);
-        k_pairs_merged<MODE == 0 ? 1 : MODE, NQ><<<(ncomp + 3) / 4, 256, 0, d.side_stream>>>(
-            P, d.cell_start, d.snap4, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
-        (void)hipEventRecord(d.ev_join, d.side_stream);
-    }
     // the hand-off flags are indexed by task number, which starts at 0 in every pass of a frame:
     // each pass has its own block of them (both zeroed with the frame)
     int *task_ready = d.task_ready + (size_t)pass * P.n_local_cells * P.slices;

@@ -18,7 +18,7 @@ import numpy as np
 from . import build as _build
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpsamd.so")
+LIB_PATH = os.environ.get("PSAMD_LIB") or os.path.join(HERE, "libpsamd.so")   # PSAMD_LIB: another build, for A/B measurements
 
 MAX_RANKS = 64
 FLAG_EXPLOSIONS = 0x1

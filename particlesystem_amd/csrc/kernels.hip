@@ -620,6 +620,23 @@ __device__ __forceinline__ float inv_sqrt_selected(float six)
     return rcp_rn_newton(sqrt_rn_short(six));
 }
 
+// One transcendental instead of two: the reciprocal's Newton step starts from the rsq estimate
+// itself (r ~ 1/sqrt(a) ~ 1/s).  That is RN(1/s) for every float of the range EXCEPT where s has
+// an all-ones mantissa (1/s lies a hair above a rounding tie and the step lands on the tie: 124
+// inputs in [2^-62, 2^62]); there the residual e is exactly 2^-24, which is what `tie` reports so
+// that the caller can redo the group with inv_sqrt_selected.  Checked for every float of the
+// range by psamd_selftest_math: no mismatch that is not reported.  v_rcp_f32 costs 3.3 issue
+// slots on gfx950 (profiles/r1_microbench_valu_rates.txt), the compare one.
+__device__ __forceinline__ float inv_sqrt_guarded(float a, bool &tie)
+{
+    const float r = __builtin_amdgcn_rsqf(a);
+    const float g = a * r, h = 0.5f * r;
+    const float s = __builtin_fmaf(__builtin_fmaf(-g, g, a), h, g);
+    const float e = __builtin_fmaf(-s, r, 1.0f);
+    tie = tie || e == 0x1p-24f;
+    return __builtin_fmaf(e, r, r);
+}
+
 // A tempting shortcut that is NOT exact, kept only so the self test can show it: start
 // the reciprocal's Newton step from the rsq estimate (2h ~ 1/g) instead of a second
 // transcendental.  124 of the 1.04e9 floats in range come out one ulp off.
@@ -704,6 +721,18 @@ __device__ __forceinline__ v2f inv_sqrt_selected2(v2f six)
     return __builtin_elementwise_fma(__builtin_elementwise_fma(-s, x, one), x, x);          // rcp_rn_newton
 }
 
+// inv_sqrt_guarded on two pairs
+__device__ __forceinline__ v2f inv_sqrt_guarded2(v2f six, bool &tie)
+{
+    v2f r; r.x = __builtin_amdgcn_rsqf(six.x); r.y = __builtin_amdgcn_rsqf(six.y);
+    const v2f g = six * r, h = 0.5f * r;
+    const v2f s = __builtin_elementwise_fma(__builtin_elementwise_fma(-g, g, six), h, g);
+    const v2f one = {1.0f, 1.0f};
+    const v2f e = __builtin_elementwise_fma(-s, r, one);
+    tie = tie || e.x == 0x1p-24f || e.y == 0x1p-24f;
+    return __builtin_elementwise_fma(e, r, r);
+}
+
 // NQ pairs in two stages, so that a caller can start fetching the next group's bodies
 // between them: distances first (the only use of the positions), then everything else.
 template <int NQ>
@@ -759,8 +788,20 @@ __device__ __forceinline__ void pairs_finish_exact(const DevParams &P, const Pai
         for (int i = 0; i < H; i++) e[i] = r.d[i] + eps;
     }
     v2f sc[H];
+#if defined(PSAMD_TWO_TRANSCENDENTALS)
 #pragma unroll
     for (int i = 0; i < H; i++) sc[i] = qw[i] * inv_sqrt_selected2(e[i] * e[i] * e[i]);
+#else
+    bool tie = false;
+#pragma unroll
+    for (int i = 0; i < H; i++) sc[i] = inv_sqrt_guarded2(e[i] * e[i] * e[i], tie);
+    if (__any(tie)) {                                   // about once in 2^23 pairs
+#pragma unroll
+        for (int i = 0; i < H; i++) sc[i] = inv_sqrt_selected2(e[i] * e[i] * e[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < H; i++) sc[i] = qw[i] * sc[i];
+#endif
 #pragma unroll
     for (int i = 0; i < H; i++) {                       // sums in list order
         const v2f px = r.rx[i] * sc[i], py = r.ry[i] * sc[i], pz = r.rz[i] * sc[i];
@@ -2659,14 +2700,15 @@ __global__ void k_outbox_header(int *__restrict__ msg_down, int *__restrict__ ms
 // Compare the hand-written sqrt / reciprocal with the compiler's correctly rounded forms
 // on every float whose bit pattern lies in [lo_bits, hi_bits].  out[0..3] = mismatch
 // counts of sqrt_rn_short, rcp_rn_newton, their composition (what the pair kernel uses)
-// and of the rejected one-transcendental shortcut; out[8..15] / out[16..23] = first
+// and of the rejected one-transcendental shortcut; out[4] = mismatches of inv_sqrt_guarded that it
+// did not report, out[5] = inputs it reported; out[8..15] / out[16..23] = first
 // offending inputs of sqrt / composition; out[24], out[25] = cursors.
 __global__ void k_selftest_math(uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out)
 {
     const uint64_t span = (uint64_t)hi_bits - lo_bits + 1;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    unsigned long long bad[4] = {0, 0, 0, 0};
+    unsigned long long bad[6] = {0, 0, 0, 0, 0, 0};
     for (; i < span; i += stride) {
         const float a = __uint_as_float(lo_bits + (uint32_t)i);
         const float s_ref = sqrtf(a), r_ref = 1.0f / a, c_ref = 1.0f / s_ref;
@@ -2682,8 +2724,12 @@ __global__ void k_selftest_math(uint32_t lo_bits, uint32_t hi_bits, unsigned lon
             if (k < 8) out[16 + k] = __float_as_uint(a);
         }
         if (__float_as_uint(inv_sqrt_one_transcendental(a)) != __float_as_uint(c_ref)) bad[3]++;
+        bool tie = false;
+        const float gq = inv_sqrt_guarded(a, tie);
+        if (tie) bad[5]++;
+        else if (__float_as_uint(gq) != __float_as_uint(c_ref)) bad[4]++;
     }
-    for (int k = 0; k < 4; k++) if (bad[k]) atomicAdd(&out[k], bad[k]);
+    for (int k = 0; k < 6; k++) if (bad[k]) atomicAdd(&out[k], bad[k]);
 }
 
 // out[0] += number of floats x with bits in [lo_bits, hi_bits] for which the fp32 add of

@@ -26,4 +26,7 @@ def test_lean_sqrt_and_rcp_are_correctly_rounded_everywhere_in_range():
     assert out[1] == 0, "rcp_rn_newton differs from the correctly rounded 1/x"
     assert out[2] == 0, "the pair kernel's 1/sqrt differs from RN(1/RN(sqrt x))"
     assert out[3] > 0, "the rejected shortcut is expected to miss some inputs (documented in DESIGN.md)"
+    print("one-transcendental form with the tie report: unreported mismatches %d, reported inputs %d" % (out[4], out[5]))
+    assert out[4] == 0, "inv_sqrt_guarded returned a wrong value without reporting the tie"
+    assert 0 < out[5] < 100000, "the tie report must be rare (it sends the wave through the two-transcendental form)"
     g.close()

@@ -759,7 +759,11 @@ __device__ __forceinline__ void pairs_dist(const PairCtx &c, const v2f (&qx)[NQ 
     }
 }
 
-template <int NQ>
+// ONE_T: one transcendental per pair (inv_sqrt_guarded2) -- fewer issue slots, for passes that are
+// throughput-bound (four or more waves per SIMD: -3.7 % on the N = 2^20 force pass); the two-
+// transcendental form has the shorter dependency chain and wins where a SIMD holds one or two waves
+// (a 1/8 slab's tile walk: 0.57 against 0.64 ms).
+template <int NQ, bool ONE_T>
 __device__ __forceinline__ void pairs_finish_exact(const DevParams &P, const PairCtx &c, const PairRows<NQ> &r,
                                                    const v2f (&qw)[NQ / 2], int gj0,
                                                    const float *__restrict__ snap_age,
@@ -788,20 +792,20 @@ __device__ __forceinline__ void pairs_finish_exact(const DevParams &P, const Pai
         for (int i = 0; i < H; i++) e[i] = r.d[i] + eps;
     }
     v2f sc[H];
-#if defined(PSAMD_TWO_TRANSCENDENTALS)
+    if (!ONE_T) {
 #pragma unroll
-    for (int i = 0; i < H; i++) sc[i] = qw[i] * inv_sqrt_selected2(e[i] * e[i] * e[i]);
-#else
-    bool tie = false;
+        for (int i = 0; i < H; i++) sc[i] = qw[i] * inv_sqrt_selected2(e[i] * e[i] * e[i]);
+    } else {
+        bool tie = false;
 #pragma unroll
-    for (int i = 0; i < H; i++) sc[i] = inv_sqrt_guarded2(e[i] * e[i] * e[i], tie);
-    if (__any(tie)) {                                   // about once in 2^23 pairs
+        for (int i = 0; i < H; i++) sc[i] = inv_sqrt_guarded2(e[i] * e[i] * e[i], tie);
+        if (__any(tie)) {                               // about one group in 500
 #pragma unroll
-        for (int i = 0; i < H; i++) sc[i] = inv_sqrt_selected2(e[i] * e[i] * e[i]);
+            for (int i = 0; i < H; i++) sc[i] = inv_sqrt_selected2(e[i] * e[i] * e[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < H; i++) sc[i] = qw[i] * sc[i];
     }
-#pragma unroll
-    for (int i = 0; i < H; i++) sc[i] = qw[i] * sc[i];
-#endif
 #pragma unroll
     for (int i = 0; i < H; i++) {                       // sums in list order
         const v2f px = r.rx[i] * sc[i], py = r.ry[i] * sc[i], pz = r.rz[i] * sc[i];
@@ -829,7 +833,7 @@ __device__ __forceinline__ void pairs_finish_fast(const PairRows<NQ> &r, const v
     }
 }
 
-template <int NQ>
+template <int NQ, bool ONE_T = true>
 __device__ __forceinline__ void pairsN_exact_lean(const DevParams &P, const PairCtx &c, const v2f (&qx)[NQ / 2],
                                                   const v2f (&qy)[NQ / 2], const v2f (&qz)[NQ / 2],
                                                   const v2f (&qw)[NQ / 2], int gj0,
@@ -839,7 +843,7 @@ __device__ __forceinline__ void pairsN_exact_lean(const DevParams &P, const Pair
 {
     PairRows<NQ> r;
     pairs_dist<NQ, false>(c, qx, qy, qz, 0.f, r);
-    pairs_finish_exact<NQ>(P, c, r, qw, gj0, snap_age, sorted_id, ax, ay, az, flag);
+    pairs_finish_exact<NQ, ONE_T>(P, c, r, qw, gj0, snap_age, sorted_id, ax, ay, az, flag);
 }
 
 // returns the smallest softened squared distance (d2 + eps2) of the group, for the collision gate
@@ -1528,7 +1532,7 @@ struct TileGroups {
 };
 
 // NG: how many groups the code is built for (1: an ordinary task, nothing per-group left in it; 4: a pack)
-template <int MODE, int NQ, int NG>
+template <int MODE, int NQ, int NG, bool ONE_T>
 __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *__restrict__ cell_start,
                                                 const float4 *__restrict__ snap4, float4 *__restrict__ force4,
                                                 const TileGroups &G, float *tile, const int *__restrict__ active_list,
@@ -1629,7 +1633,7 @@ __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *_
                 qw[i] = v2f{vw.x, vw.y}; qw[i + 1] = v2f{vw.z, vw.w};
             }
             if (MODE == 1)
-                pairsN_exact_lean<NQ>(P, ctx, qx, qy, qz, qw, 0, nullptr, nullptr, ax, ay, az, flag);
+                pairsN_exact_lean<NQ, ONE_T>(P, ctx, qx, qy, qz, qw, 0, nullptr, nullptr, ax, ay, az, flag);
             else
                 dmin = fminf(dmin, pairsN_fast<NQ>(ctx, qx, qy, qz, qw, eps2f, ax, ay, az));
         }
@@ -1706,8 +1710,8 @@ __global__ __launch_bounds__(256) void k_pairs_balanced(DevParams P, const int *
                     if (on) G.ng = q + 1;
                 }
             }
-            if (t < nord) pairs_task_tile<MODE, NQ, 1>(P, cell_start, snap4, force4, G, tiles[TILES ? wave : 0], active_list, k0, k1, task_ready + t, fs);
-            else pairs_task_tile<MODE, NQ, 4>(P, cell_start, snap4, force4, G, tiles[TILES ? wave : 0], active_list, k0, k1, task_ready + t, fs);
+            if (t < nord) pairs_task_tile<MODE, NQ, 1, WALK != 1>(P, cell_start, snap4, force4, G, tiles[TILES ? wave : 0], active_list, k0, k1, task_ready + t, fs);
+            else pairs_task_tile<MODE, NQ, 4, WALK != 1>(P, cell_start, snap4, force4, G, tiles[TILES ? wave : 0], active_list, k0, k1, task_ready + t, fs);
         } else
             pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, task_list[t], nullptr, trace,
                                  active_list, active_count, k0, k1, task_ready + t, fs);

@@ -60,9 +60,9 @@ __global__ __launch_bounds__(256) void k(float *out, float seed, unsigned long l
 }
 
 template <int OP, int LANES = 64>
-int run(const char *name, int per_iter, float *out, unsigned long long *clk)
+int run(const char *name, int per_iter, float *out, unsigned long long *clk, int waves_per_simd = 8)
 {
-    const int blocks = 256 * 8, threads = 256;   // 8 waves per SIMD
+    const int blocks = 256 * waves_per_simd, threads = 256;   // one 256-thread workgroup = one wave on each SIMD of a CU
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     k<OP, LANES><<<blocks, threads>>>(out, 1.0001f, clk);
@@ -106,5 +106,12 @@ int main()
     run<0, 16>("v_fma_f32, 16 lanes active", 8, out, clk);
     run<11, 32>("v_pk_fma_f32, 32 lanes active", 4, out, clk);
     run<3, 32>("v_rsq_f32, 32 lanes active", 8, out, clk);
+    // how fast can ONE wave issue (8 independent chains each)?  waves per SIMD = 1, 2, 3, 4
+    for (int w = 1; w <= 4; w++) {
+        char name[64];
+        snprintf(name, sizeof name, "v_fma_f32, %d wave(s)/SIMD", w); run<0>(name, 8, out, clk, w);
+        snprintf(name, sizeof name, "v_pk_fma_f32, %d wave(s)/SIMD", w); run<11>(name, 4, out, clk, w);
+        snprintf(name, sizeof name, "v_rsq_f32, %d wave(s)/SIMD", w); run<3>(name, 8, out, clk, w);
+    }
     return 0;
 }

@@ -436,6 +436,22 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.snap_age, SC));
     PS_HIP(c, dev_alloc(c, &d.force4, SC));
     PS_HIP(c, dev_alloc(c, &d.celltab, (size_t)g.num_cells));
+    if (P.world == 1) {                                  // the chunk lists' capacity rule (k_chunk_cap)
+        PS_HIP(c, dev_alloc(c, &d.chunk_skip, C));
+        PS_HIP(c, dev_alloc(c, &d.chunk_segs, (size_t)g.num_chunks * 27));
+        std::vector<int2> segs((size_t)g.num_chunks * 27);
+        for (int ch = 0; ch < g.num_chunks; ch++) {
+            Pair pk[27];
+            g.chunk_segments(ch, pk);
+            for (int j = 0; j < 27; j++) {
+                const int k = seg_index(pk[j].c);
+                segs[(size_t)ch * 27 + j] = make_int2(g.seg_base[k] + pk[j].p * g.seg_size_t[k], g.seg_size_t[k]);
+            }
+            for (int j = 1; j < 27; j++)
+                if (segs[(size_t)ch * 27 + j].x <= segs[(size_t)ch * 27 + j - 1].x) return fail(c, PSAMD_ERR_STATE, "chunk segment table is not in slot order");
+        }
+        PS_HIP(c, hipMemcpy(d.chunk_segs, segs.data(), segs.size() * sizeof(int2), hipMemcpyHostToDevice));
+    }
     PS_HIP(c, dev_alloc(c, &d.op_keys, (size_t)d.ops_cap));
     PS_HIP(c, dev_alloc(c, &d.op_keys_sorted, (size_t)d.ops_cap));
     PS_HIP(c, dev_alloc(c, &d.op_args, (size_t)d.ops_cap));

@@ -171,7 +171,7 @@ struct FrameScalars {
     int32_t n_merged;       // ... and merged tasks (up to four cells' partly filled last slices in one wave)
     int32_t n_out[2];       // slab mode: relocation / birth records leaving for the rank below [0] / above [1]
     int32_t n_lent;         // slab mode: bodies in the lent-in region this frame
-    int32_t pad_i;
+    int32_t chunk_over;     // a chunk's count passed MAX_PARTICLES_PER_CHUNK this frame: the tail of its list is skipped (k_chunk_cap)
     long long cost_total;   // two-pass mode: sum over the force pass's tasks of the bodies each walks (its stencil's population)
 };
 

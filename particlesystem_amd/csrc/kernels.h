@@ -30,6 +30,8 @@ struct DeviceState {
     // per-frame grid
     int *cell_count = nullptr;    // [num_cells]   \ zeroed together
     int *chunk_count = nullptr;   // [num_chunks]  / by init_iframe
+    uint8_t *chunk_skip = nullptr;   // [slots] 1: not in its chunk's (capped) list this frame; valid for the slots of over-cap chunks only
+    int2 *chunk_segs = nullptr;      // [num_chunks * 27] (first slot, slots) of the segments a chunk's particles live in, in slot order
     FrameScalars *fs = nullptr;
     int *cell_start = nullptr;    // [num_cells+1]
     int *cursor = nullptr;        // [num_cells]

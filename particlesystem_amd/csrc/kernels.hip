@@ -373,8 +373,49 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
     if (cm > 0) atomicMax(&fs->gridmax[0], cm);
     // The reference stores only MAX_PARTICLES_PER_CHUNK ids per chunk and calc_forces walks the
     // stored list (ps.cpp:1502-1508): past that (only possible while cells overflow, the count
-    // includes the killed) its tail would be skipped.  Not reproduced: refuse loudly instead.
-    if (over) atomicOr(&fs->error, ERR_CHUNK_CAP);
+    // includes the killed) the tail of the chunk's slot-ordered list is not processed that step.
+    // One GPU: k_chunk_cap marks that tail and k_apply leaves it alone.  A slab holds only part
+    // of a boundary chunk's slots and cannot rank them: refuse loudly there.
+    if (over) {
+        if (P.world == 1) fs->chunk_over = 1;
+        else atomicOr(&fs->error, ERR_CHUNK_CAP);
+    }
+}
+
+// The chunk lists' capacity (ps.cpp:1502-1508): build_grid walks the slots in order and appends
+// a live particle to the list of the chunk of its cell only while that list holds fewer than
+// MAX_PARTICLES_PER_CHUNK ids (the ones the cell-overflow rule kills a moment later included);
+// calc_forces walks the stored lists, so a particle ranked at or past the capacity among its
+// chunk's particles in slot order is not aged, collided or integrated that step (others still
+// meet it as a neighbour: it is in its cell's list and in T_DATA).  One workgroup per chunk, at
+// work only if the chunk's count passed the capacity: it walks the chunk's 27 segments (the
+// only slots that can hold its particles) in slot order and writes chunk_skip for every
+// particle of the chunk.  Runs before k_sort_cells resets the slots of overflowing cells.
+__global__ __launch_bounds__(1024) void k_chunk_cap(DevParams P, const int *__restrict__ chunk_count,
+                                                    const int *__restrict__ cell_arr, const CellInfo *__restrict__ celltab,
+                                                    const int2 *__restrict__ chunk_segs, uint8_t *__restrict__ chunk_skip)
+{
+    __shared__ int wave_tot[16];
+    const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (chunk_count[ch] <= P.max_per_chunk) return;
+    int run = 0;                                          // particles of the chunk in the slots before the current batch
+    for (int sgi = 0; sgi < 27; sgi++) {
+        const int2 sg = chunk_segs[ch * 27 + sgi];
+        for (int b = 0; b < sg.y; b += 1024) {
+            const int slot = sg.x + b + tid;
+            int c = -1;
+            if (b + tid < sg.y) c = cell_arr[slot_index(P, slot)];
+            const bool in = c >= 0 && c < P.num_cells_global && celltab[c].chunk == ch;
+            const unsigned long long m = __ballot(in);
+            if (lane == 0) wave_tot[wv] = __popcll(m);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int k = 0; k < 16; k++) { if (k < wv) before += wave_tot[k]; total += wave_tot[k]; }
+            if (in) chunk_skip[slot_index(P, slot)] = (run + before + __popcll(m & ((1ull << lane) - 1ull))) >= P.max_per_chunk ? 1 : 0;
+            run += total;
+            __syncthreads();
+        }
+    }
 }
 
 // the pair kernel's work list: one entry per non-empty (cell, 64-particle slice) of the own
@@ -1875,6 +1916,7 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
                                                 uint64_t *op_keys, int *op_args, int ops_cap,
                                                 MoveRec *moves, int moves_cap,
                                                 XferRec *out_down, XferRec *out_up,
+                                                const int *__restrict__ chunk_count, const uint8_t *__restrict__ chunk_skip,
                                                 FrameScalars *fs, DevCounters *ctr)
 {
     __shared__ int s_ops, s_moves, s_base_ops, s_base_moves;
@@ -1884,7 +1926,9 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
     int old_cell = -1;
     if (si < P.slots_total) old_cell = cell_arr[si];
     // free slots (and the ones the cell-overflow rule just killed) have cell == -1
-    const bool active = old_cell >= 0 && old_cell < P.num_cells_global;
+    bool active = old_cell >= 0 && old_cell < P.num_cells_global;
+    // a particle past the capacity of its chunk's list is not in calc_forces' loop (k_chunk_cap)
+    if (fs->chunk_over && active && chunk_count[celltab[old_cell].chunk] > P.max_per_chunk && chunk_skip[si]) active = false;
     if (!__syncthreads_or(active)) return;                        // nothing alive in this workgroup
     const int id = active ? slot_of_index(P, si) : 0;             // slot == particle id
     const int gi = active ? rank_of_slot[si] : 0;
@@ -2889,6 +2933,8 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     if (ev) (void)hipEventRecord(ev[1], st);
     k_scan<<<1, 1024, 0, st>>>(P, d.cell_count, d.cell_start, d.cursor, d.task_start, d.chunk_count, d.celltab, d.fs);
     PS_LAUNCH_CHECK();
+    if (P.world == 1) k_chunk_cap<<<P.num_chunks, 1024, 0, st>>>(P, d.chunk_count, d.cell, d.celltab, d.chunk_segs, d.chunk_skip);
+    PS_LAUNCH_CHECK();
     if (P.own_comp1 > P.own_comp0) k_build_tasks<<<(P.own_comp1 - P.own_comp0 + 255) / 256, 256, 0, st>>>(P, d.task_start, d.task_list);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[2], st);
@@ -3059,7 +3105,7 @@ hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, 
     if (P.slots_total <= 0) return hipSuccess;
     k_apply<<<(P.slots_total + 1023) / 1024, 1024, 0, st>>>(P, S, step, d.rank_of_slot, d.force4, d.pos4,
                                                       d.vel4, d.acc4, d.cell, d.pflags, d.celltab, d.op_keys, d.op_args, d.ops_cap,
-                                                      d.moves, d.moves_cap, d.xfer_out[0], d.xfer_out[1], d.fs, d.ctr);
+                                                      d.moves, d.moves_cap, d.xfer_out[0], d.xfer_out[1], d.chunk_count, d.chunk_skip, d.fs, d.ctr);
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }

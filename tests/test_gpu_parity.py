@@ -168,6 +168,38 @@ def test_cell_overflow_rule():
     compare_all(g, o, "overflow step 2")
 
 
+def test_chunk_list_capacity_rule():
+    """More particles in one chunk than its list holds (MAX_PARTICLES_PER_CHUNK = 64 cells x 4 here;
+    only possible while cells overflow, the count includes the ones the overflow rule kills):
+    build_grid stores the first 256 ids in slot order and calc_forces walks the stored list
+    (ps.cpp:1502-1508), so the tail is neither aged nor collided nor moved that step."""
+    over = {"max_particles_num": 4096}
+    cfg = ps.default_config(**over)
+    G, cs = cfg.chunk_factor * cfg.chunk_dim, cfg.cell_size
+    rng = np.random.default_rng(5)
+    pts = []
+    for i3 in range(4, 8):                 # chunk (1,1,1): 4 particles in its interior cells, more towards its corners
+        for i1 in range(4, 8):
+            for i2 in range(4, 8):
+                k = {0: 4, 1: 6, 2: 7, 3: 9}[sum(v in (4, 7) for v in (i1, i2, i3))]
+                for _ in range(k):
+                    u = rng.uniform(0.05, 0.95, 3)
+                    pts.append(((i2 - G / 2 + u[0]) * cs, -(i1 - G / 2 + u[1]) * cs, -(i3 - G / 2 + u[2]) * cs))
+    rest = cloud(1500, 23)                 # ordinary traffic elsewhere (the segments around the chunk are full)
+    idx = np.floor(rest.astype(np.float64) * [1, -1, -1] / cs).astype(int) + G // 2
+    rest = rest[~((idx >= 2) & (idx <= 9)).all(1)]
+    xyz = np.concatenate([np.array(pts, np.float32), rest])
+    age = np.random.default_rng(6).uniform(2.2, 7.0, len(xyz)).astype(np.float32)
+    g, o = make_pair(xyz, age=age, fert=1e6, **over)
+    for k in range(4):
+        g.step(1); o.step(1)
+        if k == 0:
+            assert o.chunkgrid[:, 0].max() > o.d.max_per_chunk, "the scenario must pass the chunk list's capacity"
+            assert g.gridmax()[0] == o.d.max_per_chunk
+        compare_all(g, o, "chunk capacity step %d" % (k + 1))
+    assert o.counters["cell_overflow_kills"] > 100 and o.counters["integrated"] > 0
+
+
 def test_small_grids_and_empty():
     for over, n in (({"chunk_factor": 1, "chunk_dim": 3, "max_particles_num": 200}, 150),
                     ({"chunk_factor": 2, "chunk_dim": 3, "max_particles_num": 2000}, 1500),

@@ -225,3 +225,30 @@ def test_slab_message_overflow_is_loud():
             g.synchronize()
     for g in ranks:
         g.close()
+
+
+def test_slab_refuses_a_chunk_past_its_list_capacity():
+    """The chunk lists' capacity rule (ps.cpp:1502-1508; one GPU: test_gpu_parity's
+    test_chunk_list_capacity_rule) needs the rank of a particle among ALL slots of its chunk; a
+    slab holds only part of a boundary chunk's segments, so it refuses loudly instead."""
+    over = {"max_particles_num": 4096}
+    cfg = ps.default_config(**over)
+    G, cs = cfg.chunk_factor * cfg.chunk_dim, cfg.cell_size
+    rng = np.random.default_rng(5)
+    pts = []
+    for i3 in range(4, 8):
+        for i1 in range(4, 8):
+            for i2 in range(4, 8):
+                for _ in range({0: 4, 1: 6, 2: 7, 3: 9}[sum(v in (4, 7) for v in (i1, i2, i3))]):
+                    u = rng.uniform(0.05, 0.95, 3)
+                    pts.append(((i2 - G / 2 + u[0]) * cs, -(i1 - G / 2 + u[1]) * cs, -(i3 - G / 2 + u[2]) * cs))
+    xyz = np.array(pts, np.float32)
+    ranks = [ps.ParticleSystem(ps.default_config(rank=r, world=2, **over)) for r in range(2)]
+    for g in ranks:
+        g.fill_particles(xyz, age=np.float32(3.0), fert_age=np.float32(1e6))
+    with pytest.raises(ps.PsamdError, match="MAX_PARTICLES_PER_CHUNK"):
+        step_local(ranks)
+        for g in ranks:
+            g.synchronize()
+    for g in ranks:
+        g.close()

@@ -230,7 +230,7 @@ constexpr int SORT_MAX = 4096;   // ids one cell may hold for the in-LDS ranking
 constexpr int REPLAY_CHUNK = 2048;   // queue ops staged through LDS at a time
 constexpr int QUEUE_WINDOW = 6144;   // largest segment (slots) whose queue is replayed in LDS
 constexpr int BUCKET_MAX = 4096;     // ops per segment the one-workgroup fast replay sorts in LDS (52 KB)
-constexpr int MAX_PAIR_WAVES = 6144;    // wave slots of the balanced force pass: 256 CUs x 4 SIMDs x 6 resident waves (78 VGPRs)
+constexpr int MAX_PAIR_WAVES = 12288;    // wave slots of the balanced force pass: 256 CUs x 4 SIMDs x 6 resident waves (78 VGPRs)
 constexpr int STENCIL = 27;          // cells a particle's force walk visits, in the reference's order (app.cu:370-409)
 constexpr int HALO_CAP = 768;        // collision candidates one cell can list from its neighbours (else: full stencil)
 

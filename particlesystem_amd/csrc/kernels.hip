@@ -839,7 +839,12 @@ __device__ __forceinline__ void pairs_finish_exact(const DevParams &P, const Pai
     } else {
         bool tie = false;
 #pragma unroll
-        for (int i = 0; i < H; i++) sc[i] = inv_sqrt_guarded2(e[i] * e[i] * e[i], tie);
+        for (int i = 0; i < H; i++) {
+            sc[i] = inv_sqrt_guarded2(e[i] * e[i] * e[i], tie);
+            // (keeps the step's last fma above the branch: sunk below it, its operands -- 16 VGPRs --
+            // stay live across the branch and the kernel drops from 6 to 5 waves per SIMD)
+            asm volatile("" : "+v"(sc[i]));
+        }
         if (__any(tie)) {                               // about one group in 500
 #pragma unroll
             for (int i = 0; i < H; i++) sc[i] = inv_sqrt_selected2(e[i] * e[i] * e[i]);
@@ -874,7 +879,12 @@ __device__ __forceinline__ void pairs_finish_fast(const PairRows<NQ> &r, const v
     }
 }
 
-template <int NQ, bool ONE_T = true>
+#if defined(PSAMD_TWO_TRANSCENDENTALS)      // (A/B builds)
+constexpr bool ONE_T_DEFAULT = false;
+#else
+constexpr bool ONE_T_DEFAULT = true;
+#endif
+template <int NQ, bool ONE_T = ONE_T_DEFAULT>
 __device__ __forceinline__ void pairsN_exact_lean(const DevParams &P, const PairCtx &c, const v2f (&qx)[NQ / 2],
                                                   const v2f (&qy)[NQ / 2], const v2f (&qz)[NQ / 2],
                                                   const v2f (&qw)[NQ / 2], int gj0,
@@ -1698,7 +1708,7 @@ __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *_
 //      1: tile walk for everything, packs of partial slices included (few waves per SIMD);
 //      2: scalar-load walk for the ordinary tasks, tile walk for the packs, all in one balanced list.
 template <int MODE, int NQ, int WALK>
-__global__ __launch_bounds__(256) void k_pairs_balanced(DevParams P, const int *__restrict__ cell_start,
+__global__ __launch_bounds__(256, WALK == 0 ? 6 : 4) void k_pairs_balanced(DevParams P, const int *__restrict__ cell_start,
                                                         const float4 *__restrict__ snap4,
                                                         const float *__restrict__ snap_soa,
                                                         const float *__restrict__ snap_age,
@@ -1770,7 +1780,7 @@ __global__ __launch_bounds__(256) void k_pairs_balanced(DevParams P, const int *
 // on its own (different register budget from k_pairs).
 
 template <int MODE, int NQ>
-__global__ __launch_bounds__(256) void k_pairs_merged(DevParams P, const int *__restrict__ cell_start,
+__global__ __launch_bounds__(256, 6) void k_pairs_merged(DevParams P, const int *__restrict__ cell_start,
                                                       const float4 *__restrict__ snap4,
                                                       const int *__restrict__ active_list,
                                                       const int *__restrict__ active_count,

@@ -308,6 +308,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
+    # the host driver of this pool only supports dmabuf IPC (RCCL between processes needs it); set before HIP loads
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     if args.launch_check:
         import torch.distributed as dist

@@ -1297,9 +1297,8 @@ static int snapshot_copy(psamd_ctx *c, bool save)
         PS_HIP(c, hipMemcpyAsync(s_qinfo, c->d.qinfo, (size_t)c->geo.queue_infos * sizeof(QueueInfo), hipMemcpyDeviceToDevice, c->stream));
         PS_HIP(c, hipMemcpyAsync(s_queue, c->d.queue, C * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
     } else {
-        PS_HIP(c, launch_restore(c->stream, (int)C, s_pos, s_vel, s_acc, s_cell, s_flags, c->d));
-        PS_HIP(c, hipMemcpyAsync(c->d.qinfo, s_qinfo, (size_t)c->geo.queue_infos * sizeof(QueueInfo), hipMemcpyDeviceToDevice, c->stream));
-        PS_HIP(c, hipMemcpyAsync(c->d.queue, s_queue, C * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+        PS_HIP(c, launch_restore(c->stream, (int)C, s_pos, s_vel, s_acc, s_cell, s_flags, s_queue, s_qinfo,
+                                 (int)((size_t)c->geo.queue_infos * sizeof(QueueInfo) / sizeof(int)), c->d));
     }
     return PSAMD_OK;
 }

@@ -88,7 +88,8 @@ hipError_t launch_place(hipStream_t st, const DevParams &P, int n, const int *id
                         const int *cells, const DeviceState &d);
 hipError_t launch_fill_int(hipStream_t st, int *p, int v, size_t n);
 hipError_t launch_restore(hipStream_t st, int n, const void *s_pos, const void *s_vel, const void *s_acc,
-                          const void *s_cell, const void *s_flags, const DeviceState &d);
+                          const void *s_cell, const void *s_flags, const void *s_queue, const void *s_qinfo, int qinfo_words,
+                          const DeviceState &d);
 hipError_t launch_validate_eps(hipStream_t st, uint32_t lo_bits, uint32_t hi_bits, double eps2, float eps2f,
                                unsigned long long *out);
 hipError_t launch_selftest_math(hipStream_t st, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out24);

@@ -148,14 +148,18 @@ __global__ void k_place(DevParams P, int n, const int *__restrict__ ids, const f
 }
 
 // snapshot_restore: a slot that is free both now and in the snapshot holds the same
-// (all-zero) record in both, so only slots occupied on either side are copied
+// (all-zero) record in both, so only slots occupied on either side are copied; the queue array
+// (one word per slot) and the QUEUE_INFO records ride along in the same launch
 __global__ void k_restore(int n, const float4 *__restrict__ s_pos, const float4 *__restrict__ s_vel,
                           const float4 *__restrict__ s_acc, const int *__restrict__ s_cell,
-                          const uint8_t *__restrict__ s_flags,
-                          float4 *pos4, float4 *vel4, float4 *acc4, int *cell, uint8_t *pflags)
+                          const uint8_t *__restrict__ s_flags, const int *__restrict__ s_queue,
+                          const int *__restrict__ s_qinfo, int qinfo_words,
+                          float4 *pos4, float4 *vel4, float4 *acc4, int *cell, uint8_t *pflags, int *queue, int *qinfo)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < qinfo_words) qinfo[i] = s_qinfo[i];
     if (i >= n) return;
+    queue[i] = s_queue[i];
     const int cs = s_cell[i];
     if (cs < 0 && cell[i] < 0) return;
     pos4[i] = s_pos[i]; vel4[i] = s_vel[i]; acc4[i] = s_acc[i];
@@ -163,11 +167,14 @@ __global__ void k_restore(int n, const float4 *__restrict__ s_pos, const float4 
 }
 
 hipError_t launch_restore(hipStream_t st, int n, const void *s_pos, const void *s_vel, const void *s_acc,
-                          const void *s_cell, const void *s_flags, const DeviceState &d)
+                          const void *s_cell, const void *s_flags, const void *s_queue, const void *s_qinfo, int qinfo_words,
+                          const DeviceState &d)
 {
-    k_restore<<<(n + 255) / 256, 256, 0, st>>>(n, (const float4 *)s_pos, (const float4 *)s_vel, (const float4 *)s_acc,
-                                              (const int *)s_cell, (const uint8_t *)s_flags, d.pos4, d.vel4, d.acc4,
-                                              d.cell, d.pflags);
+    const int threads = std::max(n, qinfo_words);
+    k_restore<<<(threads + 255) / 256, 256, 0, st>>>(n, (const float4 *)s_pos, (const float4 *)s_vel, (const float4 *)s_acc,
+                                                    (const int *)s_cell, (const uint8_t *)s_flags, (const int *)s_queue,
+                                                    (const int *)s_qinfo, qinfo_words, d.pos4, d.vel4, d.acc4,
+                                                    d.cell, d.pflags, d.queue, (int *)d.qinfo);
     return hipGetLastError();
 }
 

@@ -1924,6 +1924,17 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 // as (key, arg) queue operations and MoveRec records and replayed afterwards.  A particle
 // (or a child) whose new segment belongs to a neighbour rank leaves through the outbox:
 // that rank's queue hands out its slot, in the same serial order.
+// What one slot's update leaves for the list-writing phase of k_apply.
+struct ApplyEmit {
+    int id, new_cell, new_rec, old_chunk;
+    unsigned bits;          // 1 killed, 2 born, 4 relocate, 8 remote, 16 up
+};
+
+// ITEMS slots per thread (item `it` of workgroup b is slot (b * ITEMS + it) * 1024 + tid: coalesced).
+// Measured on the full N = 2^20 container: 1 / 2 / 4 slots per thread 44 / 55 / 50 us, and 256-thread
+// workgroups 71 us -- neither the per-workgroup list reservation (one same-address atomic each) nor
+// the workgroup count is what bounds it; one slot per thread in 1024-thread workgroups stays.
+template <int ITEMS>
 __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int step,
                                                 const int *__restrict__ rank_of_slot,
                                                 const float4 *__restrict__ force4,
@@ -1938,23 +1949,39 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
 {
     __shared__ int s_ops, s_moves, s_base_ops, s_base_moves;
     __shared__ unsigned int s_cnt[4];
-    const int si = blockIdx.x * blockDim.x + threadIdx.x;       // storage index of the slot
     if (threadIdx.x == 0) { s_ops = 0; s_moves = 0; s_cnt[0] = s_cnt[1] = s_cnt[2] = s_cnt[3] = 0; }
-    int old_cell = -1;
-    if (si < P.slots_total) old_cell = cell_arr[si];
-    // free slots (and the ones the cell-overflow rule just killed) have cell == -1
-    bool active = old_cell >= 0 && old_cell < P.num_cells_global;
-    // a particle past the capacity of its chunk's list is not in calc_forces' loop (k_chunk_cap)
-    if (fs->chunk_over && active && chunk_count[celltab[old_cell].chunk] > P.max_per_chunk && chunk_skip[si]) active = false;
-    if (!__syncthreads_or(active)) return;                        // nothing alive in this workgroup
-    const int id = active ? slot_of_index(P, si) : 0;             // slot == particle id
-    const int gi = active ? rank_of_slot[si] : 0;
+    const int chunk_over = fs->chunk_over;
+    int old_cells[ITEMS];
+    bool any_active = false;
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const int si = (blockIdx.x * ITEMS + it) * 1024 + (int)threadIdx.x;       // storage index of the slot
+        int oc = -1;
+        if (si < P.slots_total) oc = cell_arr[si];
+        // free slots (and the ones the cell-overflow rule just killed) have cell == -1
+        bool act = oc >= 0 && oc < P.num_cells_global;
+        // a particle past the capacity of its chunk's list is not in calc_forces' loop (k_chunk_cap)
+        if (chunk_over && act && chunk_count[celltab[oc].chunk] > P.max_per_chunk && chunk_skip[si]) act = false;
+        old_cells[it] = act ? oc : -1;
+        any_active |= act;
+    }
+    if (!__syncthreads_or(any_active)) return;                    // nothing alive in this workgroup
+
+    ApplyEmit em[ITEMS];
+    int n_op = 0, n_mv = 0;
+    unsigned cnt_moved = 0, cnt_surv = 0, cnt_age = 0, cnt_coll = 0;
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const int si = (blockIdx.x * ITEMS + it) * 1024 + (int)threadIdx.x;
+        const int old_cell = old_cells[it];
+        const bool active = old_cell >= 0;
+        const int id = active ? slot_of_index(P, si) : 0;             // slot == particle id
+        const int gi = active ? rank_of_slot[si] : 0;
 
     int flag = 0, new_cell = 0;
     float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) { f = force4[gi]; flag = __float_as_int(f.w); }
     const CellInfo old_ci = active ? celltab[old_cell] : CellInfo{0, 1, 0, 0};
-    const uint64_t key = ((uint64_t)(uint32_t)(old_ci.chunk + 1) << P.key_chunk_shift) | ((uint64_t)(uint32_t)id << 2);
 
     const bool killed = active && flag == 2, survived = active && flag == 1, moved = active && flag == 0;
     bool died_of_age = false, born = false, relocate = false;
@@ -2037,29 +2064,34 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
     // Does the new segment's queue live on a neighbour rank?  Its layer is then the one above
     // or below the old one (a step moves a particle by at most one cell, MAX_DX = CELL_SIZE;
     // the box is periodic, so "above" the top layer is layer 0 on the ring's next rank).
-    const bool remote = (born || relocate) && P.world > 1 && !owns_record(P, new_rec);
+    const bool remote_ = (born || relocate) && P.world > 1 && !owns_record(P, new_rec);
     const int GG = P.G * P.G;
-    const bool up = remote && (new_cell / GG) == ((old_cell / GG) + 1) % P.G;
+    const bool up_ = remote_ && (new_cell / GG) == ((old_cell / GG) + 1) % P.G;
+
+        em[it].id = id; em[it].new_cell = new_cell; em[it].new_rec = new_rec; em[it].old_chunk = old_ci.chunk;
+        em[it].bits = (killed ? 1u : 0u) | (born ? 2u : 0u) | (relocate ? 4u : 0u) | (remote_ ? 8u : 0u) | (up_ ? 16u : 0u);
+        n_op += (killed ? 1 : 0) + ((born && !remote_) ? 1 : 0) + (relocate ? (remote_ ? 1 : 2) : 0);
+        n_mv += (born ? 1 : 0) + (relocate ? 1 : 0);
+        cnt_moved += (unsigned)__popcll(__ballot(moved)); cnt_surv += (unsigned)__popcll(__ballot(survived));
+        cnt_age += (unsigned)__popcll(__ballot(killed && died_of_age)); cnt_coll += (unsigned)__popcll(__ballot(killed && !died_of_age));
+    }
 
     // Event counters and list space: wave -> workgroup (LDS) -> one global atomic per
     // workgroup.  Queue operations: kill -> insert; birth -> remove; relocation ->
     // remove + insert.  Moves: one record per birth / relocation.  A remove on a neighbour's
-    // queue is not a local operation: it travels in the outbox.
+    // queue is not a local operation: it travels in the outbox.  A thread's operations are
+    // consecutive in the lists (their order there is immaterial: they are bucketed by key).
     const int lane = (int)__lane_id();
-    const int n_op = (killed ? 1 : 0) + ((born && !remote) ? 1 : 0) + (relocate ? (remote ? 1 : 2) : 0);
-    const int n_mv = (born ? 1 : 0) + (relocate ? 1 : 0);
     const int op_incl = wave_incl_scan(n_op), mv_incl = wave_incl_scan(n_mv);
-    const unsigned long long b0 = __ballot(moved), b1 = __ballot(survived),
-                             b2 = __ballot(killed && died_of_age), b3 = __ballot(killed && !died_of_age);
     __syncthreads();                                     // s_* zeroed
     int wave_ops = 0, wave_moves = 0;
     if (lane == 63) {
         if (op_incl) wave_ops = atomicAdd(&s_ops, op_incl);
         if (mv_incl) wave_moves = atomicAdd(&s_moves, mv_incl);
-        if (b0) atomicAdd(&s_cnt[0], (unsigned)__popcll(b0));
-        if (b1) atomicAdd(&s_cnt[1], (unsigned)__popcll(b1));
-        if (b2) atomicAdd(&s_cnt[2], (unsigned)__popcll(b2));
-        if (b3) atomicAdd(&s_cnt[3], (unsigned)__popcll(b3));
+        if (cnt_moved) atomicAdd(&s_cnt[0], cnt_moved);
+        if (cnt_surv) atomicAdd(&s_cnt[1], cnt_surv);
+        if (cnt_age) atomicAdd(&s_cnt[2], cnt_age);
+        if (cnt_coll) atomicAdd(&s_cnt[3], cnt_coll);
     }
     wave_ops = __shfl(wave_ops, 63); wave_moves = __shfl(wave_moves, 63);
     __syncthreads();
@@ -2081,34 +2113,43 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
     int k = s_base_ops + wave_ops + op_incl - n_op;
     int m = s_base_moves + wave_moves + mv_incl - n_mv;
     if (k + n_op > ops_cap || m + n_mv > moves_cap) { atomicOr(&fs->error, ERR_OPS_OVERFLOW); return; }
-    const uint64_t own_rec = (uint64_t)(uint32_t)segment_record_of_slot(S, id) << P.key_rec_shift;
-    const uint64_t dst_rec = (uint64_t)(uint32_t)new_rec << P.key_rec_shift;
-    // a departure: reserve its outbox entry and put the key there; k_moves_stage adds the state
-    auto depart = [&](int kind, uint64_t sub) -> int {
-        const int o = atomicAdd(&fs->n_out[up ? 1 : 0], 1);
-        if (o >= P.xfer_cap) { atomicOr(&fs->error, ERR_HALO_OVERFLOW); return -1; }
-        XferRec *x = (up ? out_up : out_down) + o;
-        x->key = dst_rec | key | sub; x->new_cell = new_cell; x->kind = kind;
-        return o;
-    };
-    if (killed) { op_keys[k] = own_rec | key | 2ull; op_args[k] = id; }
-    if (born) {
-        if (remote) moves[m] = {id, depart(1, 0ull), 1 | MOVE_OUT | (up ? MOVE_UP : 0), new_cell};
-        else {
-            moves[m] = {id, -1, 1, new_cell};
-            op_keys[k] = dst_rec | key | 0ull; op_args[k] = m;
-            k++;
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const unsigned bits = em[it].bits;
+        if (!(bits & 7u)) continue;
+        const bool killed = bits & 1u, born = bits & 2u, relocate = bits & 4u, remote = bits & 8u, up = bits & 16u;
+        const int id = em[it].id, new_cell = em[it].new_cell;
+        const uint64_t key = ((uint64_t)(uint32_t)(em[it].old_chunk + 1) << P.key_chunk_shift) | ((uint64_t)(uint32_t)id << 2);
+        const uint64_t own_rec = (uint64_t)(uint32_t)segment_record_of_slot(S, id) << P.key_rec_shift;
+        const uint64_t dst_rec = (uint64_t)(uint32_t)em[it].new_rec << P.key_rec_shift;
+        // a departure: reserve its outbox entry and put the key there; k_moves_stage adds the state
+        auto depart = [&](int kind, uint64_t sub) -> int {
+            const int o = atomicAdd(&fs->n_out[up ? 1 : 0], 1);
+            if (o >= P.xfer_cap) { atomicOr(&fs->error, ERR_HALO_OVERFLOW); return -1; }
+            XferRec *x = (up ? out_up : out_down) + o;
+            x->key = dst_rec | key | sub; x->new_cell = new_cell; x->kind = kind;
+            return o;
+        };
+        if (killed) { op_keys[k] = own_rec | key | 2ull; op_args[k] = id; k++; }
+        if (born) {
+            if (remote) moves[m] = {id, depart(1, 0ull), 1 | MOVE_OUT | (up ? MOVE_UP : 0), new_cell};
+            else {
+                moves[m] = {id, -1, 1, new_cell};
+                op_keys[k] = dst_rec | key | 0ull; op_args[k] = m;
+                k++;
+            }
+            m++;
         }
-        m++;
-    }
-    if (relocate) {
-        if (remote) moves[m] = {id, depart(0, 1ull), 0 | MOVE_OUT | (up ? MOVE_UP : 0), new_cell};
-        else {
-            moves[m] = {id, -1, 0, new_cell};
-            op_keys[k] = dst_rec | key | 1ull; op_args[k] = m;
-            k++;
+        if (relocate) {
+            if (remote) moves[m] = {id, depart(0, 1ull), 0 | MOVE_OUT | (up ? MOVE_UP : 0), new_cell};
+            else {
+                moves[m] = {id, -1, 0, new_cell};
+                op_keys[k] = dst_rec | key | 1ull; op_args[k] = m;
+                k++;
+            }
+            m++;
+            op_keys[k] = own_rec | key | 2ull; op_args[k] = id; k++;
         }
-        op_keys[k] = own_rec | key | 2ull; op_args[k] = id;
     }
 }
 
@@ -3120,9 +3161,14 @@ hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step)
 {
     if (P.slots_total <= 0) return hipSuccess;
-    k_apply<<<(P.slots_total + 1023) / 1024, 1024, 0, st>>>(P, S, step, d.rank_of_slot, d.force4, d.pos4,
-                                                      d.vel4, d.acc4, d.cell, d.pflags, d.celltab, d.op_keys, d.op_args, d.ops_cap,
-                                                      d.moves, d.moves_cap, d.xfer_out[0], d.xfer_out[1], d.chunk_count, d.chunk_skip, d.fs, d.ctr);
+    // slots per thread: one (PSAMD_APPLY_ITEMS: the measurement quoted at the kernel)
+#define PS_APPLY(I) k_apply<I><<<(P.slots_total + I * 1024 - 1) / (I * 1024), 1024, 0, st>>>(P, S, step, d.rank_of_slot, d.force4, d.pos4, \
+        d.vel4, d.acc4, d.cell, d.pflags, d.celltab, d.op_keys, d.op_args, d.ops_cap, \
+        d.moves, d.moves_cap, d.xfer_out[0], d.xfer_out[1], d.chunk_count, d.chunk_skip, d.fs, d.ctr)
+    static const int items_env = std::getenv("PSAMD_APPLY_ITEMS") ? std::atoi(std::getenv("PSAMD_APPLY_ITEMS")) : 0;
+    const int items = items_env ? items_env : 1;
+    if (items >= 4) PS_APPLY(4); else if (items >= 2) PS_APPLY(2); else PS_APPLY(1);
+#undef PS_APPLY
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -2,7 +2,7 @@
 one owner, neighbours hold what a rank reads.  (2) The orchestration bench.py uses on GPUs
 (particlesystem_amd.slab: message routes, ring order, the four stage calls) driven with a host
 stand-in per rank that holds only its slab (tests/oracle_slab.py): in one process, and as a
-world_size-2 gloo job -- the union of the ranks must be the serial reference state."""
+world_size-2 and -3 gloo job -- the union of the ranks must be the serial reference state."""
 import hashlib
 import os
 import subprocess
@@ -154,22 +154,25 @@ def _worker():
 
 
 @pytest.mark.timeout(600)
-def test_world_size_2_gloo_matches_serial(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_job_matches_serial(tmp_path, world):
     """bench.py's multi-GPU loop (slab.HostRing: batched isend/irecv between ring neighbours)
-    over gloo, one process per rank, 10 steps, particles changing owner every step."""
+    over gloo, one process per rank, 10 steps, particles changing owner every step.  World 2: both
+    neighbours are the same peer (two messages each way in one batch, matched by order); world 3:
+    a middle rank with two different peers, and the periodic wrap between the first and last rank."""
     xyz, age, fert = gloo_inputs()
     ref = O.System()
     ref.fill(xyz, age=age, fert_age=fert)
     ref.step(STEPS_GLOO)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2", PS_OUT=str(tmp_path / "rank"),
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29531 + world), WORLD_SIZE=str(world), PS_OUT=str(tmp_path / "rank"),
                PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]))
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker"], env=dict(env, RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=560)[0] for p in procs]
     for p, out in zip(procs, outs):
         assert p.returncode == 0, out
-    got = [np.load(str(tmp_path / "rank") + ".%d.npz" % r) for r in range(2)]
-    plans = plans_of(2)
+    got = [np.load(str(tmp_path / "rank") + ".%d.npz" % r) for r in range(world)]
+    plans = plans_of(world)
     p = merge_owned([g["p"] for g in got], plans)
     qi = merge_owned([g["qi"] for g in got], plans, "records")
     q = merge_owned([g["q"] for g in got], plans)
@@ -184,7 +187,7 @@ if __name__ == "__main__" and "--worker" in sys.argv:
 @pytest.mark.timeout(300)
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it: bench.py starts the ranks itself
-    (torch.distributed.run, fresh processes), relays rank 0's single JSON line and exits 0."""
+    (fresh processes with RANK / WORLD_SIZE / MASTER_* set), relays rank 0's single JSON line and exits 0."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check", "--steps", "7", "--warmup", "3"],

@@ -290,7 +290,7 @@ def sim_world(args, ps, cfg_over, flags):
     step_ms = float((per_rank + np.array(comm_ms)).max())
     out = {"sim_world": W, "n": args.n, "stage_ms_per_rank": {name: [round(float(x), 4) for x in tot[:, k]] for k, name in enumerate(stages)},
            "compute_ms_per_rank": [round(float(x), 4) for x in per_rank], "modelled_comm_ms_per_rank": [round(x, 4) for x in comm_ms],
-           "message_bytes_rank1": msg[min(1, W - 1)], "modelled_step_ms": step_ms,
+           "message_bytes_rank1": msg[min(1, W - 1)], "halo_cap_cell": int(args.halo_cap_cell), "modelled_step_ms": step_ms,
            "modelled_updates_per_s": updates / (step_ms * 1e-3), "updates_per_step": updates,
            "note": "one GPU runs the ranks one after the other; compute times are measured (HIP events); a transfer is modelled "
                    "as 10 us + bytes / %.0f GB/s (halo up, force, the two xfer messages in parallel); the halo overlaps the "
@@ -360,6 +360,14 @@ def main():
 
     cfg_over = dict(chunk_factor=args.chunk_factor, chunk_dim=args.chunk_dim,
                     max_particles_num=max(args.n, 1 << 20))
+    if args.halo_cap_cell == 0 and not args.evolve and (world > 1 or args.sim_world):
+        # Slab messages have a fixed size, cells x halo_cap_cell bodies (the library's default is the
+        # cell capacity, 2x the mean density at the reference's settings).  The replayed step never
+        # changes the cloud, so size them for it: 1.5x the mean density of the uniform cloud + 64
+        # (mean + 4 sigma of a boundary layer's fullest cell is well below; a message that did not
+        # fit would be a loud error, not a truncation).  A free-running cloud (--evolve) keeps the default.
+        cells = (args.chunk_factor * args.chunk_dim) ** 3
+        args.halo_cap_cell = int(1.5 * args.n / cells) + 64
     flags = ps.FLAG_FAST_MATH if args.fast_math else 0
     if args.sim_world:
         print(json.dumps(sim_world(args, ps, cfg_over, flags)))
@@ -518,6 +526,7 @@ def main():
             "kernel_us_per_step": {k: v / max(launches, 1) for k, v in tim.items() if v > 0},
         }
         if world > 1:
+            out["config"]["halo_cap_cell"] = int(args.halo_cap_cell)
             out["config"]["message_bytes_rank0"] = {name: int(g.msg_bytes(k)) for name, k in
                                                     (("halo_up", 1), ("halo_down", 0), ("force_in", 5), ("xfer_each", 6))}
         if world == 1 and not args.no_cpu:

@@ -89,14 +89,34 @@ def launch_ranks(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PSAMD_BENCH_CHILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out = procs[0].communicate()[0]
+    # rank 0's stdout is read by a thread; meanwhile watch the ranks: one that dies would leave
+    # the others waiting in a collective for ever, so end them (exact PIDs) and report its status
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        failed = next((p.returncode for p in procs if p.poll() not in (None, 0)), None)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
     codes = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    out = "".join(chunks)
     lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
     if lines:
         print(lines[-1])
     else:
         sys.stderr.write(out)
-    rc = max((abs(c) for c in codes), default=0)
+    rc = abs(failed) if failed is not None else max((abs(c) for c in codes), default=0)
     sys.exit(rc if rc else (0 if lines else 1))
 
 
@@ -311,6 +331,8 @@ def main():
     # the host driver of this pool only supports dmabuf IPC (RCCL between processes needs it); set before HIP loads
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+    if os.environ.get("PSAMD_BENCH_FAIL_RANK") == str(rank) and world > 1:
+        sys.exit(3)                     # (test hook: a rank that dies before the rendezvous)
     if args.launch_check:
         import torch.distributed as dist
         dist.init_process_group(args.backend if args.backend != "nccl" else "gloo")

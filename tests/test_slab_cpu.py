@@ -197,3 +197,15 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["launch_check"] and d["steps"] == 7 and d["warmup"] == 3
+
+
+@pytest.mark.timeout(120)
+def test_bench_launcher_ends_the_job_when_a_rank_dies():
+    """rank 1 exits before the rendezvous: rank 0 would wait for it for ever; the launcher notices,
+    ends rank 0 and exits with the dead rank's status."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PSAMD_BENCH_FAIL_RANK"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=100)
+    assert p.returncode == 3, (p.returncode, p.stderr[-1000:])
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -58,8 +58,25 @@ def build_driver(force=False):
     return DRIVER
 
 
+RING_SRC = os.path.join(os.path.dirname(HERE), "host", "ps_ring_rccl.cpp")
+RING = os.path.join(os.path.dirname(HERE), "host", "ps_ring_rccl")
+
+
+def build_ring(force=False):
+    """host/ps_ring_rccl: the multi-GPU step in C++ with RCCL moving the messages (hipcc: it uses
+    the HIP runtime and rccl.h; links libpsamd.so by relative rpath and the image's librccl)."""
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    if not force and os.path.exists(RING) and os.path.getmtime(RING) > max(
+            os.path.getmtime(RING_SRC), os.path.getmtime(os.path.join(inc, "psamd.h")), os.path.getmtime(LIB)):
+        return RING
+    subprocess.check_call([HIPCC, "-std=c++17", "-O2", "-Wall", "-I" + inc, RING_SRC, "-L" + HERE, "-lpsamd", "-lrccl",
+                           "-Wl,-rpath,$ORIGIN/../particlesystem_amd", "-o", RING])
+    return RING
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True,
           extra=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else ())
     print(LIB)
     print(build_driver(force=True))
+    print(build_ring(force=True))

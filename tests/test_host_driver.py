@@ -56,3 +56,23 @@ def test_driver_ends_in_the_oracle_state(fetch_back):
     assert int(m.group(2)) == int((o.particles["cell"] >= 0).sum())
     assert int(m.group(1), 16) == digest(o.particles), out
     assert out.count(">>>>>>>>>>> Execution time of iteration (sec):") == 10    # the reference's per-iteration print
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_cpp_ring_moves_every_message_with_rccl(world):
+    """host/ps_ring_rccl --loopback: all slabs in one C++ process on this GPU, a communicator of one
+    rank, every halo / force / transfer message an ncclSend to self matched by an ncclRecv from self
+    on the contexts' stream, the status records by ncclAllGather.  The program itself requires the
+    union of the slabs to equal the single-context run byte for byte (which the parity tests tie to
+    the oracle) and exits non-zero otherwise."""
+    exe = psbuild.build_ring()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([exe, "--loopback", "--world", str(world), "--n", "60000", "--iters", "8"], env=env,
+                       capture_output=True, text=True, timeout=560)
+    print(p.stdout)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    m = re.search(r"ring-rccl ok: 0 of \d+ records differ from the single context after 8 steps \((\d+) relocations", p.stdout)
+    assert m and int(m.group(1)) > 0, p.stdout
+    assert float(re.search(r"([0-9.]+) MB through RCCL", p.stdout).group(1)) > 1.0

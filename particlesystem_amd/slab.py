@@ -176,6 +176,7 @@ class DeviceRing(_Ring):
         self.t = {slot: torch.as_tensor(_DevPtr(p, n), device="cuda") for slot, (p, n) in ptrs.items() if p and n}
         self.stream = torch_stream
         sysr.set_stream(torch_stream.cuda_stream)
+        self._phase_ops = {}     # the operations of a phase never change (fixed buffers, fixed peers): built once, on first use
 
     def start(self, phase):
         """Post the phase's sends and receives.  RCCL runs them on its own stream once the work
@@ -183,7 +184,9 @@ class DeviceRing(_Ring):
         stream is NOT held up -- whatever is enqueued next runs beside the transfer -- until
         finish() makes it wait for the arrivals."""
         import torch
-        ops = self._ops(phase, lambda slot: self.t[slot])
+        if phase not in self._phase_ops:
+            self._phase_ops[phase] = self._ops(phase, lambda slot: self.t[slot])
+        ops = self._phase_ops[phase]
         if not ops:
             return []
         with torch.cuda.stream(self.stream):       # RCCL orders against torch's CURRENT stream: make it the context's

@@ -955,6 +955,9 @@ __device__ __forceinline__ void collide_scan(const DevParams &P, float xi, float
                                              const float *__restrict__ bz, const int *__restrict__ bcid, int n,
                                              bool &met_higher, bool &met_lower)
 {
+    // (Two groups of eight in flight -- wait for A, send B's loads, work on A -- was tried: 45 % of
+    // this kernel's wave cycles are parked at s_waitcnt.  Slower, 241 against 211 us for the stage:
+    // nearly every group has a hit, and the scalar load of the hit's id waits for the prefetch too.)
     constexpr int NB = 16;                      // bodies per group: 4 x 16 dwords of scalar loads in flight
     const v2f x2 = {xi, xi}, y2 = {yi, yi}, z2 = {zi, zi};
     const float dmax = P.coll_d2_max;

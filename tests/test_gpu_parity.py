@@ -331,6 +331,27 @@ def test_other_softening_lengths(eps2):
         compare_all(g, o, "eps2=%g step %d" % (eps2, k + 1))
 
 
+def test_kid_at_the_position_of_an_adult_with_vanishing_softening():
+    """bodyBodyInteraction returns ai unchanged for a kid neighbour (app_common.cu:240-243).  The
+    GPU encodes a kid as a body of mass 0 and multiplies -- fine while 1/sqrt(eps2^3) is finite.
+    With EPS2 = 1e-20 (generic arithmetic) a kid at EXACTLY an adult's position would give
+    0 * inf = NaN there; the generic walk skips such bodies instead, like the reference."""
+    n = 6000
+    xyz = cloud(n, 131)
+    rng = np.random.default_rng(131)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    twins = xyz[:200].copy()                      # 200 kids, each exactly on top of an adult
+    xyz = np.concatenate([xyz, twins])
+    age = np.concatenate([age, np.full(200, 0.1, np.float32)])
+    g, o = make_pair(xyz, age=age, fert=1e6, eps2=1e-20)
+    for k in range(2):
+        g.step(1); o.step(1)
+        compare_all(g, o, "coincident kid step %d" % (k + 1))
+    p = g.download_particles()
+    live = p["cell"] >= 0
+    assert np.isfinite(p["ax"][live]).all() and np.isfinite(p["x"][live]).all()
+
+
 def test_big_segments_replay_in_global_memory():
     """chunk_dim = 8: interior segments hold 216 cells x 514 slots, more than the LDS queue
     window, so their free-slot queues are replayed in global memory."""

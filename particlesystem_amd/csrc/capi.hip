@@ -447,8 +447,8 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
                 const int k = seg_index(pk[j].c);
                 segs[(size_t)ch * 27 + j] = make_int2(g.seg_base[k] + pk[j].p * g.seg_size_t[k], g.seg_size_t[k]);
             }
-            for (int j = 1; j < 27; j++)
-                if (segs[(size_t)ch * 27 + j].x <= segs[(size_t)ch * 27 + j - 1].x) return fail(c, PSAMD_ERR_STATE, "chunk segment table is not in slot order");
+            // slot order (set_pkg_segments lists them so already; the walk must not depend on it)
+            std::sort(segs.begin() + (size_t)ch * 27, segs.begin() + (size_t)ch * 27 + 27, [](const int2 &a, const int2 &b) { return a.x < b.x; });
         }
         PS_HIP(c, hipMemcpy(d.chunk_segs, segs.data(), segs.size() * sizeof(int2), hipMemcpyHostToDevice));
     }

@@ -563,11 +563,69 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
     if (n == 0) return;
     int ci1, ci2, ci3;
     cell_coords(P, c, ci1, ci2, ci3);
+    // A cell may hold more ids than fit the LDS ranking (its segment's capacity is the bound: a
+    // dense clump in one cell of an 8-cell segment reaches 8 x 514 = 4112).  All but the
+    // MAX_PARTICLES_PER_CELL lowest are killed anyway, so such a cell first finds that many lowest
+    // ids -- bisection on the id value, counting in global memory -- ranks those in LDS as usual
+    // and treats the rest as the overflow it is (rare: slow is fine, wrong is not).
+    const int n_all = n;
+    int big_limit = 0x7fffffff;                      // ids >= big_limit are past the list capacity (big cells only)
     if (n > SORT_MAX) {
-        if (tid == 0) atomicOr(&fs->error, ERR_CELL_TOO_BIG);
-        n = SORT_MAX;
+        __shared__ int s_count;
+        int lo = 0, hi = 0x7fffffff;                 // smallest t with #(id < t) >= max_per_cell
+        while (lo < hi) {
+            const int mid = lo + (hi - lo) / 2;
+            if (tid == 0) s_count = 0;
+            __syncthreads();
+            int mine = 0;
+            for (int e = tid; e < n_all; e += 256) mine += sorted_id[start + e] < mid ? 1 : 0;
+            atomicAdd(&s_count, mine);
+            __syncthreads();
+            const int cnt = s_count;
+            __syncthreads();
+            if (cnt >= P.max_per_cell) hi = mid; else lo = mid + 1;
+        }
+        big_limit = lo;
+        // gather the kept ids (exactly max_per_cell of them: ids are distinct) to the front of the LDS list
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+        for (int e = tid; e < n_all; e += 256) {
+            const int id = sorted_id[start + e];
+            if (id < big_limit) ids[atomicAdd(&s_count, 1)] = id;
+        }
+        __syncthreads();
+        n = s_count;                                 // == max_per_cell
+        __syncthreads();
+        // the overflow: same treatment as the ranked tail below, in any order (the frees are keyed by id)
+        for (int e = tid; e < n_all; e += 256) {
+            const int id = sorted_id[start + e];
+            if (id < big_limit) continue;
+            const int si = slot_index(P, id);
+            const float4 p = pos4[si];
+            const float age = vel4[si].w;
+            uint32_t *t = tdata + (size_t)6 * si;
+            t[0] = (uint32_t)id; t[1] = __float_as_uint(p.x); t[2] = __float_as_uint(p.y);
+            t[3] = __float_as_uint(p.z); t[4] = __float_as_uint(p.w); t[5] = __float_as_uint(age);
+            cell_arr[si] = -1; pflags[si] = 0;
+            pos4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vel4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
+            acc4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
+            atomicAdd(&(ctr + (blockIdx.x % COUNTER_COPIES))->cell_overflow_kills, 1ull);
+            if (owns_record(P, 0)) {
+                const int k = atomicAdd(&fs->n_ops, 1);
+                if (k < ops_cap) { op_keys[k] = ((uint64_t)(uint32_t)id << 2) | 2ull; op_args[k] = id; }
+                else atomicOr(&fs->error, ERR_OPS_OVERFLOW);
+            } else {
+                const int k = atomicAdd(&status_out[0], 1);
+                if (k < STATUS_KILL_CAP) status_out[MSG_HEADER_WORDS + k] = id;
+                else atomicOr(&fs->error, ERR_REMOTE_RECORD0);
+            }
+        }
+        __syncthreads();                             // (all reads of the arrival-order list are done)
+        for (int e = n + tid; e < n_all; e += 256) sorted_id[start + e] = -1;
+    } else {
+        for (int e = tid; e < n; e += 256) ids[e] = sorted_id[start + e];
     }
-    for (int e = tid; e < n; e += 256) ids[e] = sorted_id[start + e];
     __syncthreads();
     // pad to a multiple of 4 with INT_MAX so the ranking reads whole 16-byte LDS words
     for (int e = n + tid; e < ((n + 3) & ~3); e += 256) ids[e] = 0x7fffffff;

@@ -1,0 +1,126 @@
+"""Randomised GPU-vs-oracle parity run (not part of the test suite: minutes of oracle time).
+Each case draws a size, a density profile, velocities, ages (kids, adults, elders), dt, EPS2, the
+life-cycle switches and a world size (1 = plain context, 2..4 = slab contexts on this GPU), runs a
+few steps and compares every byte of the reference-layout state with the oracle after each.
+usage: python scripts/fuzz_parity.py [--cases 40] [--seed 1] [--log gpurun_out/fuzz.log]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+for d in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, os.path.abspath(d))
+import oracle_py as O                     # noqa: E402  (the checker)
+import particlesystem_amd as ps           # noqa: E402
+from particlesystem_amd.slab import merge_owned, step_local   # noqa: E402
+from util import assert_same_particles, explosion_rng, oracle_cfg_from   # noqa: E402
+
+
+def draw_case(rng):
+    n = int(rng.choice([3000, 12000, 40000, 90000]))
+    geo = [{}, {}, {"chunk_factor": 2, "chunk_dim": 6}, {"chunk_factor": 3, "chunk_dim": 4}, {"chunk_factor": 5, "chunk_dim": 4},
+           {"chunk_factor": 4, "chunk_dim": 3, "cell_size": 2.5}][int(rng.integers(0, 6))]
+    G = geo.get("chunk_factor", 4) * geo.get("chunk_dim", 4)
+    L = 0.5 * G * geo.get("cell_size", 5.0) * 0.9975               # (even grids only: the box is centred)
+    half = float(rng.choice([L, L, L / 2, L / 5]))                 # whole box, or a denser blob (cell overflow, collapse)
+    xyz = rng.uniform(-half, half, (n, 3)).astype(np.float32)
+    if rng.random() < 0.3:                                         # a second, very dense clump
+        m = n // 10
+        xyz[:m] = (rng.normal(0, 1.5, (m, 3)) + rng.uniform(-0.7 * L, 0.7 * L, 3)).clip(-L, L).astype(np.float32)
+    vmax = float(rng.choice([0.0, 5.0, 60.0, 300.0]))
+    v = rng.uniform(-vmax, vmax, (n, 3)).astype(np.float32) if vmax else None
+    age = rng.uniform(0.0, 8.0, n).astype(np.float32)              # kids (< 0.75), adults, over-age (> 7.5)
+    births = rng.random() < 0.5
+    fert = rng.uniform(2.5, 9.0, n).astype(np.float32) if births else (1e6 + np.arange(n)).astype(np.float32)
+    over = dict(geo)
+    if rng.random() < 0.4:
+        over["dt"] = float(rng.choice([0.01, 0.05, 0.2]))
+    if rng.random() < 0.3:
+        over["eps2"] = float(rng.choice([1e-20, 0.01, 1.0]))
+    if rng.random() < 0.2:
+        over["collision_radius"] = float(rng.choice([0.0, 0.1, 1.0]))
+    world = int(rng.choice([1, 1, 2, 3, 4]))
+    world = min(world, G // 2)
+    return dict(n=n, xyz=xyz, v=v, age=age, fert=fert, births=births, over=over, world=world, steps=int(rng.integers(2, 7)),
+                desc="n=%d G=%d half=%.1f vmax=%g births=%d world=%d %r" % (n, G, half, vmax, births, world, over))
+
+
+def run_case(c, seed):
+    flags = ps.FLAG_EXPLOSIONS if c["births"] else 0
+    extra = dict(seed=seed) if c["births"] else {}
+    W = c["world"]
+    ranks = [ps.ParticleSystem(ps.default_config(rank=r, world=W, flags=flags, **extra, **c["over"])) for r in range(W)]
+    o = O.System(oracle_cfg_from(ranks[0].cfg))
+    if c["births"]:
+        o.set_rng(explosion_rng(seed))
+    try:
+        ids_o = o.fill(c["xyz"], age=c["age"], fert_age=c["fert"])
+    except Exception as e:                                           # the segment of a dense clump is full: not a parity case
+        for g in ranks:
+            g.close()
+        o.close()
+        return "skipped (%s)" % str(e)[:60]
+    if c["v"] is not None:
+        p = o.particles
+        p["vx"][ids_o], p["vy"][ids_o], p["vz"][ids_o] = c["v"].T
+    for g in ranks:
+        g.fill_particles(c["xyz"], age=c["age"], fert_age=c["fert"], vxyz=c["v"])
+    for k in range(c["steps"]):
+        try:
+            if W == 1:
+                ranks[0].step(1)
+            else:
+                step_local(ranks)
+                for g in ranks:
+                    g.synchronize()
+        except ps.PsamdError as e:
+            if W > 1 and ("MAX_PARTICLES_PER_CHUNK" in str(e) or "status message" in str(e)):
+                for g in ranks:
+                    g.close()
+                o.close()
+                return "refused (%s)" % str(e)[:70]
+            raise
+        o.step(1)
+        plans = [g.slab_plan() for g in ranks]
+        got = ranks[0].download_particles() if W == 1 else merge_owned([g.download_particles() for g in ranks], plans)
+        assert_same_particles(got, o.particles, "step %d" % (k + 1))
+        qs = [g.download_queues() for g in ranks]
+        qi = qs[0][0] if W == 1 else merge_owned([q[0] for q in qs], plans, "records")
+        q = qs[0][1] if W == 1 else merge_owned([q[1] for q in qs], plans)
+        assert qi.tobytes() == o.queue_info.tobytes() and np.array_equal(q, o.queue), "queues differ at step %d" % (k + 1)
+    cnt = {k: sum(g.counters[k] for g in ranks) for k in ("relocations", "births", "deaths_collision", "cell_overflow_kills")}
+    for k, v in cnt.items():
+        assert v == o.counters[k], (k, v, o.counters[k])
+    for g in ranks:
+        g.close()
+    o.close()
+    return "ok %r" % cnt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--log", default=None)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    log = open(a.log, "a") if a.log else sys.stdout
+    bad = 0
+    for i in range(a.cases):
+        c = draw_case(rng)
+        t = time.time()
+        try:
+            res = run_case(c, 1000 + i)
+        except AssertionError as e:
+            res = "MISMATCH %s" % str(e)[:300]
+            bad += 1
+        print("case %d [%s] %.1fs: %s" % (i, c["desc"], time.time() - t, res), file=log, flush=True)
+    print("fuzz done: %d cases, %d mismatches" % (a.cases, bad), file=log, flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

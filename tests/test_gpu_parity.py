@@ -200,6 +200,28 @@ def test_chunk_list_capacity_rule():
     assert o.counters["cell_overflow_kills"] > 100 and o.counters["integrated"] > 0
 
 
+def test_cell_with_more_ids_than_the_lds_ranking_holds():
+    """4105 particles in ONE cell of an 8-cell interior segment (capacity 8 x 514 = 4112 slots): more
+    than the 4096 ids k_sort_cells ranks in LDS.  The 514 lowest ids stay, the rest is the overflow
+    the reference kills (ps.cpp:1517-1526) -- found by bisection on the id value instead."""
+    rng = np.random.default_rng(141)
+    blob = rng.uniform(5.1, 9.9, (4105, 3)).astype(np.float32)        # cell (i1, i2, i3) = (6, 9, 6): inner cell of chunk (1, 2, 1)
+    blob[:, 1] *= -1; blob[:, 2] *= -1
+    rest = cloud(3000, 142)
+    rest = rest[(np.abs(rest) > 20.0).any(axis=1)]
+    xyz = np.concatenate([blob, rest])
+    age = rng.uniform(2.2, 7.0, len(xyz)).astype(np.float32)
+    g, o = make_pair(xyz, age=age, fert=1e6)
+    g.init_iframe(); g.build_grid()
+    assert g.download_cellgrid()[:, 0].max() == g.sizes.max_per_cell
+    g.calc_forces()
+    o.step(1)
+    compare_all(g, o, "big cell step 1")
+    assert o.counters["cell_overflow_kills"] == 4105 - g.sizes.max_per_cell
+    g.step(1); o.step(1)
+    compare_all(g, o, "big cell step 2")
+
+
 def test_small_grids_and_empty():
     for over, n in (({"chunk_factor": 1, "chunk_dim": 3, "max_particles_num": 200}, 150),
                     ({"chunk_factor": 2, "chunk_dim": 3, "max_particles_num": 2000}, 1500),

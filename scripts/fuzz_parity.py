@@ -22,11 +22,14 @@ from util import assert_same_particles, explosion_rng, oracle_cfg_from   # noqa:
 def draw_case(rng):
     n = int(rng.choice([3000, 12000, 40000, 90000]))
     geo = [{}, {}, {"chunk_factor": 2, "chunk_dim": 6}, {"chunk_factor": 3, "chunk_dim": 4}, {"chunk_factor": 5, "chunk_dim": 4},
-           {"chunk_factor": 4, "chunk_dim": 3, "cell_size": 2.5}][int(rng.integers(0, 6))]
+           {"chunk_factor": 4, "chunk_dim": 3, "cell_size": 2.5}, {"chunk_factor": 5, "chunk_dim": 3}][int(rng.integers(0, 7))]
     G = geo.get("chunk_factor", 4) * geo.get("chunk_dim", 4)
-    L = 0.5 * G * geo.get("cell_size", 5.0) * 0.9975               # (even grids only: the box is centred)
+    cs = geo.get("cell_size", 5.0)
+    L = 0.5 * G * cs * 0.9975
     half = float(rng.choice([L, L, L / 2, L / 5]))                 # whole box, or a denser blob (cell overflow, collapse)
     xyz = rng.uniform(-half, half, (n, 3)).astype(np.float32)
+    if G % 2:                                                      # odd grids are not centred: i = floor(+-c / cs) + G // 2
+        xyz += np.float32(0.5 * cs) * np.array([1, -1, -1], np.float32)
     if rng.random() < 0.3:                                         # a second, very dense clump
         m = n // 10
         xyz[:m] = (rng.normal(0, 1.5, (m, 3)) + rng.uniform(-0.7 * L, 0.7 * L, 3)).clip(-L, L).astype(np.float32)
@@ -44,15 +47,36 @@ def draw_case(rng):
         over["collision_radius"] = float(rng.choice([0.0, 0.1, 1.0]))
     world = int(rng.choice([1, 1, 2, 3, 4]))
     world = min(world, G // 2)
+    cuts = None
+    if world > 1 and rng.random() < 0.4:                           # the caller's own cuts: >= 2 layers per rank
+        while True:
+            inner = np.sort(rng.choice(np.arange(2, G - 1), world - 1, replace=False))
+            cuts = [0] + [int(v) for v in inner] + [G]
+            if min(b - a for a, b in zip(cuts, cuts[1:])) >= 2:
+                break
+    interior = bool(world > 1 and rng.random() < 0.3)
+    reupload = bool(world == 1 and not births and rng.random() < 0.4)   # hand the state to a fresh context half way
+    # (not with births: the birth RNG is keyed on the context's step counter, which a fresh context restarts)
     return dict(n=n, xyz=xyz, v=v, age=age, fert=fert, births=births, over=over, world=world, steps=int(rng.integers(2, 7)),
-                desc="n=%d G=%d half=%.1f vmax=%g births=%d world=%d %r" % (n, G, half, vmax, births, world, over))
+                cuts=cuts, interior=interior, reupload=reupload,
+                desc="n=%d G=%d half=%.1f vmax=%g births=%d world=%d cuts=%r interior=%d reupload=%d %r" %
+                     (n, G, half, vmax, births, world, cuts, interior, reupload, over))
 
 
 def run_case(c, seed):
     flags = ps.FLAG_EXPLOSIONS if c["births"] else 0
     extra = dict(seed=seed) if c["births"] else {}
     W = c["world"]
-    ranks = [ps.ParticleSystem(ps.default_config(rank=r, world=W, flags=flags, **extra, **c["over"])) for r in range(W)]
+    if c["cuts"]:
+        extra["cuts"] = c["cuts"]
+    mk = lambda r: ps.ParticleSystem(ps.default_config(rank=r, world=W, flags=flags, **extra, **c["over"]))
+    try:
+        ranks = [mk(r) for r in range(W)]
+    except ps.PsamdError as e:
+        if c["cuts"] and "no slab partition" in str(e):        # random cuts may leave a rank's reads with a non-neighbour
+            return "plan refused (%r)" % (c["cuts"],)
+        raise
+    carried = {}                                                 # counters of a context that handed its state on
     o = O.System(oracle_cfg_from(ranks[0].cfg))
     if c["births"]:
         o.set_rng(explosion_rng(seed))
@@ -71,9 +95,18 @@ def run_case(c, seed):
     for k in range(c["steps"]):
         try:
             if W == 1:
+                if c["reupload"] and k == c["steps"] // 2:
+                    # the reference's buffers out of one context and into a fresh one
+                    old = ranks[0]
+                    p, (qi, q) = old.download_particles(), old.download_queues()
+                    new = mk(0)
+                    new.upload_particles(p); new.upload_queues(qi, q)
+                    carried = dict(old.counters)
+                    old.close()
+                    ranks[0] = new
                 ranks[0].step(1)
             else:
-                step_local(ranks)
+                step_local(ranks, overlap_interior=c["interior"])
                 for g in ranks:
                     g.synchronize()
         except ps.PsamdError as e:
@@ -91,7 +124,7 @@ def run_case(c, seed):
         qi = qs[0][0] if W == 1 else merge_owned([q[0] for q in qs], plans, "records")
         q = qs[0][1] if W == 1 else merge_owned([q[1] for q in qs], plans)
         assert qi.tobytes() == o.queue_info.tobytes() and np.array_equal(q, o.queue), "queues differ at step %d" % (k + 1)
-    cnt = {k: sum(g.counters[k] for g in ranks) for k in ("relocations", "births", "deaths_collision", "cell_overflow_kills")}
+    cnt = {k: sum(g.counters[k] for g in ranks) + carried.get(k, 0) for k in ("relocations", "births", "deaths_collision", "cell_overflow_kills")}
     for k, v in cnt.items():
         assert v == o.counters[k], (k, v, o.counters[k])
     for g in ranks:

@@ -19,8 +19,8 @@ from particlesystem_amd.slab import merge_owned, step_local   # noqa: E402
 from util import assert_same_particles, explosion_rng, oracle_cfg_from   # noqa: E402
 
 
-def draw_case(rng):
-    n = int(rng.choice([3000, 12000, 40000, 90000]))
+def draw_case(rng, sizes):
+    n = int(rng.choice(sizes))
     geo = [{}, {}, {"chunk_factor": 2, "chunk_dim": 6}, {"chunk_factor": 3, "chunk_dim": 4}, {"chunk_factor": 5, "chunk_dim": 4},
            {"chunk_factor": 4, "chunk_dim": 3, "cell_size": 2.5}, {"chunk_factor": 5, "chunk_dim": 3}][int(rng.integers(0, 7))]
     G = geo.get("chunk_factor", 4) * geo.get("chunk_dim", 4)
@@ -138,12 +138,13 @@ def main():
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--log", default=None)
+    ap.add_argument("--sizes", default="3000,12000,40000,90000", help="particle counts to draw from")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     log = open(a.log, "a") if a.log else sys.stdout
     bad = 0
     for i in range(a.cases):
-        c = draw_case(rng)
+        c = draw_case(rng, [int(v) for v in a.sizes.split(",")])
         t = time.time()
         try:
             res = run_case(c, 1000 + i)

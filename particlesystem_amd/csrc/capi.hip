@@ -123,7 +123,11 @@ hipError_t dev_alloc(psamd_ctx *c, T **out, size_t n)
     if (e != hipSuccess) return e;
     c->allocs.push_back(p);
     *out = (T *)p;
-    return hipSuccess;
+    // PSAMD_POISON (tests): fresh device memory is usually zero, reused memory is not -- fill every
+    // allocation with a pattern so that anything read before it is written shows up
+    static const bool poison = std::getenv("PSAMD_POISON") != nullptr;
+    if (poison) e = hipMemset(p, 0xA5, std::max<size_t>(n, 1) * sizeof(T));
+    return e;
 }
 
 int ensure_staging(psamd_ctx *c, size_t bytes)

@@ -126,7 +126,10 @@ hipError_t dev_alloc(psamd_ctx *c, T **out, size_t n)
     // PSAMD_POISON (tests): fresh device memory is usually zero, reused memory is not -- fill every
     // allocation with a pattern so that anything read before it is written shows up
     static const bool poison = std::getenv("PSAMD_POISON") != nullptr;
-    if (poison) e = hipMemset(p, 0xA5, std::max<size_t>(n, 1) * sizeof(T));
+    if (poison) {
+        e = hipMemset(p, 0xA5, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) e = hipDeviceSynchronize();     // (the fill must not overtake the context's own stream)
+    }
     return e;
 }
 

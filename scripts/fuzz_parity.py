@@ -145,6 +145,8 @@ def main():
     bad = 0
     for i in range(a.cases):
         c = draw_case(rng, [int(v) for v in a.sizes.split(",")])
+        if os.environ.get("FUZZ_ANNOUNCE"):
+            print("start case %d [%s]" % (i, c["desc"]), file=log, flush=True)
         t = time.time()
         try:
             res = run_case(c, 1000 + i)

@@ -2122,12 +2122,17 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
         relocate = (new_ci.seg_type != old_ci.seg_type || new_ci.seg_tid != old_ci.seg_tid);
     }
 
-    // Does the new segment's queue live on a neighbour rank?  Its layer is then the one above
-    // or below the old one (a step moves a particle by at most one cell, MAX_DX = CELL_SIZE;
-    // the box is periodic, so "above" the top layer is layer 0 on the ring's next rank).
+    // Does the new segment's queue live on a neighbour rank?  A step moves a particle by at most
+    // CELL_SIZE (MAX_DX), i.e. one cell layer -- or TWO when the rounded sum lands exactly on the
+    // far face (a particle one ulp below a face, moved by exactly +CELL_SIZE); the box is periodic,
+    // so "above" the top layer is layer 0 on the ring's next rank.  One or two layers up the ring:
+    // the record goes up; one or two down: down.  (Every rank computes at least two layers; whether
+    // the neighbour really owns the record is checked where the record arrives.)
     const bool remote_ = (born || relocate) && P.world > 1 && !owns_record(P, new_rec);
     const int GG = P.G * P.G;
-    const bool up_ = remote_ && (new_cell / GG) == ((old_cell / GG) + 1) % P.G;
+    const int layers_up = ((new_cell / GG) - (old_cell / GG) + P.G) % P.G;
+    const bool up_ = remote_ && (layers_up == 1 || layers_up == 2);
+    if (remote_ && !up_ && layers_up < P.G - 2) atomicOr(&fs->error, ERR_FOREIGN_CELL);     // not a neighbour's: cannot happen with MAX_DX
 
         em[it].id = id; em[it].new_cell = new_cell; em[it].new_rec = new_rec; em[it].old_chunk = old_ci.chunk;
         em[it].bits = (killed ? 1u : 0u) | (born ? 2u : 0u) | (relocate ? 4u : 0u) | (remote_ ? 8u : 0u) | (up_ ? 16u : 0u);
@@ -2842,6 +2847,9 @@ __global__ void k_inbox_merge(DevParams P, const int *__restrict__ msg, uint64_t
     if (i == 0 && msg[2]) atomicOr(&fs->error, msg[2]);
     if (i >= n) return;
     const XferRec x = in[i];
+    // the record names the queue it is for: it must be one of this rank's (anything else would be
+    // replayed on a queue array this rank does not hold)
+    if (!owns_record(P, (int)(x.key >> P.key_rec_shift))) { atomicOr(&fs->error, ERR_SLAB_MISMATCH); return; }
     const unsigned long long old = atomicAdd((unsigned long long *)&fs->n_ops, (1ull << 32) | 1ull);
     const int k = (int)(old & 0xffffffffull), m = (int)(old >> 32);
     if (k >= ops_cap || m >= moves_cap) { atomicOr(&fs->error, ERR_OPS_OVERFLOW); return; }

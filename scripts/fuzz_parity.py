@@ -33,6 +33,21 @@ def draw_case(rng, sizes):
     if rng.random() < 0.3:                                         # a second, very dense clump
         m = n // 10
         xyz[:m] = (rng.normal(0, 1.5, (m, 3)) + rng.uniform(-0.7 * L, 0.7 * L, 3)).clip(-L, L).astype(np.float32)
+    if rng.random() < 0.5:                                         # some coordinates exactly on cell faces, or one ulp beside them
+        m = n // 8
+        pick = rng.choice(n, m, replace=False)
+        axis = rng.integers(0, 3, m)
+        face = (np.round(xyz[pick, axis] / np.float32(cs)) * np.float32(cs)).astype(np.float32)
+        nudge = rng.integers(-1, 2, m)
+        face = np.where(nudge < 0, np.nextafter(face, np.float32(-1e9)), np.where(nudge > 0, np.nextafter(face, np.float32(1e9)), face)).astype(np.float32)
+        lim = np.float32(0.5 * G * cs)
+        lo_edge, hi_edge = (-(G // 2) * cs, (G - G // 2) * cs)
+        xyz[pick, axis] = face
+        # keep every point inside the box [lo, hi) of its axis (x runs with +, y and z with -)
+        sgn = np.array([1.0, -1.0, -1.0], np.float32)
+        u = xyz * sgn
+        u = np.clip(u, np.float32(lo_edge), np.nextafter(np.float32(hi_edge), np.float32(-1e9)))
+        xyz = (u * sgn).astype(np.float32)
     vmax = float(rng.choice([0.0, 5.0, 60.0, 300.0]))
     v = rng.uniform(-vmax, vmax, (n, 3)).astype(np.float32) if vmax else None
     age = rng.uniform(0.0, 8.0, n).astype(np.float32)              # kids (< 0.75), adults, over-age (> 7.5)

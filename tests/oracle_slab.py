@@ -171,7 +171,9 @@ class OracleSlabRank:
         self.own_ops = ops[own]
         away = ops[~own]
         assert (away["kind"] != 0).all(), "an insert can only concern an own queue"
-        up = (away["body"]["cell"] // self.GG) == ((away["old_cell"] // self.GG) + 1) % self.G
+        # one layer up the ring -- or two, when the rounded sum lands exactly on the far face
+        layers_up = ((away["body"]["cell"] // self.GG) - (away["old_cell"] // self.GG)) % self.G
+        up = (layers_up == 1) | (layers_up == 2)
         for which, sel in ((XFER_OUT + 0, away[~up]), (XFER_OUT + 1, away[up])):
             if not self.sizes[which]:
                 assert len(sel) == 0

@@ -252,3 +252,42 @@ def test_slab_refuses_a_chunk_past_its_list_capacity():
             g.synchronize()
     for g in ranks:
         g.close()
+
+
+def test_slab_two_layer_jump_across_a_cut():
+    """MAX_DX = CELL_SIZE moves a particle one cell layer -- or two: one ulp below a cell face,
+    moved by exactly +CELL_SIZE, the rounded sum lands ON the far face (4.9999995 + 5 = 10.0 in
+    fp32).  Across a slab cut that is a transfer to the neighbour two layers in; it used to be
+    sent the wrong way round the ring (found by scripts/fuzz_parity.py as a device fault)."""
+    n = 4000
+    rng = np.random.default_rng(171)
+    cs = np.float32(5.0)
+    xyz = np.zeros((n, 3), np.float32)
+    xyz[:, 0] = rng.uniform(-39, 39, n)
+    xyz[:, 1] = rng.uniform(-39, 39, n)
+    u3 = np.nextafter(cs, np.float32(0))                       # one ulp below the face between layers 8 and 9
+    xyz[:, 2] = -u3
+    xyz[n // 2:, 2] = -np.nextafter(np.float32(-5.0), np.float32(-10))   # and one ulp below the face -5 (layer 6), moving up too
+    v = np.zeros((n, 3), np.float32)
+    v[:, 2] = -300.0                                           # -z is up the layers; clamped to one CELL_SIZE per step
+    age = np.full(n, 3.0, np.float32)
+    fert = (1e6 + np.arange(n)).astype(np.float32)
+    over = dict(collision_radius=0.0, cuts=[0, 9, 16])
+    ranks = [ps.ParticleSystem(ps.default_config(rank=r, world=2, **over)) for r in range(2)]
+    o = O.System(oracle_cfg_from(ranks[0].cfg))
+    ids = o.fill(xyz, age=age, fert_age=fert)
+    p = o.particles
+    p["vx"][ids], p["vy"][ids], p["vz"][ids] = v.T
+    for g in ranks:
+        g.fill_particles(xyz, age=age, fert_age=fert, vxyz=v)
+    GG = 16 * 16
+    layer0 = {int(t): int(c) // GG for t, c in zip(p["fertility_age"][ids], p["cell"][ids])}
+    for step in range(3):
+        step_local(ranks); o.step(1)
+        compare_world(ranks, o, "two-layer jump step %d" % (step + 1))
+        if step == 0:
+            live = o.particles["cell"] >= 0
+            jumps = [int(c) // GG - layer0[int(t)] for t, c in zip(o.particles["fertility_age"][live], o.particles["cell"][live])]
+            assert jumps.count(2) >= n // 2, "the scenario must contain two-layer jumps (8 -> 10 across the cut at 9)"
+    for g in ranks:
+        g.close()

@@ -28,7 +28,7 @@ def main():
         try:
             for flags in (0, ps.FLAG_FAST_MATH):
                 g = ps.ParticleSystem(ps.default_config(flags=flags, **over))
-                g.fill_particles(c["xyz"], age=c["age"], fert_age=np.float32(1e6), vxyz=c["v"])
+                g.fill_particles(c["xyz"], age=c["age"], fert_age=np.float32(1e6), vxyz=c["v"], w=c["w"])
                 g.init_iframe(); g.build_grid(); g.calc_forces_pairs()
                 total = int(g.download_cellgrid()[:, 0].sum())
                 res.append(g.download_force4(0, total))

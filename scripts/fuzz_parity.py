@@ -50,16 +50,32 @@ def draw_case(rng, sizes):
         xyz = (u * sgn).astype(np.float32)
     vmax = float(rng.choice([0.0, 5.0, 60.0, 300.0]))
     v = rng.uniform(-vmax, vmax, (n, 3)).astype(np.float32) if vmax else None
-    age = rng.uniform(0.0, 8.0, n).astype(np.float32)              # kids (< 0.75), adults, over-age (> 7.5)
-    births = rng.random() < 0.5
-    fert = rng.uniform(2.5, 9.0, n).astype(np.float32) if births else (1e6 + np.arange(n)).astype(np.float32)
     over = dict(geo)
     if rng.random() < 0.4:
         over["dt"] = float(rng.choice([0.01, 0.05, 0.2]))
+    # ages against the thresholds of this dt: PARTICLE_LIFE = 300 dt, KID_AGE = life / 10 (common.h:58-61)
+    life = 300.0 * over.get("dt", 0.05)
+    kid = life / 10.0
+    age = rng.uniform(0.0, 0.6 * life, n).astype(np.float32)       # kids and adults
+    sel = rng.random(n)
+    ulps = lambda v, k: (np.float32(v).view(np.int32) + k).view(np.float32)      # v moved by k ulps
+    around = rng.integers(-3, 4, n).astype(np.int32)
+    age = np.where(sel < 0.08, ulps(kid, around), age)             # at the kid threshold, to the ulp
+    age = np.where((sel >= 0.08) & (sel < 0.16), ulps(life, around), age)          # at the end of life
+    age = np.where((sel >= 0.16) & (sel < 0.22), np.float32(life) - np.float32(over.get("dt", 0.05)) * rng.integers(0, 3, n).astype(np.float32), age)
+    age = np.where((sel >= 0.22) & (sel < 0.26), rng.uniform(life, 2 * life, n), age).astype(np.float32)       # over age
+    births = rng.random() < 0.5
+    fert = rng.uniform(0.2 * life, 0.7 * life, n).astype(np.float32) if births else (1e6 + np.arange(n)).astype(np.float32)
+    if births and rng.random() < 0.5:                              # fertility age exactly the age some steps from now
+        k = rng.integers(0, 4, n).astype(np.float32)
+        fert = np.where(rng.random(n) < 0.3, age + k * np.float32(over.get("dt", 0.05)), fert).astype(np.float32)
     if rng.random() < 0.3:
         over["eps2"] = float(rng.choice([1e-20, 0.01, 1.0]))
     if rng.random() < 0.2:
         over["collision_radius"] = float(rng.choice([0.0, 0.1, 1.0]))
+    w = None
+    if rng.random() < 0.3:                                         # other masses, some of them zero
+        w = np.where(rng.random(n) < 0.1, 0.0, rng.uniform(1.0, 100.0, n)).astype(np.float32)
     world = int(rng.choice([1, 1, 2, 3, 4]))
     world = min(world, G // 2)
     cuts = None
@@ -72,10 +88,10 @@ def draw_case(rng, sizes):
     interior = bool(world > 1 and rng.random() < 0.3)
     reupload = bool(world == 1 and not births and rng.random() < 0.4)   # hand the state to a fresh context half way
     # (not with births: the birth RNG is keyed on the context's step counter, which a fresh context restarts)
-    return dict(n=n, xyz=xyz, v=v, age=age, fert=fert, births=births, over=over, world=world, steps=int(rng.integers(2, 7)),
+    return dict(n=n, xyz=xyz, v=v, age=age, fert=fert, w=w, births=births, over=over, world=world, steps=int(rng.integers(2, 7)),
                 cuts=cuts, interior=interior, reupload=reupload,
-                desc="n=%d G=%d half=%.1f vmax=%g births=%d world=%d cuts=%r interior=%d reupload=%d %r" %
-                     (n, G, half, vmax, births, world, cuts, interior, reupload, over))
+                desc="n=%d G=%d half=%.1f vmax=%g births=%d masses=%d world=%d cuts=%r interior=%d reupload=%d %r" %
+                     (n, G, half, vmax, births, w is not None, world, cuts, interior, reupload, over))
 
 
 def run_case(c, seed):
@@ -96,7 +112,7 @@ def run_case(c, seed):
     if c["births"]:
         o.set_rng(explosion_rng(seed))
     try:
-        ids_o = o.fill(c["xyz"], age=c["age"], fert_age=c["fert"])
+        ids_o = o.fill(c["xyz"], age=c["age"], fert_age=c["fert"], w=c["w"])
     except Exception as e:                                           # the segment of a dense clump is full: not a parity case
         for g in ranks:
             g.close()
@@ -106,7 +122,7 @@ def run_case(c, seed):
         p = o.particles
         p["vx"][ids_o], p["vy"][ids_o], p["vz"][ids_o] = c["v"].T
     for g in ranks:
-        g.fill_particles(c["xyz"], age=c["age"], fert_age=c["fert"], vxyz=c["v"])
+        g.fill_particles(c["xyz"], age=c["age"], fert_age=c["fert"], vxyz=c["v"], w=c["w"])
     for k in range(c["steps"]):
         try:
             if W == 1:

@@ -89,7 +89,7 @@ def draw_case(rng, sizes):
     reupload = bool(world == 1 and not births and rng.random() < 0.4)   # hand the state to a fresh context half way
     # (not with births: the birth RNG is keyed on the context's step counter, which a fresh context restarts)
     return dict(n=n, xyz=xyz, v=v, age=age, fert=fert, w=w, births=births, over=over, world=world, steps=int(rng.integers(2, 7)),
-                cuts=cuts, interior=interior, reupload=reupload,
+                cuts=cuts, interior=interior, reupload=reupload, replay=bool(rng.random() < 0.35),
                 desc="n=%d G=%d half=%.1f vmax=%g births=%d masses=%d world=%d cuts=%r interior=%d reupload=%d %r" %
                      (n, G, half, vmax, births, w is not None, world, cuts, interior, reupload, over))
 
@@ -123,6 +123,8 @@ def run_case(c, seed):
         p["vx"][ids_o], p["vy"][ids_o], p["vz"][ids_o] = c["v"].T
     for g in ranks:
         g.fill_particles(c["xyz"], age=c["age"], fert_age=c["fert"], vxyz=c["v"], w=c["w"])
+        if c.get("replay"):
+            g.snapshot_save()
     for k in range(c["steps"]):
         try:
             if W == 1:
@@ -157,9 +159,27 @@ def run_case(c, seed):
         qi = qs[0][0] if W == 1 else merge_owned([q[0] for q in qs], plans, "records")
         q = qs[0][1] if W == 1 else merge_owned([q[1] for q in qs], plans)
         assert qi.tobytes() == o.queue_info.tobytes() and np.array_equal(q, o.queue), "queues differ at step %d" % (k + 1)
+    if c.get("replay") and not c["reupload"]:
+        # what bench.py's timed loop relies on: restore the snapshot taken after the fill, run the same steps
+        # again -- the state must come out the same, byte for byte (one context and slabs alike)
+        want = [g.download_particles() for g in ranks], [g.download_queues() for g in ranks]
+        for g in ranks:
+            g.snapshot_restore()
+        for k in range(c["steps"]):
+            if W == 1:
+                ranks[0].step(1)
+            else:
+                step_local(ranks, overlap_interior=c["interior"])
+        for r, g in enumerate(ranks):
+            g.synchronize()
+            assert g.download_particles().tobytes() == want[0][r].tobytes(), "replay after snapshot_restore differs (rank %d)" % r
+            qi, q = g.download_queues()
+            assert qi.tobytes() == want[1][r][0].tobytes() and np.array_equal(q, want[1][r][1]), "queues differ after replay (rank %d)" % r
     cnt = {k: sum(g.counters[k] for g in ranks) + carried.get(k, 0) for k in ("relocations", "births", "deaths_collision", "cell_overflow_kills")}
+    twice = 2 if (c.get("replay") and not c["reupload"]) else 1              # the event counters are cumulative: a replay counts again
     for k, v in cnt.items():
-        assert v == o.counters[k], (k, v, o.counters[k])
+        assert v == twice * o.counters[k], (k, v, o.counters[k], twice)
+    cnt = {k: v // twice for k, v in cnt.items()}
     for g in ranks:
         g.close()
     o.close()

@@ -568,6 +568,12 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
     // MAX_PARTICLES_PER_CELL lowest are killed anyway, so such a cell first finds that many lowest
     // ids -- bisection on the id value, counting in global memory -- ranks those in LDS as usual
     // and treats the rest as the overflow it is (rare: slow is fine, wrong is not).
+    if (n > SORT_MAX && P.max_per_cell > SORT_MAX) {
+        // (a list capacity above what the LDS ranking holds -- N = 2^24 in 16^3 cells -- AND a cell that
+        // full: the kept ids alone do not fit; refused as before)
+        if (tid == 0) atomicOr(&fs->error, ERR_CELL_TOO_BIG);
+        n = SORT_MAX;
+    }
     const int n_all = n;
     int big_limit = 0x7fffffff;                      // ids >= big_limit are past the list capacity (big cells only)
     if (n > SORT_MAX) {

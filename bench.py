@@ -390,6 +390,12 @@ def main():
         # fit would be a loud error, not a truncation).  A free-running cloud (--evolve) keeps the default.
         cells = (args.chunk_factor * args.chunk_dim) ** 3
         args.halo_cap_cell = int(1.5 * args.n / cells) + 64
+        # likewise the transfer messages (particles changing owner per step and direction): the library's
+        # default has room for a quarter of what a layer can hold (a fast, dense cloud); this cloud's busiest
+        # face is the box surface, whose layer implodes by up to a cell in the replayed step: an eighth of a
+        # layer's population (n / G) is what it sends, measured; a message that did not fit is a loud error
+        G = args.chunk_factor * args.chunk_dim
+        cfg_over["xfer_cap"] = max(4096, int(args.n / G / 8) + 1024)
     flags = ps.FLAG_FAST_MATH if args.fast_math else 0
     if args.sim_world:
         print(json.dumps(sim_world(args, ps, cfg_over, flags)))

@@ -81,7 +81,7 @@ typedef struct psamd_config {
     int32_t  rank;
     int32_t  world;
     int32_t  halo_cap_cell;      /* bodies per cell a halo message has room for; 0 = MAX_PARTICLES_PER_CELL (never overflows) */
-    int32_t  xfer_cap;           /* particles per step and direction that may change owner; 0 = a sixteenth of what a cell layer can hold */
+    int32_t  xfer_cap;           /* particles per step and direction that may change owner; 0 = a quarter of what a cell layer can hold */
     int32_t  cuts[PSAMD_MAX_RANKS + 1];
     /* Not in the reference (BASELINE.json asks for them; nothing there can pin them): */
     double   drag;               /* linear drag k >= 0: the acceleration that is integrated and stored is a - k*v; 0 = the

@@ -289,7 +289,7 @@ static void fill_slab_params(const Geometry &g, const SlabPlan &pl, const psamd_
     const int first[4] = {pl.state_lo, pl.below_lo, pl.lentin_lo, pl.above_lo};
     const int layers[4] = {pl.state_hi - pl.state_lo, pl.lentin_lo - pl.below_lo, pl.lentin_hi - pl.lentin_lo, pl.above_hi - pl.above_lo};
     P.halo_cap_cell = (cfg.halo_cap_cell > 0 && cfg.halo_cap_cell < g.max_per_cell) ? cfg.halo_cap_cell : g.max_per_cell;
-    P.xfer_cap = pl.world > 1 ? (cfg.xfer_cap > 0 ? cfg.xfer_cap : std::max(4096, GG * g.max_per_cell / 16)) : 0;
+    P.xfer_cap = pl.world > 1 ? (cfg.xfer_cap > 0 ? cfg.xfer_cap : std::max(4096, GG * g.max_per_cell / 4)) : 0;
     int64_t slots = 0;
     for (int t = 0; t < 4; t++) { P.slot_lo[t] = pl.slot_lo[t]; P.slot_n[t] = pl.slot_hi[t] - pl.slot_lo[t]; slots += P.slot_n[t];
                                   P.rec_lo[t] = pl.rec_lo[t]; P.rec_hi[t] = pl.rec_hi[t]; }

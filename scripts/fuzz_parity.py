@@ -19,7 +19,7 @@ from particlesystem_amd.slab import merge_owned, step_local   # noqa: E402
 from util import assert_same_particles, explosion_rng, oracle_cfg_from   # noqa: E402
 
 
-def draw_case(rng, sizes):
+def draw_case(rng, sizes, max_steps=6):
     n = int(rng.choice(sizes))
     geo = [{}, {}, {"chunk_factor": 2, "chunk_dim": 6}, {"chunk_factor": 3, "chunk_dim": 4}, {"chunk_factor": 5, "chunk_dim": 4},
            {"chunk_factor": 4, "chunk_dim": 3, "cell_size": 2.5}, {"chunk_factor": 5, "chunk_dim": 3}][int(rng.integers(0, 7))]
@@ -88,7 +88,7 @@ def draw_case(rng, sizes):
     interior = bool(world > 1 and rng.random() < 0.3)
     reupload = bool(world == 1 and not births and rng.random() < 0.4)   # hand the state to a fresh context half way
     # (not with births: the birth RNG is keyed on the context's step counter, which a fresh context restarts)
-    return dict(n=n, xyz=xyz, v=v, age=age, fert=fert, w=w, births=births, over=over, world=world, steps=int(rng.integers(2, 7)),
+    return dict(n=n, xyz=xyz, v=v, age=age, fert=fert, w=w, births=births, over=over, world=world, steps=int(rng.integers(2, max_steps + 1)),
                 cuts=cuts, interior=interior, reupload=reupload, replay=bool(rng.random() < 0.35),
                 desc="n=%d G=%d half=%.1f vmax=%g births=%d masses=%d world=%d cuts=%r interior=%d reupload=%d %r" %
                      (n, G, half, vmax, births, w is not None, world, cuts, interior, reupload, over))
@@ -192,12 +192,13 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--log", default=None)
     ap.add_argument("--sizes", default="3000,12000,40000,90000", help="particle counts to draw from")
+    ap.add_argument("--max-steps", type=int, default=6)
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     log = open(a.log, "a") if a.log else sys.stdout
     bad = 0
     for i in range(a.cases):
-        c = draw_case(rng, [int(v) for v in a.sizes.split(",")])
+        c = draw_case(rng, [int(v) for v in a.sizes.split(",")], a.max_steps)
         if os.environ.get("FUZZ_ANNOUNCE"):
             print("start case %d [%s]" % (i, c["desc"]), file=log, flush=True)
         t = time.time()

@@ -19,7 +19,7 @@ from particlesystem_amd.slab import merge_owned, step_local   # noqa: E402
 from util import assert_same_particles, explosion_rng, oracle_cfg_from   # noqa: E402
 
 
-def draw_case(rng, sizes, max_steps=6):
+def draw_case(rng, sizes, max_steps=6, worlds=(1, 1, 2, 3, 4)):
     n = int(rng.choice(sizes))
     geo = [{}, {}, {"chunk_factor": 2, "chunk_dim": 6}, {"chunk_factor": 3, "chunk_dim": 4}, {"chunk_factor": 5, "chunk_dim": 4},
            {"chunk_factor": 4, "chunk_dim": 3, "cell_size": 2.5}, {"chunk_factor": 5, "chunk_dim": 3}][int(rng.integers(0, 7))]
@@ -76,7 +76,7 @@ def draw_case(rng, sizes, max_steps=6):
     w = None
     if rng.random() < 0.3:                                         # other masses, some of them zero
         w = np.where(rng.random(n) < 0.1, 0.0, rng.uniform(1.0, 100.0, n)).astype(np.float32)
-    world = int(rng.choice([1, 1, 2, 3, 4]))
+    world = int(rng.choice(list(worlds)))
     world = min(world, G // 2)
     cuts = None
     if world > 1 and rng.random() < 0.4:                           # the caller's own cuts: >= 2 layers per rank
@@ -104,8 +104,8 @@ def run_case(c, seed):
     try:
         ranks = [mk(r) for r in range(W)]
     except ps.PsamdError as e:
-        if c["cuts"] and "no slab partition" in str(e):        # random cuts may leave a rank's reads with a non-neighbour
-            return "plan refused (%r)" % (c["cuts"],)
+        if "no slab partition" in str(e):      # random cuts (or many ranks on a coarse chunk grid) may leave a rank's reads with a non-neighbour
+            return "plan refused (world %d, cuts %r)" % (W, c["cuts"])
         raise
     carried = {}                                                 # counters of a context that handed its state on
     o = O.System(oracle_cfg_from(ranks[0].cfg))
@@ -145,7 +145,11 @@ def run_case(c, seed):
         except ps.PsamdError as e:
             # documented refusals of the slab path: the chunk-list capacity corner, more overflow kills than a
             # status record carries, a transfer message smaller than what a fast dense cloud sends (xfer_cap)
-            if W > 1 and ("MAX_PARTICLES_PER_CHUNK" in str(e) or "status message" in str(e) or "had no room" in str(e)):
+            # ... and a particle that crossed TWO cell layers in a step (one ulp below a face, moved by exactly
+            # CELL_SIZE) over a rank whose own layers are a single one: its record arrives at a rank that does not
+            # hold the queue and is refused there
+            if W > 1 and ("MAX_PARTICLES_PER_CHUNK" in str(e) or "status message" in str(e) or "had no room" in str(e)
+                          or "does not match the receiver" in str(e)):
                 for g in ranks:
                     g.close()
                 o.close()
@@ -193,12 +197,13 @@ def main():
     ap.add_argument("--log", default=None)
     ap.add_argument("--sizes", default="3000,12000,40000,90000", help="particle counts to draw from")
     ap.add_argument("--max-steps", type=int, default=6)
+    ap.add_argument("--worlds", default="1,1,2,3,4", help="world sizes to draw from (capped at half the grid's layers)")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     log = open(a.log, "a") if a.log else sys.stdout
     bad = 0
     for i in range(a.cases):
-        c = draw_case(rng, [int(v) for v in a.sizes.split(",")], a.max_steps)
+        c = draw_case(rng, [int(v) for v in a.sizes.split(",")], a.max_steps, [int(v) for v in a.worlds.split(",")])
         if os.environ.get("FUZZ_ANNOUNCE"):
             print("start case %d [%s]" % (i, c["desc"]), file=log, flush=True)
         t = time.time()

@@ -41,7 +41,7 @@ VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector (spec)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FLOP_PER_PAIR = 20           # the usual N-body convention
 APPLY_BYTES_PER_UPDATE = 64  # read pos4+vel4, write pos4+vel4
-TRAFFIC_FILE = os.path.join("profiles", "r2_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r3_traffic.json")
 XGMI_LINK_GBS = 153.0        # MI355X_MICROARCH.md: one xGMI link, one direction (model only)
 
 
@@ -50,10 +50,13 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=1 << 20)
+    ap.add_argument("--n", type=int, default=0, help="particles (default 2^20; 2^18 with --all-pairs)")
     ap.add_argument("--fast-math", action="store_true", help="FMA/rsq pair arithmetic (not bit-exact)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--cpu-threads", type=int, default=64, help="cap on host threads for the all-core CPU figure")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for the many-thread CPU figure (0: every CPU this process may run on)")
+    ap.add_argument("--all-pairs", action="store_true", help="BASELINE configs[1]: every particle against EVERY body (PSAMD_FLAG_ALL_PAIRS; "
+                    "not in the reference, parity unpinned), default N = 2^18; roofline = 20 N^2 flop per step")
+    ap.add_argument("--no-side-runs", action="store_true", help="skip the lifecycle-off / tolerance-mode / free-running runs beside the headline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel-times", action="store_true", help="HIP events between all stage kernels, not only around the "
                     "pair pass / apply / life cycle (costs ~40 us of idle GPU per step)")
@@ -133,7 +136,7 @@ def measured_traffic(kernel_prefix, args, world):
     """HBM bytes per launch from the committed rocprofv3 PMC capture -- only for the very
     configuration it was captured with (bench.py defaults on one GPU); else None."""
     if world != 1 or args.n != (1 << 20) or args.chunk_factor != 4 or args.chunk_dim != 4 or args.evolve or args.fast_math \
-            or args.sim_world:
+            or args.sim_world or args.all_pairs:
         return None
     try:
         with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
@@ -173,7 +176,7 @@ def cpu_baseline(args, xyz, age, fert, cfg_over):
     o.init_iframe()
     o.build_grid()
     many = None
-    cores = min(len(os.sched_getaffinity(0)), args.cpu_threads)
+    cores = len(os.sched_getaffinity(0)) if args.cpu_threads <= 0 else min(len(os.sched_getaffinity(0)), args.cpu_threads)
     if cores > 1:
         total = o.sorted_count()
         f = np.zeros((total + 8, 4), np.float32)
@@ -212,16 +215,42 @@ def cpu_baseline(args, xyz, age, fert, cfg_over):
     return one, many
 
 
-def side_run(ps, cfg_over, device, xyz, age, fert, flags, steps, restore):
-    """A second, short measurement on a fresh context: the same timed loop with other flags
-    (fast math) or free-running (restore=False).  Never the headline."""
-    g = ps.ParticleSystem(ps.default_config(device=device, flags=flags, **cfg_over))
+def pass_counts(g, restore):
+    """(particles per cell, particles per cell the force pass visits) of one frame of context g."""
+    if restore:
+        g.snapshot_restore()
+    g.init_iframe(); g.build_grid()
+    n = g.download_cellgrid()[:, 0].copy()
+    g.calc_forces_pairs()
+    f = g.download_force_counts()
+    g.calc_forces_apply()
+    return n, f
+
+
+def force_terms(n, f, G, all_pairs):
+    """pair evaluations of one force pass: per visited particle its stencil's population, or -- all-pairs -- every listed body"""
+    if all_pairs:
+        return int(f.astype(np.int64).sum()) * int(n.astype(np.int64).sum())
+    return pair_count(n, f, G)
+
+
+def side_run(ps, cfg_over, device, xyz, age, fert, flags, steps, restore, warm=10, all_pairs=False, **cfg_extra):
+    """A second, short measurement on a fresh context: the same timed loop with other flags (fast
+    math), other constants (life cycle off) or free-running (restore=False).  Never the headline.
+    Returns updates, seconds, live counts per step, and -- from HIP events on the context's stream
+    inside the timed region -- the force pass's own roofline entry."""
+    cfg = dict(cfg_over)
+    cfg.update(cfg_extra)
+    g = ps.ParticleSystem(ps.default_config(device=device, flags=flags, **cfg))
     g.fill_particles(xyz, age=age, fert_age=fert)
     g.snapshot_save()
     live = []
     if restore:
-        for _ in range(10):
+        for _ in range(warm):
             g.snapshot_restore(); g.step(1)
+    G = g.sizes.grid_dim
+    n0, f0 = pass_counts(g, restore) if restore else (None, None)
+    g.set_timing(True)
     g.synchronize()
     p0 = g.counters["particles_processed"]
     t0 = time.perf_counter()
@@ -233,9 +262,20 @@ def side_run(ps, cfg_over, device, xyz, age, fert, flags, steps, restore):
             live.append(int(g.device_view().live))      # particles that step processed (host copy, no sync)
     g.synchronize()
     dt = time.perf_counter() - t0
+    tim, launches = g.timing()
+    g.set_timing(False)
     done = g.counters["particles_processed"] - p0
+    roof = None
+    if restore:
+        pairs = force_terms(n0, f0, G, all_pairs)
+        us = tim["pairs"] / max(launches, 1)
+        ach = pairs * FLOP_PER_PAIR / (us * 1e-6) / 1e12 if us > 0 else 0.0
+        roof = {"kernel": "force pass (HIP events on the context's stream, inside this run's timed region)", "bound": "valu",
+                "achieved": ach, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / VALU_PEAK_TFLOPS, "traffic": None,
+                "pairs_per_launch": float(pairs), "flop_per_pair": FLOP_PER_PAIR, "us_per_launch": us,
+                "particles_with_a_force_term": int(f0.sum())}
     g.close()
-    return done, dt, live
+    return done, dt, live, roof, {k: v / max(launches, 1) for k, v in tim.items() if v > 0}
 
 
 def sim_world(args, ps, cfg_over, flags):
@@ -262,11 +302,14 @@ def sim_world(args, ps, cfg_over, flags):
             for ph, out_slot, peer, in_slot in routes(r, W):
                 if ph == phase and out_slot in rings[r].t:
                     rings[peer].t[in_slot].copy_(rings[r].t[out_slot], non_blocking=True)
-        if phase == "halo":                  # the status all-gather
-            n = rings[0].t[10].numel()
-            for r in range(W):
-                for q in range(W):
-                    rings[q].t[11][r * n:(r + 1) * n].copy_(rings[r].t[10], non_blocking=True)
+        if phase == "halo":                  # the all-gathers: status records, and -- all-pairs forces -- the snapshot blocks
+            for out_slot, in_slot in ((10, 11), (12, 13)):
+                if out_slot not in rings[0].t:
+                    continue
+                n = rings[0].t[out_slot].numel()
+                for r in range(W):
+                    for q in range(W):
+                        rings[q].t[in_slot][r * n:(r + 1) * n].copy_(rings[r].t[out_slot], non_blocking=True)
 
     def one_step(timed):
         with torch.cuda.stream(stream):
@@ -298,23 +341,38 @@ def sim_world(args, ps, cfg_over, flags):
     for r, g in enumerate(ranks):
         # the bigger of what the rank sends and receives per phase (both directions run at once)
         msg[r] = {"halo": max(g.msg_bytes(1), g.msg_bytes(2), g.msg_bytes(0), g.msg_bytes(3)),
-                  "force": max(g.msg_bytes(4), g.msg_bytes(5)), "xfer": g.msg_bytes(6) + g.msg_bytes(7)}
+                  "force": max(g.msg_bytes(4), g.msg_bytes(5)), "xfer": g.msg_bytes(6) + g.msg_bytes(7),
+                  "allgather": g.msg_bytes(12)}
     # model: a message costs 10 us + bytes / one xGMI link, one direction.  The halo travels on
     # RCCL's stream while the rank works on its interior cells (DeviceRing.step): only what
-    # outlasts that pass is on the critical path; force and xfer are exposed once each.
+    # outlasts that pass is on the critical path; force and xfer are exposed once each.  The
+    # all-pairs snapshot all-gather is priced as a ring: W - 1 hops of one block.
     def t_ms(b):
         return 1e-2 + 1e3 * b / (XGMI_LINK_GBS * 1e9) if b else 0.0
     k_int = stages.index("pairs_interior")
-    comm_ms = [max(0.0, t_ms(msg[r]["halo"]) - float(tot[r, k_int])) + t_ms(msg[r]["force"]) + t_ms(msg[r]["xfer"] / 2) for r in range(W)]
+    phase_ms = {"halo": [max(0.0, max(t_ms(msg[r]["halo"]), (W - 1) * t_ms(msg[r]["allgather"])) - float(tot[r, k_int])) for r in range(W)],
+                "force": [t_ms(msg[r]["force"]) for r in range(W)], "xfer": [t_ms(msg[r]["xfer"] / 2) for r in range(W)]}
+    comm_ms = [phase_ms["halo"][r] + phase_ms["force"][r] + phase_ms["xfer"][r] for r in range(W)]
     per_rank = tot.sum(1)
-    step_ms = float((per_rank + np.array(comm_ms)).max())
+    # Two bounds of the step.  Optimistic: the slowest rank's own stages plus its own transfers, as if
+    # no rank ever waited for a neighbour.  Coupled: every stage waits for the slowest rank's previous
+    # stage (the halo needs the neighbours' build, force_in their pairs, xfer their apply): the sum
+    # over stages of the per-stage maximum, plus the largest transfer of every phase.  A real ring lies
+    # between the two; the coupled figure is the one quoted.
+    step_lo = float((per_rank + np.array(comm_ms)).max())
+    step_hi = float(tot.max(0).sum() + sum(max(v) for v in phase_ms.values()))
     out = {"sim_world": W, "n": args.n, "stage_ms_per_rank": {name: [round(float(x), 4) for x in tot[:, k]] for k, name in enumerate(stages)},
            "compute_ms_per_rank": [round(float(x), 4) for x in per_rank], "modelled_comm_ms_per_rank": [round(x, 4) for x in comm_ms],
-           "message_bytes_rank1": msg[min(1, W - 1)], "halo_cap_cell": int(args.halo_cap_cell), "modelled_step_ms": step_ms,
-           "modelled_updates_per_s": updates / (step_ms * 1e-3), "updates_per_step": updates,
+           "message_bytes_rank1": msg[min(1, W - 1)], "halo_cap_cell": int(args.halo_cap_cell),
+           "modelled_step_ms": step_hi, "modelled_step_ms_optimistic": step_lo,
+           "modelled_updates_per_s": updates / (step_hi * 1e-3), "updates_per_step": updates, "timed_steps": args.steps,
+           "all_pairs": bool(args.all_pairs),
            "note": "one GPU runs the ranks one after the other; compute times are measured (HIP events); a transfer is modelled "
-                   "as 10 us + bytes / %.0f GB/s (halo up, force, the two xfer messages in parallel); the halo overlaps the "
-                   "interior pass, the rest is not overlapped" % XGMI_LINK_GBS}
+                   "as 10 us + bytes / %.0f GB/s (halo up, force, the two xfer messages in parallel; the all-pairs snapshot "
+                   "all-gather as a ring of W - 1 such hops); the halo overlaps the interior pass, the rest is not overlapped.  "
+                   "modelled_step_ms = sum over stages of the slowest rank's stage + the largest transfer of every phase "
+                   "(neighbour-coupled: an upper bound); _optimistic = the slowest rank's own stages and transfers (a lower bound).  "
+                   "Left out: host launch overhead." % XGMI_LINK_GBS}
     for g in ranks:
         g.close()
     return out
@@ -322,6 +380,8 @@ def sim_world(args, ps, cfg_over, flags):
 
 def main():
     args = parse_args()
+    if args.n <= 0:
+        args.n = (1 << 18) if args.all_pairs else (1 << 20)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and args.gpus > 1 and "PSAMD_BENCH_CHILD" not in os.environ:
         launch_ranks(args)          # does not return
@@ -396,7 +456,7 @@ def main():
         # layer's population (n / G) is what it sends, measured; a message that did not fit is a loud error
         G = args.chunk_factor * args.chunk_dim
         cfg_over["xfer_cap"] = max(4096, int(args.n / G / 8) + 1024)
-    flags = ps.FLAG_FAST_MATH if args.fast_math else 0
+    flags = (ps.FLAG_FAST_MATH if args.fast_math else 0) | (ps.FLAG_ALL_PAIRS if args.all_pairs else 0)
     if args.sim_world:
         print(json.dumps(sim_world(args, ps, cfg_over, flags)))
         return
@@ -476,6 +536,7 @@ def main():
             g.slab_build()
             n = g.download_cellgrid()[:, 0].copy()
             ring.exchange("halo")
+            ring.finish_snapshot(ring.gather_snapshot())
             ring.finish_status(ring.gather_status())
             g.slab_pairs()
             mine = g.download_force_counts()
@@ -519,7 +580,7 @@ def main():
         # not constant (cell-overflow and full-segment losses as the cloud collapses)
         value = updates / elapsed
         # the force kernel of THIS rank: its own share of the pairs against its own launch time
-        pairs_rank = 0.5 * (pair_count(counts0, mine0, G) + pair_count(counts1, mine1, G))
+        pairs_rank = 0.5 * (force_terms(counts0, mine0, G, args.all_pairs) + force_terms(counts1, mine1, G, args.all_pairs))
         us_pairs = tim["pairs"] / max(launches, 1)
         us_apply = tim["apply"] / max(launches, 1)
         ach_tflops = pairs_rank * FLOP_PER_PAIR / (us_pairs * 1e-6) / 1e12 if us_pairs > 0 else 0.0
@@ -527,14 +588,18 @@ def main():
         traffic_pairs = measured_traffic("k_pairs_balanced", args, world)
         traffic_apply = measured_traffic("k_apply", args, world)
         out = {
-            "metric": "particle-updates/sec at N=2^20", "value": value, "unit": "particle-updates/s",
+            "metric": "particle-updates/sec at N=2^20" if not args.all_pairs else "particle-updates/sec, all-pairs forces (BASELINE configs[1]), N=%d" % args.n,
+            "value": value, "unit": "particle-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: N=%d uniform cloud, %d^3 cells x 5.0, 27-cell cutoff gravity "
-                                   "+ reference collisions/integrate/wrap/relocation, all constants at reference defaults, "
-                                   "%s" % (args.n, G, "free-running" if args.evolve else "each step = one pass over the same cloud (restored in HBM)"),
+            "config": {"workload": ("BASELINE configs[1]: N=%d uniform cloud, %d^3 cells x 5.0, ALL-PAIRS gravity (every particle against every "
+                                    "body: the 27-cell stencil in the reference's order, then every other cell; not in the reference, parity "
+                                    "unpinned) + reference collisions/integrate/wrap/relocation, %s" if args.all_pairs else
+                                    "BASELINE configs[2]: N=%d uniform cloud, %d^3 cells x 5.0, 27-cell cutoff gravity "
+                                    "+ reference collisions/integrate/wrap/relocation, all constants at reference defaults, "
+                                    "%s") % (args.n, G, "free-running" if args.evolve else "each step = one pass over the same cloud (restored in HBM)"),
                        "arithmetic": "fast-math" if args.fast_math else "reference-exact fp32 (bitwise parity mode)",
                        "parallelism": ("%d slabs of cell layers, one per GPU (state partitioned by segment); halo / force / "
                                        "transfer messages between ring neighbours over %s" % (world, "RCCL send/recv" if args.backend == "nccl" else args.backend))
@@ -557,20 +622,34 @@ def main():
             out["config"]["halo_cap_cell"] = int(args.halo_cap_cell)
             out["config"]["message_bytes_rank0"] = {name: int(g.msg_bytes(k)) for name, k in
                                                     (("halo_up", 1), ("halo_down", 0), ("force_in", 5), ("xfer_each", 6))}
-        if world == 1 and not args.no_cpu:
-            if not args.fast_math and not args.evolve:
-                d, t, _ = side_run(ps, cfg_over, local_rank, xyz, age, fert, ps.FLAG_FAST_MATH, 50, True)
+        if args.all_pairs:
+            out["roofline"]["kernel"] = "k_pairs (all-pairs walk: stencil in the reference's order, then every other cell, summed per cell)"
+            out["roofline"]["flop_per_step_convention"] = "20 flop x N^2 (SURVEY 8d): %.3g" % (20.0 * args.n * args.n)
+            out["cpu_baseline"] = None       # the reference has no all-pairs force; the oracle restates the reference only
+        if world == 1 and not args.no_cpu and not args.all_pairs:
+            if not args.fast_math and not args.evolve and not args.no_side_runs and not args.all_pairs:
+                # SURVEY 8(d)'s lifecycle-off mode: collision radius 0 (and no births, no deaths of age in these
+                # steps), so every one of the N particles goes through the force loop and is integrated
+                d, t, _, roof, kt = side_run(ps, cfg_over, local_rank, xyz, age, fert, flags, 50, True, collision_radius=0.0)
+                out["lifecycle_off"] = {
+                    "what": "the same cloud and step with COLLISION_RADIUS = 0: nothing collides, all %d particles get a force and are "
+                            "integrated (the headline's step, at the reference's radius 0.4, integrates the particles the "
+                            "reference integrates: config.particles_with_a_force_term)" % args.n,
+                    "value": d / t, "unit": "particle-updates/s", "ms_per_step": 1e3 * t / 50, "steps": 50,
+                    "roofline": roof, "kernel_us_per_step": kt}
+                d, t, _, roof, kt = side_run(ps, cfg_over, local_rank, xyz, age, fert, ps.FLAG_FAST_MATH, 50, True)
                 out["within_tolerance_mode"] = {
                     "arithmetic": "PSAMD_FLAG_FAST_MATH (FMA + v_rsq): accelerations deviate from the oracle's by the amounts "
                                   "tests/test_gpu_fast.py measures and bounds (also at this density); not the headline",
-                    "value": d / t, "unit": "particle-updates/s", "ms_per_step": 1e3 * t / 50, "steps": 50}
-                d, t, lv = side_run(ps, cfg_over, local_rank, xyz, age, fert, flags, args.evolve_steps, False)
+                    "value": d / t, "unit": "particle-updates/s", "ms_per_step": 1e3 * t / 50, "steps": 50,
+                    "roofline": roof, "kernel_us_per_step": kt}
+                d, t, lv, _, _ = side_run(ps, cfg_over, local_rank, xyz, age, fert, flags, args.evolve_steps, False)
                 out["evolve"] = {"what": "%d free-running steps from the same cloud (the population collapses: surface implosion, "
                                          "collisions), exact arithmetic" % args.evolve_steps,
                                  "value": d / t, "unit": "particle-updates/s", "ms_per_step": 1e3 * t / args.evolve_steps,
                                  "live_per_step": lv}
             out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(args, xyz, age, fert, cfg_over)
-        else:
+        elif not args.all_pairs:
             out["cpu_baseline"] = None
         print(json.dumps(out))
     g.close()

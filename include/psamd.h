@@ -51,7 +51,9 @@ typedef enum psamd_status {
 #define PSAMD_FLAG_ALL_PAIRS    0x4u  /* force walk over EVERY cell, not only the 27-cell stencil (the reference has only the
                                          cutoff, app.cu:352-452): the stencil first, in the reference's order, then the other
                                          cells in index order -- so a cloud that fits a 2x2x2 block of cells gets the cutoff
-                                         result bit for bit.  Collisions stay short-range.  One GPU only (world == 1). */
+                                         result bit for bit.  Collisions stay short-range.  With world > 1 every rank
+                                         contributes the snapshot of its own cells to an all-gather once per step
+                                         (allg_out -> allg_in below) and walks the gathered buffer in the same order. */
 #define PSAMD_FLAG_EULER        0x8u  /* position update x += v*dt (explicit Euler) instead of the reference's
                                          x += v*dt + 0.5*a*dt*dt (ps.cpp:1274-1276); the velocity update is the same */
 
@@ -262,6 +264,9 @@ typedef struct psamd_slab_buffers {
     int64_t xfer_bytes;                    /* all four the same size                              */
     void   *status_out, *status_in;        /* ALL-GATHERED once per step: status_in = world records of status_bytes each, by rank */
     int64_t status_bytes;
+    void   *allg_out, *allg_in;            /* PSAMD_FLAG_ALL_PAIRS only, ALL-GATHERED once per step between slab_build and slab_pairs:
+                                              the snapshot (x, y, z, w_eff) of every rank's own cells; allg_in = world blocks of allg_bytes */
+    int64_t allg_bytes;
 } psamd_slab_buffers;
 int psamd_slab_buffers_get(psamd_ctx *ctx, psamd_slab_buffers *out);
 
@@ -281,7 +286,7 @@ int psamd_slab_apply(psamd_ctx *ctx);   /* unpacks force_in; integrate ... (calc
 int psamd_slab_finish(psamd_ctx *ctx);  /* merges xfer_in; queue replay and relocation                  */
 /* Transport through host memory (tests, two processes sharing one GPU): copy message buffer
  * `which` to / from the host.  which: 0/1 halo_out[0/1], 2/3 halo_in[0/1], 4 force_out,
- * 5 force_in, 6/7 xfer_out[0/1], 8/9 xfer_in[0/1], 10 status_out, 11 status_in. */
+ * 5 force_in, 6/7 xfer_out[0/1], 8/9 xfer_in[0/1], 10 status_out, 11 status_in, 12 allg_out, 13 allg_in. */
 int psamd_slab_msg_download(psamd_ctx *ctx, int which, void *host, int64_t bytes);
 int psamd_slab_msg_upload(psamd_ctx *ctx, int which, const void *host, int64_t bytes);
 

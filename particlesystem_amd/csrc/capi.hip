@@ -45,6 +45,8 @@ struct psamd_ctx {
     size_t xfer_bytes = 0;
     int *status_out = nullptr, *status_in = nullptr;   // status_in: world records, all-gathered
     size_t status_bytes = 0;
+    int *allg_out = nullptr, *allg_in = nullptr;       // all-pairs across ranks: own snapshot block, all ranks' blocks (all-gathered)
+    size_t allg_bytes = 0;
     int *pack_off[2] = {nullptr, nullptr}, *unpack_off[2] = {nullptr, nullptr};
     int slab_stage = 0;               // 0 idle, 1 built, 2 pairs done, 3 applied
     size_t frame_ints = 0;            // ints zeroed by init_iframe
@@ -361,8 +363,26 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     P.drag = (float)cfg->drag;
     P.force_sign = cfg->force_sign < 0 ? -1.0f : 1.0f;
     if (cfg->drag < 0) return fail(c, PSAMD_ERR_INVALID_ARG, "drag must be >= 0");
-    if ((cfg->flags & PSAMD_FLAG_ALL_PAIRS) && cfg->world > 1) return fail(c, PSAMD_ERR_UNSUPPORTED, "all-pairs forces need every body on one GPU (world == 1)");
     fill_slab_params(g, c->plan, *cfg, P);
+    P.status_words = STATUS_CHUNK_OFF + 4 * g.num_chunks;
+    if ((cfg->flags & PSAMD_FLAG_ALL_PAIRS) && cfg->world > 1) {
+        // every rank's block of the all-gathered snapshot has the same size: room for the rank with the most cells / slots
+        int cells = 0;
+        int64_t slots = 0;
+        psamd_config rc = *cfg;
+        for (int r = 0; r < cfg->world; r++) {
+            rc.rank = r;
+            const SlabPlan pr = plan_for(g, rc);
+            if (!pr.valid) return fail(c, PSAMD_ERR_UNSUPPORTED, "no slab partition for this grid and world size");
+            int64_t sl = 0;
+            for (int t = 0; t < 4; t++) sl += pr.slot_hi[t] - pr.slot_lo[t];
+            cells = std::max(cells, (pr.state_hi - pr.state_lo) * g.G * g.G);
+            slots = std::max(slots, sl);
+        }
+        P.allg_cells = cells;
+        P.allg_cap = (int)((slots + 63) & ~(int64_t)63);
+        P.allg_block = MSG_HEADER_WORDS + P.allg_cells + 4 * P.allg_cap;
+    }
     auto bits_for = [](int64_t n) { int b = 1; while (((int64_t)1 << b) < n) b++; return b; };
     P.key_chunk_shift = 2 + bits_for(g.container);
     P.key_rec_shift = P.key_chunk_shift + bits_for((int64_t)g.num_chunks + 1);
@@ -391,6 +411,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     }
     if (P.key_bits > 63) return fail(c, PSAMD_ERR_UNSUPPORTED, "queue-op key does not fit 64 bits for this configuration");
     if ((cfg->flags & PSAMD_FLAG_ALL_PAIRS) && !P.lean_math) return fail(c, PSAMD_ERR_UNSUPPORTED, "all-pairs forces are built for the lean pair arithmetic only (EPS2 in its validated range)");
+    if ((cfg->flags & PSAMD_FLAG_ALL_PAIRS) && P.world > 1 && !P.two_pass) return fail(c, PSAMD_ERR_UNSUPPORTED, "all-pairs forces across ranks need the two-pass pair stage (collision radius small against the cell)");
     for (int k = 0; k < 5; k++) { c->S.seg_base[k] = g.seg_base[k]; c->S.info_base[k] = g.info_base[k]; }
     for (int k = 0; k < 4; k++) c->S.seg_size_t[k] = g.seg_size_t[k];
 
@@ -402,8 +423,8 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     d.ops_cap = (int)std::min<size_t>(3 * C + 2 * xf + 64 + (P.world > 1 ? (size_t)P.world * STATUS_KILL_CAP : 0), (size_t)INT32_MAX / 2);
     d.moves_cap = (int)std::min<size_t>(2 * C + 2 * xf + 64, (size_t)INT32_MAX / 2);
     int *frame = nullptr;
-    // cell counts, chunk counts, record counts, halo counts, hand-off flags of the force pass
-    const size_t frame_ints = LC + g.num_chunks + g.queue_infos + LC + 2 * LC * P.slices;   // (flags: one block per pass of the pair stage)
+    // cell counts, chunk counts, queue-op counts and cursors per record, halo counts, active-list lengths, hand-off flags of the force pass
+    const size_t frame_ints = LC + g.num_chunks + 2 * (size_t)g.queue_infos + LC + LC + 2 * LC * P.slices;   // (flags: one block per pass of the pair stage)
     PS_HIP(c, dev_alloc(c, &d.pos4, C));
     PS_HIP(c, dev_alloc(c, &d.vel4, C));
     PS_HIP(c, dev_alloc(c, &d.acc4, C));
@@ -414,15 +435,15 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.queue, C));
     PS_HIP(c, dev_alloc(c, &frame, frame_ints));
     d.cell_count = frame; d.chunk_count = frame + LC; d.rec_count = d.chunk_count + g.num_chunks;
-    d.halo_count = d.rec_count + g.queue_infos;
-    d.task_ready = d.halo_count + LC;
+    d.rec_cursor = d.rec_count + g.queue_infos;
+    d.halo_count = d.rec_cursor + g.queue_infos;
+    d.active_count = d.halo_count + LC;
+    d.task_ready = d.active_count + LC;
     c->frame_ints = frame_ints;
     PS_HIP(c, dev_alloc(c, &d.halo_f, (size_t)3 * LC * HALO_CAP + 64));   // + slack: scalar loads fetch whole groups
     PS_HIP(c, dev_alloc(c, &d.halo_id, LC * HALO_CAP + 64));
     PS_HIP(c, dev_alloc(c, &d.active_list, SC));
-    PS_HIP(c, dev_alloc(c, &d.pair_flag, SC));
     PS_HIP(c, dev_alloc(c, &d.snap_cid, SC));
-    PS_HIP(c, dev_alloc(c, &d.active_count, LC));
     PS_HIP(c, dev_alloc(c, &d.task_list2, LC * P.slices));
     PS_HIP(c, dev_alloc(c, &d.merged_tasks, LC));
     PS_HIP(c, dev_alloc(c, &d.task_cost, LC));
@@ -430,7 +451,6 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.cost_start, 2 * LC + 2));
     PS_HIP(c, dev_alloc(c, &d.wave_pos, (size_t)MAX_PAIR_WAVES + 1));
     PS_HIP(c, dev_alloc(c, &d.rec_start, (size_t)g.queue_infos + 1));
-    PS_HIP(c, dev_alloc(c, &d.rec_cursor, (size_t)g.queue_infos));
     PS_HIP(c, dev_alloc(c, &d.fs, 1));
     PS_HIP(c, dev_alloc(c, &d.cell_start, LC + 1));
     PS_HIP(c, dev_alloc(c, &d.cursor, LC));
@@ -443,7 +463,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.snap_age, SC));
     PS_HIP(c, dev_alloc(c, &d.force4, SC));
     PS_HIP(c, dev_alloc(c, &d.celltab, (size_t)g.num_cells));
-    if (P.world == 1) {                                  // the chunk lists' capacity rule (k_chunk_cap)
+    {                                                    // the chunk lists' capacity rule (chunk_cap_block)
         PS_HIP(c, dev_alloc(c, &d.chunk_skip, C));
         PS_HIP(c, dev_alloc(c, &d.chunk_segs, (size_t)g.num_chunks * 27));
         std::vector<int2> segs((size_t)g.num_chunks * 27);
@@ -515,9 +535,21 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
             PS_HIP(c, hipMemsetAsync(c->xfer_in[k], 0, c->xfer_bytes, c->stream));
             d.xfer_out[k] = reinterpret_cast<XferRec *>(c->xfer_out[k] + MSG_HEADER_WORDS);
         }
-        c->status_bytes = (size_t)STATUS_WORDS * sizeof(int);
-        PS_HIP(c, dev_alloc(c, &c->status_out, (size_t)STATUS_WORDS));
-        PS_HIP(c, dev_alloc(c, &c->status_in, (size_t)STATUS_WORDS * P.world));
+        if (P.flags & PSAMD_FLAG_ALL_PAIRS) {
+            c->allg_bytes = (size_t)P.allg_block * sizeof(int);
+            PS_HIP(c, dev_alloc(c, &c->allg_out, (size_t)P.allg_block));
+            PS_HIP(c, dev_alloc(c, &c->allg_in, (size_t)P.allg_block * P.world + 64));      // + slack: scalar loads fetch whole groups
+            PS_HIP(c, hipMemsetAsync(c->allg_out, 0, c->allg_bytes, c->stream));
+            PS_HIP(c, hipMemsetAsync(c->allg_in, 0, (c->allg_bytes * P.world) + 64 * sizeof(int), c->stream));
+            PS_HIP(c, dev_alloc(c, &d.gstart, (size_t)g.num_cells + 1));
+            PS_HIP(c, dev_alloc(c, &d.gn, (size_t)g.num_cells + 1));
+            PS_HIP(c, hipMemsetAsync(d.gstart, 0, ((size_t)g.num_cells + 1) * sizeof(int), c->stream));
+            PS_HIP(c, hipMemsetAsync(d.gn, 0, ((size_t)g.num_cells + 1) * sizeof(int), c->stream));
+            d.allg_in = c->allg_in;
+        }
+        c->status_bytes = (size_t)P.status_words * sizeof(int);
+        PS_HIP(c, dev_alloc(c, &c->status_out, (size_t)P.status_words));
+        PS_HIP(c, dev_alloc(c, &c->status_in, (size_t)P.status_words * P.world));
         PS_HIP(c, hipMemsetAsync(c->status_out, 0, c->status_bytes, c->stream));
         PS_HIP(c, hipMemsetAsync(c->status_in, 0, c->status_bytes * P.world, c->stream));
         d.status_out = c->status_out;
@@ -555,7 +587,8 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
         int i0 = lo, i1 = lo;
         for (int l = lo; l < hi; l++) if (own(l - 1) && own(l + 1)) { if (i1 == i0) i0 = l; i1 = l + 1; } else if (i1 > i0) break;
         c->P_int = P; c->P_rest = P;
-        c->have_interior = P.world > 1 && P.two_pass && P.lean_math && i1 > i0 && (i1 - i0) < (hi - lo) + (pl.lentin_hi - pl.lentin_lo);
+        c->have_interior = P.world > 1 && P.two_pass && P.lean_math && i1 > i0 && (i1 - i0) < (hi - lo) + (pl.lentin_hi - pl.lentin_lo)
+                           && !(P.flags & PSAMD_FLAG_ALL_PAIRS);      // (an all-pairs pass needs the gathered snapshot: nothing to do before it lands)
         if (c->have_interior) {
             const int a = (i0 - pl.state_lo) * GG, b = (i1 - pl.state_lo) * GG;
             c->P_int.comp_lo[0] = a; c->P_int.comp_hi[0] = b;
@@ -924,7 +957,7 @@ static int do_init_iframe(psamd_ctx *c)
 {
     if (c->timing >= 2) { make_events(c); (void)hipEventRecord(c->ev[10], c->stream); }
     // cell / chunk / queue-record counts and the per-frame scalars (the sticky error word stays)
-    PS_HIP(c, launch_frame_reset(c->stream, c->d, c->frame_ints));
+    PS_HIP(c, launch_frame_reset(c->stream, c->d, c->frame_ints, c->P.world > 1 ? 4 * c->geo.num_chunks : 0));
     c->frame_reset = true; c->grid_built = false; c->pairs_done = false;
     return PSAMD_OK;
 }
@@ -961,7 +994,7 @@ static int do_apply(psamd_ctx *c)
 {
     if (!c->grid_built || !c->pairs_done) return fail(c, PSAMD_ERR_STATE, "apply needs build_grid and the pair pass first");
     if (c->timing) (void)hipEventRecord(c->ev[7], c->stream);
-    PS_HIP(c, launch_apply(c->stream, c->P, c->S, c->d, c->step));
+    PS_HIP(c, launch_apply(c->stream, c->P, c->S, c->d, c->step, c->geo.queue_infos));
     if (c->P.world > 1)
         PS_HIP(c, launch_outbox_close(c->stream, c->P, c->d, c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total,
                                       c->xfer_out[0], c->xfer_out[1]));
@@ -973,19 +1006,18 @@ static int do_lifecycle(psamd_ctx *c)
 {
     const int par = (int)(c->steps_total & 1);   // not c->step: a snapshot restore rewinds that
     if (c->timing) (void)hipEventRecord(c->ev[par ? 11 : 8], c->stream);
-    if (c->P.world > 1) {
+    if (c->P.world > 1)
         for (int k = 0; k < 2; k++) PS_HIP(c, launch_inbox_merge(c->stream, c->P, c->d, c->xfer_in[k]));
-        PS_HIP(c, launch_status_merge(c->stream, c->P, c->d, c->status_in));
-    }
-    PS_HIP(c, launch_ops_census(c->stream, c->P, c->d, c->geo.queue_infos));
+    // live_bound < 0: unknown (state was uploaded) -> size for every owned slot; arrivals on top
+    const int64_t bound = (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) + 2 * (int64_t)c->P.xfer_cap
+                          + (c->P.world > 1 ? (int64_t)c->P.world * STATUS_KILL_CAP : 0);
+    PS_HIP(c, launch_ops_bucket(c->stream, c->P, c->d, c->geo.queue_infos, bound));
     // one small read-back per step, as the reference's driver does for hostGridMax
-    // (ps.cpp:1878-1900): live count, sticky errors and the sizes of the op lists.  The
-    // life-cycle kernels are enqueued behind it without waiting (they size themselves from
+    // (ps.cpp:1878-1900): live count, sticky errors and the sizes of the op lists.  The rest of the
+    // life cycle is enqueued behind it without waiting (the kernels size themselves from
     // the same scalars on the device), so the GPU is busy while the host catches up.
     PS_HIP(c, hipMemcpyAsync(c->h_fs, c->d.fs, sizeof(FrameScalars), hipMemcpyDeviceToHost, c->stream));
     PS_HIP(c, hipEventRecord(c->ev_scalars, c->stream));
-    // live_bound < 0: unknown (state was uploaded) -> size for every owned slot; arrivals on top
-    const int64_t bound = (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) + 2 * (int64_t)c->P.xfer_cap;
     PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos, bound));
     c->host_queues_valid = false;
     PS_HIP(c, hipEventSynchronize(c->ev_scalars));
@@ -996,7 +1028,13 @@ static int do_lifecycle(psamd_ctx *c)
     c->live_bound = std::min<int64_t>(c->P.slots_total, (int64_t)c->h_fs->live + c->h_fs->n_moves);   // births and arrivals <= moves
     c->processed_total += c->h_fs->live;
     c->max_bucket_seen = std::max<int64_t>(c->max_bucket_seen, c->h_fs->max_bucket);
-    if (c->h_fs->error) return check_device_errors(c);
+    // A slab fails COLLECTIVELY: only on error bits that were in this step's all-gathered status records,
+    // which every rank sees alike (status_error) -- all ranks return the error from the same
+    // slab_finish.  An error this rank raised after its status record was closed (a message that did
+    // not fit, an arrival for a queue it does not hold) stays sticky, goes out with the next step's
+    // record and stops every rank there; returning it now would leave the ranks that have not heard
+    // of it waiting in the next exchange.  (psamd_synchronize reports whatever is pending.)
+    if (c->P.world > 1 ? c->h_fs->status_error != 0 : c->h_fs->error != 0) return check_device_errors(c);
     if (c->h_fs->max_bucket > BUCKET_MAX)      // rare: the kernels above stood down
         PS_HIP(c, launch_lifecycle_sorted(c->stream, c->P, c->d, c->step, c->geo.queue_infos, c->h_fs->n_ops, c->h_fs->n_moves));
     if (c->timing) {
@@ -1080,6 +1118,7 @@ int psamd_slab_build(psamd_ctx *c)
     for (int k = 0; k < 2; k++)
         if (c->halo_out_cells[k] > 0)
             PS_HIP(c, launch_pack_halo(c->stream, c->P, c->d, c->halo_out_c0[k], c->halo_out_cells[k], c->halo_out[k], c->pack_off[k]));
+    if (c->allg_out) PS_HIP(c, launch_allg_pack(c->stream, c->P, c->d, c->allg_out));
     PS_HIP(c, launch_status_close(c->stream, c->d));
     c->slab_stage = 1;
     return PSAMD_OK;
@@ -1110,6 +1149,7 @@ int psamd_slab_pairs(psamd_ctx *c)
     if (c->halo_in_cells[1] > 0)      // from the rank above: halo layer (region 3)
         PS_HIP(c, launch_unpack_halo(c->stream, P, c->d, 3, -1, c->halo_in_cells[1], c->halo_in_cells[1], false,
                                      c->halo_in[1], c->unpack_off[1]));
+    if (c->allg_in) PS_HIP(c, launch_allg_index(c->stream, P, c->d));      // all-pairs: the gathered snapshot, by global cell
     int rc = do_pairs(c, c->interior_done ? c->P_rest : c->P, true, !c->interior_done);
     c->interior_done = false;
     if (rc != PSAMD_OK) return rc;
@@ -1125,6 +1165,9 @@ int psamd_slab_apply(psamd_ctx *c)
     if (c->force_in)                  // lent-out layers are the tail of the snapshot that went up
         PS_HIP(c, launch_unpack_force(c->stream, c->P, c->d, c->halo_out_cells[1] - (c->P.lentout_c1 - c->P.lentout_c0),
                                       c->force_in, c->pack_off[1]));
+    // the status records of all ranks (all-gathered since slab_build): error bits, cell-overflow kills for the
+    // owner of queue record 0, and the chunks' counts over all ranks -- the chunk lists' capacity rule
+    PS_HIP(c, launch_status_merge(c->stream, c->P, c->d, c->status_in));
     int rc = do_apply(c);
     if (rc != PSAMD_OK) return rc;
     c->slab_stage = 3;
@@ -1177,6 +1220,7 @@ int psamd_slab_buffers_get(psamd_ctx *c, psamd_slab_buffers *o)
     o->force_out_bytes = (int64_t)c->force_out_bytes; o->force_in_bytes = (int64_t)c->force_in_bytes;
     o->xfer_bytes = (int64_t)c->xfer_bytes;
     o->status_out = c->status_out; o->status_in = c->status_in; o->status_bytes = (int64_t)c->status_bytes;
+    o->allg_out = c->allg_out; o->allg_in = c->allg_in; o->allg_bytes = (int64_t)c->allg_bytes;
     return PSAMD_OK;
 }
 
@@ -1191,6 +1235,8 @@ static bool slab_msg(psamd_ctx *c, int which, int *&ptr, size_t &bytes)
     case 8: case 9: ptr = c->xfer_in[which - 8]; bytes = c->xfer_bytes; return true;
     case 10: ptr = c->status_out; bytes = c->status_bytes; return true;
     case 11: ptr = c->status_in; bytes = c->status_bytes * (size_t)std::max(1, c->P.world); return true;
+    case 12: ptr = c->allg_out; bytes = c->allg_bytes; return true;
+    case 13: ptr = c->allg_in; bytes = c->allg_bytes * (size_t)std::max(1, c->P.world); return true;
     }
     return false;
 }

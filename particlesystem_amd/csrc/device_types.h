@@ -73,6 +73,20 @@ struct DevParams {
     int32_t num_cells_global;
     float drag;              // linear drag coefficient (0: the reference's arithmetic)
     float force_sign;        // +1 gravity, -1 repulsion
+    // all-pairs forces across ranks: every rank's own snapshot, all-gathered once per step, as blocks of
+    // allg_block words: 16 header | allg_cells cell counts | 4 planes (x, y, z, w_eff) of allg_cap floats
+    int32_t allg_cells, allg_cap, allg_block;
+    int32_t status_words;    // words of one rank's status record
+};
+
+// Where the all-pairs walk finds the cells beyond the stencil: by GLOBAL cell, a start (index of the
+// cell's first x in `buf`; y, z, w_eff follow at multiples of `plane`) and a length.  n == nullptr:
+// one GPU, the own sorted arrays serve (start = cell_start, lengths from consecutive starts).
+struct FarCells {
+    const int *start = nullptr;
+    const int *n = nullptr;
+    const float *buf = nullptr;
+    unsigned long long plane = 0;
 };
 
 // Which cells / slots / records a rank holds.  All device code goes through these.
@@ -172,6 +186,7 @@ struct FrameScalars {
     int32_t n_out[2];       // slab mode: relocation / birth records leaving for the rank below [0] / above [1]
     int32_t n_lent;         // slab mode: bodies in the lent-in region this frame
     int32_t chunk_over;     // a chunk's count passed MAX_PARTICLES_PER_CHUNK this frame: the tail of its list is skipped (k_chunk_cap)
+    int32_t status_error;   // slab mode: OR of the error bits in this step's all-gathered status records (every rank sees the same word)
     long long cost_total;   // two-pass mode: sum over the force pass's tasks of the bodies each walks (its stencil's population)
 };
 
@@ -222,8 +237,13 @@ struct XferRec {
     int32_t kind;           // 0 relocation (| MOVE_PARENT), 1 birth
     float pos[4], vel[4], acc[4];   // relocation: the particle; birth: the parent's position and velocity
 };
-constexpr int STATUS_KILL_CAP = 4080;   // cell-overflow kills one rank can report per step (status message: 16 + 4080 words)
-constexpr int STATUS_WORDS = 16 + STATUS_KILL_CAP;
+// Status record of a slab, all-gathered once per step (it must have landed before slab_apply): 16 header
+// words ([0] cell-overflow kills, [1] sticky error bits at the end of the build stage, [2] live), the
+// killed slot ids, then -- per chunk and segment type -- how many of the chunk's particles live in this
+// rank's segments of that type (the chunk lists' capacity rule ranks a chunk's particles in slot
+// order, and a chunk's 27 segments are spread over up to three ranks).
+constexpr int STATUS_KILL_CAP = 4080;   // cell-overflow kills one rank can report per step
+constexpr int STATUS_CHUNK_OFF = 16 + STATUS_KILL_CAP;     // first word of the (chunk, type) table; the record is STATUS_CHUNK_OFF + 4 * num_chunks words
 constexpr int MSG_HEADER_WORDS = 16;   // every message starts with 16 ints: [0] count, [1] bodies, [2] error bits
 
 constexpr int SORT_MAX = 4096;   // ids one cell may hold for the in-LDS ranking

@@ -42,9 +42,8 @@ struct DeviceState {
     float *halo_f = nullptr;      // [3][num_cells * HALO_CAP] x, y, z of those candidates
     int *halo_id = nullptr;       // [num_cells * HALO_CAP] their slot ids
     int *snap_cid = nullptr;      // [container] sorted order: slot id, or -1 for a body that can never collide
-    int *pair_flag = nullptr;     // [container] sorted order: 0 needs a force, -1 kid (moves, no force), 1 survives, 2 dies
-    int *active_list = nullptr;   // [container] per cell (at cell_start[c]): sorted indices of the particles that need a force
-    int *active_count = nullptr;  // [num_cells]
+    int *active_list = nullptr;   // [container] per cell (at cell_start[c]): sorted indices of the particles that need a force (written by k_collide)
+    int *active_count = nullptr;  // [num_cells] zeroed with the frame
     int *task_list2 = nullptr;    // [num_cells * slices]
     // balanced force pass: every wave walks the same number of bodies; a task may be cut at a stencil-cell boundary
     int *task_cost = nullptr;     // [local cells] bodies in the cell's stencil = what one task of the cell walks
@@ -77,6 +76,9 @@ struct DeviceState {
     float4 *stage = nullptr;      // 3 float4 per move
     XferRec *xfer_out[2] = {nullptr, nullptr};   // slab mode: records leaving for the rank below / above (inside the messages)
     int *status_out = nullptr;    // slab mode: [0] cell-overflow kills this frame, [1] error bits, [2] live, [16..] the killed slot ids
+    // all-pairs across ranks: the gathered snapshot blocks (inside the context's message buffer) and their index by global cell
+    const int *allg_in = nullptr;
+    int *gstart = nullptr, *gn = nullptr;
     DevCounters *ctr = nullptr;
     unsigned long long *trace = nullptr;  // 3 words per pair-kernel wave slot (diagnostic builds only)
 };
@@ -99,13 +101,12 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
 // tasks_hint: about how many force tasks the pass will have (sizes the balanced force pass)
 // pass: 0 or 1, which of a frame's (up to two) passes of the pair stage this is
 hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint, int pass);
-hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step);
-// after apply, before the per-step read-back: ops per queue record, their prefix and maximum
-hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints);   // also clears the status message's header
-hipError_t launch_ops_census(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec);
-// n_ops / n_moves / max_bucket are the counts read back from FrameScalars
-hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
-                            int64_t live_bound);
+hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step, int nrec);
+hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints, int status_table);   // also clears the status record's header and census table
+// the bucketed life cycle, sized from a bound of the live count: bucket the operations (afterwards the
+// frame scalars are complete), then replay + relocation
+hipError_t launch_ops_bucket(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_bound);
+hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec, int64_t live_bound);
 hipError_t launch_lifecycle_sorted(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
                                    int n_ops, int n_moves);
 // slab exchange (messages are int arrays with a 16-word header, see kernels.hip)
@@ -116,6 +117,8 @@ hipError_t launch_pack_force(hipStream_t st, const DevParams &P, const DeviceSta
 hipError_t launch_unpack_force(hipStream_t st, const DevParams &P, const DeviceState &d, int j0, const int *msg, const int *pack_off);
 hipError_t launch_outbox_close(hipStream_t st, const DevParams &P, const DeviceState &d, int64_t live_bound, int *msg_down, int *msg_up);
 hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *msg);
+hipError_t launch_allg_pack(hipStream_t st, const DevParams &P, const DeviceState &d, int *msg);
+hipError_t launch_allg_index(hipStream_t st, const DevParams &P, const DeviceState &d);
 hipError_t launch_status_close(hipStream_t st, const DeviceState &d);
 hipError_t launch_status_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *status_all);
 // lifecycle_sort.hip (rocPRIM radix sort of the op keys; library code, not a hot path)

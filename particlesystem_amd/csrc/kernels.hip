@@ -4,7 +4,7 @@
 //   k_hist_lds / k_scatter_lds   counting sort of the live slots by cell, histogram
 //               private to a workgroup in LDS (a window of 8192 cells from the first
 //               cell the workgroup meets)                               (streaming, HBM)
-//   k_scan, k_build_tasks   prefix over cells, hostGridMax, the pair kernel's work list
+//   k_scan      prefix over cells, hostGridMax, the collide work list
 //   k_sort_cells   rank ids inside each cell (ascending = the reference's cell-list
 //               order, ps.cpp:1510-1516), gather the T_DATA snapshot in that order
 //   k_pairs     27-cell softened gravity + collision flags: one WAVE per 64 particles of
@@ -259,9 +259,19 @@ __global__ __launch_bounds__(1024) void k_hist_lds(DevParams P, const int *__res
     }
 }
 
-__global__ __launch_bounds__(1024) void k_scatter_lds(DevParams P, const int *__restrict__ cell, int *__restrict__ cursor,
-                                                       int *__restrict__ sorted_id)
+__device__ __forceinline__ void chunk_cap_block(const DevParams &P, int ch, const int *__restrict__ chunk_count,
+                                                const int *__restrict__ cell_arr, const CellInfo *__restrict__ celltab,
+                                                const int2 *__restrict__ chunk_segs, uint8_t *__restrict__ chunk_skip,
+                                                const int *__restrict__ before4);
+
+// Workgroups [0, nwg): the scatter.  Workgroups [nwg, nwg + num_chunks), one GPU only: the chunk
+// lists' capacity rule for chunk blockIdx.x - nwg (chunk_cap_block; idle unless the chunk is over).
+__global__ __launch_bounds__(1024) void k_scatter_lds(DevParams P, int nwg, const int *__restrict__ cell, int *__restrict__ cursor,
+                                                       int *__restrict__ sorted_id, const int *__restrict__ chunk_count,
+                                                       const CellInfo *__restrict__ celltab, const int2 *__restrict__ chunk_segs,
+                                                       uint8_t *__restrict__ chunk_skip)
 {
+    if ((int)blockIdx.x >= nwg) { chunk_cap_block(P, (int)blockIdx.x - nwg, chunk_count, cell, celltab, chunk_segs, chunk_skip, nullptr); return; }
     __shared__ int h[LDS_CELLS];
     __shared__ int s_min;
     const int tid = threadIdx.x, base = blockIdx.x * SLOTS_PER_WG, ncell = P.n_own_cells;
@@ -304,8 +314,9 @@ __global__ __launch_bounds__(1024) void k_scatter_lds(DevParams P, const int *__
 // totals and hostGridMax (ps.cpp:1504-1516: maxima are of stored entries, so capped).
 __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restrict__ cell_count,
                                                 int *__restrict__ cell_start, int *__restrict__ cursor,
-                                                int *__restrict__ task_start, int *__restrict__ chunk_count,
-                                                const CellInfo *__restrict__ celltab, FrameScalars *fs)
+                                                int *__restrict__ task_start, int *__restrict__ task_list,
+                                                int *__restrict__ chunk_count,
+                                                const CellInfo *__restrict__ celltab, int *__restrict__ status_out, FrameScalars *fs)
 {
     // Two prefix sums at once, packed in 64 bits: particles per cell (low word) and
     // 64-particle pair-kernel tasks per cell (high word; only the cells this rank computes).
@@ -333,8 +344,12 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
         mymax = max(mymax, min(v, P.max_per_cell));
         mine += word(c, v);
         if (v > 0) {
-            if (chunks_in_lds) atomicAdd(&chunk_s[celltab[c + cell_off].chunk], v);
-            else atomicAdd(&chunk_count[celltab[c + cell_off].chunk], v);
+            const CellInfo ci = celltab[c + cell_off];
+            if (chunks_in_lds) atomicAdd(&chunk_s[ci.chunk], v);
+            else atomicAdd(&chunk_count[ci.chunk], v);
+            // slab: a particle lives in the segment of its cell, so this is also the census of the chunk's
+            // particles per segment type held here, for the other ranks (status record, zeroed with the frame)
+            if (P.world > 1) atomicAdd(&status_out[STATUS_CHUNK_OFF + 4 * ci.chunk + (ci.seg_type == 1 ? 0 : ci.seg_type == 2 ? 1 : ci.seg_type == 4 ? 2 : 3)], v);
         }
     }
     long long incl = mine;
@@ -352,8 +367,13 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
         const int excl = (int)(run & 0xffffffffll);
         cell_start[c] = excl;
         cursor[c] = excl;
-        task_start[c] = (int)(run >> 32);
-        run += word(c, v);
+        const int t0 = (int)(run >> 32);
+        task_start[c] = t0;
+        const long long w = word(c, v);
+        // the collide work list: one entry per non-empty (cell, 64-particle slice) of the own computed
+        // cells (the lent ones are appended when their snapshot has arrived, k_halo_prefix_in)
+        for (int sl = 0; sl < (int)(w >> 32); sl++) task_list[t0 + sl] = c * P.slices + sl;
+        run += w;
     }
     if (tid == 0) {
         cell_start[ncell] = (int)(total & 0xffffffffll);     // the gap cell after region 0: end of the own bodies
@@ -381,12 +401,11 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
     // The reference stores only MAX_PARTICLES_PER_CHUNK ids per chunk and calc_forces walks the
     // stored list (ps.cpp:1502-1508): past that (only possible while cells overflow, the count
     // includes the killed) the tail of the chunk's slot-ordered list is not processed that step.
-    // One GPU: k_chunk_cap marks that tail and k_apply leaves it alone.  A slab holds only part
-    // of a boundary chunk's slots and cannot rank them: refuse loudly there.
-    if (over) {
-        if (P.world == 1) fs->chunk_over = 1;
-        else atomicOr(&fs->error, ERR_CHUNK_CAP);
-    }
+    // One GPU: chunk_cap_block (riding on the scatter launch) marks that tail and k_apply leaves it
+    // alone.  A slab holds only part of a chunk's segments: whether a chunk is over, and where this
+    // rank's particles stand in its list, is settled when the status records of all ranks are in
+    // (k_status_merge, before k_apply); the count above is this rank's part only.
+    if (over && P.world == 1) fs->chunk_over = 1;
 }
 
 // The chunk lists' capacity (ps.cpp:1502-1508): build_grid walks the slots in order and appends
@@ -397,21 +416,35 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
 // meet it as a neighbour: it is in its cell's list and in T_DATA).  One workgroup per chunk, at
 // work only if the chunk's count passed the capacity: it walks the chunk's 27 segments (the
 // only slots that can hold its particles) in slot order and writes chunk_skip for every
-// particle of the chunk.  Runs before k_sort_cells resets the slots of overflowing cells.
-__global__ __launch_bounds__(1024) void k_chunk_cap(DevParams P, const int *__restrict__ chunk_count,
-                                                    const int *__restrict__ cell_arr, const CellInfo *__restrict__ celltab,
-                                                    const int2 *__restrict__ chunk_segs, uint8_t *__restrict__ chunk_skip)
+// particle of the chunk.  Runs before k_sort_cells resets the slots of overflowing cells: as extra
+// workgroups of the scatter launch (k_scatter_lds only reads cell[]), so the usual frame, in which
+// no chunk is over, pays no launch for it.
+__device__ __forceinline__ void chunk_cap_block(const DevParams &P, int ch, const int *__restrict__ chunk_count,
+                                                const int *__restrict__ cell_arr, const CellInfo *__restrict__ celltab,
+                                                const int2 *__restrict__ chunk_segs, uint8_t *__restrict__ chunk_skip,
+                                                const int *__restrict__ before4)
 {
+    // before4 (slab): per segment type, the chunk's particles in the slots BEFORE this rank's segments of
+    // that type -- every lower type wherever it lives, and the same type on the ranks below (a rank's
+    // slot range per type follows the lower ranks'); the walk then covers the own segments only.  By then
+    // the cell-overflow rule has reset its victims: k_sort_cells left their cell as -2 - cell for this
+    // walk (they were in the chunk's list), k_apply puts -1 there.
     __shared__ int wave_tot[16];
-    const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (chunk_count[ch] <= P.max_per_chunk) return;
-    int run = 0;                                          // particles of the chunk in the slots before the current batch
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (!before4 && chunk_count[ch] <= P.max_per_chunk) return;
+    int run = 0, cur_t = -1;                              // particles of the chunk in the slots before the current batch
     for (int sgi = 0; sgi < 27; sgi++) {
         const int2 sg = chunk_segs[ch * 27 + sgi];
+        if (before4) {
+            if (slot_index(P, sg.x) < 0) continue;        // another rank's segment
+            const int t = sgi < 1 ? 0 : sgi < 7 ? 1 : sgi < 19 ? 2 : 3;      // slot order = type order: 1 interior, 6 face, 12 edge, 8 corner segments
+            if (t != cur_t) { cur_t = t; run = before4[t]; }
+        }
         for (int b = 0; b < sg.y; b += 1024) {
             const int slot = sg.x + b + tid;
             int c = -1;
             if (b + tid < sg.y) c = cell_arr[slot_index(P, slot)];
+            if (c <= -2) c = -2 - c;
             const bool in = c >= 0 && c < P.num_cells_global && celltab[c].chunk == ch;
             const unsigned long long m = __ballot(in);
             if (lane == 0) wave_tot[wv] = __popcll(m);
@@ -423,16 +456,6 @@ __global__ __launch_bounds__(1024) void k_chunk_cap(DevParams P, const int *__re
             __syncthreads();
         }
     }
-}
-
-// the pair kernel's work list: one entry per non-empty (cell, 64-particle slice) of the own
-// computed cells (the lent ones are appended when their snapshot has arrived, k_remote_cells)
-__global__ void k_build_tasks(DevParams P, const int *__restrict__ task_start, int *__restrict__ task_list)
-{
-    const int c = P.own_comp0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= P.own_comp1) return;
-    const int t0 = task_start[c], n = task_start[c + 1] - t0;
-    for (int s = 0; s < n; s++) task_list[t0 + s] = c * P.slices + s;
 }
 
 // Halo bookkeeping of the two-pass pair stage.  Cell axes: i2 ~ +x, i1 ~ -y, i3 ~ -z
@@ -551,7 +574,8 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
                                                      uint64_t *op_keys, int *op_args, int ops_cap,
                                                      int *__restrict__ halo_count, float *__restrict__ halo_f,
                                                      int *__restrict__ halo_id, int *__restrict__ snap_cid,
-                                                     int *__restrict__ status_out, FrameScalars *fs, DevCounters *ctr)
+                                                     int *__restrict__ status_out, int *__restrict__ rec_count,
+                                                     FrameScalars *fs, DevCounters *ctr)
 {
     __shared__ __attribute__((aligned(16))) int ids[SORT_MAX + 4];
     __shared__ int ordered[SORT_MAX];
@@ -612,7 +636,7 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
             uint32_t *t = tdata + (size_t)6 * si;
             t[0] = (uint32_t)id; t[1] = __float_as_uint(p.x); t[2] = __float_as_uint(p.y);
             t[3] = __float_as_uint(p.z); t[4] = __float_as_uint(p.w); t[5] = __float_as_uint(age);
-            cell_arr[si] = -1; pflags[si] = 0;
+            cell_arr[si] = P.world > 1 ? -2 - cell_arr[si] : -1; pflags[si] = 0;       // (slab: the chunk-capacity walk still needs the cell, see chunk_cap_block)
             pos4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
             vel4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
             acc4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -679,7 +703,7 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
             }
         } else {
             sorted_id[start + e] = -1;
-            cell_arr[si] = -1; pflags[si] = 0;
+            cell_arr[si] = P.world > 1 ? -2 - cell_arr[si] : -1; pflags[si] = 0;       // (slab: the chunk-capacity walk still needs the cell, see chunk_cap_block)
             pos4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
             vel4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
             acc4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1069,7 +1093,8 @@ __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restr
                                                  const int *__restrict__ sorted_id, const int *__restrict__ snap_cid,
                                                  const int *__restrict__ task_list, const int *__restrict__ task_start,
                                                  const int *__restrict__ halo_count, const float *__restrict__ halo_f,
-                                                 const int *__restrict__ halo_id, int *__restrict__ flag_out,
+                                                 const int *__restrict__ halo_id, int *__restrict__ active_list,
+                                                 int *__restrict__ active_count, int *__restrict__ task_cost,
                                                  float4 *__restrict__ force4, const FrameScalars *__restrict__ fs)
 {
     // (readfirstlane: the wave index is uniform but the compiler cannot know; with uniform
@@ -1126,25 +1151,21 @@ __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restr
     }
     int flag = met_higher ? 2 : met_lower ? 1 : 0;
     if (dead) flag = 2;                                          // ps.cpp:1183
-    if (valid) {
-        flag_out[gi] = (flag == 0 && kid) ? -1 : flag;           // -1: moves, but every force term is skipped
-        force4[gi] = make_float4(0.f, 0.f, 0.f, __int_as_float(flag));   // final unless the force pass overwrites it
+    if (valid) force4[gi] = make_float4(0.f, 0.f, 0.f, __int_as_float(flag));   // final unless the force pass overwrites it
+    // The particles the force pass has to visit (flag 0 and not a kid: a kid moves, but every force
+    // term is skipped for it), packed at active_list[cell_start[c] ...] in whatever order the cell's
+    // waves arrive (a particle's sum is its own lane's chain, so the grouping into tasks is free);
+    // active_count is zeroed with the frame.
+    const bool on = valid && flag == 0 && !kid;
+    const unsigned long long m = __ballot(on);
+    if (m) {
+        int off = 0;
+        if (lane == 0) off = atomicAdd(&active_count[c], __popcll(m));
+        off = __builtin_amdgcn_readfirstlane(off);
+        if (on) active_list[base + off + __popcll(m & ((1ull << lane) - 1ull))] = gi;
     }
-}
-
-// One workgroup per computed cell: the sorted indices of the particles the force pass has to
-// visit (flag 0 and not a kid), packed at active_list[cell_start[c] ...], and their number.
-__global__ __launch_bounds__(256) void k_build_active(DevParams P, const int *__restrict__ cell_start,
-                                                      const int *__restrict__ flag_in, int *__restrict__ active_list,
-                                                      int *__restrict__ active_count, int *__restrict__ task_cost)
-{
-    __shared__ int s_n;
-    const int c = comp_cell(P, blockIdx.x), tid = threadIdx.x, lane = tid & 63;
-    const int base = cell_start[c];
-    const int cnt = min(cell_start[c + 1] - base, P.max_per_cell);
-    if (tid == 0) s_n = 0;
-    if (tid < 64) {
-        // what one force task of this cell walks: the population of its stencil
+    // what one force task of this cell walks: the population of its stencil (the cell's first slice reports it)
+    if (slice == 0) {
         int n = 0;
         if (lane < STENCIL) {
             int i1, i2, i3;
@@ -1155,39 +1176,65 @@ __global__ __launch_bounds__(256) void k_build_active(DevParams P, const int *__
         n = wave_incl_scan(n);
         if (lane == 63) task_cost[c] = n;
     }
-    __syncthreads();
-    for (int e0 = 0; e0 < cnt; e0 += 256) {
-        const int e = e0 + tid;
-        const bool on = e < cnt && flag_in[base + e] == 0;
-        const unsigned long long m = __ballot(on);
-        int wbase = 0;
-        if (lane == 0 && m) wbase = atomicAdd(&s_n, __popcll(m));
-        wbase = __shfl(wbase, 0);
-        if (on) active_list[base + wbase + __popcll(m & ((1ull << lane) - 1ull))] = base + e;
-        __syncthreads();
-    }
-    if (tid == 0) active_count[c] = s_n;
 }
 
-// One workgroup: prefix of the active lists' 64-slices over the computed cells (the lent ones
-// first: their results travel back to the rank that owns them) and the task list of
-// the force pass.  With `merge`, only full slices become ordinary tasks; the leftovers (a cell's
-// last, partly filled slice: 20 of 64 lanes on average once the collided particles are gone)
-// are packed, up to four cells to a wave, into the merged tasks of k_pairs_merged.
-__global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *__restrict__ active_count,
-                                                       const int *__restrict__ task_cost,
-                                                       int *__restrict__ task_list2, int *__restrict__ ctask_start,
-                                                       long long *__restrict__ cost_start,
-                                                       int4 *__restrict__ merged_tasks, FrameScalars *fs,
-                                                       int merge)
+// The plan of the balanced force pass, one launch of eight workgroups (one per XCD run of wave
+// slots).  Every workgroup works out, for itself, in LDS:
+//   (1) the prefix over the computed cells (the lent ones first: their results travel back to the
+//       rank that owns them) of the 64-slices of the active lists and of what those tasks walk
+//       (a task of cell c walks task_cost[c] bodies, the population of the cell's stencil);
+//       with `merge`, only full slices become ordinary tasks and the leftovers (a cell's last,
+//       partly filled slice: 20 of 64 lanes on average once the collided particles are gone) are
+//       packed, up to four cells to a wave, into merged tasks;
+//   (2) where every wave slot of ITS run starts: the pass's work is the list of (task, stencil
+//       step) units -- task-major, 27 steps per task -- a unit costs the bodies of the neighbour
+//       cell it visits, and wave slot s takes the units from wave_pos[s] up to wave_pos[s + 1]:
+//       equal shares of the cost, cut at unit boundaries.  The eight runs start at whole tasks, so a
+//       task that is cut is always continued by a workgroup of the same run.
+// The task list, the packs and the frame scalars are the same whichever workgroup writes them; each
+// writes a share.  (These were three launches, k_build_active / k_active_tasks / k_split_tasks, 60 us
+// of mostly one-workgroup latency on the step's critical path; the prefixes are cheap enough to
+// be recomputed eight times.)
+// merge: 0 every slice is an ordinary task; 1 the packs are the merged tasks of k_pairs_merged (run
+// beside the balanced pass); 2 the packs are tasks of the balanced pass itself (tile walk): pack m is
+// task n_tasks2 + m, with one virtual "cell" ncomp + m in the prefix arrays.
+constexpr int PLAN_LDS = 6144;        // prefix entries (computed cells + virtual pack cells + 1) kept in LDS
+constexpr int PLAN_LDS_CELLS = 8192;  // local cells whose starts are kept in LDS
+__global__ __launch_bounds__(1024) void k_plan_force(DevParams P, int nw, int merge, const int *__restrict__ cell_start_g,
+                                                     const int *__restrict__ active_count, const int *__restrict__ task_cost,
+                                                     int *__restrict__ task_list2, int *__restrict__ ctask_start_g,
+                                                     long long *__restrict__ cost_start_g, int4 *__restrict__ merged_tasks,
+                                                     int *__restrict__ wave_pos, FrameScalars *fs, unsigned long long *trace)
 {
-    // merge: 0 every slice is an ordinary task; 1 partly filled last slices are packed, up to four
-    // cells to a wave, into merged tasks for k_pairs_merged (run beside the balanced pass);
-    // 2 the same packs, appended to the balanced pass's own task list (tile walk): pack m is task
-    // n_tasks2 + m, with one virtual "cell" ncomp + m in the cost prefix arrays
+#ifdef PSAMD_PLAN_TRACE    // diagnostic build: time stamps (100 MHz) of workgroup x's phases in trace[8 x ...]
+#define PT(i) do { if (threadIdx.x == 0) trace[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PT(i) do {} while (0)
+#endif
+    PT(0);
+    __shared__ long long s_cost[PLAN_LDS + 1];
+    __shared__ int s_task[PLAN_LDS + 1];
+    __shared__ int s_ac[PLAN_LDS];                     // active_count | task_cost << 13 of the j-th computed cell
+    __shared__ int s_cstart[PLAN_LDS_CELLS + 1];
     __shared__ long long wave_tot[16], wave_cost[16], wave_pcost[16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ int s_run[2];
+    __shared__ long long s_runcost[2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, x = blockIdx.x;
     const int ncomp = comp_count(P);
+    const bool ext = merge == 2;
+    const bool in_lds = (ext ? 2 * ncomp : ncomp) + 1 <= PLAN_LDS && P.max_per_cell < (1 << 13);
+    const bool cells_in_lds = P.n_local_cells <= PLAN_LDS_CELLS;
+    long long *cost_start = in_lds ? s_cost : cost_start_g;
+    int *ctask_start = in_lds ? s_task : ctask_start_g;
+    const int *cell_start = cells_in_lds ? s_cstart : cell_start_g;
+    if (cells_in_lds) for (int j = tid; j <= P.n_local_cells; j += 1024) s_cstart[j] = cell_start_g[j];
+    if (in_lds) for (int j = tid; j < ncomp; j += 1024) { const int c = comp_cell(P, j), n = active_count[c]; s_ac[j] = n | ((n ? task_cost[c] : 0) << 13); }
+    __syncthreads();
+    PT(1);
+    auto act_of = [&](int j) { return in_lds ? (s_ac[j] & 0x1fff) : active_count[comp_cell(P, j)]; };
+    auto cost_of = [&](int j) { return in_lds ? (s_ac[j] >> 13) : task_cost[comp_cell(P, j)]; };
+
+    // ---- (1) prefixes, task list, packs ----
     const int per = (ncomp + 1023) / 1024;
     const int c0 = min(ncomp, tid * per), c1 = min(ncomp, c0 + per);
     // the first 256 threads each pack the leftovers of a longer run of cells greedily, in
@@ -1206,12 +1253,12 @@ __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *_
             cur = make_int4(-1, -1, -1, -1); used = 0; ng = 0; pc = 0;
         };
         for (int j = p0; j < p1; j++) {
-            const int c = comp_cell(P, j);
-            const int r = active_count[c] & 63;
+            const int r = act_of(j) & 63;
             if (r == 0) continue;
+            const int c = comp_cell(P, j);
             if (ng == 4 || used + r > 64) flush();
             if (ng == 0) cur.x = c; else if (ng == 1) cur.y = c; else if (ng == 2) cur.z = c; else cur.w = c;
-            ng++; used += r; pc = max(pc, task_cost[c]);
+            ng++; used += r; pc = max(pc, cost_of(j));
         }
         if (ng) flush();
         if (cost_sum) *cost_sum = acc;
@@ -1219,9 +1266,9 @@ __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *_
     };
     long long mine = 0, mycost = 0, mypcost = 0;   // tasks (low word) and packs (high word); bodies the tasks walk; ... the packs walk
     for (int j = c0; j < c1; j++) {
-        const int c = comp_cell(P, j), n = active_count[c], nt = merge ? (n >> 6) : ((n + 63) >> 6);
+        const int n = act_of(j), nt = merge ? (n >> 6) : ((n + 63) >> 6);
         mine += nt;
-        mycost += (long long)nt * task_cost[c];
+        mycost += (long long)nt * cost_of(j);
     }
     if (merge) mine |= (long long)pack(nullptr, nullptr, 0, &mypcost) << 32;
     long long incl = mine, cincl = mycost, pincl = mypcost;
@@ -1238,71 +1285,48 @@ __global__ __launch_bounds__(1024) void k_active_tasks(DevParams P, const int *_
     }
     int run = (int)(run2 & 0xffffffffll);
     const int total = (int)(total2 & 0xffffffffll), npacks = (int)(total2 >> 32);
+    PT(2);
+    const bool my_share = (tid & 7) == x;           // the lists in memory: each workgroup writes an eighth
     for (int j = c0; j < c1; j++) {
-        const int c = comp_cell(P, j);
-        const int n = merge ? (active_count[c] >> 6) : ((active_count[c] + 63) >> 6);
+        const int n = merge ? (act_of(j) >> 6) : ((act_of(j) + 63) >> 6);
         ctask_start[j] = run; cost_start[j] = crun;
-        for (int sl = 0; sl < n; sl++) task_list2[run + sl] = c * P.slices + sl;
+        if (my_share && n) { const int c = comp_cell(P, j); for (int sl = 0; sl < n; sl++) task_list2[run + sl] = c * P.slices + sl; }
         run += n;
-        crun += (long long)n * task_cost[c];
+        crun += (long long)n * cost_of(j);
     }
     if (merge) {
         const int m0 = (int)(run2 >> 32);
-        const int np = pack(merged_tasks + m0, merge == 2 ? cost_start + ncomp + m0 : nullptr, ctotal + prun, nullptr);
-        if (merge == 2) for (int m = 0; m < np; m++) ctask_start[ncomp + m0 + m] = total + m0 + m;
+        const int np = pack(x == 0 ? merged_tasks + m0 : nullptr, ext ? cost_start + ncomp + m0 : nullptr, ctotal + prun, nullptr);
+        if (ext) for (int m = 0; m < np; m++) ctask_start[ncomp + m0 + m] = total + m0 + m;
     }
+    const int ncells = ncomp, nent = ncomp + (ext ? npacks : 0), ntask = total + (ext ? npacks : 0);
+    const long long T = ctotal + (ext ? ptotal : 0);
     if (tid == 0) {
-        const bool ext = merge == 2;
-        ctask_start[ncomp + (ext ? npacks : 0)] = total + (ext ? npacks : 0);
-        cost_start[ncomp + (ext ? npacks : 0)] = ctotal + (ext ? ptotal : 0);
-        fs->n_tasks2 = total; fs->n_merged = npacks; fs->cost_total = ctotal + (ext ? ptotal : 0);
+        ctask_start[nent] = ntask;
+        cost_start[nent] = T;
+        if (x == 0) { fs->n_tasks2 = total; fs->n_merged = npacks; fs->cost_total = T; }
     }
-}
+    if (!in_lds) __threadfence();                    // (every workgroup wrote the same values; this one reads its own)
+    __syncthreads();
+    PT(3);
+    if (nw <= 0) return;                             // (unbalanced pass: only the lists were wanted)
 
-// Where does every wave of the balanced force pass start?  The pass's work is the list of
-// (task, stencil step) units -- task-major, 27 steps per task -- and a unit costs the bodies
-// of the neighbour cell it visits.  Wave s of `nw` takes the units from wave_pos[s] up to
-// wave_pos[s + 1]: equal shares of the total cost, cut at unit boundaries.  The eight runs of
-// waves that share an XCD (wave slots are dealt XCD by XCD, see k_pairs) start at whole tasks,
-// so a task that is cut is always continued by a workgroup of the same run.
-// SPLIT_SUB workgroups per run (everything here is latency: many threads, few steps each);
-// the two prefix arrays are searched in LDS when they fit.
-constexpr int SPLIT_LDS_CELLS = 4096;
-constexpr int SPLIT_SUB = 1;     // (a run has at most 768 wave slots: one workgroup of 1024 threads covers it)
-__global__ __launch_bounds__(1024) void k_split_tasks(DevParams P, int nw, const int *__restrict__ cell_start, const int *__restrict__ task_cost,
-                                                      const int *__restrict__ ctask_start_g, const long long *__restrict__ cost_start_g,
-                                                      int *__restrict__ wave_pos, const FrameScalars *__restrict__ fs, int ext)
-{
-    __shared__ long long s_cost[SPLIT_LDS_CELLS + 1];
-    __shared__ int s_task[SPLIT_LDS_CELLS + 1];
-    __shared__ int s_run[2];
-    __shared__ long long s_runcost[2];
-    // ext: the merged packs are tasks of this pass too (one virtual cell each, after the real ones)
-    const int ncells = comp_count(P), ncomp = ncells + (ext ? fs->n_merged : 0), ntask = fs->n_tasks2 + (ext ? fs->n_merged : 0);
-    const int tid = threadIdx.x;
-    const long long T = fs->cost_total;
-    const bool in_lds = ncomp <= SPLIT_LDS_CELLS;
-    if (in_lds) {
-        for (int j = tid; j <= ncomp; j += 1024) { s_cost[j] = cost_start_g[j]; s_task[j] = ctask_start_g[j]; }
-        __syncthreads();
-    }
-    const long long *cost_start = in_lds ? s_cost : cost_start_g;
-    const int *ctask_start = in_lds ? s_task : ctask_start_g;
-    // unit (task index * 27 + step) at which the cumulative cost reaches x; whole = round up to the next task start
-    auto unit_at = [&](long long x, bool whole) -> int {
-        if (x >= T) return ntask * STENCIL;
-        int a = 0, b = ncomp - 1;                         // last computed cell whose tasks start at or before x
-        while (a < b) { const int m = (a + b + 1) >> 1; if (cost_start[m] <= x) a = m; else b = m - 1; }
+    // ---- (2) the wave slots of run x ----
+    // unit (task index * 27 + step) at which the cumulative cost reaches v; whole = round up to the next task start
+    auto unit_at = [&](long long v, bool whole) -> int {
+        if (v >= T) return ntask * STENCIL;
+        int a = 0, b = nent - 1;                          // last entry whose tasks start at or before v
+        while (a < b) { const int m = (a + b + 1) >> 1; if (cost_start[m] <= v) a = m; else b = m - 1; }
         const int nt = ctask_start[a + 1] - ctask_start[a];
         if (a >= ncells) {                                // a merged pack: one task, its steps taken as equally long
-            const long long S = cost_start[a + 1] - cost_start[a], off = x - cost_start[a];
+            const long long S = cost_start[a + 1] - cost_start[a], off = v - cost_start[a];
             const int k = S > 0 ? (int)min((long long)(STENCIL - 1), off * STENCIL / S) : 0;
             if (whole) return (ctask_start[a] + (off > 0 ? 1 : 0)) * STENCIL;
             return ctask_start[a] * STENCIL + k;
         }
-        const int c = comp_cell(P, a), S = task_cost[c];
-        if (nt == 0 || S <= 0) return ctask_start[a + 1] * STENCIL;     // (x < T: cannot be the last cell)
-        const long long off = x - cost_start[a];
+        const int c = comp_cell(P, a), S = cost_of(a);
+        if (nt == 0 || S <= 0) return ctask_start[a + 1] * STENCIL;     // (v < T: cannot be the last cell)
+        const long long off = v - cost_start[a];
         const int q = (int)min((long long)(nt - 1), off / S);
         int r = (int)(off - (long long)q * S), k = 0;
         int i1, i2, i3;
@@ -1323,23 +1347,26 @@ __global__ __launch_bounds__(1024) void k_split_tasks(DevParams P, int nw, const
     auto cost_of_task_start = [&](int unit) -> long long {
         const int t = unit / STENCIL;
         if (t >= ntask) return T;
-        int a = 0, b = ncomp - 1;
+        int a = 0, b = nent - 1;
         while (a < b) { const int mm = (a + b + 1) >> 1; if (ctask_start[mm] <= t) a = mm; else b = mm - 1; }
         if (a >= ncells) return cost_start[a];             // a merged pack is one task
-        return cost_start[a] + (long long)(t - ctask_start[a]) * task_cost[comp_cell(P, a)];
+        return cost_start[a] + (long long)(t - ctask_start[a]) * cost_of(a);
     };
     const int m = nw >> 3;                                // wave slots per XCD run (nw is a multiple of 32)
-    const int x = blockIdx.x / SPLIT_SUB, sub = blockIdx.x % SPLIT_SUB;   // this workgroup's run, and its part of the run's slots
     if (tid < 2) {
         s_run[tid] = unit_at(T * (x + tid) / 8, true);
         s_runcost[tid] = cost_of_task_start(s_run[tid]);
     }
     __syncthreads();
+    PT(4);
     const int run_lo = s_run[0], run_hi = s_run[1];
     const long long lo = s_runcost[0], hi = s_runcost[1];
-    for (int j = sub * 1024 + tid; j < m; j += SPLIT_SUB * 1024)     // equal shares of the run's own cost range
+    for (int j = tid; j < m; j += 1024)                   // equal shares of the run's own cost range
         wave_pos[x * m + j] = j == 0 ? run_lo : max(run_lo, min(run_hi, unit_at(lo + (hi - lo) * j / m, false)));
-    if (x == 7 && sub == 0 && tid == 0) wave_pos[nw] = run_hi;       // = ntask * 27
+    if (x == 7 && tid == 0) wave_pos[nw] = run_hi;        // = ntask * 27
+    __syncthreads();
+    PT(5);
+#undef PT
 }
 
 // One wave = 64 consecutive particles of one cell (four independent waves per workgroup).
@@ -1432,7 +1459,8 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
                                            float4 *tile, unsigned long long *trace,
                                            const int *__restrict__ active_list = nullptr,
                                            const int *__restrict__ active_count = nullptr,
-                                           int k0 = 0, int k1 = STENCIL, int *ready = nullptr, FrameScalars *fs = nullptr)
+                                           int k0 = 0, int k1 = STENCIL, int *ready = nullptr, FrameScalars *fs = nullptr,
+                                           const FarCells far = FarCells())
 {
     PS_TRACE_BEGIN();
     const int c = task / P.slices, slice = task - c * P.slices;
@@ -1475,7 +1503,7 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
             if (lane == 0) atomicOr(&fs->error, ERR_HANDOFF_TIMEOUT);
         }
         // all-pairs mode (not in the reference): after the stencil, every other cell in index order
-        const int kend = ((P.flags & PSAMD_FLAG_ALL_PAIRS) && k1 == STENCIL) ? STENCIL + P.n_own_cells : k1;
+        const int kend = ((P.flags & PSAMD_FLAG_ALL_PAIRS) && k1 == STENCIL) ? STENCIL + P.num_cells_global : k1;
         for (int k = k0; k < kend; k++) {
             int nb, n;
             // a far cell's bodies are summed on their own and the cell's sum added to the particle's:
@@ -1484,15 +1512,21 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
             float near_x = 0.f, near_y = 0.f, near_z = 0.f;
             if (k < STENCIL) { nb = __builtin_amdgcn_readlane(my_nb, k); n = __builtin_amdgcn_readlane(my_cnt, k); }
             else {
-                const int c2 = k - STENCIL;
-                int j1, j2, j3;
-                cell_coords(P, c2, j1, j2, j3);
+                const int c2 = k - STENCIL, GG = P.G * P.G;                    // a GLOBAL cell
+                const int j3 = c2 / GG, rem = c2 - j3 * GG, j1 = rem / P.G, j2 = rem - j1 * P.G;
                 if (abs(j1 - i1) <= 1 && abs(j2 - i2) <= 1 && abs(j3 - i3) <= 1) continue;      // a stencil cell: done above
-                nb = __builtin_amdgcn_readfirstlane(cell_start[c2]);
-                n = __builtin_amdgcn_readfirstlane(min(cell_start[c2 + 1] - nb, P.max_per_cell));
+                if (far.n) {        // several ranks: the all-gathered snapshot
+                    nb = __builtin_amdgcn_readfirstlane(far.start[c2]);
+                    n = __builtin_amdgcn_readfirstlane(far.n[c2]);
+                } else {            // one GPU: local cell == global cell
+                    nb = __builtin_amdgcn_readfirstlane(cell_start[c2]);
+                    n = __builtin_amdgcn_readfirstlane(min(cell_start[c2 + 1] - nb, P.max_per_cell));
+                }
                 near_x = ax; near_y = ay; near_z = az; ax = 0.f; ay = 0.f; az = 0.f;
             }
-            const float *sx = snap_soa + nb, *sy = sx + cap, *sz = sy + cap, *sw = sz + cap;   // wave-uniform
+            const bool remote = k >= STENCIL && far.n;
+            const size_t plane = remote ? (size_t)far.plane : cap;
+            const float *sx = (remote ? far.buf : snap_soa) + nb, *sy = sx + plane, *sz = sy + plane, *sw = sz + plane;   // wave-uniform
             float dmin = 3.0e38f;
             int jj = 0;
             // NQ bodies per group.  (Fetching the next group between the distance stage and
@@ -1609,7 +1643,8 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
                                                const int *__restrict__ task_list,
                                                float4 *__restrict__ force4,
                                                FrameScalars *fs, unsigned long long *trace,
-                                               const int *__restrict__ active_list, const int *__restrict__ active_count)
+                                               const int *__restrict__ active_list, const int *__restrict__ active_count,
+                                               const FarCells far)
 {
     // Workgroups of four INDEPENDENT waves (no workgroup barrier anywhere): the hardware
     // deals a workgroup's waves over the four SIMDs of its CU and workgroups over the
@@ -1630,7 +1665,7 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
     const int slot = xcd_contiguous(blockIdx.x, nwg) * 4 + wave;
     if (slot >= ntask) return;
     pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4,
-                         task_list[slot], tiles[MODE == 0 ? wave : 0], trace, active_list, active_count);
+                         task_list[slot], tiles[MODE == 0 ? wave : 0], trace, active_list, active_count, 0, STENCIL, nullptr, fs, far);
 }
 
 constexpr int MERGE_TILE = 4 * 64 + 4;          // floats per lane group: x[64] y[64] z[64] w[64] + skew
@@ -1781,6 +1816,20 @@ __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *_
 // WALK 0: scalar-load walk, ordinary tasks only (packs, if any, run in k_pairs_merged beside it);
 //      1: tile walk for everything, packs of partial slices included (few waves per SIMD);
 //      2: scalar-load walk for the ordinary tasks, tile walk for the packs, all in one balanced list.
+template <int MODE, int NQ>
+__device__ __forceinline__ void merged_pack_task(const DevParams &P, const int *__restrict__ cell_start,
+                                                 const float4 *__restrict__ snap4,
+                                                 const int *__restrict__ active_list,
+                                                 const int *__restrict__ active_count,
+                                                 const int4 *__restrict__ merged_tasks,
+                                                 float4 *__restrict__ force4, int slot, float *tile);
+
+// nmb (WALK 0, a multiple of 8 so that the XCD dealing is undisturbed): the first nmb workgroups of the
+// launch serve the merged packs of partly filled slices instead (merged_pack_task) -- dispatched first,
+// their waves are the oldest on their SIMDs and are served first, which is what lets these long,
+// stall-prone waves finish well inside the pass.  (As a kernel of their own on a second stream they
+// needed a head start to get that: forked at the same moment as the balanced pass they ended with it,
+// and the stage took 0.1 ms longer.)
 template <int MODE, int NQ, int WALK>
 __global__ __launch_bounds__(256, WALK == 0 ? 6 : 4) void k_pairs_balanced(DevParams P, const int *__restrict__ cell_start,
                                                         const float4 *__restrict__ snap4,
@@ -1792,12 +1841,16 @@ __global__ __launch_bounds__(256, WALK == 0 ? 6 : 4) void k_pairs_balanced(DevPa
                                                         FrameScalars *fs, unsigned long long *trace,
                                                         const int *__restrict__ active_list, const int *__restrict__ active_count,
                                                         const int *__restrict__ wave_pos, int *__restrict__ task_ready,
-                                                        const int4 *__restrict__ merged_tasks)
+                                                        const int4 *__restrict__ merged_tasks, int nmb)
 {
-    constexpr bool TILES = WALK != 0;
-    __shared__ __attribute__((aligned(16))) float tiles[TILES ? 4 : 1][TILES ? 4 * MERGE_TILE : 4];   // up to four 1-KiB tiles per wave
+    __shared__ __attribute__((aligned(16))) float tiles[4][4 * MERGE_TILE];   // up to four 1-KiB tiles per wave
     const int wave = threadIdx.x >> 6;
-    const int slot = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave;
+    if (WALK == 0 && (int)blockIdx.x < nmb) {
+        const int pack = blockIdx.x * 4 + wave;
+        if (pack < fs->n_merged) merged_pack_task<MODE, (NQ > 4 ? 4 : NQ)>(P, cell_start, snap4, active_list, active_count, merged_tasks, force4, pack, tiles[wave]);   // (4 bodies per group: the 8-wide form costs this kernel its sixth wave per SIMD)
+        return;
+    }
+    const int slot = xcd_contiguous((int)blockIdx.x - nmb, (int)gridDim.x - nmb) * 4 + wave;
     const int ub = __builtin_amdgcn_readfirstlane(wave_pos[slot]), ue = __builtin_amdgcn_readfirstlane(wave_pos[slot + 1]);
     if (ue <= ub) return;
     const int tb = ub / STENCIL, lb = ub - tb * STENCIL;            // first unit: task tb, step lb
@@ -1835,8 +1888,8 @@ __global__ __launch_bounds__(256, WALK == 0 ? 6 : 4) void k_pairs_balanced(DevPa
                     if (on) G.ng = q + 1;
                 }
             }
-            if (t < nord) pairs_task_tile<MODE, NQ, 1, WALK != 1>(P, cell_start, snap4, force4, G, tiles[TILES ? wave : 0], active_list, k0, k1, task_ready + t, fs);
-            else pairs_task_tile<MODE, NQ, 4, WALK != 1>(P, cell_start, snap4, force4, G, tiles[TILES ? wave : 0], active_list, k0, k1, task_ready + t, fs);
+            if (t < nord) pairs_task_tile<MODE, NQ, 1, WALK != 1>(P, cell_start, snap4, force4, G, tiles[wave], active_list, k0, k1, task_ready + t, fs);
+            else pairs_task_tile<MODE, NQ, 4, WALK != 1>(P, cell_start, snap4, force4, G, tiles[wave], active_list, k0, k1, task_ready + t, fs);
         } else
             pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, task_list[t], nullptr, trace,
                                  active_list, active_count, k0, k1, task_ready + t, fs);
@@ -1854,21 +1907,17 @@ __global__ __launch_bounds__(256, WALK == 0 ? 6 : 4) void k_pairs_balanced(DevPa
 // on its own (different register budget from k_pairs).
 
 template <int MODE, int NQ>
-__global__ __launch_bounds__(256, 6) void k_pairs_merged(DevParams P, const int *__restrict__ cell_start,
-                                                      const float4 *__restrict__ snap4,
-                                                      const int *__restrict__ active_list,
-                                                      const int *__restrict__ active_count,
-                                                      const int4 *__restrict__ merged_tasks,
-                                                      float4 *__restrict__ force4, const FrameScalars *__restrict__ fs)
+__device__ __forceinline__ void merged_pack_task(const DevParams &P, const int *__restrict__ cell_start,
+                                                 const float4 *__restrict__ snap4,
+                                                 const int *__restrict__ active_list,
+                                                 const int *__restrict__ active_count,
+                                                 const int4 *__restrict__ merged_tasks,
+                                                 float4 *__restrict__ force4, int slot, float *tile)
 {
-    __shared__ __attribute__((aligned(16))) float tiles[4][4 * MERGE_TILE];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + wave;
-    if (slot >= fs->n_merged) return;
+    const int lane = threadIdx.x & 63;
     // (Raising these waves' issue priority -- they run one per SIMD among six of the balanced
-    // pass and end 0.27 ms after it -- was tried: s_setprio(3) ended them 0.6 ms earlier and the
+    // pass -- was tried: s_setprio(3) ended them 0.6 ms earlier and the
     // balanced pass 0.5 ms later, 2.26 -> 2.48 ms for the stage.)
-    float *tile = tiles[wave];
     const int4 pk = merged_tasks[slot];
     const int cells[4] = {pk.x, pk.y, pk.z, pk.w};
     // lane ranges of the groups
@@ -1954,6 +2003,21 @@ __global__ __launch_bounds__(256, 6) void k_pairs_merged(DevParams P, const int 
     if (valid) force4[gi] = make_float4(ax, ay, az, 0.f);
 }
 
+template <int MODE, int NQ>
+__global__ __launch_bounds__(256, 6) void k_pairs_merged(DevParams P, const int *__restrict__ cell_start,
+                                                      const float4 *__restrict__ snap4,
+                                                      const int *__restrict__ active_list,
+                                                      const int *__restrict__ active_count,
+                                                      const int4 *__restrict__ merged_tasks,
+                                                      float4 *__restrict__ force4, const FrameScalars *__restrict__ fs)
+{
+    __shared__ __attribute__((aligned(16))) float tiles[4][4 * MERGE_TILE];
+    const int wave = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wave;
+    if (slot >= fs->n_merged) return;
+    merged_pack_task<MODE, NQ>(P, cell_start, snap4, active_list, active_count, merged_tasks, force4, slot, tiles[wave]);
+}
+
 // ------------------------------------------------------------------ apply
 __device__ __forceinline__ float clamp_mag(float v, float lim)   // ps.cpp:1279-1281, 1294-1296
 {
@@ -2012,6 +2076,7 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
                                                 MoveRec *moves, int moves_cap,
                                                 XferRec *out_down, XferRec *out_up,
                                                 const int *__restrict__ chunk_count, const uint8_t *__restrict__ chunk_skip,
+                                                int nrec, int *__restrict__ rec_count,
                                                 FrameScalars *fs, DevCounters *ctr)
 {
     __shared__ int s_ops, s_moves, s_base_ops, s_base_moves;
@@ -2025,6 +2090,7 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
         const int si = (blockIdx.x * ITEMS + it) * 1024 + (int)threadIdx.x;       // storage index of the slot
         int oc = -1;
         if (si < P.slots_total) oc = cell_arr[si];
+        if (oc <= -2) { cell_arr[si] = -1; oc = -1; }            // a slot the cell-overflow rule reset this frame (slab encoding)
         // free slots (and the ones the cell-overflow rule just killed) have cell == -1
         bool act = oc >= 0 && oc < P.num_cells_global;
         // a particle past the capacity of its chunk's list is not in calc_forces' loop (k_chunk_cap)
@@ -2047,7 +2113,11 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
 
     int flag = 0, new_cell = 0;
     float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (active) { f = force4[gi]; flag = __float_as_int(f.w); }
+    // the particle's own state is asked for together with its force record (its address needs
+    // nothing but the slot), not after the flag in that record has come back
+    float4 p = f, v = f;
+    float fert = 0.f;
+    if (active) { p = pos4[si]; v = vel4[si]; fert = acc4[si].w; f = force4[gi]; flag = __float_as_int(f.w); }
     const CellInfo old_ci = active ? celltab[old_cell] : CellInfo{0, 1, 0, 0};
 
     const bool killed = active && flag == 2, survived = active && flag == 1, moved = active && flag == 0;
@@ -2055,20 +2125,16 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
     int new_rec = 0;
 
     if (killed) {                                        // kill, ps.cpp:1211-1235
-        died_of_age = vel4[si].w > P.life_thr;
+        died_of_age = v.w > P.life_thr;
         cell_arr[si] = -1; pflags[si] = 0;
         pos4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
         vel4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
         acc4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else if (survived) {                               // survive_particle, app.cu:271-283
-        const float fert = acc4[si].w;
         vel4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
         acc4[si] = make_float4(0.f, 0.f, 0.f, fert);
         pflags[si] = 0;
     } else if (moved) {
-        const float4 p = pos4[si];
-        const float4 v = vel4[si];
-        const float fert = acc4[si].w;
         float axv = f.x, ayv = f.y, azv = f.z;
         const float t = P.t;
         if (P.drag > 0.f) { axv -= P.drag * v.x; ayv -= P.drag * v.y; azv -= P.drag * v.z; }    // not in the reference
@@ -2181,18 +2247,19 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
         }
     }
     __syncthreads();
-    if (n_op == 0 && n_mv == 0) return;
     int k = s_base_ops + wave_ops + op_incl - n_op;
     int m = s_base_moves + wave_moves + mv_incl - n_mv;
-    if (k + n_op > ops_cap || m + n_mv > moves_cap) { atomicOr(&fs->error, ERR_OPS_OVERFLOW); return; }
+    const bool room = k + n_op <= ops_cap && m + n_mv <= moves_cap;
+    if (!room && (n_op || n_mv)) atomicOr(&fs->error, ERR_OPS_OVERFLOW);
 #pragma unroll
     for (int it = 0; it < ITEMS; it++) {
-        const unsigned bits = em[it].bits;
-        if (!(bits & 7u)) continue;
+        const unsigned bits = (room && (n_op || n_mv)) ? em[it].bits : 0u;
         const bool killed = bits & 1u, born = bits & 2u, relocate = bits & 4u, remote = bits & 8u, up = bits & 16u;
         const int id = em[it].id, new_cell = em[it].new_cell;
+        const int own_r = segment_record_of_slot(S, id);
+        if (!(bits & 7u)) continue;
         const uint64_t key = ((uint64_t)(uint32_t)(em[it].old_chunk + 1) << P.key_chunk_shift) | ((uint64_t)(uint32_t)id << 2);
-        const uint64_t own_rec = (uint64_t)(uint32_t)segment_record_of_slot(S, id) << P.key_rec_shift;
+        const uint64_t own_rec = (uint64_t)(uint32_t)own_r << P.key_rec_shift;
         const uint64_t dst_rec = (uint64_t)(uint32_t)em[it].new_rec << P.key_rec_shift;
         // a departure: reserve its outbox entry and put the key there; k_moves_stage adds the state
         auto depart = [&](int kind, uint64_t sub) -> int {
@@ -2307,7 +2374,11 @@ __global__ __launch_bounds__(256) void k_replay(DevParams P, int n_ops,
 // ---- fast path: bucket the operations by queue record, then one workgroup per record
 // sorts its (<= BUCKET_MAX) operations in LDS and replays them in parallel ----------
 
-// ops per record; n_ops is still on the device at this point
+// ops per record (rec_count and rec_cursor are zeroed with the frame); n_ops is still on the device at
+// this point.  (Counting where the operations are made, inside k_apply, was tried twice: a
+// workgroup-wide LDS histogram cost that kernel 21 us -- two more barriers per 1024-thread workgroup --
+// and per-wave aggregated global atomics 80 us: the 729 counters share 46 cache lines and same-line
+// atomics are served one at a time.  This kernel takes 5 us.)
 __global__ __launch_bounds__(1024) void k_ops_hist(const uint64_t *__restrict__ keys, const FrameScalars *fs,
                                                     int ops_cap, int rec_shift, int nrec, int *rec_count)
 {
@@ -2330,9 +2401,10 @@ __global__ __launch_bounds__(1024) void k_ops_hist(const uint64_t *__restrict__ 
     }
 }
 
+// exclusive prefix of rec_count and its maximum, for configurations with more queue records than
+// k_ops_scatter scans for itself in LDS
 __global__ __launch_bounds__(1024) void k_ops_scan(int nrec, const int *__restrict__ rec_count,
-                                                    int *__restrict__ rec_start, int *__restrict__ rec_cursor,
-                                                    FrameScalars *fs)
+                                                    int *__restrict__ rec_start, FrameScalars *fs)
 {
     __shared__ int wave_tot[16];
     __shared__ int carry_s, max_s;
@@ -2350,7 +2422,7 @@ __global__ __launch_bounds__(1024) void k_ops_scan(int nrec, const int *__restri
         int woff = 0;
         for (int k = 0; k < wv; k++) woff += wave_tot[k];
         const int excl = carry_s + woff + incl - v;
-        if (r < nrec) { rec_start[r] = excl; rec_cursor[r] = excl; }
+        if (r < nrec) rec_start[r] = excl;
         __syncthreads();
         if (tid == 1023) carry_s = excl + v;
         __syncthreads();
@@ -2366,36 +2438,72 @@ __global__ __launch_bounds__(1024) void k_ops_scan(int nrec, const int *__restri
 // replay -- the host then runs the sort-based path once it has seen the counts.
 __device__ __forceinline__ bool lifecycle_deferred(const FrameScalars *fs) { return fs->max_bucket > BUCKET_MAX; }
 
+// Bucket the operations by queue record.  SCAN: every workgroup first works out the buckets' starts
+// for itself (an exclusive prefix of rec_count in LDS: a few hundred records) instead of waiting
+// for a one-workgroup kernel to do it; workgroup 0 also leaves them in rec_start for the replay and
+// publishes the longest bucket.  Grid-stride over the operations: the grid is sized from a bound of
+// the live count, whatever the step really produced is covered.
+template <bool SCAN>
 __global__ __launch_bounds__(1024) void k_ops_scatter(const uint64_t *__restrict__ keys, const int *__restrict__ args,
-                                                       const FrameScalars *__restrict__ fs, int rec_shift, int nrec,
-                                                       int *rec_cursor,
+                                                       FrameScalars *fs, int ops_cap, int rec_shift, int nrec,
+                                                       const int *__restrict__ rec_count, int *__restrict__ rec_start,
+                                                       int *__restrict__ rec_cursor,
                                                        uint64_t *__restrict__ keys_out, int *__restrict__ args_out)
 {
     __shared__ int h[LDS_CELLS];
-    const int n = fs->n_ops;
-    const int tid = threadIdx.x, base = blockIdx.x * SLOTS_PER_WG;
-    if (base >= n || lifecycle_deferred(fs)) return;
-    const bool lds = nrec <= LDS_CELLS;
-    int mine[SLOTS_PER_WG / 1024];
-    if (lds) { for (int r = tid; r < nrec; r += 1024) h[r] = 0; __syncthreads(); }
-#pragma unroll
-    for (int i = 0; i < SLOTS_PER_WG / 1024; i++) {
-        const int e = base + i * 1024 + tid;
-        mine[i] = (e < n) ? (int)(keys[e] >> rec_shift) : -1;
-        if (lds && mine[i] >= 0) atomicAdd(&h[mine[i]], 1);
-    }
-    if (lds) {
+    __shared__ int s_start[SCAN ? LDS_CELLS + 1 : 1];
+    __shared__ int wave_tot[16];
+    __shared__ int max_s;
+    const int n = min(fs->n_ops, ops_cap);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if ((long long)blockIdx.x * SLOTS_PER_WG >= n && (!SCAN || blockIdx.x != 0)) return;
+    const int *start = rec_start;
+    if (SCAN) {
+        if (tid == 0) max_s = 0;
+        const int per = (nrec + 1023) / 1024, r0 = min(nrec, tid * per), r1 = min(nrec, r0 + per);
+        int mine = 0, mymax = 0;
+        for (int r = r0; r < r1; r++) { const int v = rec_count[r]; mine += v; mymax = max(mymax, v); }
+        const int incl = wave_incl_scan(mine);
+        if (lane == 63) wave_tot[wv] = incl;
         __syncthreads();
-        for (int r = tid; r < nrec; r += 1024) { const int v = h[r]; if (v) h[r] = atomicAdd(&rec_cursor[r], v); }
+        if (mymax) atomicMax(&max_s, mymax);
+        int run = incl - mine, total = 0;
+        for (int k = 0; k < 16; k++) { if (k < wv) run += wave_tot[k]; total += wave_tot[k]; }
+        for (int r = r0; r < r1; r++) { s_start[r] = run; run += rec_count[r]; }
+        if (tid == 0) s_start[nrec] = total;
         __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < SLOTS_PER_WG / 1024; i++)
-        if (mine[i] >= 0) {
-            const int e = base + i * 1024 + tid;
-            const int pos = lds ? atomicAdd(&h[mine[i]], 1) : atomicAdd(&rec_cursor[mine[i]], 1);
-            keys_out[pos] = keys[e]; args_out[pos] = args[e];
+        const int longest = max_s;
+        if (blockIdx.x == 0) {
+            for (int r = tid; r <= nrec; r += 1024) rec_start[r] = s_start[r];
+            if (tid == 0) fs->max_bucket = longest;
         }
+        if (longest > BUCKET_MAX) return;                       // (lifecycle_deferred, from this workgroup's own scan)
+        start = s_start;
+    } else if (lifecycle_deferred(fs)) return;
+    const bool lds = nrec <= LDS_CELLS;
+    for (long long base = (long long)blockIdx.x * SLOTS_PER_WG; base < n; base += (long long)gridDim.x * SLOTS_PER_WG) {
+        int mine[SLOTS_PER_WG / 1024];
+        __syncthreads();
+        if (lds) { for (int r = tid; r < nrec; r += 1024) h[r] = 0; __syncthreads(); }
+#pragma unroll
+        for (int i = 0; i < SLOTS_PER_WG / 1024; i++) {
+            const long long e = base + i * 1024 + tid;
+            mine[i] = (e < n) ? (int)(keys[e] >> rec_shift) : -1;
+            if (lds && mine[i] >= 0) atomicAdd(&h[mine[i]], 1);
+        }
+        if (lds) {
+            __syncthreads();
+            for (int r = tid; r < nrec; r += 1024) { const int v = h[r]; if (v) h[r] = start[r] + atomicAdd(&rec_cursor[r], v); }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < SLOTS_PER_WG / 1024; i++)
+            if (mine[i] >= 0) {
+                const long long e = base + i * 1024 + tid;
+                const int pos = lds ? atomicAdd(&h[mine[i]], 1) : start[mine[i]] + atomicAdd(&rec_cursor[mine[i]], 1);
+                keys_out[pos] = keys[e]; args_out[pos] = args[e];
+            }
+    }
 }
 
 // One workgroup per queue record with at most BUCKET_MAX operations: rank them by key in
@@ -2405,13 +2513,61 @@ __global__ __launch_bounds__(1024) void k_ops_scatter(const uint64_t *__restrict
 // k-th insert becomes logical element count0 + k -- and all of them are applied at once;
 // otherwise one lane walks the list exactly as q_insert / q_remove do.
 constexpr int REPLAY_THREADS = 512;
-__global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, const int *__restrict__ rec_start,
+
+// Relocation phase 1 for move record m, run by the workgroups of the replay launch past the queue
+// records (nothing here depends on the replay, so it rides along instead of being two launches).
+// One GPU: read the moving particle (copy_particle, ps.cpp:1363) or the parent of a child to be
+// born into the staging area, and reset_particle the slot a relocation vacates (ps.cpp:1367).  A
+// parent that also relocates this step has two records, written side by side by its k_apply
+// thread (birth, then relocation): the relocation's thread stages for both and then resets, the
+// birth's thread stands back -- so no record reads a slot another thread zeroes.
+// Slab: everything local was staged when the outboxes were closed (k_moves_stage); only the reset is left.
+__device__ __forceinline__ void moves_stage_reset(const DevParams &P, int m, MoveRec *moves, const FrameScalars *__restrict__ fs,
+                                                  float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr, uint8_t *pflags,
+                                                  float4 *stage)
+{
+    if (lifecycle_deferred(fs)) return;
+    const int n = fs->n_moves;
+    if (m >= n) return;
+    const MoveRec r = moves[m];
+    if (r.kind & MOVE_IN) return;                         // arrived from a neighbour: staged on arrival, vacates nothing here
+    const int kind = r.kind & 0xff;
+    const int si = slot_index(P, r.src);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (P.world > 1) {
+        if (kind == 0) { cell_arr[si] = -1; pflags[si] = 0; pos4[si] = zero; vel4[si] = zero; acc4[si] = zero; }
+        return;
+    }
+    if (kind == 1) {
+        if (m + 1 < n) { const MoveRec nx = moves[m + 1]; if (nx.src == r.src && (nx.kind & 0xff) == 0) return; }
+        float4 *s = stage + (size_t)3 * m;
+        s[0] = pos4[si]; s[1] = vel4[si]; s[2] = acc4[si];
+        return;
+    }
+    const float4 p = pos4[si], v = vel4[si], a = acc4[si];
+    float4 *s = stage + (size_t)3 * m;
+    s[0] = p; s[1] = v; s[2] = a;
+    if (pflags[si]) moves[m].kind = MOVE_PARENT;          // is_parent travels in bit 8
+    if (m > 0) {
+        const MoveRec pv = moves[m - 1];
+        if (pv.src == r.src && (pv.kind & 0xff) == 1) { float4 *b = stage + (size_t)3 * (m - 1); b[0] = p; b[1] = v; b[2] = a; }
+    }
+    cell_arr[si] = -1; pflags[si] = 0; pos4[si] = zero; vel4[si] = zero; acc4[si] = zero;
+}
+
+__global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, int nrec, const int *__restrict__ rec_start,
                                                         const uint64_t *__restrict__ keys,
                                                         const int *__restrict__ args,
                                                         QueueInfo *qinfo, int *queue, MoveRec *moves,
                                                         DevCounters *ctr, const FrameScalars *__restrict__ fs,
-                                                        unsigned long long *trace)
+                                                        unsigned long long *trace,
+                                                        float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr, uint8_t *pflags,
+                                                        float4 *stage)
 {
+    if ((int)blockIdx.x >= nrec) {
+        moves_stage_reset(P, ((int)blockIdx.x - nrec) * REPLAY_THREADS + (int)threadIdx.x, moves, fs, pos4, vel4, acc4, cell_arr, pflags, stage);
+        return;
+    }
 #ifdef PSAMD_REPLAY_TRACE
     unsigned long long tk[6]; int ti = 0;
 #define RT() do { if (threadIdx.x == 0 && ti < 6) tk[ti++] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -2845,7 +3001,7 @@ __global__ __launch_bounds__(256) void k_unpack_force(DevParams P, int j0, const
 // Arrivals: every record a neighbour sent becomes a MoveRec whose state is staged already,
 // plus the remove operation on this rank's queue, keyed as the sender keyed it.
 __global__ void k_inbox_merge(DevParams P, const int *__restrict__ msg, uint64_t *op_keys, int *op_args, int ops_cap,
-                              MoveRec *moves, int moves_cap, float4 *stage, FrameScalars *fs)
+                              MoveRec *moves, int moves_cap, float4 *stage, int *__restrict__ rec_count, FrameScalars *fs)
 {
     const int n = min(msg[0], P.xfer_cap);
     const XferRec *in = reinterpret_cast<const XferRec *>(msg + MSG_HEADER_WORDS);
@@ -2875,6 +3031,82 @@ __global__ void k_outbox_header(int *__restrict__ msg_down, int *__restrict__ ms
         msg_down[0] = min(fs->n_out[0], cap); msg_down[1] = 0; msg_down[2] = fs->error;
         msg_up[0] = min(fs->n_out[1], cap); msg_up[1] = 0; msg_up[2] = fs->error;
     }
+}
+
+// ---- all-pairs forces across ranks (PSAMD_FLAG_ALL_PAIRS, world > 1) ----
+// SURVEY 8(e)'s first row, literally: every rank contributes the snapshot of its own cells and an
+// all-gather hands every rank all of them, once per step.  A rank's block: 16 header words ([0] own
+// cells, [1] bodies, [2] the sender's error bits, [3] its first global cell), allg_cells raw cell
+// counts, then the own block of snap_soa as it is -- x, y, z, w_eff planes of allg_cap floats, bodies
+// cell-major in list order -- so the far walk reads the gathered buffer in place, in the same order
+// a single GPU reads its own snapshot: same order, same bits.
+__global__ void k_allg_pack(DevParams P, const int *__restrict__ cell_start, const float *__restrict__ snap_soa,
+                            int *__restrict__ msg, FrameScalars *fs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nb = cell_start[P.n_own_cells];
+    if (i == 0) {
+        if (nb > P.allg_cap) atomicOr(&fs->error, ERR_HALO_OVERFLOW);
+        msg[0] = P.n_own_cells; msg[1] = min(nb, P.allg_cap); msg[2] = fs->error; msg[3] = P.reg_first[0] * P.G * P.G;
+    }
+    if (i < P.n_own_cells) msg[MSG_HEADER_WORDS + i] = cell_start[i + 1] - cell_start[i];
+    if (i < nb && i < P.allg_cap) {
+        float *body = reinterpret_cast<float *>(msg + MSG_HEADER_WORDS + P.allg_cells);
+        const size_t sc = (size_t)P.sorted_cap, cap = (size_t)P.allg_cap;
+#pragma unroll
+        for (int k = 0; k < 4; k++) body[k * cap + i] = snap_soa[k * sc + i];
+    }
+}
+
+// one workgroup per gathered block: where every global cell's bodies start in the gathered buffer, and how many count
+__global__ __launch_bounds__(1024) void k_allg_index(DevParams P, const int *__restrict__ all, int *__restrict__ gstart,
+                                                      int *__restrict__ gn, FrameScalars *fs)
+{
+    __shared__ int wave_tot[16];
+    __shared__ int carry;
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int *hdr = all + (size_t)r * P.allg_block;
+    const int ncell = hdr[0], first = hdr[3];
+    if (ncell < 0 || ncell > P.allg_cells || first < 0 || first + ncell > P.num_cells_global) {
+        if (tid == 0) atomicOr(&fs->error, ERR_SLAB_MISMATCH);
+        return;
+    }
+    if (tid == 0) { carry = 0; if (hdr[2]) atomicOr(&fs->error, hdr[2]); }
+    __syncthreads();
+    const int base = r * P.allg_block + MSG_HEADER_WORDS + P.allg_cells;      // index of the block's x[0] in the gathered buffer
+    for (int b = 0; b < ncell; b += 1024) {
+        const int j = b + tid;
+        const int v = j < ncell ? max(hdr[MSG_HEADER_WORDS + j], 0) : 0;
+        const int incl = wave_incl_scan(v);
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        int o = carry;
+        for (int k = 0; k < wv; k++) o += wave_tot[k];
+        if (j < ncell) {
+            const int at = o + incl - v;
+            const bool fits = at + v <= P.allg_cap;
+            gstart[first + j] = base + (fits ? at : 0);
+            gn[first + j] = fits ? min(v, P.max_per_cell) : 0;
+            if (!fits) atomicOr(&fs->error, ERR_SLAB_MISMATCH);
+        }
+        __syncthreads();
+        if (tid == 1023) carry = o + incl;
+        __syncthreads();
+    }
+}
+
+hipError_t launch_allg_pack(hipStream_t st, const DevParams &P, const DeviceState &d, int *msg)
+{
+    const int n = std::max(P.n_own_cells, P.slots_total);
+    if (n <= 0) return hipSuccess;
+    k_allg_pack<<<(n + 255) / 256, 256, 0, st>>>(P, d.cell_start, d.snap_soa, msg, d.fs);
+    return hipGetLastError();
+}
+
+hipError_t launch_allg_index(hipStream_t st, const DevParams &P, const DeviceState &d)
+{
+    k_allg_index<<<P.world, 1024, 0, st>>>(P, d.allg_in, d.gstart, d.gn, d.fs);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ self test
@@ -2981,7 +3213,7 @@ hipError_t launch_place(hipStream_t st, const DevParams &P, int n, const int *id
 
 // init_iframe: zero the per-frame counts (cells, chunks, queue records: one array) and the
 // per-frame scalars; the sticky error word survives
-__global__ void k_frame_reset(int *frame, size_t n, FrameScalars *fs, int *status_out)
+__global__ void k_frame_reset(int *frame, size_t n, FrameScalars *fs, int *status_out, int status_table)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) frame[i] = 0;
@@ -2990,12 +3222,16 @@ __global__ void k_frame_reset(int *frame, size_t n, FrameScalars *fs, int *statu
         *fs = FrameScalars{};
         fs->error = err;
     }
-    if (status_out && i < (size_t)MSG_HEADER_WORDS) status_out[i] = 0;
+    if (status_out) {
+        if (i < (size_t)MSG_HEADER_WORDS) status_out[i] = 0;
+        if (i < (size_t)status_table) status_out[STATUS_CHUNK_OFF + i] = 0;       // the (chunk, type) census
+    }
 }
 
-hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints)
+hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints, int status_table)
 {
-    k_frame_reset<<<(unsigned)((frame_ints + 1023) / 1024), 1024, 0, st>>>(d.cell_count, frame_ints, d.fs, d.status_out);
+    const size_t n = std::max(frame_ints, (size_t)status_table);
+    k_frame_reset<<<(unsigned)((n + 1023) / 1024), 1024, 0, st>>>(d.cell_count, frame_ints, d.fs, d.status_out, d.status_out ? status_table : 0);
     return hipGetLastError();
 }
 
@@ -3014,19 +3250,49 @@ hipError_t launch_status_close(hipStream_t st, const DeviceState &d)
     return hipGetLastError();
 }
 
-// one workgroup per rank's status record: adopt its error bits; the owner of queue record 0
-// queues the reported kills as the inserts build_grid would have made (ps.cpp:1523-1526): key =
-// chunk field 0 | slot | insert, i.e. before every calc_forces operation and in slot order.
-__global__ __launch_bounds__(256) void k_status_merge(DevParams P, const int *__restrict__ status_all, uint64_t *op_keys, int *op_args,
-                                                       int ops_cap, FrameScalars *fs)
+// Run once the status records of all ranks are in, before k_apply.
+// Workgroups [0, world), one per rank's record: adopt its error bits (status_error: the OR over ALL
+// records, this rank's own included -- the same word on every rank, which is what makes a failure
+// collective); the owner of queue record 0 queues the reported cell-overflow kills as the inserts
+// build_grid would have made (ps.cpp:1523-1526): key = chunk field 0 | slot | insert, i.e. before
+// every calc_forces operation and in slot order.
+// Workgroups [world, world + num_chunks), one per chunk: the chunk lists' capacity rule
+// (ps.cpp:1502-1508) across ranks.  The chunk's count is the sum of the ranks' parts (also what
+// hostGridMax[0] is the maximum of); if it passed the capacity, this rank ranks the particles in its
+// own segments of the chunk behind what the census says precedes them in slot order.
+__global__ __launch_bounds__(1024) void k_status_merge(DevParams P, const int *__restrict__ status_all, uint64_t *op_keys, int *op_args,
+                                                        int ops_cap, int *__restrict__ chunk_count, const int *__restrict__ cell_arr,
+                                                        const CellInfo *__restrict__ celltab, const int2 *__restrict__ chunk_segs,
+                                                        uint8_t *__restrict__ chunk_skip, FrameScalars *fs)
 {
+    __shared__ int s_before[4];
+    if ((int)blockIdx.x >= P.world) {
+        const int ch = (int)blockIdx.x - P.world;
+        int tot[4] = {0, 0, 0, 0}, below[4] = {0, 0, 0, 0};
+        for (int r = 0; r < P.world; r++) {
+            const int *t = status_all + (size_t)r * P.status_words + STATUS_CHUNK_OFF + 4 * ch;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int v = max(t[k], 0); tot[k] += v; if (r < P.rank) below[k] += v; }
+        }
+        const int total = tot[0] + tot[1] + tot[2] + tot[3];
+        if (threadIdx.x == 0) {
+            chunk_count[ch] = total;                                   // k_apply tests the chunk's whole count
+            atomicMax(&fs->gridmax[0], min(total, P.max_per_chunk));   // hostGridMax[0], ps.cpp:1507
+            if (total > P.max_per_chunk) fs->chunk_over = 1;
+            s_before[0] = below[0]; s_before[1] = tot[0] + below[1]; s_before[2] = tot[0] + tot[1] + below[2];
+            s_before[3] = tot[0] + tot[1] + tot[2] + below[3];
+        }
+        if (total <= P.max_per_chunk) return;
+        __syncthreads();
+        chunk_cap_block(P, ch, chunk_count, cell_arr, celltab, chunk_segs, chunk_skip, s_before);
+        return;
+    }
     const int r = blockIdx.x;
-    if (r == P.rank) return;
-    const int *st = status_all + (size_t)r * STATUS_WORDS;
-    if (threadIdx.x == 0 && st[1]) atomicOr(&fs->error, st[1]);
-    if (!owns_record(P, 0)) return;
+    const int *st = status_all + (size_t)r * P.status_words;
+    if (threadIdx.x == 0 && st[1]) { atomicOr(&fs->status_error, st[1]); if (r != P.rank) atomicOr(&fs->error, st[1]); }
+    if (r == P.rank || !owns_record(P, 0)) return;
     const int n = min(st[0], STATUS_KILL_CAP);
-    for (int e = threadIdx.x; e < n; e += 256) {
+    for (int e = threadIdx.x; e < n; e += 1024) {
         const int id = st[MSG_HEADER_WORDS + e];
         const int k = atomicAdd(&fs->n_ops, 1);
         if (k < ops_cap) { op_keys[k] = ((uint64_t)(uint32_t)id << 2) | 2ull; op_args[k] = id; }
@@ -3037,7 +3303,8 @@ __global__ __launch_bounds__(256) void k_status_merge(DevParams P, const int *__
 hipError_t launch_status_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *status_all)
 {
     if (!status_all || P.world <= 1) return hipSuccess;
-    k_status_merge<<<P.world, 256, 0, st>>>(P, status_all, d.op_keys, d.op_args, d.ops_cap, d.fs);
+    k_status_merge<<<P.world + P.num_chunks, 1024, 0, st>>>(P, status_all, d.op_keys, d.op_args, d.ops_cap, d.chunk_count, d.cell, d.celltab,
+                                                            d.chunk_segs, d.chunk_skip, d.fs);
     return hipGetLastError();
 }
 
@@ -3064,19 +3331,16 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     k_hist_lds<<<nwg, 1024, 0, st>>>(P, d.cell, d.cell_count, d.fs);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[1], st);
-    k_scan<<<1, 1024, 0, st>>>(P, d.cell_count, d.cell_start, d.cursor, d.task_start, d.chunk_count, d.celltab, d.fs);
-    PS_LAUNCH_CHECK();
-    if (P.world == 1) k_chunk_cap<<<P.num_chunks, 1024, 0, st>>>(P, d.chunk_count, d.cell, d.celltab, d.chunk_segs, d.chunk_skip);
-    PS_LAUNCH_CHECK();
-    if (P.own_comp1 > P.own_comp0) k_build_tasks<<<(P.own_comp1 - P.own_comp0 + 255) / 256, 256, 0, st>>>(P, d.task_start, d.task_list);
+    k_scan<<<1, 1024, 0, st>>>(P, d.cell_count, d.cell_start, d.cursor, d.task_start, d.task_list, d.chunk_count, d.celltab, d.status_out, d.fs);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[2], st);
-    k_scatter_lds<<<nwg, 1024, 0, st>>>(P, d.cell, d.cursor, d.sorted_id);
+    k_scatter_lds<<<nwg + (P.world == 1 ? P.num_chunks : 0), 1024, 0, st>>>(P, nwg, d.cell, d.cursor, d.sorted_id, d.chunk_count, d.celltab,
+                                                                             d.chunk_segs, d.chunk_skip);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[3], st);
     k_sort_cells<<<P.n_own_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
                                                d.pflags, d.snap4, d.snap_soa, d.snap_age, d.tdata, d.rank_of_slot, d.op_keys, d.op_args, d.ops_cap,
-                                               P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.snap_cid, d.status_out, d.fs, d.ctr);
+                                               P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.snap_cid, d.status_out, d.rec_count, d.fs, d.ctr);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[4], st);
     return hipSuccess;
@@ -3133,7 +3397,7 @@ hipError_t launch_unpack_force(hipStream_t st, const DevParams &P, const DeviceS
 hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *msg)
 {
     if (P.xfer_cap <= 0) return hipSuccess;
-    k_inbox_merge<<<(P.xfer_cap + 255) / 256, 256, 0, st>>>(P, msg, d.op_keys, d.op_args, d.ops_cap, d.moves, d.moves_cap, d.stage, d.fs);
+    k_inbox_merge<<<(P.xfer_cap + 255) / 256, 256, 0, st>>>(P, msg, d.op_keys, d.op_args, d.ops_cap, d.moves, d.moves_cap, d.stage, d.rec_count, d.fs);
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -3182,27 +3446,11 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     if (packs_in_list) { merge = false; nw = std::min(nw, 4096); }      // (98 VGPRs with the tile walk in: 4 resident waves per SIMD)
     if (tile) merge = false;                  // no separate merged kernel beside a tile-walk pass
     if (two) {
-        // collision flags, then the per-cell lists and the tasks of the particles that need a force
+        // collision flags and the per-cell lists of the particles that need a force, then the plan of the force pass
         k_collide<<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.snap_cid, d.task_list, d.task_start,
-                                                   d.halo_count, d.halo_f, d.halo_id, d.pair_flag, d.force4, d.fs);
-        k_build_active<<<ncomp, 256, 0, st>>>(P, d.cell_start, d.pair_flag, d.active_list, d.active_count, d.task_cost);
-        k_active_tasks<<<1, 1024, 0, st>>>(P, d.active_count, d.task_cost, d.task_list2, d.ctask_start, d.cost_start, d.merged_tasks, d.fs,
-                                           packs_in_list ? 2 : merge ? 1 : 0);
-        if (merge) {
-            // fork: the packs of partly filled slices run beside the ordinary tasks (their waves
-            // stall on tile loads that the ordinary waves' arithmetic covers); the join further
-            // down puts everything that follows on `st` after both.  They need only the lists, so
-            // they start while the balanced pass is still being cut up.
-            // (The packs through the balanced pass's own four-group tile walk, as a kernel of its own
-            // here, were slower than k_pairs_merged: 2.47 against 2.32 ms for the stage.)
-            (void)hipEventRecord(d.ev_fork, st);
-            (void)hipStreamWaitEvent(d.side_stream, d.ev_fork, 0);
-            k_pairs_merged<MODE == 0 ? 1 : MODE, NQ><<<(ncomp + 3) / 4, 256, 0, d.side_stream>>>(
-                P, d.cell_start, d.snap4, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
-            (void)hipEventRecord(d.ev_join, d.side_stream);
-        }
-        if (balanced) k_split_tasks<<<8 * SPLIT_SUB, 1024, 0, st>>>(P, nw, d.cell_start, d.task_cost, d.ctask_start, d.cost_start, d.wave_pos, d.fs,
-                                                                    packs_in_list ? 1 : 0);
+                                                   d.halo_count, d.halo_f, d.halo_id, d.active_list, d.active_count, d.task_cost, d.force4, d.fs);
+        k_plan_force<<<8, 1024, 0, st>>>(P, balanced ? nw : 0, packs_in_list ? 2 : merge ? 1 : 0, d.cell_start, d.active_count, d.task_cost,
+                                         d.task_list2, d.ctask_start, d.cost_start, d.merged_tasks, d.wave_pos, d.fs, d.trace);
     }
     if (ev_force) (void)hipEventRecord(ev_force, st);      // timing: the force pass proper starts here
     const int *task_list = two ? d.task_list2 : d.task_list;
@@ -3212,15 +3460,22 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     int *task_ready = d.task_ready + (size_t)pass * P.n_local_cells * P.slices;
     if (balanced) {
         constexpr int M = MODE == 0 ? 1 : MODE;
-#define PS_BALANCED(W) k_pairs_balanced<M, NQ, W><<<nw / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, \
-                                                                     d.force4, d.fs, d.trace, active_list, active_count, d.wave_pos, task_ready, d.merged_tasks)
+        // the packs of partly filled slices (merge): the first nmb workgroups of the same launch
+        const int nmb = merge ? (((ncomp + 3) / 4 + 7) & ~7) : 0;
+#define PS_BALANCED(W) k_pairs_balanced<M, NQ, W><<<nmb + nw / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, \
+                                                                     d.force4, d.fs, d.trace, active_list, active_count, d.wave_pos, task_ready, d.merged_tasks, nmb)
         if (tile) PS_BALANCED(1); else if (packs_in_list) PS_BALANCED(2); else PS_BALANCED(0);
 #undef PS_BALANCED
     }
-    else
+    else {
+        FarCells far;
+        if ((P.flags & PSAMD_FLAG_ALL_PAIRS) && P.world > 1) { far.start = d.gstart; far.n = d.gn; far.buf = reinterpret_cast<const float *>(d.allg_in); far.plane = (unsigned long long)P.allg_cap; }
         k_pairs<MODE, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
-                                                    d.fs, d.trace, active_list, active_count);
-    if (merge) (void)hipStreamWaitEvent(st, d.ev_join, 0);
+                                                    d.fs, d.trace, active_list, active_count, far);
+        // (unbalanced pass, A/B runs only: the packs as a kernel of their own behind it)
+        if (merge) k_pairs_merged<MODE == 0 ? 1 : MODE, NQ><<<(ncomp + 3) / 4, 256, 0, st>>>(
+                P, d.cell_start, d.snap4, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
+    }
     return hipGetLastError();
 }
 
@@ -3233,13 +3488,13 @@ hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d
     return launch_pairs_mode<0, 4>(st, P, d, ev_force, tasks_hint, pass);
 }
 
-hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step)
+hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step, int nrec)
 {
     if (P.slots_total <= 0) return hipSuccess;
     // slots per thread: one (PSAMD_APPLY_ITEMS: the measurement quoted at the kernel)
 #define PS_APPLY(I) k_apply<I><<<(P.slots_total + I * 1024 - 1) / (I * 1024), 1024, 0, st>>>(P, S, step, d.rank_of_slot, d.force4, d.pos4, \
         d.vel4, d.acc4, d.cell, d.pflags, d.celltab, d.op_keys, d.op_args, d.ops_cap, \
-        d.moves, d.moves_cap, d.xfer_out[0], d.xfer_out[1], d.chunk_count, d.chunk_skip, d.fs, d.ctr)
+        d.moves, d.moves_cap, d.xfer_out[0], d.xfer_out[1], d.chunk_count, d.chunk_skip, nrec, d.rec_count, d.fs, d.ctr)
     static const int items_env = std::getenv("PSAMD_APPLY_ITEMS") ? std::atoi(std::getenv("PSAMD_APPLY_ITEMS")) : 0;
     const int items = items_env ? items_env : 1;
     if (items >= 4) PS_APPLY(4); else if (items >= 2) PS_APPLY(2); else PS_APPLY(1);
@@ -3263,37 +3518,40 @@ hipError_t launch_outbox_close(hipStream_t st, const DevParams &P, const DeviceS
     return hipSuccess;
 }
 
-hipError_t launch_ops_census(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec)
+// Usual case, enqueued without waiting for the host: every queue's operations fit one
+// workgroup's LDS.  Four launches: the census of the operations per queue record, their bucketing (each
+// workgroup scanning the census for itself; after it the frame scalars are complete, longest bucket included -- the host reads them
+// back at that point), replay the queues with the first relocation phase riding along, commit.
+// `live_bound` >= live particles of the step (arrivals from the neighbour ranks included): at most 3
+// queue operations and 2 move records each.
+hipError_t launch_ops_bucket(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_bound)
 {
-    k_ops_hist<<<512, 1024, 0, st>>>(d.op_keys, d.fs, d.ops_cap, P.key_rec_shift, nrec, d.rec_count);
+    const int64_t max_ops = std::max<int64_t>(1, std::min<int64_t>(d.ops_cap, 3 * live_bound));
+    const int nwg = (int)std::min<int64_t>((max_ops + SLOTS_PER_WG - 1) / SLOTS_PER_WG, 2048);    // (grid-stride beyond)
+    k_ops_hist<<<std::min(nwg, 512), 1024, 0, st>>>(d.op_keys, d.fs, d.ops_cap, P.key_rec_shift, nrec, d.rec_count);
     PS_LAUNCH_CHECK();
-    k_ops_scan<<<1, 1024, 0, st>>>(nrec, d.rec_count, d.rec_start, d.rec_cursor, d.fs);
+    if (nrec <= LDS_CELLS)
+        k_ops_scatter<true><<<nwg, 1024, 0, st>>>(d.op_keys, d.op_args, d.fs, d.ops_cap, P.key_rec_shift, nrec, d.rec_count, d.rec_start,
+                                                  d.rec_cursor, d.op_keys_sorted, d.op_args_sorted);
+    else {
+        k_ops_scan<<<1, 1024, 0, st>>>(nrec, d.rec_count, d.rec_start, d.fs);
+        PS_LAUNCH_CHECK();
+        k_ops_scatter<false><<<nwg, 1024, 0, st>>>(d.op_keys, d.op_args, d.fs, d.ops_cap, P.key_rec_shift, nrec, d.rec_count, d.rec_start,
+                                                   d.rec_cursor, d.op_keys_sorted, d.op_args_sorted);
+    }
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }
 
-// Usual case, enqueued without waiting for the host: every queue's operations fit one
-// workgroup's LDS.  `live_bound` >= live particles of the step (arrivals from the neighbour
-// ranks included): at most 3 queue operations and 2 move records each.
-hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
-                            int64_t live_bound)
+hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec, int64_t live_bound)
 {
-    const int64_t max_ops = std::min<int64_t>(d.ops_cap, 3 * live_bound), max_moves = std::min<int64_t>(d.moves_cap, 2 * live_bound);
-    if (max_ops <= 0) return hipSuccess;
-    k_ops_scatter<<<(int)((max_ops + SLOTS_PER_WG - 1) / SLOTS_PER_WG), 1024, 0, st>>>(
-        d.op_keys, d.op_args, d.fs, P.key_rec_shift, nrec, d.rec_cursor, d.op_keys_sorted, d.op_args_sorted);
+    const int64_t max_moves = std::min<int64_t>(d.moves_cap, 2 * live_bound);
+    const int nb = (int)((max_moves + REPLAY_THREADS - 1) / REPLAY_THREADS);
+    k_replay_bucket<<<nrec + nb, REPLAY_THREADS, 0, st>>>(P, nrec, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
+                                          d.moves, d.ctr, d.fs, d.trace, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
     PS_LAUNCH_CHECK();
-    k_replay_bucket<<<nrec, REPLAY_THREADS, 0, st>>>(P, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
-                                          d.moves, d.ctr, d.fs, d.trace);
-    PS_LAUNCH_CHECK();
-    const int nb = (int)((max_moves + 255) / 256);
     if (nb > 0) {
-        // slab mode staged every local record when it closed the outboxes (launch_outbox_close)
-        if (P.world == 1) k_moves_stage<<<nb, 256, 0, st>>>(P, d.moves, -1, d.fs, d.pos4, d.vel4, d.acc4, d.pflags, d.stage, d.xfer_out[0], d.xfer_out[1]);
-        PS_LAUNCH_CHECK();
-        k_moves_reset<<<nb, 256, 0, st>>>(P, d.moves, -1, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags);
-        PS_LAUNCH_CHECK();
-        k_moves_commit<<<nb, 256, 0, st>>>(P, step, d.moves, -1, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
+        k_moves_commit<<<(int)((max_moves + 255) / 256), 256, 0, st>>>(P, step, d.moves, -1, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
         PS_LAUNCH_CHECK();
     }
     return hipSuccess;

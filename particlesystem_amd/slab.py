@@ -26,6 +26,7 @@ import numpy as np
 
 # message slots, as in psamd_slab_msg_download: out/in x below/above; the status record is all-gathered
 HALO_OUT, HALO_IN, FORCE_OUT, FORCE_IN, XFER_OUT, XFER_IN, STATUS_OUT, STATUS_IN = 0, 2, 4, 5, 6, 8, 10, 11
+ALLG_OUT, ALLG_IN = 12, 13          # all-pairs forces only: every rank's snapshot block, all-gathered between build and pairs
 BELOW, ABOVE = 0, 1
 
 
@@ -42,6 +43,14 @@ def routes(rank, world, periodic_ring=True):
         r.append(("xfer", XFER_OUT + BELOW, (rank - 1) % world, XFER_IN + ABOVE))
         r.append(("xfer", XFER_OUT + ABOVE, (rank + 1) % world, XFER_IN + BELOW))
     return r
+
+
+def _bytes(sysr, slot):
+    """size of a message slot; ranks that predate a slot (stand-ins) simply do not have it"""
+    try:
+        return sysr.msg_bytes(slot)
+    except (KeyError, IndexError):
+        return 0
 
 
 def step_local(ranks, overlap_interior=False):
@@ -63,10 +72,11 @@ def step_local(ranks, overlap_interior=False):
         for s in ranks:
             s.slab_pairs_interior()   # (in a real run: while the halo travels)
     deliver("halo")
-    if world > 1 and ranks[0].msg_bytes(STATUS_OUT):          # the "all-gather" of the status records
-        every = np.concatenate([s.msg_download(STATUS_OUT) for s in ranks])
-        for s in ranks:
-            s.msg_upload(STATUS_IN, every)
+    for out_slot, in_slot in ((STATUS_OUT, STATUS_IN), (ALLG_OUT, ALLG_IN)):      # the "all-gathers"
+        if world > 1 and _bytes(ranks[0], out_slot):
+            every = np.concatenate([s.msg_download(out_slot) for s in ranks])
+            for s in ranks:
+                s.msg_upload(in_slot, every)
     for s in ranks:
         s.slab_pairs()
     deliver("force")
@@ -126,20 +136,31 @@ class HostRing(_Ring):
     def finish_status(self, work):
         pass                                    # (gather_status is synchronous here)
 
-    def gather_status(self):
+    def _gather(self, out_slot, in_slot):
         import torch
-        n = self.s.msg_bytes(STATUS_OUT)
+        n = _bytes(self.s, out_slot)
         if not n or self.world == 1:
             return
-        mine = torch.from_numpy(self.s.msg_download(STATUS_OUT))
+        mine = torch.from_numpy(self.s.msg_download(out_slot))
         every = [torch.empty_like(mine) for _ in range(self.world)]
         self.dist.all_gather(every, mine)
-        self.s.msg_upload(STATUS_IN, torch.cat(every).numpy())
+        self.s.msg_upload(in_slot, torch.cat(every).numpy())
+
+    def gather_status(self):
+        self._gather(STATUS_OUT, STATUS_IN)
+
+    def gather_snapshot(self):
+        """all-pairs forces: every rank's snapshot block to every rank (synchronous here)"""
+        self._gather(ALLG_OUT, ALLG_IN)
+
+    def finish_snapshot(self, work):
+        pass
 
     def step(self):
         s = self.s
         s.slab_build()
         self.exchange("halo")
+        self.gather_snapshot()
         self.gather_status()
         s.slab_pairs()
         self.exchange("force")
@@ -172,7 +193,8 @@ class DeviceRing(_Ring):
                 FORCE_OUT: (b.force_out, b.force_out_bytes), FORCE_IN: (b.force_in, b.force_in_bytes),
                 XFER_OUT + 0: (b.xfer_out[0], b.xfer_bytes), XFER_OUT + 1: (b.xfer_out[1], b.xfer_bytes),
                 XFER_IN + 0: (b.xfer_in[0], b.xfer_bytes), XFER_IN + 1: (b.xfer_in[1], b.xfer_bytes),
-                STATUS_OUT: (b.status_out, b.status_bytes), STATUS_IN: (b.status_in, b.status_bytes * world)}
+                STATUS_OUT: (b.status_out, b.status_bytes), STATUS_IN: (b.status_in, b.status_bytes * world),
+                ALLG_OUT: (b.allg_out, b.allg_bytes), ALLG_IN: (b.allg_in, b.allg_bytes * world)}
         self.t = {slot: torch.as_tensor(_DevPtr(p, n), device="cuda") for slot, (p, n) in ptrs.items() if p and n}
         self.stream = torch_stream
         sysr.set_stream(torch_stream.cuda_stream)
@@ -215,16 +237,29 @@ class DeviceRing(_Ring):
             with torch.cuda.stream(self.stream):
                 work.wait()
 
+    def gather_snapshot(self):
+        """all-pairs forces: start the all-gather of the snapshot blocks (RCCL ncclAllGather over xGMI); the
+        pair stage needs it, so finish_snapshot() comes before slab_pairs"""
+        import torch
+        if self.dist is None or ALLG_OUT not in self.t or self.world == 1:
+            return None
+        with torch.cuda.stream(self.stream):
+            return self.dist.all_gather_into_tensor(self.t[ALLG_IN], self.t[ALLG_OUT], async_op=True)
+
+    finish_snapshot = finish_status
+
     def step(self):
         import torch
         s = self.s
         with torch.cuda.stream(self.stream):
             s.slab_build()
             halo = self.start("halo")
+            snap = self.gather_snapshot()      # all-pairs forces only
             status = self.gather_status()      # travels beside the pair pass
             if self.overlap_interior:
                 s.slab_pairs_interior()      # cells whose stencil lies in the own layers: no halo needed
             self.finish(halo)
+            self.finish_snapshot(snap)
             s.slab_pairs()
             self.exchange("force")
             s.slab_apply()

@@ -184,3 +184,42 @@ def test_all_pairs_at_config1_size():
     print("all-pairs N=2^18 vs fp64 direct sum (200 particles): max relative deviation %.3g" % rel.max())
     assert rel.max() < 1e-5
     g.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_all_pairs_across_slabs_equals_one_gpu(world):
+    """SURVEY 8(e) row 1 / BASELINE configs[3]'s exchange: every rank contributes the snapshot of its
+    own cells to an ALL-GATHER once per step and walks the gathered buffer -- stencil first, then every
+    other cell in global index order, summed per cell -- exactly as a single GPU walks its own
+    snapshot.  Same order, same bits: the union of the ranks' states must equal the one-GPU all-pairs
+    run byte for byte, every step (particles changing owner, collisions and relocations included)."""
+    from particlesystem_amd.slab import merge_owned, step_local
+    n = 20000
+    xyz = cloud(n, 40 + world)
+    rng = np.random.default_rng(40 + world)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    age[::23] = 0.5                                                       # kids: feel and exert nothing
+    fert = (1e6 + np.arange(n)).astype(np.float32)
+    one = ps.ParticleSystem(ps.default_config(flags=ps.FLAG_ALL_PAIRS))
+    ranks = [ps.ParticleSystem(ps.default_config(flags=ps.FLAG_ALL_PAIRS, rank=r, world=world)) for r in range(world)]
+    for s in [one] + ranks:
+        s.fill_particles(xyz, age=age, fert_age=fert)
+    assert ranks[0].msg_bytes(ps.MSG_ALLG_OUT) > 0 and ranks[0].msg_bytes(ps.MSG_ALLG_IN) == world * ranks[0].msg_bytes(ps.MSG_ALLG_OUT)
+    plans = [g.slab_plan() for g in ranks]
+    for step in range(6):
+        one.step(1)
+        step_local(ranks)
+        union = merge_owned([g.download_particles() for g in ranks], plans)
+        assert_same_particles(union, one.download_particles(), "all-pairs, %d slabs, step %d" % (world, step + 1))
+    c = one.counters
+    assert c["relocations"] > 0 and c["integrated"] > 0
+    # and the far field really is in the sums: the cutoff-only run of the same cloud differs
+    cut = ps.ParticleSystem(ps.default_config())
+    cut.fill_particles(xyz, age=age, fert_age=fert)
+    cut.step(1)
+    one2 = ps.ParticleSystem(ps.default_config(flags=ps.FLAG_ALL_PAIRS))
+    one2.fill_particles(xyz, age=age, fert_age=fert)
+    one2.step(1)
+    assert cut.download_particles().tobytes() != one2.download_particles().tobytes()
+    for s in [one, cut, one2] + ranks:
+        s.close()

@@ -227,10 +227,14 @@ def test_slab_message_overflow_is_loud():
         g.close()
 
 
-def test_slab_refuses_a_chunk_past_its_list_capacity():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_slab_chunk_list_capacity_rule(world):
     """The chunk lists' capacity rule (ps.cpp:1502-1508; one GPU: test_gpu_parity's
-    test_chunk_list_capacity_rule) needs the rank of a particle among ALL slots of its chunk; a
-    slab holds only part of a boundary chunk's segments, so it refuses loudly instead."""
+    test_chunk_list_capacity_rule) needs the rank of a particle among ALL slots of its chunk, and
+    a chunk's 27 segments are spread over up to three ranks (4 ranks: chunk layer 1 lives on ranks
+    0 and 1; 8 ranks: on 1, 2 and 3).  Every rank reports its part of every chunk per segment type in
+    the status record; with all records in, each ranks its own particles behind what precedes them in
+    slot order.  Same cloud as the one-GPU test, byte-equal to the oracle every step."""
     over = {"max_particles_num": 4096}
     cfg = ps.default_config(**over)
     G, cs = cfg.chunk_factor * cfg.chunk_dim, cfg.cell_size
@@ -242,14 +246,65 @@ def test_slab_refuses_a_chunk_past_its_list_capacity():
                 for _ in range({0: 4, 1: 6, 2: 7, 3: 9}[sum(v in (4, 7) for v in (i1, i2, i3))]):
                     u = rng.uniform(0.05, 0.95, 3)
                     pts.append(((i2 - G / 2 + u[0]) * cs, -(i1 - G / 2 + u[1]) * cs, -(i3 - G / 2 + u[2]) * cs))
-    xyz = np.array(pts, np.float32)
-    ranks = [ps.ParticleSystem(ps.default_config(rank=r, world=2, **over)) for r in range(2)]
+    rest = cloud(1500, 23)                 # ordinary traffic elsewhere
+    idx = np.floor(rest.astype(np.float64) * [1, -1, -1] / cs).astype(int) + G // 2
+    rest = rest[~((idx >= 2) & (idx <= 9)).all(1)]
+    xyz = np.concatenate([np.array(pts, np.float32), rest])
+    age = np.random.default_rng(6).uniform(2.2, 7.0, len(xyz)).astype(np.float32)
+    fert = (1e6 + np.arange(len(xyz))).astype(np.float32)
+    ranks, o = make_world(world, xyz, age, fert, **over)
+    for k in range(4):
+        step_local(ranks); o.step(1)
+        if k == 0:
+            assert o.chunkgrid[:, 0].max() > o.d.max_per_chunk, "the scenario must pass the chunk list's capacity"
+        compare_world(ranks, o, "chunk capacity on %d slabs, step %d" % (world, k + 1))
+    assert o.counters["cell_overflow_kills"] > 100 and o.counters["integrated"] > 0
     for g in ranks:
-        g.fill_particles(xyz, age=np.float32(3.0), fert_age=np.float32(1e6))
-    with pytest.raises(ps.PsamdError, match="MAX_PARTICLES_PER_CHUNK"):
-        step_local(ranks)
-        for g in ranks:
-            g.synchronize()
+        g.close()
+
+
+def test_slab_failure_is_collective():
+    """An error raised AFTER the build stage (here: a transfer message with room for 4 records) is
+    known to the rank that raised it and, through the message header, to its ring neighbours -- not
+    to the ranks further away, which would wait in the next exchange for a peer that has stopped.
+    So a slab fails only on what the all-gathered status records show: the sticky bit goes out with
+    the next step's record and EVERY rank returns the error from that step's slab_finish."""
+    world = 4
+    n = 60000
+    xyz = cloud(n, 302)
+    v = np.zeros((n, 3), np.float32)
+    v[:, 2] = 90.0                          # everything moves a layer per step: far more than 4 records per face
+    ranks = [ps.ParticleSystem(ps.default_config(rank=r, world=world, xfer_cap=4)) for r in range(world)]
+    for g in ranks:
+        g.fill_particles(xyz, age=np.float32(3.0), fert_age=np.float32(1e6), vxyz=v)
+    step_local(ranks)                       # the overflow happens in slab_apply of this step: nobody fails yet
+    failed = 0
+    for g in ranks:                         # the next step: every rank's record carries the bit; all fail together
+        g.slab_build()
+    every = np.concatenate([g.msg_download(ps.MSG_STATUS_OUT) for g in ranks])
+    from particlesystem_amd.slab import routes
+    for r, g in enumerate(ranks):
+        g.msg_upload(ps.MSG_STATUS_IN, every)
+        for ph, out_slot, peer, in_slot in routes(r, world):
+            if ph == "halo" and g.msg_bytes(out_slot):
+                ranks[peer].msg_upload(in_slot, g.msg_download(out_slot))
+    for g in ranks:
+        g.slab_pairs()
+    for r, g in enumerate(ranks):
+        for ph, out_slot, peer, in_slot in routes(r, world):
+            if ph == "force" and g.msg_bytes(out_slot):
+                ranks[peer].msg_upload(in_slot, g.msg_download(out_slot))
+    for g in ranks:
+        g.slab_apply()
+    for r, g in enumerate(ranks):
+        for ph, out_slot, peer, in_slot in routes(r, world):
+            if ph == "xfer" and g.msg_bytes(out_slot):
+                ranks[peer].msg_upload(in_slot, g.msg_download(out_slot))
+    for g in ranks:
+        with pytest.raises(ps.PsamdError):
+            g.slab_finish()
+        failed += 1
+    assert failed == world
     for g in ranks:
         g.close()
 

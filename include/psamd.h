@@ -271,11 +271,16 @@ typedef struct psamd_slab_buffers {
 int psamd_slab_buffers_get(psamd_ctx *ctx, psamd_slab_buffers *out);
 
 /* One step = build, [exchange halo_out -> neighbours' halo_in; start the all-gather of
- * status_out into every rank's status_in], pairs, [force_out -> rank-1's force_in], apply,
- * [xfer_out -> neighbours' xfer_in; the status gather must have landed], finish.  The status
- * record (16 KB) carries a rank's sticky error bits -- so that all ranks fail in the same step
- * instead of waiting for each other -- and the slots the cell-overflow rule killed, which the
- * reference frees into queue record 0 wherever they were (ps.cpp:1523-1526).  All asynchronous on the
+ * status_out into every rank's status_in; with PSAMD_FLAG_ALL_PAIRS the all-gather of allg_out into
+ * allg_in, which must have landed], pairs, [force_out -> rank-1's force_in; the status gather must
+ * have landed], apply, [xfer_out -> neighbours' xfer_in], finish.  The status record carries a rank's
+ * sticky error bits, the slots the cell-overflow rule killed, which the reference frees into queue
+ * record 0 wherever they were (ps.cpp:1523-1526), and the rank's part of every chunk's particle count
+ * per segment type, from which all ranks reproduce the chunk lists' capacity rule (ps.cpp:1502-1508)
+ * and hostGridMax[0].  A slab fails COLLECTIVELY: slab_finish returns an error only for error bits
+ * that were in this step's status records, which all ranks see alike; an error raised after a rank's
+ * record was closed goes out with the next step's record and stops every rank there (or is reported by
+ * psamd_synchronize).  All asynchronous on the
  * context's stream except finish, which ends with the per-step read-back.  With world == 1
  * the four calls are psamd_step(1) cut in four and no message exists. */
 int psamd_slab_build(psamd_ctx *ctx);   /* init_iframe + build_grid of the own layers; packs halo_out   */

@@ -220,6 +220,8 @@ int check_device_errors(psamd_ctx *c)   // after a sync: sticky error bits raise
     if (fs.error & ERR_REMOTE_RECORD0) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "more cell-overflow kills in one step than a slab's status message carries (ps.cpp:1523-1526 frees them into queue record 0)");
     if (fs.error & ERR_CHUNK_CAP) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "a chunk list passed MAX_PARTICLES_PER_CHUNK: the reference skips its tail (ps.cpp:1502-1508), this library does not reproduce that");
     if (fs.error & ERR_OPS_OVERFLOW) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "lifecycle op buffer overflow");
+    if (fs.error & ERR_HANDOFF_TIMEOUT) return fail(c, PSAMD_ERR_STATE, "force pass: a wave never saw the partial sums of the task it continues");
+    if (fs.error) return fail(c, PSAMD_ERR_STATE, "device error bits " + std::to_string(fs.error));
     return PSAMD_OK;
 }
 

@@ -224,7 +224,7 @@ class DeviceRing(_Ring):
         self.finish(self.start(phase))
 
     def gather_status(self):
-        """start the all-gather of the status records (needed only by slab_finish); returns the work or None"""
+        """start the all-gather of the status records (needed by slab_apply); returns the work or None"""
         import torch
         if self.dist is None or STATUS_OUT not in self.t or self.world == 1:
             return None
@@ -262,9 +262,9 @@ class DeviceRing(_Ring):
             self.finish_snapshot(snap)
             s.slab_pairs()
             self.exchange("force")
+            self.finish_status(status)         # slab_apply merges the status records (chunk counts over all ranks, error bits)
             s.slab_apply()
             self.exchange("xfer")
-            self.finish_status(status)
             s.slab_finish()
 
 

@@ -452,6 +452,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.ctask_start, 2 * LC + 2));     // (+ one virtual cell per merged pack)
     PS_HIP(c, dev_alloc(c, &d.cost_start, 2 * LC + 2));
     PS_HIP(c, dev_alloc(c, &d.wave_pos, (size_t)MAX_PAIR_WAVES + 1));
+    PS_HIP(c, dev_alloc(c, &d.wave_unit, (size_t)MAX_PAIR_WAVES + 1));
     PS_HIP(c, dev_alloc(c, &d.rec_start, (size_t)g.queue_infos + 1));
     PS_HIP(c, dev_alloc(c, &d.fs, 1));
     PS_HIP(c, dev_alloc(c, &d.cell_start, LC + 1));

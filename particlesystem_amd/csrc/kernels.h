@@ -49,7 +49,8 @@ struct DeviceState {
     int *task_cost = nullptr;     // [local cells] bodies in the cell's stencil = what one task of the cell walks
     int *ctask_start = nullptr;   // [computed cells + 1] first entry of task_list2 of the j-th computed cell
     long long *cost_start = nullptr;  // [computed cells + 1] cost of all tasks before the j-th computed cell
-    int *wave_pos = nullptr;      // [waves + 1] first (task, stencil step) unit of every wave: task index * 27 + step
+    long long *wave_pos = nullptr; // [waves + 1] where every wave slot of the balanced pass starts: task index << 32 | cost already walked inside the task
+    int *wave_unit = nullptr;      // [waves + 1] the same as (task, stencil step) units: task index * 27 + step
     int *task_ready = nullptr;    // [num_cells * slices] hand-off flags, zeroed with the frame
     int4 *merged_tasks = nullptr; // [num_cells] cells whose leftover slices share one wave (-1: unused)
     // the merged tasks run beside k_pairs on a stream of their own (fork / join by events)

@@ -1199,12 +1199,11 @@ __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restr
 // beside the balanced pass); 2 the packs are tasks of the balanced pass itself (tile walk): pack m is
 // task n_tasks2 + m, with one virtual "cell" ncomp + m in the prefix arrays.
 constexpr int PLAN_LDS = 6144;        // prefix entries (computed cells + virtual pack cells + 1) kept in LDS
-constexpr int PLAN_LDS_CELLS = 8192;  // local cells whose starts are kept in LDS
 __global__ __launch_bounds__(1024) void k_plan_force(DevParams P, int nw, int merge, const int *__restrict__ cell_start_g,
                                                      const int *__restrict__ active_count, const int *__restrict__ task_cost,
                                                      int *__restrict__ task_list2, int *__restrict__ ctask_start_g,
                                                      long long *__restrict__ cost_start_g, int4 *__restrict__ merged_tasks,
-                                                     int *__restrict__ wave_pos, FrameScalars *fs, unsigned long long *trace)
+                                                     long long *__restrict__ wave_pos, FrameScalars *fs, unsigned long long *trace)
 {
 #ifdef PSAMD_PLAN_TRACE    // diagnostic build: time stamps (100 MHz) of workgroup x's phases in trace[8 x ...]
 #define PT(i) do { if (threadIdx.x == 0) trace[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -1215,19 +1214,15 @@ __global__ __launch_bounds__(1024) void k_plan_force(DevParams P, int nw, int me
     __shared__ long long s_cost[PLAN_LDS + 1];
     __shared__ int s_task[PLAN_LDS + 1];
     __shared__ int s_ac[PLAN_LDS];                     // active_count | task_cost << 13 of the j-th computed cell
-    __shared__ int s_cstart[PLAN_LDS_CELLS + 1];
     __shared__ long long wave_tot[16], wave_cost[16], wave_pcost[16];
-    __shared__ int s_run[2];
+    __shared__ long long s_run[2];
     __shared__ long long s_runcost[2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, x = blockIdx.x;
     const int ncomp = comp_count(P);
     const bool ext = merge == 2;
     const bool in_lds = (ext ? 2 * ncomp : ncomp) + 1 <= PLAN_LDS && P.max_per_cell < (1 << 13);
-    const bool cells_in_lds = P.n_local_cells <= PLAN_LDS_CELLS;
     long long *cost_start = in_lds ? s_cost : cost_start_g;
     int *ctask_start = in_lds ? s_task : ctask_start_g;
-    const int *cell_start = cells_in_lds ? s_cstart : cell_start_g;
-    if (cells_in_lds) for (int j = tid; j <= P.n_local_cells; j += 1024) s_cstart[j] = cell_start_g[j];
     if (in_lds) for (int j = tid; j < ncomp; j += 1024) { const int c = comp_cell(P, j), n = active_count[c]; s_ac[j] = n | ((n ? task_cost[c] : 0) << 13); }
     __syncthreads();
     PT(1);
@@ -1237,10 +1232,11 @@ __global__ __launch_bounds__(1024) void k_plan_force(DevParams P, int nw, int me
     // ---- (1) prefixes, task list, packs ----
     const int per = (ncomp + 1023) / 1024;
     const int c0 = min(ncomp, tid * per), c1 = min(ncomp, c0 + per);
-    // the first 256 threads each pack the leftovers of a longer run of cells greedily, in
-    // cell order (longer runs leave fewer half-empty packs at their ends)
-    const int pper = (ncomp + 255) / 256;
-    const int p0 = tid < 256 ? min(ncomp, tid * pper) : 0, p1 = tid < 256 ? min(ncomp, p0 + pper) : 0;
+    // the leftovers are packed greedily, in cell order, a run of cells per thread: six (two packs of
+    // three 20-lane leftovers) where there are threads enough -- each step of the greedy walk is a
+    // dependent LDS round trip, and this walk is done twice
+    const int pper = max(6, (ncomp + 1023) / 1024);
+    const int p0 = min(ncomp, tid * pper), p1 = min(ncomp, p0 + pper);
     // out / cost_out (may be null): the packs and, per pack, what its wave walks (its longest stencil)
     auto pack = [&](int4 *out, long long *cost_out, long long cost_base, long long *cost_sum) -> int {
         int npack = 0, used = 0, ng = 0, pc = 0;
@@ -1312,40 +1308,32 @@ __global__ __launch_bounds__(1024) void k_plan_force(DevParams P, int nw, int me
     if (nw <= 0) return;                             // (unbalanced pass: only the lists were wanted)
 
     // ---- (2) the wave slots of run x ----
-    // unit (task index * 27 + step) at which the cumulative cost reaches v; whole = round up to the next task start
-    auto unit_at = [&](long long v, bool whole) -> int {
-        if (v >= T) return ntask * STENCIL;
+    // A position in the pass's work is (task, cost already walked inside the task): which stencil step
+    // that is depends on the populations of the task's stencil, which the wave that starts (or stops)
+    // there looks up anyway -- k_pairs_balanced turns the residual into a step.  (Walking the 27 counts
+    // here, per wave slot, was most of this kernel's 40 us.)  For a merged pack the residual IS the
+    // step (its steps are taken as equally long), marked by bit 30.  whole = round up to the next task start.
+    auto pos_at = [&](long long v, bool whole) -> long long {
+        if (v >= T) return (long long)ntask << 32;
         int a = 0, b = nent - 1;                          // last entry whose tasks start at or before v
         while (a < b) { const int m = (a + b + 1) >> 1; if (cost_start[m] <= v) a = m; else b = m - 1; }
         const int nt = ctask_start[a + 1] - ctask_start[a];
-        if (a >= ncells) {                                // a merged pack: one task, its steps taken as equally long
+        if (a >= ncells) {                                // a merged pack: one task
             const long long S = cost_start[a + 1] - cost_start[a], off = v - cost_start[a];
             const int k = S > 0 ? (int)min((long long)(STENCIL - 1), off * STENCIL / S) : 0;
-            if (whole) return (ctask_start[a] + (off > 0 ? 1 : 0)) * STENCIL;
-            return ctask_start[a] * STENCIL + k;
+            if (whole) return (long long)(ctask_start[a] + (off > 0 ? 1 : 0)) << 32;
+            return ((long long)ctask_start[a] << 32) | (long long)(k | (1 << 30));
         }
-        const int c = comp_cell(P, a), S = cost_of(a);
-        if (nt == 0 || S <= 0) return ctask_start[a + 1] * STENCIL;     // (v < T: cannot be the last cell)
+        const int S = cost_of(a);
+        if (nt == 0 || S <= 0) return (long long)ctask_start[a + 1] << 32;     // (v < T: cannot be the last cell)
         const long long off = v - cost_start[a];
         const int q = (int)min((long long)(nt - 1), off / S);
-        int r = (int)(off - (long long)q * S), k = 0;
-        int i1, i2, i3;
-        cell_coords(P, c, i1, i2, i3);
-        int cnts[STENCIL];                               // all 27 loads go out together, then the walk is in registers
-#pragma unroll
-        for (int kk = 0; kk < STENCIL; kk++) {
-            const int nc = local_cell(P, i3 + c_stencil[kk][2], i1 + c_stencil[kk][1], i2 + c_stencil[kk][0]);
-            cnts[kk] = nc >= 0 ? min(cell_start[nc + 1] - cell_start[nc], P.max_per_cell) : 0;
-        }
-#pragma unroll
-        for (int kk = 0; kk < STENCIL - 1; kk++)
-            if (k == kk && r >= cnts[kk]) { r -= cnts[kk]; k = kk + 1; }
+        const int r = (int)(off - (long long)q * S);
         const int t = ctask_start[a] + q;
-        if (whole) return (t + ((k > 0 || r > 0) ? 1 : 0)) * STENCIL;
-        return t * STENCIL + k;
+        if (whole) return (long long)(t + (r > 0 ? 1 : 0)) << 32;
+        return ((long long)t << 32) | (long long)r;
     };
-    auto cost_of_task_start = [&](int unit) -> long long {
-        const int t = unit / STENCIL;
+    auto cost_of_task_start = [&](int t) -> long long {
         if (t >= ntask) return T;
         int a = 0, b = nent - 1;
         while (a < b) { const int mm = (a + b + 1) >> 1; if (ctask_start[mm] <= t) a = mm; else b = mm - 1; }
@@ -1354,19 +1342,47 @@ __global__ __launch_bounds__(1024) void k_plan_force(DevParams P, int nw, int me
     };
     const int m = nw >> 3;                                // wave slots per XCD run (nw is a multiple of 32)
     if (tid < 2) {
-        s_run[tid] = unit_at(T * (x + tid) / 8, true);
-        s_runcost[tid] = cost_of_task_start(s_run[tid]);
+        s_run[tid] = pos_at(T * (x + tid) / 8, true);
+        s_runcost[tid] = cost_of_task_start((int)(s_run[tid] >> 32));
     }
     __syncthreads();
     PT(4);
-    const int run_lo = s_run[0], run_hi = s_run[1];
+    const long long run_lo = s_run[0], run_hi = s_run[1];
     const long long lo = s_runcost[0], hi = s_runcost[1];
     for (int j = tid; j < m; j += 1024)                   // equal shares of the run's own cost range
-        wave_pos[x * m + j] = j == 0 ? run_lo : max(run_lo, min(run_hi, unit_at(lo + (hi - lo) * j / m, false)));
-    if (x == 7 && tid == 0) wave_pos[nw] = run_hi;        // = ntask * 27
+        wave_pos[x * m + j] = j == 0 ? run_lo : max(run_lo, min(run_hi, pos_at(lo + (hi - lo) * j / m, false)));
+    if (x == 7 && tid == 0) wave_pos[nw] = run_hi;        // = (ntask, 0)
     __syncthreads();
     PT(5);
 #undef PT
+}
+
+// wave_pos -> wave_unit: one WAVE per wave-slot boundary.  The stencil step of a position (task, cost
+// already walked inside the task) is the number of leading stencil cells the residual covers whole:
+// 27 lanes look the cells' populations up, one scan, one ballot.  (One THREAD per boundary walking
+// the 27 counts serially -- some 2000 instructions -- was the bulk of the old split kernel.)
+__global__ __launch_bounds__(256) void k_resolve_steps(DevParams P, int nw, const int *__restrict__ cell_start,
+                                                       const int *__restrict__ task_list, const long long *__restrict__ wave_pos,
+                                                       int *__restrict__ wave_unit)
+{
+    const int s = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    if (s > nw) return;
+    const long long pos = wave_pos[s];
+    const int t = __builtin_amdgcn_readfirstlane((int)(pos >> 32)), r = __builtin_amdgcn_readfirstlane((int)(pos & 0xffffffffll));
+    int k = 0;
+    if (r & (1 << 30)) k = r & 63;                           // a merged pack: the residual is the step
+    else if (r > 0) {
+        const int c = __builtin_amdgcn_readfirstlane(task_list[t]) / P.slices;
+        int i1, i2, i3, cnt = 0;
+        cell_coords(P, c, i1, i2, i3);
+        if (lane < STENCIL) {
+            const int nc = local_cell(P, i3 + c_stencil[lane][2], i1 + c_stencil[lane][1], i2 + c_stencil[lane][0]);
+            if (nc >= 0) cnt = min(cell_start[nc + 1] - cell_start[nc], P.max_per_cell);
+        }
+        const int cum = wave_incl_scan(cnt);
+        k = __popcll(__ballot(lane < STENCIL - 1 && cum <= r));
+    }
+    if (lane == 0) wave_unit[s] = t * STENCIL + k;
 }
 
 // One wave = 64 consecutive particles of one cell (four independent waves per workgroup).
@@ -1388,6 +1404,9 @@ __global__ __launch_bounds__(1024) void k_plan_force(DevParams P, int nw, int me
 // tiles through 1 KiB of LDS per wave.  No s_barrier: a wave only ever touches its own
 // tile, and a wave's LDS operations complete in issue order, so a compiler-level fence
 // is all the ordering needed.
+#ifndef PSAMD_BALANCED_WAVES
+#define PSAMD_BALANCED_WAVES 7      // resident waves per SIMD the scalar-walk force pass is built for (70 VGPRs; measured, exact / tolerance arithmetic: 6 waves 2.15 / 1.25 ms, 7 waves 2.11 / 1.22 ms)
+#endif
 #define PS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 #ifdef PSAMD_WAVE_TRACE   // diagnostic build only: when and where did this wave run
@@ -1451,7 +1470,8 @@ __device__ __forceinline__ bool handoff_consume(const float4 *slot, float &ax, f
 // Stencil steps [k0, k1) of a task.  resume: the sums of steps < k0 come from the wave that
 // walked them (ready != nullptr); a walk that stops before step 27 publishes its sums instead
 // of finishing the particle.  The whole task is k0 = 0, k1 = 27, ready = nullptr.
-template <int MODE, int NQ>
+// SETTLED: the collision flags are known already (two-pass mode: the balanced pass) -- nothing tracks distances for them
+template <int MODE, int NQ, bool ALLP = false, bool SETTLED = false>
 __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__restrict__ cell_start,
                                            const float4 *__restrict__ snap4, const float *__restrict__ snap_soa,
                                            const float *__restrict__ snap_age, const int *__restrict__ sorted_id,
@@ -1478,7 +1498,7 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
     const int id_i = sorted_id[gi];
     const bool dead = age_i > P.life_thr;                      // ps.cpp:1183
     const bool kid = age_i < P.kid_thr;
-    const bool scan = valid && !dead && !kid && !active_list;   // two-pass mode: flags are settled already
+    const bool scan = SETTLED ? false : (valid && !dead && !kid && !active_list);   // two-pass mode: flags are settled already
 
     int i1, i2, i3;
     cell_coords(P, c, i1, i2, i3);
@@ -1502,29 +1522,37 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
         if (k0 > 0 && !handoff_consume(force4 + gi, ax, ay, az, flag, valid, ready, k0)) {
             if (lane == 0) atomicOr(&fs->error, ERR_HANDOFF_TIMEOUT);
         }
-        // all-pairs mode (not in the reference): after the stencil, every other cell in index order
-        const int kend = ((P.flags & PSAMD_FLAG_ALL_PAIRS) && k1 == STENCIL) ? STENCIL + P.num_cells_global : k1;
+        // all-pairs mode (ALLP, not in the reference): after the stencil, every other cell in GLOBAL index order
+        const int kend = (ALLP && k1 == STENCIL) ? STENCIL + P.num_cells_global : k1;
+        int far_nb = 0, far_cnt = 0;      // ranges of the 64 far cells of the current block, one per lane (0: a stencil cell, done above)
         for (int k = k0; k < kend; k++) {
             int nb, n;
             // a far cell's bodies are summed on their own and the cell's sum added to the particle's:
             // an fp32 sum of a quarter of a million terms in one chain would carry 4e-5 of rounding
             // (measured at N = 2^18); the stencil's chain is the reference's and stays as it is
             float near_x = 0.f, near_y = 0.f, near_z = 0.f;
-            if (k < STENCIL) { nb = __builtin_amdgcn_readlane(my_nb, k); n = __builtin_amdgcn_readlane(my_cnt, k); }
+            if (!ALLP || k < STENCIL) { nb = __builtin_amdgcn_readlane(my_nb, k); n = __builtin_amdgcn_readlane(my_cnt, k); }
             else {
-                const int c2 = k - STENCIL, GG = P.G * P.G;                    // a GLOBAL cell
-                const int j3 = c2 / GG, rem = c2 - j3 * GG, j1 = rem / P.G, j2 = rem - j1 * P.G;
-                if (abs(j1 - i1) <= 1 && abs(j2 - i2) <= 1 && abs(j3 - i3) <= 1) continue;      // a stencil cell: done above
-                if (far.n) {        // several ranks: the all-gathered snapshot
-                    nb = __builtin_amdgcn_readfirstlane(far.start[c2]);
-                    n = __builtin_amdgcn_readfirstlane(far.n[c2]);
-                } else {            // one GPU: local cell == global cell
-                    nb = __builtin_amdgcn_readfirstlane(cell_start[c2]);
-                    n = __builtin_amdgcn_readfirstlane(min(cell_start[c2 + 1] - nb, P.max_per_cell));
+                const int kf = k - STENCIL;
+                if ((kf & 63) == 0) {
+                    // the next 64 cells' ranges in one vector load (a scalar load per cell, and the body loads
+                    // behind it, were two dependent round trips for 64 bodies of work)
+                    const int c2 = kf + lane, GG = P.G * P.G;
+                    far_nb = 0; far_cnt = 0;
+                    if (c2 < P.num_cells_global) {
+                        const int j3 = c2 / GG, rem = c2 - j3 * GG, j1 = rem / P.G, j2 = rem - j1 * P.G;
+                        if (!(abs(j1 - i1) <= 1 && abs(j2 - i2) <= 1 && abs(j3 - i3) <= 1)) {
+                            if (far.n) { far_nb = far.start[c2]; far_cnt = far.n[c2]; }                 // several ranks: the all-gathered snapshot
+                            else { far_nb = cell_start[c2]; far_cnt = min(cell_start[c2 + 1] - far_nb, P.max_per_cell); }   // one GPU: local == global
+                        }
+                    }
                 }
+                n = __builtin_amdgcn_readlane(far_cnt, kf & 63);
+                if (n == 0) continue;
+                nb = __builtin_amdgcn_readlane(far_nb, kf & 63);
                 near_x = ax; near_y = ay; near_z = az; ax = 0.f; ay = 0.f; az = 0.f;
             }
-            const bool remote = k >= STENCIL && far.n;
+            const bool remote = ALLP && k >= STENCIL && far.n;
             const size_t plane = remote ? (size_t)far.plane : cap;
             const float *sx = (remote ? far.buf : snap_soa) + nb, *sy = sx + plane, *sz = sy + plane, *sw = sz + plane;   // wave-uniform
             float dmin = 3.0e38f;
@@ -1554,7 +1582,7 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
                 else
                     dmin = fminf(dmin, pair_fast(me.x, me.y, me.z, q, eps2f, ax, ay, az) + eps2f);
             }
-            if (k >= STENCIL) { ax = near_x + ax; ay = near_y + ay; az = near_z + az; }
+            if (ALLP && k >= STENCIL) { ax = near_x + ax; ay = near_y + ay; az = near_z + az; }
             // fast math, rare: someone in this cell is within the (widened) collision gate of
             // one of my lanes; the exact rule is then evaluated on unfused distances
             const float gate_soft = (P.coll_d2_gate + eps2f) * 1.0001f;
@@ -1634,7 +1662,7 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
     PS_TRACE_END();
 }
 
-template <int MODE, int NQ>
+template <int MODE, int NQ, bool ALLP>
 __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restrict__ cell_start,
                                                const float4 *__restrict__ snap4,
                                                const float *__restrict__ snap_soa,
@@ -1664,8 +1692,8 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
     if ((int)blockIdx.x >= nwg) return;
     const int slot = xcd_contiguous(blockIdx.x, nwg) * 4 + wave;
     if (slot >= ntask) return;
-    pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4,
-                         task_list[slot], tiles[MODE == 0 ? wave : 0], trace, active_list, active_count, 0, STENCIL, nullptr, fs, far);
+    pairs_task<MODE, NQ, ALLP>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4,
+                               task_list[slot], tiles[MODE == 0 ? wave : 0], trace, active_list, active_count, 0, STENCIL, nullptr, fs, far);
 }
 
 constexpr int MERGE_TILE = 4 * 64 + 4;          // floats per lane group: x[64] y[64] z[64] w[64] + skew
@@ -1831,7 +1859,7 @@ __device__ __forceinline__ void merged_pack_task(const DevParams &P, const int *
 // needed a head start to get that: forked at the same moment as the balanced pass they ended with it,
 // and the stage took 0.1 ms longer.)
 template <int MODE, int NQ, int WALK>
-__global__ __launch_bounds__(256, WALK == 0 ? 6 : 4) void k_pairs_balanced(DevParams P, const int *__restrict__ cell_start,
+__global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : 4) void k_pairs_balanced(DevParams P, const int *__restrict__ cell_start,
                                                         const float4 *__restrict__ snap4,
                                                         const float *__restrict__ snap_soa,
                                                         const float *__restrict__ snap_age,
@@ -1840,7 +1868,7 @@ __global__ __launch_bounds__(256, WALK == 0 ? 6 : 4) void k_pairs_balanced(DevPa
                                                         float4 *__restrict__ force4,
                                                         FrameScalars *fs, unsigned long long *trace,
                                                         const int *__restrict__ active_list, const int *__restrict__ active_count,
-                                                        const int *__restrict__ wave_pos, int *__restrict__ task_ready,
+                                                        const int *__restrict__ wave_unit, int *__restrict__ task_ready,
                                                         const int4 *__restrict__ merged_tasks, int nmb)
 {
     __shared__ __attribute__((aligned(16))) float tiles[4][4 * MERGE_TILE];   // up to four 1-KiB tiles per wave
@@ -1851,7 +1879,7 @@ __global__ __launch_bounds__(256, WALK == 0 ? 6 : 4) void k_pairs_balanced(DevPa
         return;
     }
     const int slot = xcd_contiguous((int)blockIdx.x - nmb, (int)gridDim.x - nmb) * 4 + wave;
-    const int ub = __builtin_amdgcn_readfirstlane(wave_pos[slot]), ue = __builtin_amdgcn_readfirstlane(wave_pos[slot + 1]);
+    const int ub = __builtin_amdgcn_readfirstlane(wave_unit[slot]), ue = __builtin_amdgcn_readfirstlane(wave_unit[slot + 1]);
     if (ue <= ub) return;
     const int tb = ub / STENCIL, lb = ub - tb * STENCIL;            // first unit: task tb, step lb
     const int tl = (ue - 1) / STENCIL, le = ue - tl * STENCIL;      // last task tl, its steps [.., le)
@@ -1891,8 +1919,8 @@ __global__ __launch_bounds__(256, WALK == 0 ? 6 : 4) void k_pairs_balanced(DevPa
             if (t < nord) pairs_task_tile<MODE, NQ, 1, WALK != 1>(P, cell_start, snap4, force4, G, tiles[wave], active_list, k0, k1, task_ready + t, fs);
             else pairs_task_tile<MODE, NQ, 4, WALK != 1>(P, cell_start, snap4, force4, G, tiles[wave], active_list, k0, k1, task_ready + t, fs);
         } else
-            pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, task_list[t], nullptr, trace,
-                                 active_list, active_count, k0, k1, task_ready + t, fs);
+            pairs_task<MODE, NQ, false, true>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, task_list[t], nullptr, trace,
+                                              active_list, active_count, k0, k1, task_ready + t, fs);
     }
 }
 
@@ -3425,7 +3453,8 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     // a chain of waves that wait for each other).
     int nw = 0;
     if (balanced) {
-        nw = 1024 * (int)std::min<int64_t>(6, std::max<int64_t>(1, tasks_hint / 1024));
+        static const int waves_per_simd = std::getenv("PSAMD_WAVES_PER_SIMD") ? std::atoi(std::getenv("PSAMD_WAVES_PER_SIMD")) : PSAMD_BALANCED_WAVES;      // (A/B runs)
+        nw = 1024 * (int)std::min<int64_t>(waves_per_simd, std::max<int64_t>(1, tasks_hint / 1024));
         if (waves_env >= 32) nw = std::min(waves_env & ~31, MAX_PAIR_WAVES);
     }
     // few waves per SIMD (a slab of a multi-GPU run): the scalar-load walk cannot cover its own
@@ -3451,6 +3480,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
                                                    d.halo_count, d.halo_f, d.halo_id, d.active_list, d.active_count, d.task_cost, d.force4, d.fs);
         k_plan_force<<<8, 1024, 0, st>>>(P, balanced ? nw : 0, packs_in_list ? 2 : merge ? 1 : 0, d.cell_start, d.active_count, d.task_cost,
                                          d.task_list2, d.ctask_start, d.cost_start, d.merged_tasks, d.wave_pos, d.fs, d.trace);
+        if (balanced) k_resolve_steps<<<(nw + 1 + 3) / 4, 256, 0, st>>>(P, nw, d.cell_start, d.task_list2, d.wave_pos, d.wave_unit);
     }
     if (ev_force) (void)hipEventRecord(ev_force, st);      // timing: the force pass proper starts here
     const int *task_list = two ? d.task_list2 : d.task_list;
@@ -3463,15 +3493,19 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
         // the packs of partly filled slices (merge): the first nmb workgroups of the same launch
         const int nmb = merge ? (((ncomp + 3) / 4 + 7) & ~7) : 0;
 #define PS_BALANCED(W) k_pairs_balanced<M, NQ, W><<<nmb + nw / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, \
-                                                                     d.force4, d.fs, d.trace, active_list, active_count, d.wave_pos, task_ready, d.merged_tasks, nmb)
+                                                                     d.force4, d.fs, d.trace, active_list, active_count, d.wave_unit, task_ready, d.merged_tasks, nmb)
         if (tile) PS_BALANCED(1); else if (packs_in_list) PS_BALANCED(2); else PS_BALANCED(0);
 #undef PS_BALANCED
     }
     else {
         FarCells far;
         if ((P.flags & PSAMD_FLAG_ALL_PAIRS) && P.world > 1) { far.start = d.gstart; far.n = d.gn; far.buf = reinterpret_cast<const float *>(d.allg_in); far.plane = (unsigned long long)P.allg_cap; }
-        k_pairs<MODE, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
-                                                    d.fs, d.trace, active_list, active_count, far);
+        if (MODE != 0 && (P.flags & PSAMD_FLAG_ALL_PAIRS))
+            k_pairs<MODE, NQ, MODE != 0><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
+                                                                        d.fs, d.trace, active_list, active_count, far);
+        else
+            k_pairs<MODE, NQ, false><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
+                                                                      d.fs, d.trace, active_list, active_count, far);
         // (unbalanced pass, A/B runs only: the packs as a kernel of their own behind it)
         if (merge) k_pairs_merged<MODE == 0 ? 1 : MODE, NQ><<<(ncomp + 3) / 4, 256, 0, st>>>(
                 P, d.cell_start, d.snap4, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
@@ -3482,7 +3516,9 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
 hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint, int pass)
 {
     // fast math shares the lean modes' validity range (finite 1/sqrt(eps2^3))
-    if ((P.flags & PSAMD_FLAG_FAST_MATH) && P.lean_math) return launch_pairs_mode<2, 8>(st, P, d, ev_force, tasks_hint, pass);
+    static const int fast_nq = std::getenv("PSAMD_FAST_NQ") ? std::atoi(std::getenv("PSAMD_FAST_NQ")) : 8;      // (A/B runs)
+    if ((P.flags & PSAMD_FLAG_FAST_MATH) && P.lean_math)
+        return fast_nq == 4 ? launch_pairs_mode<2, 4>(st, P, d, ev_force, tasks_hint, pass) : launch_pairs_mode<2, 8>(st, P, d, ev_force, tasks_hint, pass);
     // 8 pairs per slow-branch test: measured 3 % (full GPU) to 5 % (a 1/8 share) faster than 4
     if (P.lean_math) return launch_pairs_mode<1, 8>(st, P, d, ev_force, tasks_hint, pass);
     return launch_pairs_mode<0, 4>(st, P, d, ev_force, tasks_hint, pass);

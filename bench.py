@@ -442,7 +442,7 @@ def main():
 
     cfg_over = dict(chunk_factor=args.chunk_factor, chunk_dim=args.chunk_dim,
                     max_particles_num=max(args.n, 1 << 20))
-    if args.halo_cap_cell == 0 and not args.evolve and (world > 1 or args.sim_world):
+    if args.halo_cap_cell == 0 and not args.evolve and not args.all_pairs and (world > 1 or args.sim_world):
         # Slab messages have a fixed size, cells x halo_cap_cell bodies (the library's default is the
         # cell capacity, 2x the mean density at the reference's settings).  The replayed step never
         # changes the cloud, so size them for it: 1.5x the mean density of the uniform cloud + 64

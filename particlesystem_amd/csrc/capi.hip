@@ -413,7 +413,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     }
     if (P.key_bits > 63) return fail(c, PSAMD_ERR_UNSUPPORTED, "queue-op key does not fit 64 bits for this configuration");
     if ((cfg->flags & PSAMD_FLAG_ALL_PAIRS) && !P.lean_math) return fail(c, PSAMD_ERR_UNSUPPORTED, "all-pairs forces are built for the lean pair arithmetic only (EPS2 in its validated range)");
-    if ((cfg->flags & PSAMD_FLAG_ALL_PAIRS) && P.world > 1 && !P.two_pass) return fail(c, PSAMD_ERR_UNSUPPORTED, "all-pairs forces across ranks need the two-pass pair stage (collision radius small against the cell)");
+    if ((cfg->flags & PSAMD_FLAG_ALL_PAIRS) && !P.two_pass) return fail(c, PSAMD_ERR_UNSUPPORTED, "all-pairs forces need the two-pass pair stage (collision radius small against the cell)");
     for (int k = 0; k < 5; k++) { c->S.seg_base[k] = g.seg_base[k]; c->S.info_base[k] = g.info_base[k]; }
     for (int k = 0; k < 4; k++) c->S.seg_size_t[k] = g.seg_size_t[k];
 
@@ -466,6 +466,11 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.snap_age, SC));
     PS_HIP(c, dev_alloc(c, &d.force4, SC));
     PS_HIP(c, dev_alloc(c, &d.celltab, (size_t)g.num_cells));
+    if (P.flags & PSAMD_FLAG_ALL_PAIRS) {
+        // partial sums of the all-pairs pass: one float4 per (part, task, lane); tasks <= particles / 64 + one partly filled slice per cell
+        d.part_tasks = (int)std::min<size_t>(LC * P.slices, C / 64 + LC + 64);
+        PS_HIP(c, dev_alloc(c, &d.part_acc, (size_t)ALLP_PARTS * d.part_tasks * 64));
+    }
     {                                                    // the chunk lists' capacity rule (chunk_cap_block)
         PS_HIP(c, dev_alloc(c, &d.chunk_skip, C));
         PS_HIP(c, dev_alloc(c, &d.chunk_segs, (size_t)g.num_chunks * 27));
@@ -997,7 +1002,7 @@ static int do_apply(psamd_ctx *c)
 {
     if (!c->grid_built || !c->pairs_done) return fail(c, PSAMD_ERR_STATE, "apply needs build_grid and the pair pass first");
     if (c->timing) (void)hipEventRecord(c->ev[7], c->stream);
-    PS_HIP(c, launch_apply(c->stream, c->P, c->S, c->d, c->step, c->geo.queue_infos));
+    PS_HIP(c, launch_apply(c->stream, c->P, c->S, c->d, c->step));
     if (c->P.world > 1)
         PS_HIP(c, launch_outbox_close(c->stream, c->P, c->d, c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total,
                                       c->xfer_out[0], c->xfer_out[1]));
@@ -1009,8 +1014,7 @@ static int do_lifecycle(psamd_ctx *c)
 {
     const int par = (int)(c->steps_total & 1);   // not c->step: a snapshot restore rewinds that
     if (c->timing) (void)hipEventRecord(c->ev[par ? 11 : 8], c->stream);
-    if (c->P.world > 1)
-        for (int k = 0; k < 2; k++) PS_HIP(c, launch_inbox_merge(c->stream, c->P, c->d, c->xfer_in[k]));
+    if (c->P.world > 1) PS_HIP(c, launch_inbox_merge(c->stream, c->P, c->d, c->xfer_in[0], c->xfer_in[1]));
     // live_bound < 0: unknown (state was uploaded) -> size for every owned slot; arrivals on top
     const int64_t bound = (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) + 2 * (int64_t)c->P.xfer_cap
                           + (c->P.world > 1 ? (int64_t)c->P.world * STATUS_KILL_CAP : 0);
@@ -1118,11 +1122,8 @@ int psamd_slab_build(psamd_ctx *c)
     int rc = do_init_iframe(c);
     if (rc == PSAMD_OK) rc = do_build_grid(c);
     if (rc != PSAMD_OK) return rc;
-    for (int k = 0; k < 2; k++)
-        if (c->halo_out_cells[k] > 0)
-            PS_HIP(c, launch_pack_halo(c->stream, c->P, c->d, c->halo_out_c0[k], c->halo_out_cells[k], c->halo_out[k], c->pack_off[k]));
     if (c->allg_out) PS_HIP(c, launch_allg_pack(c->stream, c->P, c->d, c->allg_out));
-    PS_HIP(c, launch_status_close(c->stream, c->d));
+    if (c->P.world > 1) PS_HIP(c, launch_pack_halos(c->stream, c->P, c->d, c->halo_out_c0, c->halo_out_cells, c->halo_out, c->pack_off));
     c->slab_stage = 1;
     return PSAMD_OK;
 }
@@ -1146,12 +1147,9 @@ int psamd_slab_pairs(psamd_ctx *c)
     if (c->slab_stage != 1) return fail(c, PSAMD_ERR_STATE, "slab_pairs needs slab_build (and the halo exchange) first");
     const DevParams &P = c->P;
     const int GG = P.G * P.G;
-    if (c->halo_in_cells[0] > 0)      // from the rank below: halo layer (region 1), then lent layers (region 2)
-        PS_HIP(c, launch_unpack_halo(c->stream, P, c->d, 1, 2, c->halo_in_cells[0], P.reg_layers[1] * GG, P.reg_layers[2] > 0,
-                                     c->halo_in[0], c->unpack_off[0]));
-    if (c->halo_in_cells[1] > 0)      // from the rank above: halo layer (region 3)
-        PS_HIP(c, launch_unpack_halo(c->stream, P, c->d, 3, -1, c->halo_in_cells[1], c->halo_in_cells[1], false,
-                                     c->halo_in[1], c->unpack_off[1]));
+    // from the rank below: halo layer (region 1), then lent layers (region 2); from the rank above: halo layer (region 3)
+    PS_HIP(c, launch_unpack_halos(c->stream, P, c->d, c->halo_in_cells[0], c->halo_in[0], c->unpack_off[0],
+                                  c->halo_in_cells[1], c->halo_in[1], c->unpack_off[1]));
     if (c->allg_in) PS_HIP(c, launch_allg_index(c->stream, P, c->d));      // all-pairs: the gathered snapshot, by global cell
     int rc = do_pairs(c, c->interior_done ? c->P_rest : c->P, true, !c->interior_done);
     c->interior_done = false;
@@ -1165,12 +1163,11 @@ int psamd_slab_apply(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
     if (c->slab_stage != 2) return fail(c, PSAMD_ERR_STATE, "slab_apply needs slab_pairs (and the force exchange) first");
-    if (c->force_in)                  // lent-out layers are the tail of the snapshot that went up
-        PS_HIP(c, launch_unpack_force(c->stream, c->P, c->d, c->halo_out_cells[1] - (c->P.lentout_c1 - c->P.lentout_c0),
-                                      c->force_in, c->pack_off[1]));
     // the status records of all ranks (all-gathered since slab_build): error bits, cell-overflow kills for the
-    // owner of queue record 0, and the chunks' counts over all ranks -- the chunk lists' capacity rule
-    PS_HIP(c, launch_status_merge(c->stream, c->P, c->d, c->status_in));
+    // owner of queue record 0, and the chunks' counts over all ranks -- the chunk lists' capacity rule; in
+    // the same launch the force records of the lent-out layers (the tail of the snapshot that went up)
+    PS_HIP(c, launch_status_merge(c->stream, c->P, c->d, c->status_in, c->halo_out_cells[1] - (c->P.lentout_c1 - c->P.lentout_c0),
+                                  c->force_in, c->pack_off[1]));
     int rc = do_apply(c);
     if (rc != PSAMD_OK) return rc;
     c->slab_stage = 3;

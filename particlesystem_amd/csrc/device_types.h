@@ -79,15 +79,18 @@ struct DevParams {
     int32_t status_words;    // words of one rank's status record
 };
 
-// Where the all-pairs walk finds the cells beyond the stencil: by GLOBAL cell, a start (index of the
-// cell's first x in `buf`; y, z, w_eff follow at multiples of `plane`) and a length.  n == nullptr:
-// one GPU, the own sorted arrays serve (start = cell_start, lengths from consecutive starts).
+// All-pairs force pass.  The cells beyond the stencil are found by GLOBAL cell in a snapshot buffer (the own
+// one, or the all-gathered one of all ranks): x at buf[start], y, z, w_eff at multiples of `plane` behind.
+// A particle's sum is split into ALLP_PARTS partial sums, each by a wave of its own (or a lone rank of
+// eight would have half a wave per SIMD walking the whole cloud): part p covers its share of the 64-cell
+// blocks of the global cell order (part 0 the stencil first); partial sums land in
+// part_acc[p * part_plane + task * 64 + lane] and k_allpairs_combine adds them up in part order.
 struct FarCells {
-    const int *start = nullptr;
-    const int *n = nullptr;
-    const float *buf = nullptr;
     unsigned long long plane = 0;
+    float4 *part_acc = nullptr;
+    unsigned long long part_plane = 0;
 };
+constexpr int ALLP_PARTS = 16;
 
 // Which cells / slots / records a rank holds.  All device code goes through these.
 #if defined(__HIPCC__)
@@ -249,7 +252,7 @@ constexpr int MSG_HEADER_WORDS = 16;   // every message starts with 16 ints: [0]
 constexpr int SORT_MAX = 4096;   // ids one cell may hold for the in-LDS ranking
 constexpr int REPLAY_CHUNK = 2048;   // queue ops staged through LDS at a time
 constexpr int QUEUE_WINDOW = 6144;   // largest segment (slots) whose queue is replayed in LDS
-constexpr int BUCKET_MAX = 4096;     // ops per segment the one-workgroup fast replay sorts in LDS (52 KB)
+constexpr int BUCKET_MAX = 8192;     // ops per segment the one-workgroup fast replay sorts in LDS (104 of the CU's 160 KB)
 constexpr int MAX_PAIR_WAVES = 12288;    // wave slots of the balanced force pass: 256 CUs x 4 SIMDs x 6 resident waves (78 VGPRs)
 constexpr int STENCIL = 27;          // cells a particle's force walk visits, in the reference's order (app.cu:370-409)
 constexpr int HALO_CAP = 768;        // collision candidates one cell can list from its neighbours (else: full stencil)

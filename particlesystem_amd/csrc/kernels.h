@@ -80,6 +80,8 @@ struct DeviceState {
     // all-pairs across ranks: the gathered snapshot blocks (inside the context's message buffer) and their index by global cell
     const int *allg_in = nullptr;
     int *gstart = nullptr, *gn = nullptr;
+    float4 *part_acc = nullptr;   // all-pairs: [ALLP_PARTS][part_tasks * 64] partial sums of the force pass's (task, part) waves
+    int part_tasks = 0;
     DevCounters *ctr = nullptr;
     unsigned long long *trace = nullptr;  // 3 words per pair-kernel wave slot (diagnostic builds only)
 };
@@ -102,7 +104,7 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
 // tasks_hint: about how many force tasks the pass will have (sizes the balanced force pass)
 // pass: 0 or 1, which of a frame's (up to two) passes of the pair stage this is
 hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint, int pass);
-hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step, int nrec);
+hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step);
 hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints, int status_table);   // also clears the status record's header and census table
 // the bucketed life cycle, sized from a bound of the live count: bucket the operations (afterwards the
 // frame scalars are complete), then replay + relocation
@@ -111,17 +113,19 @@ hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceStat
 hipError_t launch_lifecycle_sorted(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
                                    int n_ops, int n_moves);
 // slab exchange (messages are int arrays with a 16-word header, see kernels.hip)
-hipError_t launch_pack_halo(hipStream_t st, const DevParams &P, const DeviceState &d, int c0, int ncell, int *msg, int *pack_off);
-hipError_t launch_unpack_halo(hipStream_t st, const DevParams &P, const DeviceState &d, int r0, int r1, int ncell, int split,
-                              bool lent, const int *msg, int *unpack_off);
+// the snapshots for the rank below (k = 0) / above (k = 1), both in one pair of launches; also closes the status record
+hipError_t launch_pack_halos(hipStream_t st, const DevParams &P, const DeviceState &d, const int c0[2], const int ncell[2],
+                             int *const msg[2], int *const pack_off[2]);
+hipError_t launch_unpack_halos(hipStream_t st, const DevParams &P, const DeviceState &d, int ncell_below, const int *msg_below,
+                               int *off_below, int ncell_above, const int *msg_above, int *off_above);
 hipError_t launch_pack_force(hipStream_t st, const DevParams &P, const DeviceState &d, int *msg, int cap_bodies);
-hipError_t launch_unpack_force(hipStream_t st, const DevParams &P, const DeviceState &d, int j0, const int *msg, const int *pack_off);
 hipError_t launch_outbox_close(hipStream_t st, const DevParams &P, const DeviceState &d, int64_t live_bound, int *msg_down, int *msg_up);
-hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *msg);
+hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *msg_from_below, const int *msg_from_above);
 hipError_t launch_allg_pack(hipStream_t st, const DevParams &P, const DeviceState &d, int *msg);
 hipError_t launch_allg_index(hipStream_t st, const DevParams &P, const DeviceState &d);
-hipError_t launch_status_close(hipStream_t st, const DeviceState &d);
-hipError_t launch_status_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *status_all);
+// status records of all ranks (error bits, cell-overflow kills, chunk counts) + the force records of the lent-out layers (force_msg, may be null)
+hipError_t launch_status_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *status_all,
+                               int force_j0, const int *force_msg, const int *pack_off);
 // lifecycle_sort.hip (rocPRIM radix sort of the op keys; library code, not a hot path)
 hipError_t sort_ops_tmp_bytes(size_t n, int key_bits, size_t *bytes);
 hipError_t sort_ops(hipStream_t st, const DeviceState &d, int n, int key_bits);

@@ -574,8 +574,7 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
                                                      uint64_t *op_keys, int *op_args, int ops_cap,
                                                      int *__restrict__ halo_count, float *__restrict__ halo_f,
                                                      int *__restrict__ halo_id, int *__restrict__ snap_cid,
-                                                     int *__restrict__ status_out, int *__restrict__ rec_count,
-                                                     FrameScalars *fs, DevCounters *ctr)
+                                                     int *__restrict__ status_out, FrameScalars *fs, DevCounters *ctr)
 {
     __shared__ __attribute__((aligned(16))) int ids[SORT_MAX + 4];
     __shared__ int ordered[SORT_MAX];
@@ -1480,7 +1479,9 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
                                            const int *__restrict__ active_list = nullptr,
                                            const int *__restrict__ active_count = nullptr,
                                            int k0 = 0, int k1 = STENCIL, int *ready = nullptr, FrameScalars *fs = nullptr,
-                                           const FarCells far = FarCells())
+                                           const FarCells far = FarCells(), int part = 0, int task_no = 0,
+                                           const float *__restrict__ far_buf = nullptr, const int *__restrict__ far_start = nullptr,
+                                           const int *__restrict__ far_n = nullptr)
 {
     PS_TRACE_BEGIN();
     const int c = task / P.slices, slice = task - c * P.slices;
@@ -1522,39 +1523,9 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
         if (k0 > 0 && !handoff_consume(force4 + gi, ax, ay, az, flag, valid, ready, k0)) {
             if (lane == 0) atomicOr(&fs->error, ERR_HANDOFF_TIMEOUT);
         }
-        // all-pairs mode (ALLP, not in the reference): after the stencil, every other cell in GLOBAL index order
-        const int kend = (ALLP && k1 == STENCIL) ? STENCIL + P.num_cells_global : k1;
-        int far_nb = 0, far_cnt = 0;      // ranges of the 64 far cells of the current block, one per lane (0: a stencil cell, done above)
-        for (int k = k0; k < kend; k++) {
-            int nb, n;
-            // a far cell's bodies are summed on their own and the cell's sum added to the particle's:
-            // an fp32 sum of a quarter of a million terms in one chain would carry 4e-5 of rounding
-            // (measured at N = 2^18); the stencil's chain is the reference's and stays as it is
-            float near_x = 0.f, near_y = 0.f, near_z = 0.f;
-            if (!ALLP || k < STENCIL) { nb = __builtin_amdgcn_readlane(my_nb, k); n = __builtin_amdgcn_readlane(my_cnt, k); }
-            else {
-                const int kf = k - STENCIL;
-                if ((kf & 63) == 0) {
-                    // the next 64 cells' ranges in one vector load (a scalar load per cell, and the body loads
-                    // behind it, were two dependent round trips for 64 bodies of work)
-                    const int c2 = kf + lane, GG = P.G * P.G;
-                    far_nb = 0; far_cnt = 0;
-                    if (c2 < P.num_cells_global) {
-                        const int j3 = c2 / GG, rem = c2 - j3 * GG, j1 = rem / P.G, j2 = rem - j1 * P.G;
-                        if (!(abs(j1 - i1) <= 1 && abs(j2 - i2) <= 1 && abs(j3 - i3) <= 1)) {
-                            if (far.n) { far_nb = far.start[c2]; far_cnt = far.n[c2]; }                 // several ranks: the all-gathered snapshot
-                            else { far_nb = cell_start[c2]; far_cnt = min(cell_start[c2 + 1] - far_nb, P.max_per_cell); }   // one GPU: local == global
-                        }
-                    }
-                }
-                n = __builtin_amdgcn_readlane(far_cnt, kf & 63);
-                if (n == 0) continue;
-                nb = __builtin_amdgcn_readlane(far_nb, kf & 63);
-                near_x = ax; near_y = ay; near_z = az; ax = 0.f; ay = 0.f; az = 0.f;
-            }
-            const bool remote = ALLP && k >= STENCIL && far.n;
-            const size_t plane = remote ? (size_t)far.plane : cap;
-            const float *sx = (remote ? far.buf : snap_soa) + nb, *sy = sx + plane, *sz = sy + plane, *sw = sz + plane;   // wave-uniform
+        // The bodies [nb, nb + n) of one cell, from four planes of a snapshot (wave-uniform pointers: scalar loads).
+        auto walk_cell = [&](const float *__restrict__ sx, const float *__restrict__ sy, const float *__restrict__ sz,
+                             const float *__restrict__ sw, int nb, int n) {
             float dmin = 3.0e38f;
             int jj = 0;
             // NQ bodies per group.  (Fetching the next group between the distance stage and
@@ -1582,7 +1553,6 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
                 else
                     dmin = fminf(dmin, pair_fast(me.x, me.y, me.z, q, eps2f, ax, ay, az) + eps2f);
             }
-            if (ALLP && k >= STENCIL) { ax = near_x + ax; ay = near_y + ay; az = near_z + az; }
             // fast math, rare: someone in this cell is within the (widened) collision gate of
             // one of my lanes; the exact rule is then evaluated on unfused distances
             const float gate_soft = (P.coll_d2_gate + eps2f) * 1.0001f;
@@ -1594,6 +1564,48 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
                         if (!(d2 > P.coll_d2_gate) && nb + j != gi)
                             flag = max(flag, collide_exact(P, d2, age_i, id_i, snap_age[nb + j], sorted_id[nb + j]));
                     }
+                }
+            }
+        };
+        // the stencil, in the reference's order (all-pairs mode: part 0 only)
+        if (!ALLP || part == 0)
+            for (int k = k0; k < k1; k++) {
+                const int nb = __builtin_amdgcn_readlane(my_nb, k), n = __builtin_amdgcn_readlane(my_cnt, k);
+                const float *sx = snap_soa + nb;
+                walk_cell(sx, sx + cap, sx + 2 * cap, sx + 3 * cap, nb, n);
+            }
+        // All-pairs mode (ALLP, not in the reference): then every other cell in GLOBAL index order -- this
+        // wave's part of them, the 64-cell blocks [blk_lo, blk_hi).  A far cell's bodies are summed on their
+        // own and the cell's sum added to the particle's: an fp32 sum of a quarter of a million terms in one
+        // chain would carry 4e-5 of rounding (measured at N = 2^18); the stencil's chain is the reference's
+        // and stays as it is.  The bodies come from far_buf: the own snapshot on one GPU (local cell ==
+        // global cell), the all-gathered snapshot of all ranks otherwise -- a pointer of its own, not a
+        // choice between two, or the compiler cannot keep the loads scalar.
+        if (ALLP) {
+            const int nblk = (P.num_cells_global + 63) >> 6;
+            const int blk_lo = nblk * part / ALLP_PARTS, blk_hi = nblk * (part + 1) / ALLP_PARTS;
+            const size_t plane = (size_t)far.plane;
+            for (int blk = blk_lo; blk < blk_hi; blk++) {
+                // the block's 64 cell ranges in one vector load (a scalar load per cell, and the body loads
+                // behind it, were two dependent round trips for 64 bodies of work); 0 bodies: a stencil cell
+                const int c2 = blk * 64 + lane, GG = P.G * P.G;
+                int far_nb = 0, far_cnt = 0;
+                if (c2 < P.num_cells_global) {
+                    const int j3 = c2 / GG, rem = c2 - j3 * GG, j1 = rem / P.G, j2 = rem - j1 * P.G;
+                    if (!(abs(j1 - i1) <= 1 && abs(j2 - i2) <= 1 && abs(j3 - i3) <= 1)) {
+                        far_nb = far_start[c2];
+                        far_cnt = far_n ? far_n[c2] : min(far_start[c2 + 1] - far_nb, P.max_per_cell);
+                    }
+                }
+                for (int j = 0; j < 64; j++) {
+                    const int n = __builtin_amdgcn_readlane(far_cnt, j);
+                    if (n == 0) continue;
+                    const int nb = __builtin_amdgcn_readlane(far_nb, j);
+                    const float near_x = ax, near_y = ay, near_z = az;
+                    ax = 0.f; ay = 0.f; az = 0.f;
+                    const float *sx = far_buf + nb;
+                    walk_cell(sx, sx + plane, sx + 2 * plane, sx + 3 * plane, nb, n);
+                    ax = near_x + ax; ay = near_y + ay; az = near_z + az;
                 }
             }
         }
@@ -1656,6 +1668,10 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
         PS_TRACE_END();
         return;
     }
+    if (ALLP) {                                  // a partial sum: k_allpairs_combine finishes the particle
+        if (valid) far.part_acc[(size_t)part * far.part_plane + (size_t)task_no * 64 + lane] = make_float4(ax, ay, az, 0.f);
+        return;
+    }
     if (dead) flag = 2;
     if (kid) { ax = 0.f; ay = 0.f; az = 0.f; }   // every term is skipped for a kid (app_common.cu:240)
     if (valid) force4[gi] = make_float4(ax, ay, az, __int_as_float(flag));
@@ -1672,7 +1688,8 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
                                                float4 *__restrict__ force4,
                                                FrameScalars *fs, unsigned long long *trace,
                                                const int *__restrict__ active_list, const int *__restrict__ active_count,
-                                               const FarCells far)
+                                               const FarCells far, const float *__restrict__ far_buf,
+                                               const int *__restrict__ far_start, const int *__restrict__ far_n)
 {
     // Workgroups of four INDEPENDENT waves (no workgroup barrier anywhere): the hardware
     // deals a workgroup's waves over the four SIMDs of its CU and workgroups over the
@@ -1688,12 +1705,37 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
     // launch -- were tried: the XCDs then finish together, yet the launch was only 1 %
     // shorter and the extra prefix sum cost k_scan 10 us.)
     const int ntask = active_list ? fs->n_tasks2 : fs->n_tasks;
-    const int nwg = (ntask + 3) >> 2;
+    const int nitem = ALLP ? ntask * ALLP_PARTS : ntask;         // all-pairs: a wave per (task, part)
+    const int nwg = (nitem + 3) >> 2;
     if ((int)blockIdx.x >= nwg) return;
     const int slot = xcd_contiguous(blockIdx.x, nwg) * 4 + wave;
-    if (slot >= ntask) return;
-    pairs_task<MODE, NQ, ALLP>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4,
-                               task_list[slot], tiles[MODE == 0 ? wave : 0], trace, active_list, active_count, 0, STENCIL, nullptr, fs, far);
+    if (slot >= nitem) return;
+    const int t = ALLP ? slot / ALLP_PARTS : slot, part = ALLP ? slot - t * ALLP_PARTS : 0;
+    // (an all-pairs context always runs the two-pass stage: the flags are settled)
+    pairs_task<MODE, NQ, ALLP, ALLP>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4,
+                                     task_list[t], tiles[MODE == 0 ? wave : 0], trace, active_list, active_count, 0, STENCIL, nullptr, fs, far, part, t,
+                                     far_buf, far_start, far_n);
+}
+
+// All-pairs: a particle's acceleration = ((stencil chain + part 0's far cells) + part 1) + ... + part 15,
+// the same association on one GPU and on any number of ranks.  One thread per (task, lane).
+__global__ void k_allpairs_combine(DevParams P, const int *__restrict__ cell_start, const int *__restrict__ task_list,
+                                   const int *__restrict__ active_list, const int *__restrict__ active_count,
+                                   const FarCells far, float4 *__restrict__ force4, const FrameScalars *__restrict__ fs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, t = i >> 6, lane = i & 63;
+    if (t >= fs->n_tasks2) return;
+    const int task = task_list[t], c = task / P.slices, slice = task - c * P.slices;
+    const int first = slice * 64, cnt = active_count[c];
+    if (first + lane >= cnt) return;
+    const int gi = active_list[cell_start[c] + first + lane];
+    float4 a = far.part_acc[(size_t)t * 64 + lane];
+#pragma unroll
+    for (int p = 1; p < ALLP_PARTS; p++) {
+        const float4 b = far.part_acc[(size_t)p * far.part_plane + (size_t)t * 64 + lane];
+        a.x += b.x; a.y += b.y; a.z += b.z;
+    }
+    force4[gi] = make_float4(a.x, a.y, a.z, __int_as_float(0));     // (on the active list: flag 0, not a kid)
 }
 
 constexpr int MERGE_TILE = 4 * 64 + 4;          // floats per lane group: x[64] y[64] z[64] w[64] + skew
@@ -2104,7 +2146,6 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
                                                 MoveRec *moves, int moves_cap,
                                                 XferRec *out_down, XferRec *out_up,
                                                 const int *__restrict__ chunk_count, const uint8_t *__restrict__ chunk_skip,
-                                                int nrec, int *__restrict__ rec_count,
                                                 FrameScalars *fs, DevCounters *ctr)
 {
     __shared__ int s_ops, s_moves, s_base_ops, s_base_moves;
@@ -2285,13 +2326,31 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
         const bool killed = bits & 1u, born = bits & 2u, relocate = bits & 4u, remote = bits & 8u, up = bits & 16u;
         const int id = em[it].id, new_cell = em[it].new_cell;
         const int own_r = segment_record_of_slot(S, id);
+        // Outbox entries are reserved per wave and direction: one atomic on the message's counter for all
+        // of a wave's departures (a rank whose layer empties into its neighbour -- the box surface on the
+        // last rank -- made tens of thousands of same-address atomics here, one per particle: 80 us).
+        int out_base[2] = {0, 0};               // this lane's outbox entry for [0] a relocation, [1] a birth
+        if (P.world > 1) {
+#pragma unroll
+            for (int dir = 0; dir < 2; dir++) {
+                const bool mine = remote && (up ? 1 : 0) == dir;
+                const int want = mine ? ((born ? 1 : 0) + (relocate ? 1 : 0)) : 0;
+                if (__any(want > 0)) {
+                    const int incl = wave_incl_scan(want);
+                    int base = 0;
+                    if (lane == 63) base = atomicAdd(&fs->n_out[dir], incl);
+                    base = __shfl(base, 63) + incl - want;
+                    if (mine) { out_base[1] = base; out_base[0] = base + (born ? 1 : 0); }      // birth first, as the records are written
+                }
+            }
+        }
         if (!(bits & 7u)) continue;
         const uint64_t key = ((uint64_t)(uint32_t)(em[it].old_chunk + 1) << P.key_chunk_shift) | ((uint64_t)(uint32_t)id << 2);
         const uint64_t own_rec = (uint64_t)(uint32_t)own_r << P.key_rec_shift;
         const uint64_t dst_rec = (uint64_t)(uint32_t)em[it].new_rec << P.key_rec_shift;
         // a departure: reserve its outbox entry and put the key there; k_moves_stage adds the state
         auto depart = [&](int kind, uint64_t sub) -> int {
-            const int o = atomicAdd(&fs->n_out[up ? 1 : 0], 1);
+            const int o = out_base[kind] + 0;
             if (o >= P.xfer_cap) { atomicOr(&fs->error, ERR_HALO_OVERFLOW); return -1; }
             XferRec *x = (up ? out_up : out_down) + o;
             x->key = dst_rec | key | sub; x->new_cell = new_cell; x->kind = kind;
@@ -2321,21 +2380,29 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
 }
 
 // ------------------------------------------------------------------ lifecycle replay
-// One workgroup per free-slot queue.  The step's operations arrive sorted by key
-// (record-major), so the queue's run is found by binary search; one lane then replays
-// it on the circular FIFO exactly as q_insert / q_remove do (app_common.cu:305-376).
-// The queue's slice of the queue array and the operations are staged through LDS so
-// the serial walk never waits on global memory.
-__global__ __launch_bounds__(256) void k_replay(DevParams P, int n_ops,
+// The path for a queue with more operations in one step than k_replay_bucket sorts in LDS (a
+// collapsing cloud; 1024 particles per cell): the step's operations arrive sorted by key (record-major,
+// rocPRIM radix sort of all keys), one workgroup per queue finds its run by binary search and
+// replays it on the circular FIFO as q_insert / q_remove would (app_common.cu:305-376).  Like the
+// bucketed replay it does so in CLOSED FORM when prefix sums of the +1 / -1 sequence show that the
+// queue neither runs empty nor fills up during the step -- the k-th remove takes logical element k,
+// the k-th insert becomes logical element count0 + k -- streaming the run through in chunks of one
+// operation per thread (three passes: count and check, removes, queue update); only otherwise one lane
+// walks the list (on a copy of the segment in LDS when it fits).  `scratch` (n_ops ints; the unsorted
+// argument array, free once the sort has run) holds the run's insert arguments in order.
+constexpr int RSORT_THREADS = 1024;
+__global__ __launch_bounds__(RSORT_THREADS) void k_replay(DevParams P, int n_ops,
                                                  const uint64_t *__restrict__ keys,
-                                                 const int *__restrict__ args,
+                                                 const int *__restrict__ args, int *__restrict__ scratch,
                                                  QueueInfo *qinfo, int *queue, MoveRec *moves,
                                                  DevCounters *ctr)
 {
     __shared__ int window[QUEUE_WINDOW];
     __shared__ int op_arg[REPLAY_CHUNK];
     __shared__ unsigned char op_sub[REPLAY_CHUNK];
-    const int rec = blockIdx.x, tid = threadIdx.x;
+    __shared__ int wave_tot[RSORT_THREADS / 64];
+    __shared__ int s_carry, s_bad;
+    const int rec = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // [lo, hi) = operations whose key carries this record
     const uint64_t klo = (uint64_t)(uint32_t)rec << P.key_rec_shift;
     const uint64_t khi = (uint64_t)(uint32_t)(rec + 1) << P.key_rec_shift;
@@ -2345,58 +2412,120 @@ __global__ __launch_bounds__(256) void k_replay(DevParams P, int n_ops,
     if (hi == lo) return;
 
     QueueInfo q = qinfo[rec];
-    const bool in_lds = q.seg_size <= QUEUE_WINDOW;
     // the queue array is stored like the slots: only the owned segments, back to back
     queue += slot_index(P, q.rloc) - q.rloc;
-    if (in_lds) for (int e = tid; e < q.seg_size; e += 256) window[e] = queue[q.rloc + e];
+    const int count0 = q.count, size = q.seg_size;
     unsigned long long lost = 0, reloc = 0, births = 0, births_failed = 0;
 
-    for (int c0 = lo; c0 < hi; c0 += REPLAY_CHUNK) {
-        const int n = min(REPLAY_CHUNK, hi - c0);
+    // prefix of (inserts | removes << 16) over one chunk of RSORT_THREADS operations, carried from chunk to chunk
+    auto chunk_scan = [&](int c0, int &sub, int &arg, int &ins_b, int &rem_b) {
+        const int e = c0 + tid;
+        sub = -1; arg = 0;
+        if (e < hi) { sub = (int)(keys[e] & 3ull); arg = args[e]; }
+        const int v = sub < 0 ? 0 : (sub == 2 ? 1 : (1 << 16));
+        const int incl = wave_incl_scan(v);
+        if (lane == 63) wave_tot[wv] = incl;
         __syncthreads();
-        for (int e = tid; e < n; e += 256) {
-            op_arg[e] = args[c0 + e];
-            op_sub[e] = (unsigned char)(keys[c0 + e] & 3ull);
-        }
+        int o = s_carry;
+        for (int k = 0; k < wv; k++) o += wave_tot[k];
+        const int excl = o + incl - v;
+        ins_b = excl & 0xffff; rem_b = excl >> 16;
         __syncthreads();
-        if (tid == 0) {
-            for (int e = 0; e < n; e++) {
-                const int sub = op_sub[e], arg = op_arg[e];
-                if (sub == 2) {                                // q_insert(arg)
-                    if (q.count == q.seg_size) continue;
-                    if (q.count == 0) { q.front = q.rloc; q.rear = q.rloc; }
-                    else if (q.rear == q.rloc + q.seg_size - 1) q.rear = q.rloc;
-                    else q.rear++;
-                    q.count++;
-                    if (in_lds) window[q.rear - q.rloc] = arg; else queue[q.rear] = arg;
-                } else {                                       // q_remove -> moves[arg].dst
-                    int item = -1;
-                    if (q.count > 0) {
-                        const int pos = q.front;
-                        if (q.count == 1) { q.front = -1; q.rear = -1; }
-                        else if (q.front == q.rloc + q.seg_size - 1) q.front = q.rloc;
-                        else q.front++;
-                        q.count--;
-                        if (in_lds) { item = window[pos - q.rloc]; window[pos - q.rloc] = -1; }
-                        else { item = queue[pos]; queue[pos] = -1; }
-                    }
-                    moves[arg].dst = item;
-                    if (sub == 1) { if (item >= 0) reloc++; else lost++; }
-                    else { if (item >= 0) births++; else births_failed++; }
-                }
+        if (tid == RSORT_THREADS - 1) s_carry = o + incl;
+        __syncthreads();
+    };
+    // (counts per chunk fit 16 bits; the carry is kept as two ints packed the same way only while the run is
+    // shorter than 65536 operations of either kind -- longer runs take the serial walk)
+    const bool packable = hi - lo < 65536;
+    if (tid == 0) { s_carry = 0; s_bad = (count0 <= 0 || !packable) ? 1 : 0; }
+    __syncthreads();
+    if (packable) {
+        for (int c0 = lo; c0 < hi; c0 += RSORT_THREADS) {
+            int sub, arg, ins_b, rem_b;
+            chunk_scan(c0, sub, arg, ins_b, rem_b);
+            if (sub >= 0) {
+                const int c = count0 + ins_b - rem_b;
+                if (sub == 2) { if (!(c < size)) s_bad = 1; scratch[lo + ins_b] = arg; }
+                else if (!(c >= 2)) s_bad = 1;
             }
         }
     }
     __syncthreads();
-    if (in_lds) for (int e = tid; e < q.seg_size; e += 256) queue[q.rloc + e] = window[e];
-    if (tid == 0) {
-        qinfo[rec] = q;
-        DevCounters *mine = ctr + (blockIdx.x % COUNTER_COPIES);
-        if (reloc) atomicAdd(&mine->relocations, reloc);
-        if (lost) atomicAdd(&mine->relocations_lost, lost);
-        if (births) atomicAdd(&mine->births, births);
-        if (births_failed) atomicAdd(&mine->births_failed, births_failed);
+    const int I = s_carry & 0xffff, R = s_carry >> 16;
+    if (!s_bad) {
+        int *seg = queue + q.rloc;
+        const int F = q.front - q.rloc;                // offset of logical element 0
+        __syncthreads();
+        if (tid == 0) s_carry = 0;
+        __syncthreads();
+        for (int c0 = lo; c0 < hi; c0 += RSORT_THREADS) {
+            int sub, arg, ins_b, rem_b;
+            chunk_scan(c0, sub, arg, ins_b, rem_b);
+            if (sub >= 0 && sub != 2) {
+                const int item = (rem_b < count0) ? seg[(F + rem_b) % size] : scratch[lo + rem_b - count0];
+                moves[arg].dst = item;
+                if (sub == 1) reloc++; else births++;
+            }
+        }
+        __syncthreads();
+        for (int r = tid; r < R; r += RSORT_THREADS) seg[(F + r) % size] = -1;             // every removed element
+        __syncthreads();
+        for (int k = tid; k < I; k += RSORT_THREADS)                                        // inserts that stayed
+            if (count0 + k >= R) seg[(F + count0 + k) % size] = scratch[lo + k];
+        if (tid == 0) {
+            q.count = count0 + I - R;
+            q.front = q.rloc + (F + R) % size;
+            q.rear = q.rloc + (F + count0 + I - 1) % size;
+            qinfo[rec] = q;
+        }
+    } else {
+        const bool in_lds = q.seg_size <= QUEUE_WINDOW;
+        if (in_lds) for (int e = tid; e < q.seg_size; e += RSORT_THREADS) window[e] = queue[q.rloc + e];
+        for (int c0 = lo; c0 < hi; c0 += REPLAY_CHUNK) {
+            const int n = min(REPLAY_CHUNK, hi - c0);
+            __syncthreads();
+            for (int e = tid; e < n; e += RSORT_THREADS) {
+                op_arg[e] = args[c0 + e];
+                op_sub[e] = (unsigned char)(keys[c0 + e] & 3ull);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                for (int e = 0; e < n; e++) {
+                    const int sub = op_sub[e], arg = op_arg[e];
+                    if (sub == 2) {                                // q_insert(arg)
+                        if (q.count == q.seg_size) continue;
+                        if (q.count == 0) { q.front = q.rloc; q.rear = q.rloc; }
+                        else if (q.rear == q.rloc + q.seg_size - 1) q.rear = q.rloc;
+                        else q.rear++;
+                        q.count++;
+                        if (in_lds) window[q.rear - q.rloc] = arg; else queue[q.rear] = arg;
+                    } else {                                       // q_remove -> moves[arg].dst
+                        int item = -1;
+                        if (q.count > 0) {
+                            const int pos = q.front;
+                            if (q.count == 1) { q.front = -1; q.rear = -1; }
+                            else if (q.front == q.rloc + q.seg_size - 1) q.front = q.rloc;
+                            else q.front++;
+                            q.count--;
+                            if (in_lds) { item = window[pos - q.rloc]; window[pos - q.rloc] = -1; }
+                            else { item = queue[pos]; queue[pos] = -1; }
+                        }
+                        moves[arg].dst = item;
+                        if (sub == 1) { if (item >= 0) reloc++; else lost++; }
+                        else { if (item >= 0) births++; else births_failed++; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (in_lds) for (int e = tid; e < q.seg_size; e += RSORT_THREADS) queue[q.rloc + e] = window[e];
+        if (tid == 0) qinfo[rec] = q;
     }
+    DevCounters *mine = ctr + (blockIdx.x % COUNTER_COPIES);
+    if (reloc) atomicAdd(&mine->relocations, reloc);
+    if (lost) atomicAdd(&mine->relocations_lost, lost);
+    if (births) atomicAdd(&mine->births, births);
+    if (births_failed) atomicAdd(&mine->births_failed, births_failed);
 }
 
 // ---- fast path: bucket the operations by queue record, then one workgroup per record
@@ -2771,9 +2900,14 @@ __global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, i
 // k_apply reserved; one that arrived from a neighbour (MOVE_IN) was staged on arrival.
 __global__ void k_moves_stage(DevParams P, MoveRec *moves, int n_host, const FrameScalars *__restrict__ fs,
                               const float4 *pos4, const float4 *vel4, const float4 *acc4,
-                              const uint8_t *pflags, float4 *stage, XferRec *out_down, XferRec *out_up)
+                              const uint8_t *pflags, float4 *stage, XferRec *out_down, XferRec *out_up,
+                              int *__restrict__ msg_down, int *__restrict__ msg_up)
 {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m == 0 && msg_down) {          // slab, closing the outboxes: the headers of the two relocation messages
+        msg_down[0] = min(fs->n_out[0], P.xfer_cap); msg_down[1] = 0; msg_down[2] = fs->error;
+        msg_up[0] = min(fs->n_out[1], P.xfer_cap); msg_up[1] = 0; msg_up[2] = fs->error;
+    }
     if (n_host < 0 && lifecycle_deferred(fs)) return;
     const int n = n_host < 0 ? fs->n_moves : n_host;
     if (m >= n) return;
@@ -2881,11 +3015,17 @@ __device__ __forceinline__ void block_prefix_1024(int ncell, F count, int *__res
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void k_halo_prefix_out(DevParams P, int c0, int ncell, const int *__restrict__ cell_start,
-                                                           int *__restrict__ msg, int *__restrict__ pack_off, FrameScalars *fs)
+// (both directions -- the snapshot for the rank below and the one for the rank above -- in one launch: blockIdx.x / a block range selects)
+struct HaloOut { int c0, ncell; int *msg; int *pack_off; };
+struct HaloOut2 { HaloOut h[2]; int n; };
+
+__global__ __launch_bounds__(1024) void k_halo_prefix_out(DevParams P, HaloOut2 H, const int *__restrict__ cell_start, FrameScalars *fs)
 {
     __shared__ int wave_tot[16];
     __shared__ int carry;
+    const HaloOut h = H.h[blockIdx.x];
+    const int c0 = h.c0, ncell = h.ncell;
+    int *msg = h.msg, *pack_off = h.pack_off;
     int *counts = msg + MSG_HEADER_WORDS;
     const int lim = min(P.max_per_cell, P.halo_cap_cell);
     bool over = false;
@@ -2899,13 +3039,21 @@ __global__ __launch_bounds__(1024) void k_halo_prefix_out(DevParams P, int c0, i
     if (threadIdx.x == 0) { msg[0] = ncell; msg[1] = pack_off[ncell]; msg[2] = fs->error; }
 }
 
-// one workgroup per cell of the message
-__global__ __launch_bounds__(256) void k_halo_bodies_out(DevParams P, int c0, int ncell, const int *__restrict__ cell_start,
-                                                          const int *__restrict__ pack_off, const float4 *__restrict__ snap4,
+// one workgroup per cell of the messages; the first one also closes the rank's status record (everything
+// the build stage can raise has been raised by now)
+__global__ __launch_bounds__(256) void k_halo_bodies_out(DevParams P, HaloOut2 H, const int *__restrict__ cell_start,
+                                                          const float4 *__restrict__ snap4,
                                                           const float *__restrict__ snap_age, const int *__restrict__ sorted_id,
-                                                          int *__restrict__ msg)
+                                                          int *__restrict__ status_out, const FrameScalars *__restrict__ fs)
 {
-    const int j = blockIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && status_out) { status_out[1] = fs->error; status_out[2] = fs->live; }
+    int j = blockIdx.x, k = 0;
+    if (j >= H.h[0].ncell) { j -= H.h[0].ncell; k = 1; }
+    if (k >= H.n) return;
+    const HaloOut h = H.h[k];
+    const int c0 = h.c0, ncell = h.ncell;
+    const int *pack_off = h.pack_off;
+    int *msg = h.msg;
     const size_t cap = (size_t)ncell * P.halo_cap_cell;
     float *body = reinterpret_cast<float *>(msg + MSG_HEADER_WORDS + ncell);
     const int src = cell_start[c0 + j], dst = pack_off[j], n = pack_off[j + 1] - dst;
@@ -2917,18 +3065,24 @@ __global__ __launch_bounds__(256) void k_halo_bodies_out(DevParams P, int c0, in
     }
 }
 
-// The other end: the message's cells become the local cells of one or two remote regions:
+// The other end: a message's cells become the local cells of one or two remote regions:
 // the first `split` cells those of region r0 (local cells from c0), the rest those of region
 // r1 (from c1; absent when split == ncell).  Writes cell_start for those cells and the gap
 // cell after each region, and -- when r1 holds lent layers, which this rank computes --
-// appends their slices to the collide work list.  One workgroup.
-__global__ __launch_bounds__(1024) void k_halo_prefix_in(DevParams P, int c0, int c1, int ncell, int split, int s0, int s1,
-                                                          int lent, const int *__restrict__ msg, int *__restrict__ unpack_off,
-                                                          int *__restrict__ cell_start, int *__restrict__ task_list,
+// appends their slices to the collide work list.  One workgroup per message (the one from the rank
+// below and the one from the rank above in one launch).
+struct HaloIn { int c0, c1, ncell, split, s0, s1, lent; const int *msg; int *unpack_off; };
+struct HaloIn2 { HaloIn h[2]; int n; };
+
+__global__ __launch_bounds__(1024) void k_halo_prefix_in(DevParams P, HaloIn2 H, int *__restrict__ cell_start, int *__restrict__ task_list,
                                                           FrameScalars *fs)
 {
     __shared__ int wave_tot[16];
     __shared__ int carry, task_s;
+    const HaloIn h = H.h[blockIdx.x];
+    const int c0 = h.c0, c1 = h.c1, ncell = h.ncell, split = h.split, s0 = h.s0, s1 = h.s1, lent = h.lent;
+    const int *msg = h.msg;
+    int *unpack_off = h.unpack_off;
     const int tid = threadIdx.x;
     const int *counts = msg + MSG_HEADER_WORDS;
     if (msg[0] != ncell) {                      // not the message this rank was planned to get: leave the regions empty
@@ -2960,13 +3114,16 @@ __global__ __launch_bounds__(1024) void k_halo_prefix_in(DevParams P, int c0, in
     }
 }
 
-__global__ __launch_bounds__(256) void k_halo_bodies_in(DevParams P, int c0, int c1, int ncell, int split,
-                                                         const int *__restrict__ msg, const int *__restrict__ unpack_off,
+__global__ __launch_bounds__(256) void k_halo_bodies_in(DevParams P, HaloIn2 H,
                                                          const int *__restrict__ cell_start, float4 *__restrict__ snap4,
                                                          float *__restrict__ snap_soa, float *__restrict__ snap_age,
                                                          int *__restrict__ sorted_id, int *__restrict__ snap_cid)
 {
-    const int j = blockIdx.x;
+    int j = blockIdx.x, k = 0;
+    if (j >= H.h[0].ncell) { j -= H.h[0].ncell; k = 1; }
+    const HaloIn h = H.h[k];
+    const int c0 = h.c0, c1 = h.c1, ncell = h.ncell, split = h.split;
+    const int *msg = h.msg, *unpack_off = h.unpack_off;
     const size_t cap = (size_t)ncell * P.halo_cap_cell, sc = (size_t)P.sorted_cap;
     const float *body = reinterpret_cast<const float *>(msg + MSG_HEADER_WORDS + ncell);
     const int lc = j < split ? c0 + j : c1 + (j - split);
@@ -2984,15 +3141,21 @@ __global__ __launch_bounds__(256) void k_halo_bodies_in(DevParams P, int c0, int
 }
 
 // Remote cells list their bodies in the halos of the cells around them, like k_sort_cells
-// does for the own cells.  One workgroup per remote cell (local cells [c0, c1)).
-__global__ __launch_bounds__(256) void k_remote_halo_lists(DevParams P, int c0, int c1, const int *__restrict__ cell_start,
+// does for the own cells.  One workgroup per remote cell: the local cells [lo[i], hi[i]) of up to three regions.
+struct CellRanges3 { int lo[3], hi[3]; };
+__global__ __launch_bounds__(256) void k_remote_halo_lists(DevParams P, CellRanges3 R, const int *__restrict__ cell_start,
                                                            const float4 *__restrict__ snap4, const int *__restrict__ snap_cid,
                                                            int *__restrict__ halo_count, float *__restrict__ halo_f,
                                                            int *__restrict__ halo_id)
 {
     __shared__ int s_halo[27], s_halo_base[27];
-    const int c = c0 + blockIdx.x;
-    if (c >= c1) return;
+    int b = blockIdx.x, c = -1;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int n = R.hi[i] - R.lo[i];
+        if (c < 0 && n > 0) { if (b < n) c = R.lo[i] + b; else b -= n; }
+    }
+    if (c < 0) return;
     const int start = cell_start[c], n = min(cell_start[c + 1] - start, P.max_per_cell);
     list_in_neighbour_halos(P, c, start, max(n, 0), snap4, snap_cid, halo_count, halo_f, halo_id, s_halo, s_halo_base, false);
 }
@@ -3010,11 +3173,10 @@ __global__ void k_pack_force(DevParams P, const float4 *__restrict__ force4, int
 
 // Receiver (the owner): message cell j0 + b is own local cell lentout_c0 + b; its stored bodies
 // sit at pack_off[j0 + b] - pack_off[j0] in the message.  One workgroup per lent-out cell.
-__global__ __launch_bounds__(256) void k_unpack_force(DevParams P, int j0, const int *__restrict__ msg, const int *__restrict__ pack_off,
-                                                       const int *__restrict__ cell_start, float4 *__restrict__ force4,
-                                                       FrameScalars *fs)
+__device__ __forceinline__ void unpack_force_block(const DevParams &P, int b, int j0, const int *__restrict__ msg, const int *__restrict__ pack_off,
+                                                   const int *__restrict__ cell_start, float4 *__restrict__ force4, FrameScalars *fs)
 {
-    const int b = blockIdx.x, c = P.lentout_c0 + b;
+    const int c = P.lentout_c0 + b;
     const int ncell = P.lentout_c1 - P.lentout_c0;
     const float4 *src = reinterpret_cast<const float4 *>(msg + MSG_HEADER_WORDS);
     if (b == 0 && threadIdx.x == 0) {
@@ -3023,17 +3185,20 @@ __global__ __launch_bounds__(256) void k_unpack_force(DevParams P, int j0, const
     }
     if (msg[1] != pack_off[j0 + ncell] - pack_off[j0]) return;
     const int rel = pack_off[j0 + b] - pack_off[j0], n = pack_off[j0 + b + 1] - pack_off[j0 + b], dst = cell_start[c];
-    for (int e = threadIdx.x; e < n; e += 256) force4[dst + e] = src[rel + e];
+    for (int e = threadIdx.x; e < n; e += blockDim.x) force4[dst + e] = src[rel + e];
 }
 
 // Arrivals: every record a neighbour sent becomes a MoveRec whose state is staged already,
 // plus the remove operation on this rank's queue, keyed as the sender keyed it.
-__global__ void k_inbox_merge(DevParams P, const int *__restrict__ msg, uint64_t *op_keys, int *op_args, int ops_cap,
-                              MoveRec *moves, int moves_cap, float4 *stage, int *__restrict__ rec_count, FrameScalars *fs)
+__global__ void k_inbox_merge(DevParams P, const int *__restrict__ msg0, const int *__restrict__ msg1, int blocks_each,
+                              uint64_t *op_keys, int *op_args, int ops_cap,
+                              MoveRec *moves, int moves_cap, float4 *stage, FrameScalars *fs)
 {
+    // (the message from the rank below and the one from the rank above in one launch)
+    const int *msg = (int)blockIdx.x < blocks_each ? msg0 : msg1;
     const int n = min(msg[0], P.xfer_cap);
     const XferRec *in = reinterpret_cast<const XferRec *>(msg + MSG_HEADER_WORDS);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = ((int)blockIdx.x % blocks_each) * blockDim.x + threadIdx.x;
     if (i == 0 && msg[2]) atomicOr(&fs->error, msg[2]);
     if (i >= n) return;
     const XferRec x = in[i];
@@ -3050,15 +3215,6 @@ __global__ void k_inbox_merge(DevParams P, const int *__restrict__ msg, uint64_t
     s[1] = make_float4(x.vel[0], x.vel[1], x.vel[2], x.vel[3]);
     s[2] = make_float4(x.acc[0], x.acc[1], x.acc[2], x.acc[3]);
     op_keys[k] = x.key; op_args[k] = m;
-}
-
-// close an outbox: header of the relocation message
-__global__ void k_outbox_header(int *__restrict__ msg_down, int *__restrict__ msg_up, const FrameScalars *__restrict__ fs, int cap)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        msg_down[0] = min(fs->n_out[0], cap); msg_down[1] = 0; msg_down[2] = fs->error;
-        msg_up[0] = min(fs->n_out[1], cap); msg_up[1] = 0; msg_up[2] = fs->error;
-    }
 }
 
 // ---- all-pairs forces across ranks (PSAMD_FLAG_ALL_PAIRS, world > 1) ----
@@ -3263,21 +3419,6 @@ hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame
     return hipGetLastError();
 }
 
-// Status message of a slab (all-gathered once per step, off the critical path): what the build
-// stage has to tell the other ranks -- sticky error bits, so that every rank stops in the same
-// step, and the slots the cell-overflow rule killed, for the owner of queue record 0.
-__global__ void k_status_close(int *status_out, const FrameScalars *fs)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) { status_out[1] = fs->error; status_out[2] = fs->live; }
-}
-
-hipError_t launch_status_close(hipStream_t st, const DeviceState &d)
-{
-    if (!d.status_out) return hipSuccess;
-    k_status_close<<<1, 64, 0, st>>>(d.status_out, d.fs);
-    return hipGetLastError();
-}
-
 // Run once the status records of all ranks are in, before k_apply.
 // Workgroups [0, world), one per rank's record: adopt its error bits (status_error: the OR over ALL
 // records, this rank's own included -- the same word on every rank, which is what makes a failure
@@ -3291,9 +3432,17 @@ hipError_t launch_status_close(hipStream_t st, const DeviceState &d)
 __global__ __launch_bounds__(1024) void k_status_merge(DevParams P, const int *__restrict__ status_all, uint64_t *op_keys, int *op_args,
                                                         int ops_cap, int *__restrict__ chunk_count, const int *__restrict__ cell_arr,
                                                         const CellInfo *__restrict__ celltab, const int2 *__restrict__ chunk_segs,
-                                                        uint8_t *__restrict__ chunk_skip, FrameScalars *fs)
+                                                        uint8_t *__restrict__ chunk_skip, FrameScalars *fs,
+                                                        int force_j0, const int *__restrict__ force_msg, const int *__restrict__ pack_off,
+                                                        const int *__restrict__ cell_start, float4 *__restrict__ force4)
 {
     __shared__ int s_before[4];
+    // workgroups past the status records and the chunks: the force records of the lent-out layers come home
+    // (one workgroup per lent-out cell; same stage, so the same launch)
+    if ((int)blockIdx.x >= P.world + P.num_chunks) {
+        unpack_force_block(P, (int)blockIdx.x - P.world - P.num_chunks, force_j0, force_msg, pack_off, cell_start, force4, fs);
+        return;
+    }
     if ((int)blockIdx.x >= P.world) {
         const int ch = (int)blockIdx.x - P.world;
         int tot[4] = {0, 0, 0, 0}, below[4] = {0, 0, 0, 0};
@@ -3328,11 +3477,14 @@ __global__ __launch_bounds__(1024) void k_status_merge(DevParams P, const int *_
     }
 }
 
-hipError_t launch_status_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *status_all)
+// force_msg (may be null): the force records of the lent-out layers, unpacked by extra workgroups of the same launch
+hipError_t launch_status_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *status_all,
+                               int force_j0, const int *force_msg, const int *pack_off)
 {
     if (!status_all || P.world <= 1) return hipSuccess;
-    k_status_merge<<<P.world + P.num_chunks, 1024, 0, st>>>(P, status_all, d.op_keys, d.op_args, d.ops_cap, d.chunk_count, d.cell, d.celltab,
-                                                            d.chunk_segs, d.chunk_skip, d.fs);
+    const int ncell = force_msg ? std::max(0, P.lentout_c1 - P.lentout_c0) : 0;
+    k_status_merge<<<P.world + P.num_chunks + ncell, 1024, 0, st>>>(P, status_all, d.op_keys, d.op_args, d.ops_cap, d.chunk_count, d.cell, d.celltab,
+                                                                    d.chunk_segs, d.chunk_skip, d.fs, force_j0, force_msg, pack_off, d.cell_start, d.force4);
     return hipGetLastError();
 }
 
@@ -3368,37 +3520,59 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     if (ev) (void)hipEventRecord(ev[3], st);
     k_sort_cells<<<P.n_own_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
                                                d.pflags, d.snap4, d.snap_soa, d.snap_age, d.tdata, d.rank_of_slot, d.op_keys, d.op_args, d.ops_cap,
-                                               P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.snap_cid, d.status_out, d.rec_count, d.fs, d.ctr);
+                                               P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.snap_cid, d.status_out, d.fs, d.ctr);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[4], st);
     return hipSuccess;
 }
 
 // ---- slab exchange ----
-hipError_t launch_pack_halo(hipStream_t st, const DevParams &P, const DeviceState &d, int c0, int ncell, int *msg, int *pack_off)
+// the snapshots for the rank below (k = 0) and above (k = 1); ncell[k] == 0: no such message.  Also closes the status record.
+hipError_t launch_pack_halos(hipStream_t st, const DevParams &P, const DeviceState &d, const int c0[2], const int ncell[2],
+                             int *const msg[2], int *const pack_off[2])
 {
-    if (ncell <= 0) return hipSuccess;
-    k_halo_prefix_out<<<1, 1024, 0, st>>>(P, c0, ncell, d.cell_start, msg, pack_off, d.fs);
-    PS_LAUNCH_CHECK();
-    k_halo_bodies_out<<<ncell, 256, 0, st>>>(P, c0, ncell, d.cell_start, pack_off, d.snap4, d.snap_age, d.sorted_id, msg);
+    HaloOut2 H{};
+    for (int k = 0; k < 2; k++)
+        if (ncell[k] > 0) { H.h[H.n] = HaloOut{c0[k], ncell[k], msg[k], pack_off[k]}; H.n++; }
+    if (H.n == 1) H.h[1] = HaloOut{0, 0, nullptr, nullptr};
+    if (H.n > 0) {
+        k_halo_prefix_out<<<H.n, 1024, 0, st>>>(P, H, d.cell_start, d.fs);
+        PS_LAUNCH_CHECK();
+    }
+    const int blocks = std::max(1, H.h[0].ncell + (H.n > 1 ? H.h[1].ncell : 0));
+    k_halo_bodies_out<<<blocks, 256, 0, st>>>(P, H, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.status_out, d.fs);
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }
 
-// message cells: the first `split` become region r0's cells, the rest region r1's
-hipError_t launch_unpack_halo(hipStream_t st, const DevParams &P, const DeviceState &d, int r0, int r1, int ncell, int split,
-                              bool lent, const int *msg, int *unpack_off)
+// The snapshots that arrived: from the rank below (its cells become region 1, the halo layer, then
+// region 2, the lent layers) and from the rank above (region 3).  ncell == 0: no such message.
+hipError_t launch_unpack_halos(hipStream_t st, const DevParams &P, const DeviceState &d, int ncell_below, const int *msg_below,
+                               int *off_below, int ncell_above, const int *msg_above, int *off_above)
 {
-    if (ncell <= 0) return hipSuccess;
-    const int c0 = P.reg_base[r0], c1 = r1 >= 0 ? P.reg_base[r1] : 0, s0 = P.reg_sorted[r0], s1 = r1 >= 0 ? P.reg_sorted[r1] : 0;
-    k_halo_prefix_in<<<1, 1024, 0, st>>>(P, c0, c1, ncell, split, s0, s1, lent ? 1 : 0, msg, unpack_off, d.cell_start, d.task_list, d.fs);
+    const int GG = P.G * P.G;
+    HaloIn2 H{};
+    CellRanges3 R{};
+    int nr = 0;
+    if (ncell_below > 0) {
+        const int split = P.reg_layers[1] * GG;
+        H.h[H.n++] = HaloIn{P.reg_base[1], P.reg_base[2], ncell_below, split, P.reg_sorted[1], P.reg_sorted[2], P.reg_layers[2] > 0 ? 1 : 0, msg_below, off_below};
+        if (split > 0) { R.lo[nr] = P.reg_base[1]; R.hi[nr] = P.reg_base[1] + split; nr++; }
+        if (ncell_below > split) { R.lo[nr] = P.reg_base[2]; R.hi[nr] = P.reg_base[2] + ncell_below - split; nr++; }
+    }
+    if (ncell_above > 0) {
+        H.h[H.n++] = HaloIn{P.reg_base[3], 0, ncell_above, ncell_above, P.reg_sorted[3], 0, 0, msg_above, off_above};
+        R.lo[nr] = P.reg_base[3]; R.hi[nr] = P.reg_base[3] + ncell_above; nr++;
+    }
+    if (H.n == 0) return hipSuccess;
+    if (H.n == 1) H.h[1] = HaloIn{0, 0, 0, 0, 0, 0, 0, nullptr, nullptr};
+    k_halo_prefix_in<<<H.n, 1024, 0, st>>>(P, H, d.cell_start, d.task_list, d.fs);
     PS_LAUNCH_CHECK();
-    k_halo_bodies_in<<<ncell, 256, 0, st>>>(P, c0, c1, ncell, split, msg, unpack_off, d.cell_start, d.snap4, d.snap_soa, d.snap_age,
-                                            d.sorted_id, d.snap_cid);
+    const int cells = H.h[0].ncell + H.h[1].ncell;
+    k_halo_bodies_in<<<cells, 256, 0, st>>>(P, H, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, d.snap_cid);
     PS_LAUNCH_CHECK();
     if (P.two_pass) {
-        if (split > 0) k_remote_halo_lists<<<split, 256, 0, st>>>(P, c0, c0 + split, d.cell_start, d.snap4, d.snap_cid, d.halo_count, d.halo_f, d.halo_id);
-        if (ncell > split) k_remote_halo_lists<<<ncell - split, 256, 0, st>>>(P, c1, c1 + ncell - split, d.cell_start, d.snap4, d.snap_cid, d.halo_count, d.halo_f, d.halo_id);
+        k_remote_halo_lists<<<cells, 256, 0, st>>>(P, R, d.cell_start, d.snap4, d.snap_cid, d.halo_count, d.halo_f, d.halo_id);
         PS_LAUNCH_CHECK();
     }
     return hipSuccess;
@@ -3413,19 +3587,11 @@ hipError_t launch_pack_force(hipStream_t st, const DevParams &P, const DeviceSta
     return hipSuccess;
 }
 
-hipError_t launch_unpack_force(hipStream_t st, const DevParams &P, const DeviceState &d, int j0, const int *msg, const int *pack_off)
-{
-    const int ncell = P.lentout_c1 - P.lentout_c0;
-    if (ncell <= 0) return hipSuccess;
-    k_unpack_force<<<ncell, 256, 0, st>>>(P, j0, msg, pack_off, d.cell_start, d.force4, d.fs);
-    PS_LAUNCH_CHECK();
-    return hipSuccess;
-}
-
-hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *msg)
+hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *msg_from_below, const int *msg_from_above)
 {
     if (P.xfer_cap <= 0) return hipSuccess;
-    k_inbox_merge<<<(P.xfer_cap + 255) / 256, 256, 0, st>>>(P, msg, d.op_keys, d.op_args, d.ops_cap, d.moves, d.moves_cap, d.stage, d.rec_count, d.fs);
+    const int nb = (P.xfer_cap + 255) / 256;
+    k_inbox_merge<<<2 * nb, 256, 0, st>>>(P, msg_from_below, msg_from_above, nb, d.op_keys, d.op_args, d.ops_cap, d.moves, d.moves_cap, d.stage, d.fs);
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -3499,13 +3665,22 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     }
     else {
         FarCells far;
-        if ((P.flags & PSAMD_FLAG_ALL_PAIRS) && P.world > 1) { far.start = d.gstart; far.n = d.gn; far.buf = reinterpret_cast<const float *>(d.allg_in); far.plane = (unsigned long long)P.allg_cap; }
-        if (MODE != 0 && (P.flags & PSAMD_FLAG_ALL_PAIRS))
-            k_pairs<MODE, NQ, MODE != 0><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
-                                                                        d.fs, d.trace, active_list, active_count, far);
-        else
+        // where the all-pairs walk finds the cells beyond the stencil: the own snapshot (one GPU: local cell == global cell,
+        // lengths from consecutive starts) or the all-gathered snapshot of all ranks with its index by global cell
+        const bool gathered = (P.flags & PSAMD_FLAG_ALL_PAIRS) && P.world > 1;
+        const float *far_buf = gathered ? reinterpret_cast<const float *>(d.allg_in) : d.snap_soa;
+        const int *far_start = gathered ? d.gstart : d.cell_start, *far_n = gathered ? d.gn : nullptr;
+        far.plane = gathered ? (unsigned long long)P.allg_cap : (unsigned long long)P.sorted_cap;
+        far.part_acc = d.part_acc; far.part_plane = (unsigned long long)d.part_tasks * 64;
+        if (MODE != 0 && (P.flags & PSAMD_FLAG_ALL_PAIRS)) {
+            // (two == true here: all-pairs contexts are created only with the two-pass pair stage)
+            const int items = std::min(tasks, d.part_tasks) * ALLP_PARTS;
+            k_pairs<MODE, NQ, MODE != 0><<<(items + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
+                                                                        d.fs, d.trace, active_list, active_count, far, far_buf, far_start, far_n);
+            k_allpairs_combine<<<(std::min(tasks, d.part_tasks) * 64 + 255) / 256, 256, 0, st>>>(P, d.cell_start, task_list, active_list, active_count, far, d.force4, d.fs);
+        } else
             k_pairs<MODE, NQ, false><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
-                                                                      d.fs, d.trace, active_list, active_count, far);
+                                                                      d.fs, d.trace, active_list, active_count, far, nullptr, nullptr, nullptr);
         // (unbalanced pass, A/B runs only: the packs as a kernel of their own behind it)
         if (merge) k_pairs_merged<MODE == 0 ? 1 : MODE, NQ><<<(ncomp + 3) / 4, 256, 0, st>>>(
                 P, d.cell_start, d.snap4, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
@@ -3524,13 +3699,13 @@ hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d
     return launch_pairs_mode<0, 4>(st, P, d, ev_force, tasks_hint, pass);
 }
 
-hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step, int nrec)
+hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step)
 {
     if (P.slots_total <= 0) return hipSuccess;
     // slots per thread: one (PSAMD_APPLY_ITEMS: the measurement quoted at the kernel)
 #define PS_APPLY(I) k_apply<I><<<(P.slots_total + I * 1024 - 1) / (I * 1024), 1024, 0, st>>>(P, S, step, d.rank_of_slot, d.force4, d.pos4, \
         d.vel4, d.acc4, d.cell, d.pflags, d.celltab, d.op_keys, d.op_args, d.ops_cap, \
-        d.moves, d.moves_cap, d.xfer_out[0], d.xfer_out[1], d.chunk_count, d.chunk_skip, nrec, d.rec_count, d.fs, d.ctr)
+        d.moves, d.moves_cap, d.xfer_out[0], d.xfer_out[1], d.chunk_count, d.chunk_skip, d.fs, d.ctr)
     static const int items_env = std::getenv("PSAMD_APPLY_ITEMS") ? std::atoi(std::getenv("PSAMD_APPLY_ITEMS")) : 0;
     const int items = items_env ? items_env : 1;
     if (items >= 4) PS_APPLY(4); else if (items >= 2) PS_APPLY(2); else PS_APPLY(1);
@@ -3544,12 +3719,8 @@ hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, 
 hipError_t launch_outbox_close(hipStream_t st, const DevParams &P, const DeviceState &d, int64_t live_bound, int *msg_down, int *msg_up)
 {
     const int64_t max_moves = std::min<int64_t>(d.moves_cap, 2 * live_bound);
-    const int nb = (int)((max_moves + 255) / 256);
-    if (nb > 0) {
-        k_moves_stage<<<nb, 256, 0, st>>>(P, d.moves, -2, d.fs, d.pos4, d.vel4, d.acc4, d.pflags, d.stage, d.xfer_out[0], d.xfer_out[1]);
-        PS_LAUNCH_CHECK();
-    }
-    k_outbox_header<<<1, 64, 0, st>>>(msg_down, msg_up, d.fs, P.xfer_cap);
+    const int nb = std::max(1, (int)((max_moves + 255) / 256));
+    k_moves_stage<<<nb, 256, 0, st>>>(P, d.moves, -2, d.fs, d.pos4, d.vel4, d.acc4, d.pflags, d.stage, d.xfer_out[0], d.xfer_out[1], msg_down, msg_up);
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -3601,12 +3772,12 @@ hipError_t launch_lifecycle_sorted(hipStream_t st, const DevParams &P, const Dev
     if (n_ops > 0) {
         hipError_t e = sort_ops(st, d, n_ops, P.key_bits);
         if (e != hipSuccess) return e;
-        k_replay<<<nrec, 256, 0, st>>>(P, n_ops, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue, d.moves, d.ctr);
+        k_replay<<<nrec, RSORT_THREADS, 0, st>>>(P, n_ops, d.op_keys_sorted, d.op_args_sorted, d.op_args, d.qinfo, d.queue, d.moves, d.ctr);
         PS_LAUNCH_CHECK();
     }
     if (n_moves > 0) {
         const int nb = (n_moves + 255) / 256;
-        k_moves_stage<<<nb, 256, 0, st>>>(P, d.moves, n_moves, d.fs, d.pos4, d.vel4, d.acc4, d.pflags, d.stage, d.xfer_out[0], d.xfer_out[1]);
+        k_moves_stage<<<nb, 256, 0, st>>>(P, d.moves, n_moves, d.fs, d.pos4, d.vel4, d.acc4, d.pflags, d.stage, d.xfer_out[0], d.xfer_out[1], nullptr, nullptr);
         PS_LAUNCH_CHECK();
         k_moves_reset<<<nb, 256, 0, st>>>(P, d.moves, n_moves, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags);
         PS_LAUNCH_CHECK();

@@ -391,26 +391,32 @@ def test_big_segments_replay_in_global_memory():
     assert g.counters["relocations"] > 1000
 
 
-def test_long_operation_lists_take_the_sorted_fallback():
-    """3600 fast particles fill the corner segment at the box centre (its 8 cells are
-    [-5,5)^3) and move one cell along every axis: 7/8 of them leave it in one step, while 2000
-    more, one cell further out, move INTO it -- more queue operations on one record than the
-    in-LDS replay holds (4096), so the radix-sort + serial-walk path runs."""
+@pytest.mark.parametrize("big", [False, True])
+def test_long_operation_lists(big):
+    """Fast particles fill the corner segment at the box centre (its 8 cells are [-5,5)^3) and move
+    one cell along every axis: 7/8 of them leave it in one step, while more, one cell further out,
+    move INTO it.  Small: 3600 + 2000 particles, more queue operations on one record than a
+    workgroup used to sort in LDS (4096; now 8192).  Big (twice the container, 8208-slot corner
+    segments): 7200 + 4000, more than the in-LDS replay holds at all -- the radix sort of all keys and
+    the streamed closed-form replay (k_replay) run; and with the queue nearly empty (third step) its
+    serial walk."""
     rng = np.random.default_rng(121)
-    blob = rng.uniform(-4.9, 4.9, (3600, 3)).astype(np.float32)
-    outer = rng.uniform(-9.9, -0.1, (2400, 3)).astype(np.float32)
+    nb, no = (7200, 4800) if big else (3600, 2400)
+    blob = rng.uniform(-4.9, 4.9, (nb, 3)).astype(np.float32)
+    outer = rng.uniform(-9.9, -0.1, (no, 3)).astype(np.float32)
     outer = outer[~(outer > -5.0).all(axis=1)]                        # not the centre cell itself
     rest = cloud(5000, 122)
     rest = rest[(np.abs(rest) > 10.0).any(axis=1)]
     xyz = np.concatenate([blob, outer, rest])
     v = np.zeros_like(xyz)
     v[:len(blob) + len(outer)] = 300.0                                # clamped to one cell per step
-    g, o = make_pair(xyz, age=3.0, fert=1e6, vxyz=v, collision_radius=0.0)
-    for k in range(2):
+    over = {"max_particles_num": 1 << 21} if big else {}
+    g, o = make_pair(xyz, age=3.0, fert=1e6, vxyz=v, collision_radius=0.0, **over)
+    for k in range(3):
         g.step(1); o.step(1)
         compare_all(g, o, "long list step %d" % (k + 1))
-    assert g.counters["relocations"] > 4500
-    assert g.counters["max_ops_one_queue"] > 4096      # the fallback really ran
+    assert g.counters["relocations"] > (9000 if big else 4500)
+    assert g.counters["max_ops_one_queue"] > (8192 if big else 4096)      # big: the sorted path really ran
 
 
 def test_long_free_run_with_births_and_collapse():

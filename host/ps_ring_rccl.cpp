@@ -5,8 +5,8 @@
 // nodes (subscriptions to segments, ps.cpp:380-487); here one process drives one GPU.
 //
 //   one process per GPU (what a node runs):
-//       ps_ring_rccl --world W --rank r --id-file /tmp/id [--n N] [--iters K] [--seed S]
-//     rank 0 writes the communicator's ncclUniqueId to the file, the others wait for it.
+//       ps_ring_rccl --world W --rank r --id-file /tmp/id --job J [--n N] [--iters K] [--seed S]
+//     rank 0 writes the communicator's ncclUniqueId to the file (tagged with the job's nonce J), the others wait for it.
 //   all slabs in ONE process on GPU 0 (what a one-GPU test box can run):
 //       ps_ring_rccl --world W --loopback [--n N] [--iters K] [--seed S]
 //     The communicator has a single rank; every message is an ncclSend to self matched by
@@ -40,9 +40,14 @@
 
 namespace {
 
-#define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #call, hipGetErrorString(e_)); return 1; } } while (0)
-#define NCCL_OK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { std::fprintf(stderr, "%s: %s\n", #call, ncclGetErrorString(r_)); return 1; } } while (0)
-#define PS_OK(ctx, call) do { const int rc_ = (call); if (rc_ != PSAMD_OK) { std::fprintf(stderr, "%s failed: %s (%s)\n", #call, psamd_status_string(rc_), (ctx) ? psamd_last_error(ctx) : ""); return 1; } } while (0)
+// A rank that fails must not leave its peers blocked in a receive: abort the communicator on the way out
+// (psamd's own failures are collective -- every rank returns the error from the same slab_finish -- but a
+// HIP or RCCL error, or a failure during set-up, is not).
+ncclComm_t g_comm = nullptr;
+int bail() { if (g_comm) { (void)ncclCommAbort(g_comm); g_comm = nullptr; } return 1; }
+#define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #call, hipGetErrorString(e_)); return bail(); } } while (0)
+#define NCCL_OK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { std::fprintf(stderr, "%s: %s\n", #call, ncclGetErrorString(r_)); return bail(); } } while (0)
+#define PS_OK(ctx, call) do { const int rc_ = (call); if (rc_ != PSAMD_OK) { std::fprintf(stderr, "%s failed: %s (%s)\n", #call, psamd_status_string(rc_), (ctx) ? psamd_last_error(ctx) : ""); return bail(); } } while (0)
 
 struct Slab {
     int rank = 0;
@@ -51,7 +56,7 @@ struct Slab {
     psamd_slab_plan plan{};
 };
 
-struct Msg { void *buf; int64_t bytes; int peer; int dir; };   // dir: 0 travels down the ring, 1 up
+struct Msg { void *buf; int64_t bytes; int peer; int dir; int hop; };   // dir: 0 travels down the ring, 1 up; hop: 1 to a ring neighbour, 2 to the rank beyond it
 
 enum Phase { HALO, FORCE, XFER };
 
@@ -61,27 +66,32 @@ std::vector<Msg> sends_of(const Slab &s, int world, Phase ph)
     std::vector<Msg> v;
     const int r = s.rank;
     if (ph == HALO) {
-        if (r > 0 && s.b.halo_out_bytes[0]) v.push_back({s.b.halo_out[0], s.b.halo_out_bytes[0], r - 1, 0});
-        if (r + 1 < world && s.b.halo_out_bytes[1]) v.push_back({s.b.halo_out[1], s.b.halo_out_bytes[1], r + 1, 1});
+        if (r > 0 && s.b.halo_out_bytes[0]) v.push_back({s.b.halo_out[0], s.b.halo_out_bytes[0], r - 1, 0, 1});
+        if (r + 1 < world && s.b.halo_out_bytes[1]) v.push_back({s.b.halo_out[1], s.b.halo_out_bytes[1], r + 1, 1, 1});
     } else if (ph == FORCE) {
-        if (r > 0 && s.b.force_out_bytes) v.push_back({s.b.force_out, s.b.force_out_bytes, r - 1, 0});
+        if (r > 0 && s.b.force_out_bytes) v.push_back({s.b.force_out, s.b.force_out_bytes, r - 1, 0, 1});
     } else if (world > 1 && s.b.xfer_bytes) {
-        v.push_back({s.b.xfer_out[0], s.b.xfer_bytes, (r - 1 + world) % world, 0});
-        v.push_back({s.b.xfer_out[1], s.b.xfer_bytes, (r + 1) % world, 1});
+        v.push_back({s.b.xfer_out[0], s.b.xfer_bytes, (r - 1 + world) % world, 0, 1});
+        v.push_back({s.b.xfer_out[1], s.b.xfer_bytes, (r + 1) % world, 1, 1});
+        if (world >= 4 && s.b.xfer2_bytes) {     // a two-layer jump over a rank whose state is one layer: straight to rank +-2
+            v.push_back({s.b.xfer2_out[0], s.b.xfer2_bytes, (r - 2 + world) % world, 0, 2});
+            v.push_back({s.b.xfer2_out[1], s.b.xfer2_bytes, (r + 2) % world, 1, 2});
+        }
     }
     return v;
 }
 
 // where slab `s` takes a message that rank `from` sent travelling in direction `dir`
-Msg recv_of(const Slab &s, Phase ph, int from, int dir)
+Msg recv_of(const Slab &s, Phase ph, int from, int dir, int hop = 1)
 {
     // a message travelling down arrives from above, and the other way round
-    if (ph == HALO) return {s.b.halo_in[dir == 0 ? 1 : 0], s.b.halo_in_bytes[dir == 0 ? 1 : 0], from, dir};
-    if (ph == FORCE) return {s.b.force_in, s.b.force_in_bytes, from, dir};
-    return {s.b.xfer_in[dir == 0 ? 1 : 0], s.b.xfer_bytes, from, dir};
+    if (ph == HALO) return {s.b.halo_in[dir == 0 ? 1 : 0], s.b.halo_in_bytes[dir == 0 ? 1 : 0], from, dir, 1};
+    if (ph == FORCE) return {s.b.force_in, s.b.force_in_bytes, from, dir, 1};
+    if (hop == 2) return {s.b.xfer2_in[dir == 0 ? 1 : 0], s.b.xfer2_bytes, from, dir, 2};
+    return {s.b.xfer_in[dir == 0 ? 1 : 0], s.b.xfer_bytes, from, dir, 1};
 }
 
-bool by_peer_then_dir(const Msg &a, const Msg &b) { return a.peer != b.peer ? a.peer < b.peer : a.dir < b.dir; }
+bool by_peer_then_dir(const Msg &a, const Msg &b) { return a.peer != b.peer ? a.peer < b.peer : (a.hop != b.hop ? a.hop < b.hop : a.dir < b.dir); }
 
 // One phase's messages as ONE RCCL group.  `local`: the slabs this process holds (one per
 // process in a real run; all of them in loopback mode, where every peer is comm rank 0).
@@ -92,10 +102,10 @@ int exchange(const std::vector<Slab> &local, int world, bool loopback, Phase ph,
         // k-th receive from self = k-th send to self: enumerate the routes once for both lists
         for (const Slab &s : local)
             for (const Msg &m : sends_of(s, world, ph)) {
-                const Msg r = recv_of(local[(size_t)m.peer], ph, s.rank, m.dir);
+                const Msg r = recv_of(local[(size_t)m.peer], ph, s.rank, m.dir, m.hop);
                 if (r.bytes != m.bytes) { std::fprintf(stderr, "message size mismatch %lld vs %lld\n", (long long)m.bytes, (long long)r.bytes); return 1; }
-                sends.push_back({m.buf, m.bytes, 0, m.dir});
-                recvs.push_back({r.buf, r.bytes, 0, r.dir});
+                sends.push_back({m.buf, m.bytes, 0, m.dir, m.hop});
+                recvs.push_back({r.buf, r.bytes, 0, r.dir, r.hop});
             }
     } else {
         const Slab &s = local[0];
@@ -110,6 +120,10 @@ int exchange(const std::vector<Slab> &local, int world, bool loopback, Phase ph,
         } else if (world > 1 && s.b.xfer_bytes) {
             recvs.push_back(recv_of(s, ph, (r + 1) % world, 0));
             recvs.push_back(recv_of(s, ph, (r - 1 + world) % world, 1));
+            if (world >= 4 && s.b.xfer2_bytes) {
+                recvs.push_back(recv_of(s, ph, (r + 2) % world, 0, 2));
+                recvs.push_back(recv_of(s, ph, (r - 2 + world) % world, 1, 2));
+            }
         }
         std::sort(sends.begin(), sends.end(), by_peer_then_dir);
         std::sort(recvs.begin(), recvs.end(), by_peer_then_dir);
@@ -146,7 +160,8 @@ int main(int argc, char **argv)
     int world = 2, rank = 0, iters = 8;
     int64_t n = 60000;
     uint32_t seed = 2026;
-    bool loopback = false;
+    bool loopback = false, id_only = false;
+    uint64_t job = 0;
     std::string id_file;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -158,6 +173,8 @@ int main(int argc, char **argv)
         else if (a == "--seed") seed = (uint32_t)std::atoll(next());
         else if (a == "--id-file") id_file = next();
         else if (a == "--loopback") loopback = true;
+        else if (a == "--job") job = (uint64_t)std::strtoull(next(), nullptr, 10);
+        else if (a == "--id-only") id_only = true;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     if (world < 1 || rank < 0 || rank >= world || (!loopback && world > 1 && id_file.empty())) {
@@ -165,31 +182,50 @@ int main(int argc, char **argv)
         return 2;
     }
     const int device = loopback ? 0 : rank;
-    HIP_OK(hipSetDevice(device));
-    hipStream_t st;
-    HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipStream_t st = nullptr;
+    if (!id_only) {
+        HIP_OK(hipSetDevice(device));
+        HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    }
 
     // the communicator: one rank per process
     ncclComm_t comm;
     ncclUniqueId id;
     const int comm_world = loopback ? 1 : world, comm_rank = loopback ? 0 : rank;
+    // The id file carries the job's nonce (--job, the same on every rank of one job) in front of the id: a file
+    // left behind by an earlier job is not this job's and is waited past, not read.  Rank 0 removes whatever is
+    // there before it writes (tmp + rename: never a half-written file) and again once the communicator is up.
+    struct IdFile { uint64_t magic, job; ncclUniqueId id; };
+    const uint64_t kMagic = 0x70735f72696e6731ull;        // "ps_ring1"
     if (comm_rank == 0) {
-        NCCL_OK(ncclGetUniqueId(&id));
+        if (id_only) { uint64_t x = job * 0x9E3779B97F4A7C15ull + 1; for (size_t i = 0; i < sizeof id; i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; ((char *)&id)[i] = (char)x; } }
+        else NCCL_OK(ncclGetUniqueId(&id));
         if (!id_file.empty()) {
+            std::remove(id_file.c_str());
+            IdFile rec{kMagic, job, id};
             std::ofstream f(id_file + ".tmp", std::ios::binary);
-            f.write((const char *)&id, sizeof id);
+            f.write((const char *)&rec, sizeof rec);
             f.close();
-            std::rename((id_file + ".tmp").c_str(), id_file.c_str());
+            if (!f || std::rename((id_file + ".tmp").c_str(), id_file.c_str()) != 0) { std::fprintf(stderr, "cannot write %s\n", id_file.c_str()); return 1; }
         }
     } else {
         for (int tries = 0;; tries++) {
+            IdFile rec{};
             std::ifstream f(id_file, std::ios::binary);
-            if (f && f.read((char *)&id, sizeof id)) break;
-            if (tries > 600) { std::fprintf(stderr, "no communicator id in %s\n", id_file.c_str()); return 1; }
+            if (f && f.read((char *)&rec, sizeof rec) && rec.magic == kMagic && rec.job == job) { id = rec.id; break; }
+            if (tries > 600) { std::fprintf(stderr, "no communicator id of job %llu in %s\n", (unsigned long long)job, id_file.c_str()); return 1; }
             std::this_thread::sleep_for(std::chrono::milliseconds(100));
         }
     }
+    if (id_only) {                      // (test hook: the rendezvous through the file, without a GPU or RCCL transport)
+        unsigned sum = 0;
+        for (size_t i = 0; i < sizeof id; i++) sum = sum * 131u + (unsigned char)((const char *)&id)[i];
+        std::printf("rank %d of %d: communicator id %08x (job %llu)\n", rank, world, sum, (unsigned long long)job);
+        return 0;
+    }
     NCCL_OK(ncclCommInitRank(&comm, comm_world, id, comm_rank));
+    g_comm = comm;
+    if (comm_rank == 0 && !id_file.empty()) std::remove(id_file.c_str());      // every rank has joined: the file has served
 
     // the slabs this process holds, all shown the same particles (each keeps its own segments')
     std::vector<Slab> local;
@@ -275,6 +311,7 @@ int main(int argc, char **argv)
         psamd_destroy(one);
     }
     for (Slab &s : local) psamd_destroy(s.ctx);
+    g_comm = nullptr;
     ncclCommDestroy(comm);
     (void)hipStreamDestroy(st);
     return rc;

@@ -267,6 +267,10 @@ typedef struct psamd_slab_buffers {
     void   *allg_out, *allg_in;            /* PSAMD_FLAG_ALL_PAIRS only, ALL-GATHERED once per step between slab_build and slab_pairs:
                                               the snapshot (x, y, z, w_eff) of every rank's own cells; allg_in = world blocks of allg_bytes */
     int64_t allg_bytes;
+    void   *xfer2_out[2], *xfer2_in[2];    /* same exchange as xfer_*, but between ranks TWO apart on the ring: out[0] -> rank-2's in[1],
+                                              out[1] -> rank+2's in[0].  Only in worlds (>= 4 ranks) where some rank's whole state is one
+                                              cell layer, which a particle crossing two layers in a step can fly over; else 0 bytes */
+    int64_t xfer2_bytes;
 } psamd_slab_buffers;
 int psamd_slab_buffers_get(psamd_ctx *ctx, psamd_slab_buffers *out);
 
@@ -291,7 +295,8 @@ int psamd_slab_apply(psamd_ctx *ctx);   /* unpacks force_in; integrate ... (calc
 int psamd_slab_finish(psamd_ctx *ctx);  /* merges xfer_in; queue replay and relocation                  */
 /* Transport through host memory (tests, two processes sharing one GPU): copy message buffer
  * `which` to / from the host.  which: 0/1 halo_out[0/1], 2/3 halo_in[0/1], 4 force_out,
- * 5 force_in, 6/7 xfer_out[0/1], 8/9 xfer_in[0/1], 10 status_out, 11 status_in, 12 allg_out, 13 allg_in. */
+ * 5 force_in, 6/7 xfer_out[0/1], 8/9 xfer_in[0/1], 10 status_out, 11 status_in, 12 allg_out, 13 allg_in,
+ * 14/15 xfer2_out[0/1], 16/17 xfer2_in[0/1]. */
 int psamd_slab_msg_download(psamd_ctx *ctx, int which, void *host, int64_t bytes);
 int psamd_slab_msg_upload(psamd_ctx *ctx, int which, const void *host, int64_t bytes);
 

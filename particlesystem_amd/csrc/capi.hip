@@ -41,8 +41,8 @@ struct psamd_ctx {
     int halo_out_c0[2] = {0, 0}, halo_out_cells[2] = {0, 0}, halo_in_cells[2] = {0, 0};
     int *force_out = nullptr, *force_in = nullptr;
     size_t force_out_bytes = 0, force_in_bytes = 0;
-    int *xfer_out[2] = {nullptr, nullptr}, *xfer_in[2] = {nullptr, nullptr};
-    size_t xfer_bytes = 0;
+    int *xfer_out[4] = {nullptr, nullptr, nullptr, nullptr}, *xfer_in[4] = {nullptr, nullptr, nullptr, nullptr};   // [2], [3]: two ranks below / above
+    size_t xfer_bytes = 0, xfer2_bytes = 0;
     int *status_out = nullptr, *status_in = nullptr;   // status_in: world records, all-gathered
     size_t status_bytes = 0;
     int *allg_out = nullptr, *allg_in = nullptr;       // all-pairs across ranks: own snapshot block, all ranks' blocks (all-gathered)
@@ -367,6 +367,23 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     if (cfg->drag < 0) return fail(c, PSAMD_ERR_INVALID_ARG, "drag must be >= 0");
     fill_slab_params(g, c->plan, *cfg, P);
     P.status_words = STATUS_CHUNK_OFF + 4 * g.num_chunks;
+    if (cfg->world > 1) {
+        // the ring neighbours' queue records; and whether any rank's whole state is ONE cell layer: a particle
+        // that crosses two layers in a step (from one ulp below a face, moved by exactly CELL_SIZE) can fly over
+        // such a rank, to the rank beyond it -- those records get outboxes of their own, sent straight to rank +-2
+        bool single = false;
+        psamd_config rc = *cfg;
+        for (int r = 0; r < cfg->world; r++) {
+            rc.rank = r;
+            const SlabPlan pr = plan_for(g, rc);
+            if (!pr.valid) return fail(c, PSAMD_ERR_UNSUPPORTED, "no slab partition for this grid and world size");
+            single |= pr.state_hi - pr.state_lo < 2;
+            const int which = r == (cfg->rank + cfg->world - 1) % cfg->world ? 0 : -1, which2 = r == (cfg->rank + 1) % cfg->world ? 1 : -1;
+            for (int w : {which, which2})
+                if (w >= 0) for (int t = 0; t < 4; t++) { P.nbr_rec_lo[w][t] = pr.rec_lo[t]; P.nbr_rec_hi[w][t] = pr.rec_hi[t]; }
+        }
+        P.xfer2_cap = (single && cfg->world >= 4) ? 1024 : 0;       // (a ring of two or three has no rank beyond the neighbours)
+    }
     if ((cfg->flags & PSAMD_FLAG_ALL_PAIRS) && cfg->world > 1) {
         // every rank's block of the all-gathered snapshot has the same size: room for the rank with the most cells / slots
         int cells = 0;
@@ -421,7 +438,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     const size_t C = (size_t)P.slots_total;          // owned slots
     const size_t SC = (size_t)P.sorted_cap + 64;     // sorted-order arrays (+ slack: scalar loads fetch whole groups)
     const size_t LC = (size_t)P.n_local_cells;
-    const size_t xf = (size_t)P.xfer_cap;
+    const size_t xf = (size_t)P.xfer_cap + (size_t)P.xfer2_cap;
     d.ops_cap = (int)std::min<size_t>(3 * C + 2 * xf + 64 + (P.world > 1 ? (size_t)P.world * STATUS_KILL_CAP : 0), (size_t)INT32_MAX / 2);
     d.moves_cap = (int)std::min<size_t>(2 * C + 2 * xf + 64, (size_t)INT32_MAX / 2);
     int *frame = nullptr;
@@ -536,11 +553,14 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
             PS_HIP(c, hipMemsetAsync(c->force_in, 0, c->force_in_bytes, c->stream));
         }
         c->xfer_bytes = ((size_t)MSG_HEADER_WORDS + xf * (sizeof(XferRec) / sizeof(int))) * sizeof(int);
-        for (int k = 0; k < 2; k++) {
-            PS_HIP(c, dev_alloc(c, &c->xfer_out[k], c->xfer_bytes / sizeof(int)));
-            PS_HIP(c, dev_alloc(c, &c->xfer_in[k], c->xfer_bytes / sizeof(int)));
-            PS_HIP(c, hipMemsetAsync(c->xfer_out[k], 0, c->xfer_bytes, c->stream));
-            PS_HIP(c, hipMemsetAsync(c->xfer_in[k], 0, c->xfer_bytes, c->stream));
+        c->xfer2_bytes = P.xfer2_cap > 0 ? ((size_t)MSG_HEADER_WORDS + (size_t)P.xfer2_cap * (sizeof(XferRec) / sizeof(int))) * sizeof(int) : 0;
+        for (int k = 0; k < 4; k++) {
+            const size_t bytes = k < 2 ? c->xfer_bytes : c->xfer2_bytes;
+            if (bytes == 0) continue;
+            PS_HIP(c, dev_alloc(c, &c->xfer_out[k], bytes / sizeof(int)));
+            PS_HIP(c, dev_alloc(c, &c->xfer_in[k], bytes / sizeof(int)));
+            PS_HIP(c, hipMemsetAsync(c->xfer_out[k], 0, bytes, c->stream));
+            PS_HIP(c, hipMemsetAsync(c->xfer_in[k], 0, bytes, c->stream));
             d.xfer_out[k] = reinterpret_cast<XferRec *>(c->xfer_out[k] + MSG_HEADER_WORDS);
         }
         if (P.flags & PSAMD_FLAG_ALL_PAIRS) {
@@ -1004,8 +1024,7 @@ static int do_apply(psamd_ctx *c)
     if (c->timing) (void)hipEventRecord(c->ev[7], c->stream);
     PS_HIP(c, launch_apply(c->stream, c->P, c->S, c->d, c->step));
     if (c->P.world > 1)
-        PS_HIP(c, launch_outbox_close(c->stream, c->P, c->d, c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total,
-                                      c->xfer_out[0], c->xfer_out[1]));
+        PS_HIP(c, launch_outbox_close(c->stream, c->P, c->d, c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total, c->xfer_out));
     return PSAMD_OK;
 }
 
@@ -1014,9 +1033,9 @@ static int do_lifecycle(psamd_ctx *c)
 {
     const int par = (int)(c->steps_total & 1);   // not c->step: a snapshot restore rewinds that
     if (c->timing) (void)hipEventRecord(c->ev[par ? 11 : 8], c->stream);
-    if (c->P.world > 1) PS_HIP(c, launch_inbox_merge(c->stream, c->P, c->d, c->xfer_in[0], c->xfer_in[1]));
+    if (c->P.world > 1) PS_HIP(c, launch_inbox_merge(c->stream, c->P, c->d, c->xfer_in));
     // live_bound < 0: unknown (state was uploaded) -> size for every owned slot; arrivals on top
-    const int64_t bound = (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) + 2 * (int64_t)c->P.xfer_cap
+    const int64_t bound = (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) + 2 * (int64_t)c->P.xfer_cap + 2 * (int64_t)c->P.xfer2_cap
                           + (c->P.world > 1 ? (int64_t)c->P.world * STATUS_KILL_CAP : 0);
     PS_HIP(c, launch_ops_bucket(c->stream, c->P, c->d, c->geo.queue_infos, bound));
     // one small read-back per step, as the reference's driver does for hostGridMax
@@ -1216,6 +1235,8 @@ int psamd_slab_buffers_get(psamd_ctx *c, psamd_slab_buffers *o)
         o->halo_out_bytes[k] = (int64_t)c->halo_out_bytes[k]; o->halo_in_bytes[k] = (int64_t)c->halo_in_bytes[k];
         o->xfer_out[k] = c->xfer_out[k]; o->xfer_in[k] = c->xfer_in[k];
     }
+    for (int k = 0; k < 2; k++) { o->xfer2_out[k] = c->xfer_out[2 + k]; o->xfer2_in[k] = c->xfer_in[2 + k]; }
+    o->xfer2_bytes = (int64_t)c->xfer2_bytes;
     o->force_out = c->force_out; o->force_in = c->force_in;
     o->force_out_bytes = (int64_t)c->force_out_bytes; o->force_in_bytes = (int64_t)c->force_in_bytes;
     o->xfer_bytes = (int64_t)c->xfer_bytes;
@@ -1237,6 +1258,8 @@ static bool slab_msg(psamd_ctx *c, int which, int *&ptr, size_t &bytes)
     case 11: ptr = c->status_in; bytes = c->status_bytes * (size_t)std::max(1, c->P.world); return true;
     case 12: ptr = c->allg_out; bytes = c->allg_bytes; return true;
     case 13: ptr = c->allg_in; bytes = c->allg_bytes * (size_t)std::max(1, c->P.world); return true;
+    case 14: case 15: ptr = c->xfer_out[which - 12]; bytes = c->xfer2_bytes; return true;
+    case 16: case 17: ptr = c->xfer_in[which - 14]; bytes = c->xfer2_bytes; return true;
     }
     return false;
 }

@@ -77,7 +77,11 @@ struct DevParams {
     // allg_block words: 16 header | allg_cells cell counts | 4 planes (x, y, z, w_eff) of allg_cap floats
     int32_t allg_cells, allg_cap, allg_block;
     int32_t status_words;    // words of one rank's status record
+    // the ring neighbours' QUEUE_INFO records (0: the rank below, 1: above): which of them a departing record is for
+    int32_t nbr_rec_lo[2][4], nbr_rec_hi[2][4];
+    int32_t xfer2_cap;       // records per step and direction that may go TWO ranks away (0: no rank of this world can be flown over)
 };
+
 
 // All-pairs force pass.  The cells beyond the stencil are found by GLOBAL cell in a snapshot buffer (the own
 // one, or the all-gathered one of all ranks): x at buf[start], y, z, w_eff at multiples of `plane` behind.
@@ -169,6 +173,12 @@ PS_HD int slot_of_index(const DevParams &P, int idx)
     return P.slot_lo[3] + idx;
 }
 
+PS_HD bool nbr_owns_record(const DevParams &P, int which, int rec)      // which: 0 the rank below, 1 the rank above
+{
+    for (int t = 0; t < 4; t++) if (rec >= P.nbr_rec_lo[which][t] && rec < P.nbr_rec_hi[which][t]) return true;
+    return false;
+}
+
 PS_HD bool owns_record(const DevParams &P, int rec)
 {
     for (int t = 0; t < 4; t++) if (rec >= P.rec_lo[t] && rec < P.rec_hi[t]) return true;
@@ -186,7 +196,7 @@ struct FrameScalars {
     int32_t n_tasks;        // non-empty (cell, slice) tasks of the pair kernel this frame
     int32_t n_tasks2;       // two-pass mode: (cell, 64-slice) tasks over the particles that need a force
     int32_t n_merged;       // ... and merged tasks (up to four cells' partly filled last slices in one wave)
-    int32_t n_out[2];       // slab mode: relocation / birth records leaving for the rank below [0] / above [1]
+    int32_t n_out[4];       // slab mode: relocation / birth records leaving for the rank below [0] / above [1], two ranks below [2] / above [3]
     int32_t n_lent;         // slab mode: bodies in the lent-in region this frame
     int32_t chunk_over;     // a chunk's count passed MAX_PARTICLES_PER_CHUNK this frame: the tail of its list is skipped (k_chunk_cap)
     int32_t status_error;   // slab mode: OR of the error bits in this step's all-gathered status records (every rank sees the same word)
@@ -231,6 +241,7 @@ constexpr int MOVE_PARENT = 0x100;   // the relocating particle has is_parent se
 constexpr int MOVE_IN = 0x200;       // arrived from a neighbour rank: state already in the staging area, no local source
 constexpr int MOVE_OUT = 0x400;      // leaves for a neighbour rank (whose queue hands out the slot); | MOVE_UP: the rank above
 constexpr int MOVE_UP = 0x800;
+constexpr int MOVE_HOP2 = 0x1000;    // ... two ranks away (a two-layer jump over a rank whose state is a single layer)
 
 // One particle on its way to a segment another rank owns (relocation or birth): the queue
 // operation's key in the reference's serial order, and the state to place.  64 bytes.

@@ -27,6 +27,7 @@ import numpy as np
 # message slots, as in psamd_slab_msg_download: out/in x below/above; the status record is all-gathered
 HALO_OUT, HALO_IN, FORCE_OUT, FORCE_IN, XFER_OUT, XFER_IN, STATUS_OUT, STATUS_IN = 0, 2, 4, 5, 6, 8, 10, 11
 ALLG_OUT, ALLG_IN = 12, 13          # all-pairs forces only: every rank's snapshot block, all-gathered between build and pairs
+XFER2_OUT, XFER2_IN = 14, 16        # particles changing owner to a rank TWO away (worlds where a single-layer rank can be flown over)
 BELOW, ABOVE = 0, 1
 
 
@@ -42,6 +43,9 @@ def routes(rank, world, periodic_ring=True):
     if world > 1:
         r.append(("xfer", XFER_OUT + BELOW, (rank - 1) % world, XFER_IN + ABOVE))
         r.append(("xfer", XFER_OUT + ABOVE, (rank + 1) % world, XFER_IN + BELOW))
+    if world >= 4:      # (0 bytes unless the plan has a rank whose whole state is one layer)
+        r.append(("xfer", XFER2_OUT + BELOW, (rank - 2) % world, XFER2_IN + ABOVE))
+        r.append(("xfer", XFER2_OUT + ABOVE, (rank + 2) % world, XFER2_IN + BELOW))
     return r
 
 
@@ -60,7 +64,7 @@ def step_local(ranks, overlap_interior=False):
     def deliver(phase):
         for r, sysr in enumerate(ranks):
             for ph, out_slot, peer, in_slot in routes(r, world):
-                n = sysr.msg_bytes(out_slot)
+                n = _bytes(sysr, out_slot)
                 if ph != phase or n == 0:
                     continue
                 assert ranks[peer].msg_bytes(in_slot) == n, (phase, r, peer, n, ranks[peer].msg_bytes(in_slot))
@@ -95,12 +99,12 @@ class _Ring:
         self.sends = {}      # phase -> [(out slot, peer)]
         self.recvs = {}      # phase -> [(in slot, peer)]
         for ph, out_slot, peer, _ in routes(rank, world):
-            if sysr.msg_bytes(out_slot):
+            if _bytes(sysr, out_slot):
                 self.sends.setdefault(ph, []).append((out_slot, peer))
-        # what the neighbours send here: their routes, seen from this side
-        for peer in sorted({(rank - 1) % world, (rank + 1) % world}):
+        # what the neighbours (and, hop two, their neighbours) send here: their routes, seen from this side
+        for peer in sorted({(rank - 1) % world, (rank + 1) % world, (rank - 2) % world, (rank + 2) % world} - {rank}):
             for ph, _, dst, in_slot in routes(peer, world):
-                if dst == rank and sysr.msg_bytes(in_slot):
+                if dst == rank and _bytes(sysr, in_slot):
                     self.recvs.setdefault(ph, []).append((in_slot, peer))
         # both sides must post the operations between one pair of ranks in the same order
         # (RCCL matches sends and receives of a pair by order, there are no tags): order every
@@ -194,7 +198,9 @@ class DeviceRing(_Ring):
                 XFER_OUT + 0: (b.xfer_out[0], b.xfer_bytes), XFER_OUT + 1: (b.xfer_out[1], b.xfer_bytes),
                 XFER_IN + 0: (b.xfer_in[0], b.xfer_bytes), XFER_IN + 1: (b.xfer_in[1], b.xfer_bytes),
                 STATUS_OUT: (b.status_out, b.status_bytes), STATUS_IN: (b.status_in, b.status_bytes * world),
-                ALLG_OUT: (b.allg_out, b.allg_bytes), ALLG_IN: (b.allg_in, b.allg_bytes * world)}
+                ALLG_OUT: (b.allg_out, b.allg_bytes), ALLG_IN: (b.allg_in, b.allg_bytes * world),
+                XFER2_OUT + 0: (b.xfer2_out[0], b.xfer2_bytes), XFER2_OUT + 1: (b.xfer2_out[1], b.xfer2_bytes),
+                XFER2_IN + 0: (b.xfer2_in[0], b.xfer2_bytes), XFER2_IN + 1: (b.xfer2_in[1], b.xfer2_bytes)}
         self.t = {slot: torch.as_tensor(_DevPtr(p, n), device="cuda") for slot, (p, n) in ptrs.items() if p and n}
         self.stream = torch_stream
         sysr.set_stream(torch_stream.cuda_stream)

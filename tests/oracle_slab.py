@@ -11,7 +11,7 @@ import numpy as np
 
 import oracle_py as O
 import particlesystem_amd as ps
-from particlesystem_amd.slab import FORCE_IN, FORCE_OUT, HALO_IN, HALO_OUT, XFER_IN, XFER_OUT
+from particlesystem_amd.slab import ALLG_IN, ALLG_OUT, FORCE_IN, FORCE_OUT, HALO_IN, HALO_OUT, XFER_IN, XFER_OUT
 
 OP_WORDS = O.OP_DTYPE.itemsize // 4
 
@@ -22,9 +22,15 @@ def group_of_layer(i3, D):
 
 
 class OracleSlabRank:
-    def __init__(self, cfg, xfer_cap=4096):
-        """cfg: a particlesystem_amd Config (rank, world and the reference constants)."""
+    def __init__(self, cfg, xfer_cap=4096, all_pairs=False):
+        """cfg: a particlesystem_amd Config (rank, world and the reference constants).
+        all_pairs: the stand-in of PSAMD_FLAG_ALL_PAIRS across ranks -- every rank contributes the
+        snapshot of its own cells to an all-gather (slots ALLG_OUT / ALLG_IN) and adds, to the cutoff
+        forces of the particles it computes, the field of every cell beyond their stencil, summed per
+        cell in fp32 and then over the cells in global order (numpy; what is compared is a world of N
+        stand-ins against a world of one, which see the same arrays in the same order)."""
         self.cfg = cfg
+        self.all_pairs = all_pairs
         self.plan = ps.slab_plan(cfg)                      # host-only geometry, no GPU involved
         ocfg = O.default_config(**{k: getattr(cfg, k) for k in
                                    ("max_particles_num", "x_factor", "chunk_factor", "chunk_dim", "cell_size", "eps2",
@@ -46,7 +52,16 @@ class OracleSlabRank:
                       HALO_IN + 0: halo_words(lay(p.below_lo, p.below_hi)), HALO_IN + 1: halo_words(lay(p.above_lo, p.above_hi)),
                       FORCE_OUT: force_words(lay(p.lentin_lo, p.lentin_hi)), FORCE_IN: force_words(lay(p.lentout_lo, p.lentout_hi)),
                       XFER_OUT + 0: xfer_words, XFER_OUT + 1: xfer_words, XFER_IN + 0: xfer_words, XFER_IN + 1: xfer_words,
-                      10: 0, 11: 0}        # no status record: this stand-in neither overflows cells nor fails
+                      10: 0, 11: 0,        # no status record: this stand-in neither overflows cells nor fails
+                      ALLG_OUT: 0, ALLG_IN: 0}
+        if all_pairs:
+            plans = [ps.slab_plan(ps.default_config(**dict({k: getattr(cfg, k) for k in ("max_particles_num", "x_factor", "chunk_factor", "chunk_dim")},
+                                                           rank=r, world=p.world))) for r in range(p.world)]
+            self.ag_cells = max(q.state_hi - q.state_lo for q in plans) * self.GG
+            self.ag_cap = int(cfg.max_particles_num)
+            self.ag_words = 16 + self.ag_cells + 5 * self.ag_cap
+            self.sizes[ALLG_OUT] = self.ag_words
+            self.sizes[ALLG_IN] = self.ag_words * p.world
         self.msgs = {k: np.zeros(n, np.int32) for k, n in self.sizes.items()}
         self.sent = 0
 
@@ -132,6 +147,65 @@ class OracleSlabRank:
             self._pack_layers(p.send_down_lo, p.send_down_hi, HALO_OUT + 0)
         if self.sizes[HALO_OUT + 1]:
             self._pack_layers(p.send_up_lo, p.send_up_hi, HALO_OUT + 1)
+        if self.all_pairs:
+            self._pack_snapshot()
+
+    # ---- all-pairs: the snapshot block of the own cells, and the far field from all ranks' blocks ----
+    def _pack_snapshot(self):
+        p, m = self.plan, self.msgs[ALLG_OUT]
+        cells = list(self._cells(p.state_lo, p.state_hi))
+        cg, t = self.o.cellgrid, self.o.tdata
+        m[:] = 0
+        m[0], m[3] = len(cells), cells[0]
+        body = m[16 + self.ag_cells:].reshape(5, self.ag_cap)
+        at = 0
+        for j, c in enumerate(cells):
+            n = int(cg[c, 0])
+            m[16 + j] = n
+            rows = t[cg[c, 1:1 + n]]
+            for k, f in enumerate(("x", "y", "z", "w", "age")):
+                body[k, at:at + n] = rows[f].view(np.int32)
+            at += n
+        m[1] = at
+
+    def _far_field(self, st):
+        """adds, for every particle this rank computes that feels a force, the field of the cells beyond its stencil"""
+        p, G, GG = self.plan, self.G, self.GG
+        blocks = self.msgs[ALLG_IN] if p.world > 1 else self.msgs[ALLG_OUT]
+        ncells_total = G * GG
+        count = np.zeros(ncells_total, np.int64)
+        planes = []
+        for r in range(p.world if p.world > 1 else 1):
+            b = blocks[r * self.ag_words:(r + 1) * self.ag_words]
+            nc, nb, first = int(b[0]), int(b[1]), int(b[3])
+            count[first:first + nc] = b[16:16 + nc]
+            planes.append(b[16 + self.ag_cells:].reshape(5, self.ag_cap)[:, :nb].view(np.float32))
+        bx, by, bz, bw, bage = np.concatenate(planes, axis=1)             # ranks hold ascending layers: global cell order
+        kid = np.float32(self.cfg.life_steps * self.cfg.dt / 10.0)
+        w_eff = np.where(bage < kid, np.float32(0), bw).astype(np.float32)
+        start = np.concatenate([[0], np.cumsum(count)])
+        cell_of_body = np.repeat(np.arange(ncells_total), count)
+        b3, b1, b2 = cell_of_body // GG, (cell_of_body % GG) // G, cell_of_body % G
+        seg = start[:-1][count > 0]                                        # reduceat boundaries: the non-empty cells
+        eps = np.float32(self.cfg.eps2)
+        cg, part = self.o.cellgrid, self.o.particles
+        for c in self._cells(p.cut_lo, p.cut_hi):
+            n = int(cg[c, 0])
+            if n == 0 or len(bx) == 0:
+                continue
+            i3, i1, i2 = c // GG, (c % GG) // G, c % G
+            far = (np.abs(b3 - i3) > 1) | (np.abs(b1 - i1) > 1) | (np.abs(b2 - i2) > 1)
+            wf = np.where(far, w_eff, np.float32(0))
+            for e in range(n):
+                gi = int(st[c]) + e
+                pid = int(cg[c, 1 + e])
+                if self.force[gi, 3].view(np.int32) != 0 or part["age"][pid] < kid:
+                    continue
+                rx, ry, rz = bx - part["x"][pid], by - part["y"][pid], bz - part["z"][pid]
+                d = (rx * rx + ry * ry + rz * rz + eps).astype(np.float32)
+                sc = (wf / (d * np.sqrt(d))).astype(np.float32)
+                per_cell = np.stack([np.add.reduceat(rx * sc, seg), np.add.reduceat(ry * sc, seg), np.add.reduceat(rz * sc, seg)], 1)
+                self.force[gi, :3] += per_cell.sum(0, dtype=np.float32)
 
     def slab_pairs_interior(self):
         pass                                   # an optimisation of the product (overlap); nothing to model
@@ -146,6 +220,8 @@ class OracleSlabRank:
         st = self._sorted_start()
         self.force = np.zeros((int(st[-1]) + 8, 4), np.float32)
         self.o.calc_pairs(int(st[p.cut_lo * self.GG]), int(st[p.cut_hi * self.GG]), self.force)
+        if self.all_pairs:
+            self._far_field(st)
         if self.sizes[FORCE_OUT]:
             a, b = int(st[p.lentin_lo * self.GG]), int(st[p.lentin_hi * self.GG])
             m = self.msgs[FORCE_OUT]

@@ -346,3 +346,48 @@ def test_slab_two_layer_jump_across_a_cut():
             assert jumps.count(2) >= n // 2, "the scenario must contain two-layer jumps (8 -> 10 across the cut at 9)"
     for g in ranks:
         g.close()
+
+
+def test_slab_two_layer_jump_over_a_single_layer_rank():
+    """A 15^3 grid (3-cell chunks) cut every two layers: rank 3 of 7 holds ONE layer of state (layer 7,
+    the interior layer of chunk layer 2).  Particles in layer 6, a hair below the face z = 0, move by
+    exactly one CELL_SIZE: the rounded sum lands ON the face 5 -- layer 8, two layers up, which belongs
+    to rank 4.  The record flies over rank 3: it travels in the hop-two outbox, rank 2 -> rank 4
+    (psamd_slab_buffers.xfer2_*), and takes its slot from rank 4's queue in the reference's serial
+    order (ps.cpp:1335-1374 relocates to any segment).  This used to be a refusal (ERR_SLAB_MISMATCH)."""
+    n = 1600                                            # (800 jumpers: the hop-two messages have room for 1024 records)
+    rng = np.random.default_rng(181)
+    xyz = np.zeros((n, 3), np.float32)
+    xyz[:, 0] = rng.uniform(-34, 39, n)                 # (an odd grid is not centred: i = floor(c / 5) + 7, c in [-35, 40))
+    xyz[:, 1] = rng.uniform(-39, 34, n)
+    xyz[:, 2] = np.float32(1e-10)                       # -z = -1e-10: layer 6 (of 0..14), a hair below the face
+    xyz[n // 2:, 2] = rng.uniform(0.5, 4.5, n - n // 2)     # and ordinary particles of layer 6, one layer per step
+    v = np.zeros((n, 3), np.float32)
+    v[:, 2] = -300.0                                    # -z grows: up the layers; clamped to one CELL_SIZE per step
+    age = np.full(n, 3.0, np.float32)
+    fert = (1e6 + np.arange(n)).astype(np.float32)
+    over = dict(collision_radius=0.0, chunk_factor=5, chunk_dim=3, max_particles_num=60000, cuts=[0, 2, 4, 6, 8, 10, 12, 15])
+    world = 7
+    ranks = [ps.ParticleSystem(ps.default_config(rank=r, world=world, **over)) for r in range(world)]
+    assert ranks[3].slab_plan().state_hi - ranks[3].slab_plan().state_lo == 1
+    assert ranks[2].msg_bytes(ps.MSG_XFER2_OUT + 1) > 0
+    o = O.System(oracle_cfg_from(ranks[0].cfg))
+    ids = o.fill(xyz, age=age, fert_age=fert)
+    p = o.particles
+    p["vx"][ids], p["vy"][ids], p["vz"][ids] = v.T
+    for g in ranks:
+        g.fill_particles(xyz, age=age, fert_age=fert, vxyz=v)
+    GG = 15 * 15
+    layer0 = {int(t): int(c) // GG for t, c in zip(p["fertility_age"][ids], p["cell"][ids])}
+    flew = 0
+    for step in range(4):
+        step_local(ranks); o.step(1)
+        compare_world(ranks, o, "jump over a single-layer rank, step %d" % (step + 1))
+        flew += int(ranks[2].msg_download(ps.MSG_XFER2_OUT + 1)[0])
+        if step == 0:
+            live = o.particles["cell"] >= 0
+            jumps = [int(c) // GG - layer0[int(t)] for t, c in zip(o.particles["fertility_age"][live], o.particles["cell"][live])]
+            assert jumps.count(2) >= n // 2 - 5, "the scenario must contain two-layer jumps (6 -> 8 over rank 3's layer 7)"
+    assert flew >= n // 2 - 5, "the records must have gone two ranks up in one hop"
+    for g in ranks:
+        g.close()

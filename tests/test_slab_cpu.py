@@ -136,15 +136,28 @@ def gloo_inputs():
     return xyz, rng.uniform(15 / 7, 7.5, N_GLOO).astype(np.float32), (1e6 + np.arange(N_GLOO)).astype(np.float32)
 
 
+def allpairs_inputs():
+    xyz = g2_cloud()
+    n = len(xyz)
+    rng = np.random.default_rng(29)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    age[::19] = 0.5                                   # kids: feel and exert nothing
+    return xyz, age, (1e6 + np.arange(n)).astype(np.float32)
+
+
+STEPS_ALLPAIRS = 4
+
+
 def _worker():
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    xyz, age, fert = gloo_inputs()
-    s = OracleSlabRank(ps.default_config(rank=rank, world=world))
+    allp = os.environ.get("PS_ALLPAIRS") == "1"
+    xyz, age, fert = allpairs_inputs() if allp else gloo_inputs()
+    s = OracleSlabRank(ps.default_config(rank=rank, world=world), all_pairs=allp)
     s.fill_particles(xyz, age, fert)
     ring = HostRing(s, dist, rank, world)
-    for _ in range(STEPS_GLOO):
+    for _ in range(STEPS_ALLPAIRS if allp else STEPS_GLOO):
         ring.step()
     out = os.environ["PS_OUT"] + ".%d.npz" % rank
     qi, q = s.download_queues()
@@ -178,6 +191,38 @@ def test_gloo_job_matches_serial(tmp_path, world):
     q = merge_owned([g["q"] for g in got], plans)
     assert state_hash(p, qi, q) == state_hash(ref.particles, ref.queue_info, ref.queue)
     assert sum(int(g["sent"]) for g in got) > 0 and sum(int(g["reloc"]) for g in got) == ref.counters["relocations"] > 0
+
+
+@pytest.mark.timeout(600)
+def test_gloo_job_all_pairs_snapshot_gather(tmp_path):
+    """All-pairs forces across ranks: every rank contributes the snapshot of its
+    own cells to an ALL-GATHER between slab_build and slab_pairs (slab.HostRing.gather_snapshot, the
+    same call sequence DeviceRing makes with RCCL's ncclAllGather) and adds the far field of all
+    ranks' cells to its particles.  A world_size-2 gloo job of stand-in ranks must end in the state a
+    world of ONE stand-in reaches -- which sees the same bodies in the same global cell order."""
+    xyz, age, fert = allpairs_inputs()
+    one = OracleSlabRank(ps.default_config(rank=0, world=1), all_pairs=True)
+    one.fill_particles(xyz, age, fert)
+    cut = OracleSlabRank(ps.default_config(rank=0, world=1))
+    cut.fill_particles(xyz, age, fert)
+    for _ in range(STEPS_ALLPAIRS):
+        step_local([one]); step_local([cut])
+    assert one.download_particles().tobytes() != cut.download_particles().tobytes(), "the far field must matter"
+    world = 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE=str(world), PS_OUT=str(tmp_path / "rank"), PS_ALLPAIRS="1",
+               PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker"], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=560)[0] for p in procs]
+    for p, out in zip(procs, outs):
+        assert p.returncode == 0, out
+    got = [np.load(str(tmp_path / "rank") + ".%d.npz" % r) for r in range(world)]
+    plans = plans_of(world)
+    p = merge_owned([g["p"] for g in got], plans)
+    qi = merge_owned([g["qi"] for g in got], plans, "records")
+    q = merge_owned([g["q"] for g in got], plans)
+    qi1, q1 = one.download_queues()
+    assert state_hash(p, qi, q) == state_hash(one.download_particles(), qi1, q1)
 
 
 if __name__ == "__main__" and "--worker" in sys.argv:

@@ -1040,47 +1040,49 @@ __device__ __forceinline__ void pair1_exact_lean(const DevParams &P, const PairC
 __device__ __forceinline__ void collide_scan(const DevParams &P, float xi, float yi, float zi, int id_i, bool scan,
                                              const float *__restrict__ bx, const float *__restrict__ by,
                                              const float *__restrict__ bz, const int *__restrict__ bcid, int n,
-                                             bool &met_higher, bool &met_lower)
+                                             unsigned long long &hi_mask, unsigned long long &lo_mask)
 {
-    // (Two groups of eight in flight -- wait for A, send B's loads, work on A -- was tried: 45 % of
-    // this kernel's wave cycles are parked at s_waitcnt.  Slower, 241 against 211 us for the stage:
-    // nearly every group has a hit, and the scalar load of the hit's id waits for the prefetch too.)
-    constexpr int NB = 16;                      // bodies per group: 4 x 16 dwords of scalar loads in flight
+    // hi_mask / lo_mask: lanes that met a body with a higher / lower id (wave-uniform words: the
+    // bookkeeping is scalar work).  A group's sixteen bodies AND their ids arrive in one batch of scalar
+    // loads; a body's test is its distance arithmetic and one compare, the two id compares happen only
+    // for the body some lane is within reach of (about one in eight at the benchmark's density), behind
+    // a scalar branch.  (Before: a group minimum first, then -- nearly every group has a hit -- a loop of
+    // sixteen compare-and-branch steps and a scalar load of the hit's id that the walk had to wait
+    // for; that bookkeeping cost as much as the arithmetic.  Two groups of loads in flight were
+    // tried and were slower.)
+    constexpr int NB = 16;
     const v2f x2 = {xi, xi}, y2 = {yi, yi}, z2 = {zi, zi};
     const float dmax = P.coll_d2_max;
+    const unsigned uid = (unsigned)id_i;
+    const unsigned long long scan_mask = __builtin_amdgcn_ballot_w64(scan);
+    auto hit = [&](float d2, int cj) {
+        const unsigned long long hm = __builtin_amdgcn_ballot_w64(!(d2 > dmax)) & scan_mask;
+        if (hm) {
+            hi_mask |= hm & __builtin_amdgcn_ballot_w64(cj > id_i);
+            lo_mask |= hm & __builtin_amdgcn_ballot_w64((unsigned)cj < uid);      // (a body that never collides carries -1: not below any id)
+        }
+    };
     int j = 0;
     for (; j + NB <= n; j += NB) {
-        // distances of the whole group first; the ids are looked at only for the bodies some
-        // lane is actually within reach of (a couple per group at the benchmark's density)
+        // all the group's loads and distances first (one batch of scalar loads, one wait), then the tests
+        int cid[NB];
         v2f d[NB / 2];
-        float dm = 3.0e38f;
+#pragma unroll
+        for (int i = 0; i < NB; i++) cid[i] = bcid[j + i];
 #pragma unroll
         for (int i = 0; i < NB / 2; i++) {
             const v2f rx = v2f{bx[j + 2 * i], bx[j + 2 * i + 1]} - x2, ry = v2f{by[j + 2 * i], by[j + 2 * i + 1]} - y2,
                       rz = v2f{bz[j + 2 * i], bz[j + 2 * i + 1]} - z2;
             d[i] = rx * rx + ry * ry + rz * rz;
-            dm = fminf(fminf(dm, d[i].x), d[i].y);
         }
-        if (__any(scan && !(dm > dmax))) {
 #pragma unroll
-            for (int i = 0; i < NB; i++) {
-                const float di = (i & 1) ? d[i >> 1].y : d[i >> 1].x;
-                const bool h = scan && !(di > dmax);
-                if (__any(h)) {
-                    const int cj = bcid[j + i];
-                    met_higher |= h && cj > id_i;
-                    met_lower |= h && cj >= 0 && cj < id_i;
-                }
-            }
-        }
+        for (int i = 0; i < NB / 2; i++) { asm volatile("" : "+v"(d[i])); }      // (keeps the tests below the arithmetic: the loads stay one batch)
+#pragma unroll
+        for (int i = 0; i < NB / 2; i++) { hit(d[i].x, cid[2 * i]); hit(d[i].y, cid[2 * i + 1]); }
     }
     for (; j < n; j++) {
         const float rx = bx[j] - xi, ry = by[j] - yi, rz = bz[j] - zi;
-        const float d2 = rx * rx + ry * ry + rz * rz;
-        const int cj = bcid[j];
-        const bool h = scan && !(d2 > dmax);
-        met_higher |= h && cj > id_i;
-        met_lower |= h && cj >= 0 && cj < id_i;
+        hit(rx * rx + ry * ry + rz * rz, bcid[j]);
     }
 }
 
@@ -1126,15 +1128,15 @@ __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restr
     const int id_i = sorted_id[gi];
     const bool dead = age_i > P.life_thr, kid = age_i < P.kid_thr;
     const bool scan = valid && !dead && !kid;
-    bool met_higher = false, met_lower = false;
+    unsigned long long hi_mask = 0, lo_mask = 0;
     // own cell
     collide_scan(P, xi, yi, zi, id_i, scan, snap_soa + base, snap_soa + cap + base, snap_soa + 2 * cap + base,
-                 snap_cid + base, cnt, met_higher, met_lower);
+                 snap_cid + base, cnt, hi_mask, lo_mask);
     const int nh = __builtin_amdgcn_readfirstlane(halo_count[c]);
     if (nh <= HALO_CAP) {
         const size_t at = (size_t)c * HALO_CAP, plane = (size_t)P.n_local_cells * HALO_CAP;
         collide_scan(P, xi, yi, zi, id_i, scan, halo_f + at, halo_f + plane + at, halo_f + 2 * plane + at, halo_id + at, nh,
-                     met_higher, met_lower);
+                     hi_mask, lo_mask);
     } else {
         // the halo list overflowed (denser than the container admits in steady state): whole stencil
         int i1, i2, i3;
@@ -1145,9 +1147,10 @@ __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restr
             const int nb = __builtin_amdgcn_readfirstlane(cell_start[nc]);
             const int n = __builtin_amdgcn_readfirstlane(min(cell_start[nc + 1] - nb, P.max_per_cell));
             collide_scan(P, xi, yi, zi, id_i, scan, snap_soa + nb, snap_soa + cap + nb, snap_soa + 2 * cap + nb, snap_cid + nb, n,
-                         met_higher, met_lower);
+                         hi_mask, lo_mask);
         }
     }
+    const bool met_higher = (hi_mask >> lane) & 1ull, met_lower = (lo_mask >> lane) & 1ull;
     int flag = met_higher ? 2 : met_lower ? 1 : 0;
     if (dead) flag = 2;                                          // ps.cpp:1183
     if (valid) force4[gi] = make_float4(0.f, 0.f, 0.f, __int_as_float(flag));   // final unless the force pass overwrites it
@@ -2728,6 +2731,12 @@ __device__ __forceinline__ void moves_stage_reset(const DevParams &P, int m, Mov
     cell_arr[si] = -1; pflags[si] = 0; pos4[si] = zero; vel4[si] = zero; acc4[si] = zero;
 }
 
+// CAP: the longest list this instance holds in LDS.  Two instances are launched back to back: CAP = 2048
+// (27 KB of LDS: five workgroups per CU, every queue of the usual step at once; counting rank) serves
+// the queues with up to 2048 operations, CAP = BUCKET_MAX (104 KB, one workgroup per CU; bitonic
+// network) the longer lists -- its workgroups leave at once where there is none.  (One instance sized
+// for the longest list ran one workgroup per CU for every queue: 66 us instead of 36 for the usual step.)
+template <int CAP>
 __global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, int nrec, const int *__restrict__ rec_start,
                                                         const uint64_t *__restrict__ keys,
                                                         const int *__restrict__ args,
@@ -2750,16 +2759,19 @@ __global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, i
     RT();
     // keys + args while sorting; afterwards the same bytes hold ins_arg (closed form) or the
     // copy of the segment the serial walk works on
-    constexpr int KEY_BYTES = (BUCKET_MAX + 2) * 8, SORT_BYTES = KEY_BYTES + BUCKET_MAX * 4;
-    constexpr int RAW_BYTES = SORT_BYTES > QUEUE_WINDOW * 4 ? SORT_BYTES : QUEUE_WINDOW * 4;
+    constexpr int RANK_MAX = 2048;
+    static_assert(CAP == RANK_MAX || CAP == BUCKET_MAX, "two instances: short lists, long lists");
+    constexpr int KEY_BYTES = (CAP + 64) * 8, SORT_BYTES = KEY_BYTES + CAP * 4;
+    constexpr int RAW_BYTES = SORT_BYTES;
+    constexpr int WINDOW_SLOTS = KEY_BYTES / 4;         // largest segment the serial walk copies into the key area (4224 / 16512 slots)
     __shared__ __attribute__((aligned(16))) unsigned char raw[RAW_BYTES];
     uint64_t *kbuf = reinterpret_cast<uint64_t *>(raw);
     int *abuf = reinterpret_cast<int *>(raw + KEY_BYTES);
     int *window = reinterpret_cast<int *>(raw);
     // (the sorted args stay where the sort left them, behind the keys: the segment copy of the serial
     // walk and the insert list of the closed form both fit in the key area in front of them)
-    static_assert(QUEUE_WINDOW * 4 <= KEY_BYTES && BUCKET_MAX * 4 <= KEY_BYTES, "abuf must survive the reuse of the key area");
-    __shared__ unsigned char s_sub[BUCKET_MAX];
+    static_assert(CAP * 4 <= KEY_BYTES, "abuf must survive the reuse of the key area");
+    __shared__ unsigned char s_sub[CAP];
     constexpr int NT = REPLAY_THREADS;
     __shared__ int wave_tot[NT / 64];
     __shared__ int s_bad;
@@ -2767,15 +2779,17 @@ __global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, i
     if (lifecycle_deferred(fs)) return;
     const int start = rec_start[rec];
     const int n = min(rec_start[rec + 1] - start, BUCKET_MAX);
-    if (n == 0) return;
+    if (n == 0 || (CAP == RANK_MAX ? n > RANK_MAX : n <= RANK_MAX)) return;       // (the other instance's)
     QueueInfo q = qinfo[rec];
-    const bool in_lds = q.seg_size <= QUEUE_WINDOW;
+    const bool in_lds = q.seg_size <= WINDOW_SLOTS;
     queue += slot_index(P, q.rloc) - q.rloc;           // owned segments only, back to back
     for (int e = tid; e < n; e += NT) { kbuf[e] = keys[start + e]; abuf[e] = args[start + e]; }
     if (tid == 0) s_bad = 0;
     __syncthreads();
     RT();
-    // bitonic sort of (key, arg) in LDS, padded to a power of two with +inf keys
+    // bitonic sort of (key, arg) in LDS, padded to a power of two with +inf keys.  (Ranking by counting --
+    // every thread compares its keys with all of them, two per 16-byte broadcast read, no barriers -- was
+    // tried for the short lists: LDS-bandwidth-bound, 65 us against the network's 36 for the usual step.)
     int np = 2;
     while (np < n) np <<= 1;
     for (int e = n + tid; e < np; e += NT) { kbuf[e] = ~0ull; abuf[e] = -1; }
@@ -2803,8 +2817,8 @@ __global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, i
         }
     __syncthreads();
     for (int e = tid; e < n; e += NT) s_sub[e] = (unsigned char)(kbuf[e] & 3ull);
-    const int *s_arg = abuf;
     __syncthreads();
+    const int *s_arg = abuf;
     RT();
     int *ins_arg = (int *)kbuf;                        // keys no longer needed
 
@@ -3776,7 +3790,10 @@ hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceStat
 {
     const int64_t max_moves = std::min<int64_t>(d.moves_cap, 2 * live_bound);
     const int nb = (int)((max_moves + REPLAY_THREADS - 1) / REPLAY_THREADS);
-    k_replay_bucket<<<nrec + nb, REPLAY_THREADS, 0, st>>>(P, nrec, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
+    k_replay_bucket<2048><<<nrec + nb, REPLAY_THREADS, 0, st>>>(P, nrec, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
+                                          d.moves, d.ctr, d.fs, d.trace, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
+    PS_LAUNCH_CHECK();
+    k_replay_bucket<BUCKET_MAX><<<nrec, REPLAY_THREADS, 0, st>>>(P, nrec, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
                                           d.moves, d.ctr, d.fs, d.trace, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
     PS_LAUNCH_CHECK();
     if (nb > 0) {

@@ -81,7 +81,8 @@ def test_balanced_cuts_and_ring_routes():
             for ph, out_slot, peer, in_slot in routes(r, world):
                 assert (ph, peer, in_slot) not in got
                 got[(ph, peer, in_slot)] = (r, out_slot)
-        assert sum(1 for k in got if k[0] == "xfer") == 2 * world
+        # ring neighbours, and from four ranks on the hop-two routes (rank +-2; 0 bytes unless a rank's state is one layer)
+        assert sum(1 for k in got if k[0] == "xfer") == (2 if world < 4 else 4) * world
 
 
 def make_ranks(world, xyz, age, fert, **over):

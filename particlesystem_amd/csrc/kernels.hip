@@ -1092,6 +1092,10 @@ __device__ __forceinline__ void collide_scan(const DevParams &P, float xi, float
 // One wave per (cell, 64-particle slice) of the ordinary task list.  Writes the flag of every
 // particle and, for those that will not be integrated or feel no force (kids), the final
 // force4 record.
+// (A workgroup per cell that brings the cell's ~400 bodies into LDS once and reads them back as broadcast
+// 16-byte rows was built and measured in round 3: 133 us against this kernel's 123 -- a broadcast
+// ds_read_b128 still occupies the LDS pipe for its 64 lanes, and 6.5 M of them per launch are more than
+// the scalar cache's misses cost.)
 __global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restrict__ cell_start,
                                                  const float *__restrict__ snap_soa, const float *__restrict__ snap_age,
                                                  const int *__restrict__ sorted_id, const int *__restrict__ snap_cid,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PSAMD_ABI_VERSION 2
+#define PSAMD_ABI_VERSION 3
 
 #define PSAMD_MAX_RANKS 64
 
@@ -122,12 +122,13 @@ typedef struct psamd_device_view {
     void    *cell;        /* int[container]     cell index, -1 = free slot      */
     void    *pflags;      /* uint8[container]   bit0 = is_parent                */
     void    *sorted_id;   /* int[container]     slot ids, cell-major, id-ascending in a cell */
-    void    *snap4;       /* float4[container]  snapshot x,y,z,w_eff in sorted order */
+    void    *snap_soa;    /* float[4][sorted_cap] snapshot in sorted order: x, y, z, w_eff planes */
     void    *force4;      /* float4[container]  ax,ay,az,collision flag in sorted order */
     void    *cell_start;  /* int[num_cells+1]   exclusive prefix of cell counts */
     int64_t  container_size;
     int32_t  num_cells;
     int32_t  live;        /* live particles at the last build_grid             */
+    int64_t  sorted_cap;  /* plane stride of snap_soa, in floats                */
     void    *stream;      /* hipStream_t the stages are enqueued on            */
 } psamd_device_view;
 

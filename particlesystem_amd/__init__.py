@@ -71,9 +71,9 @@ class Counters(C.Structure):
 
 class DeviceView(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("pos4", "vel4", "acc4", "cell", "pflags", "sorted_id", "snap4", "force4", "cell_start")] + \
+                ("pos4", "vel4", "acc4", "cell", "pflags", "sorted_id", "snap_soa", "force4", "cell_start")] + \
                [("container_size", C.c_int64), ("num_cells", C.c_int32), ("live", C.c_int32),
-                ("stream", C.c_void_p)]
+                ("sorted_cap", C.c_int64), ("stream", C.c_void_p)]
 
 
 class SlabPlan(C.Structure):

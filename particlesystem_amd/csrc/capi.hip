@@ -478,7 +478,6 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.task_list, LC * P.slices));
     PS_HIP(c, dev_alloc(c, &d.sorted_id, SC));
     PS_HIP(c, dev_alloc(c, &d.rank_of_slot, C));
-    PS_HIP(c, dev_alloc(c, &d.snap4, SC));
     PS_HIP(c, dev_alloc(c, &d.snap_soa, 4 * (size_t)P.sorted_cap + 64));
     PS_HIP(c, dev_alloc(c, &d.snap_age, SC));
     PS_HIP(c, dev_alloc(c, &d.force4, SC));
@@ -1330,7 +1329,7 @@ int psamd_device_view_get(psamd_ctx *c, psamd_device_view *o)
 {
     if (!c || !o) return PSAMD_ERR_INVALID_ARG;
     o->pos4 = c->d.pos4; o->vel4 = c->d.vel4; o->acc4 = c->d.acc4; o->cell = c->d.cell; o->pflags = c->d.pflags;
-    o->sorted_id = c->d.sorted_id; o->snap4 = c->d.snap4; o->force4 = c->d.force4; o->cell_start = c->d.cell_start;
+    o->sorted_id = c->d.sorted_id; o->snap_soa = c->d.snap_soa; o->sorted_cap = c->P.sorted_cap; o->force4 = c->d.force4; o->cell_start = c->d.cell_start;
     o->container_size = c->P.slots_total; o->num_cells = c->P.n_own_cells;
     o->live = c->live_at_build;
     o->stream = (void *)c->stream;

@@ -58,8 +58,7 @@ struct DeviceState {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int *sorted_id = nullptr;     // [container] cell-major, id ascending inside a cell
     int *rank_of_slot = nullptr;  // [container] inverse of sorted_id for the slots of this frame
-    float4 *snap4 = nullptr;      // [container] sorted order: x,y,z,w_eff
-    float *snap_soa = nullptr;    // [4][container] the same as four arrays (what k_pairs streams)
+    float *snap_soa = nullptr;    // [4][sorted_cap] sorted order: x, y, z, w_eff as four arrays (what the pair walk streams)
     float *snap_age = nullptr;    // [container] sorted order
     float4 *force4 = nullptr;     // [container] sorted order: ax,ay,az,flag
     CellInfo *celltab = nullptr;  // [num_cells]

@@ -266,10 +266,16 @@ __device__ __forceinline__ void chunk_cap_block(const DevParams &P, int ch, cons
 
 // Workgroups [0, nwg): the scatter.  Workgroups [nwg, nwg + num_chunks), one GPU only: the chunk
 // lists' capacity rule for chunk blockIdx.x - nwg (chunk_cap_block; idle unless the chunk is over).
+// The scatter also writes the T_DATA snapshot rows (id, x, y, z, w, age; ps.cpp:1495-1500): here a
+// workgroup's live slots are consecutive, so are their 24-byte rows, and k_sort_cells gathers a
+// particle's snapshot from its row -- one scattered read instead of two (pos4, vel4) and no scattered
+// 24-byte row writes (which cost that kernel half again what it stored).
 __global__ __launch_bounds__(1024) void k_scatter_lds(DevParams P, int nwg, const int *__restrict__ cell, int *__restrict__ cursor,
                                                        int *__restrict__ sorted_id, const int *__restrict__ chunk_count,
                                                        const CellInfo *__restrict__ celltab, const int2 *__restrict__ chunk_segs,
-                                                       uint8_t *__restrict__ chunk_skip)
+                                                       uint8_t *__restrict__ chunk_skip,
+                                                       const float4 *__restrict__ pos4, const float4 *__restrict__ vel4,
+                                                       uint32_t *__restrict__ tdata)
 {
     if ((int)blockIdx.x >= nwg) { chunk_cap_block(P, (int)blockIdx.x - nwg, chunk_count, cell, celltab, chunk_segs, chunk_skip, nullptr); return; }
     __shared__ int h[LDS_CELLS];
@@ -306,7 +312,14 @@ __global__ __launch_bounds__(1024) void k_scatter_lds(DevParams P, int nwg, cons
         if (mine[i] >= 0) {
             const int c = mine[i];
             const int pos = c - w0 < LDS_CELLS ? atomicAdd(&h[c - w0], 1) : atomicAdd(&cursor[c], 1);
-            sorted_id[pos] = slot_of_index(P, base + i * 1024 + tid);
+            const int si = base + i * 1024 + tid, id = slot_of_index(P, si);
+            sorted_id[pos] = id;
+            const float4 p = pos4[si];
+            const float age = vel4[si].w;
+            uint2 *t = reinterpret_cast<uint2 *>(tdata + (size_t)6 * si);
+            t[0] = make_uint2((uint32_t)id, __float_as_uint(p.x));
+            t[1] = make_uint2(__float_as_uint(p.y), __float_as_uint(p.z));
+            t[2] = make_uint2(__float_as_uint(p.w), __float_as_uint(age));
         }
 }
 
@@ -495,15 +508,24 @@ __device__ __forceinline__ int halo_neighbour(const DevParams &P, int i1, int i2
     return local_cell(P, i3 + d3, i1 + d1, i2 + d2);
 }
 
+// The snapshot in sorted order is kept once, as four arrays (x, y, z, w_eff planes of snap_soa: what the
+// scalar-load walk streams); where a lane wants one body's four values, this reads them from the planes.
+// (Round 2 also kept them as an array of float4: 16 bytes per particle written and never needed.)
+struct SnapSoa {
+    const float *p;
+    size_t cap;
+    __device__ __forceinline__ float4 operator[](int i) const { return make_float4(p[i], p[cap + i], p[2 * cap + i], p[3 * cap + i]); }
+};
+
 // Collision candidates of the neighbour cells (k_collide): a body within HALO_REACH of a
 // face, edge or corner of its cell is listed in the halo of the cell(s) beyond it.  Two
 // bodies in different cells can only collide (distance <= COLLISION_RADIUS < HALO_REACH) if
 // each is in the other's halo.  Called by all threads of a workgroup for one cell whose `kept`
-// bodies start at sorted index `start` (snap4 / snap_cid / sorted_id already written): count the
+// bodies start at sorted index `start` (snap_soa / snap_cid / sorted_id already written): count the
 // cell's contributions per direction, reserve the room with one global atomic per direction,
 // then write the bodies.  s_halo / s_halo_base: 27 ints of LDS each.
 __device__ __forceinline__ void list_in_neighbour_halos(const DevParams &P, int lc, int start, int kept,
-                                                        const float4 *__restrict__ snap4, const int *__restrict__ snap_cid,
+                                                        const SnapSoa snap4, const int *__restrict__ snap_cid,
                                                         int *__restrict__ halo_count, float *__restrict__ halo_f,
                                                         int *__restrict__ halo_id, int *s_halo, int *s_halo_base,
                                                         bool counted)
@@ -564,26 +586,33 @@ __device__ __forceinline__ void list_in_neighbour_halos(const DevParams &P, int 
 // adding r*0 = +-0 leaves an fp32 sum that started at +0 bit-identical).
 // Ids ranked at or past the list capacity are the ones the reference kills
 // (ps.cpp:1517-1526): their sorted_id entry becomes -1 and the slot is reset.
+// CAP: the ids an instance ranks in LDS.  Two instances are launched back to back: CAP = 1024 (8 KB of
+// LDS: the workgroups of sixteen cells per CU in flight -- the kernel is a chain of global round trips
+// per cell, not a stream) serves the cells with up to 1024 ids, CAP = SORT_MAX (33 KB: four cells per
+// CU) the fuller ones; a workgroup leaves at once where the cell is the other instance's.
+template <int CAP>
 __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__restrict__ cell_start,
                                                      int *__restrict__ sorted_id,
                                                      float4 *pos4, float4 *vel4, float4 *acc4,
                                                      int *cell_arr, uint8_t *pflags,
-                                                     float4 *__restrict__ snap4, float *__restrict__ snap_soa,
+                                                     float *__restrict__ snap_soa,
                                                      float *__restrict__ snap_age,
-                                                     uint32_t *__restrict__ tdata, int *__restrict__ rank_of_slot,
+                                                     const uint32_t *__restrict__ tdata, int *__restrict__ rank_of_slot,
                                                      uint64_t *op_keys, int *op_args, int ops_cap,
                                                      int *__restrict__ halo_count, float *__restrict__ halo_f,
                                                      int *__restrict__ halo_id, int *__restrict__ snap_cid,
                                                      int *__restrict__ status_out, FrameScalars *fs, DevCounters *ctr)
 {
-    __shared__ __attribute__((aligned(16))) int ids[SORT_MAX + 4];
-    __shared__ int ordered[SORT_MAX];
+    constexpr int SMALL = 1024;
+    static_assert(CAP == SMALL || CAP == SORT_MAX, "two instances: ordinary cells, crowded cells");
+    __shared__ __attribute__((aligned(16))) int ids[CAP + 4];
+    __shared__ int ordered[CAP];
     __shared__ int s_halo[27], s_halo_base[27];    // bodies this cell lists in each neighbour's halo
     const int c = blockIdx.x, tid = threadIdx.x;
     if (tid < 27) s_halo[tid] = 0;
     const int start = cell_start[c];
     int n = cell_start[c + 1] - start;
-    if (n == 0) return;
+    if (n == 0 || (CAP == SMALL ? n > SMALL : n <= SMALL)) return;       // (empty, or the other instance's)
     int ci1, ci2, ci3;
     cell_coords(P, c, ci1, ci2, ci3);
     // A cell may hold more ids than fit the LDS ranking (its segment's capacity is the bound: a
@@ -629,12 +658,7 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
         for (int e = tid; e < n_all; e += 256) {
             const int id = sorted_id[start + e];
             if (id < big_limit) continue;
-            const int si = slot_index(P, id);
-            const float4 p = pos4[si];
-            const float age = vel4[si].w;
-            uint32_t *t = tdata + (size_t)6 * si;
-            t[0] = (uint32_t)id; t[1] = __float_as_uint(p.x); t[2] = __float_as_uint(p.y);
-            t[3] = __float_as_uint(p.z); t[4] = __float_as_uint(p.w); t[5] = __float_as_uint(age);
+            const int si = slot_index(P, id);                      // (its snapshot row was written by the scatter pass)
             cell_arr[si] = P.world > 1 ? -2 - cell_arr[si] : -1; pflags[si] = 0;       // (slab: the chunk-capacity walk still needs the cell, see chunk_cap_block)
             pos4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
             vel4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -673,17 +697,16 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
     __syncthreads();
     for (int e = tid; e < n; e += 256) {
         const int id = ordered[e], si = slot_index(P, id);
-        const float4 p = pos4[si];
-        const float age = vel4[si].w;
-        // the snapshot row is written before the overflow check, as in ps.cpp:1495-1500
-        uint32_t *t = tdata + (size_t)6 * si;
-        t[0] = (uint32_t)id; t[1] = __float_as_uint(p.x); t[2] = __float_as_uint(p.y);
-        t[3] = __float_as_uint(p.z); t[4] = __float_as_uint(p.w); t[5] = __float_as_uint(age);
+        // the particle's T_DATA row (written by the scatter pass for every live slot, before the overflow
+        // check as in ps.cpp:1495-1500): x, y, z, w, age in one 24-byte read
+        const uint2 *t = reinterpret_cast<const uint2 *>(tdata + (size_t)6 * si);
+        const uint2 t0 = t[0], t1 = t[1], t2 = t[2];
+        const float4 p = make_float4(__uint_as_float(t0.y), __uint_as_float(t1.x), __uint_as_float(t1.y), __uint_as_float(t2.x));
+        const float age = __uint_as_float(t2.y);
         if (e < P.max_per_cell) {
             sorted_id[start + e] = id;
             rank_of_slot[si] = start + e;
             const float w_eff = (age < P.kid_thr) ? 0.0f : (P.force_sign < 0.f ? -p.w : p.w);
-            snap4[start + e] = make_float4(p.x, p.y, p.z, w_eff);
             {   // the same four values as separate arrays: what the pair kernel streams
                 const size_t cap = (size_t)P.sorted_cap;
                 snap_soa[start + e] = p.x; snap_soa[cap + start + e] = p.y;
@@ -722,7 +745,7 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
     }
     if (!halo_count) return;
     __syncthreads();                                     // the snapshot rows of this cell are in memory
-    list_in_neighbour_halos(P, c, start, min(n, P.max_per_cell), snap4, snap_cid, halo_count, halo_f, halo_id, s_halo, s_halo_base, true);
+    list_in_neighbour_halos(P, c, start, min(n, P.max_per_cell), SnapSoa{snap_soa, (size_t)P.sorted_cap}, snap_cid, halo_count, halo_f, halo_id, s_halo, s_halo_base, true);
 }
 
 // ------------------------------------------------------------------ pair kernel
@@ -1482,7 +1505,7 @@ __device__ __forceinline__ bool handoff_consume(const float4 *slot, float &ax, f
 // SETTLED: the collision flags are known already (two-pass mode: the balanced pass) -- nothing tracks distances for them
 template <int MODE, int NQ, bool ALLP = false, bool SETTLED = false>
 __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__restrict__ cell_start,
-                                           const float4 *__restrict__ snap4, const float *__restrict__ snap_soa,
+                                           const SnapSoa snap4, const float *__restrict__ snap_soa,
                                            const float *__restrict__ snap_age, const int *__restrict__ sorted_id,
                                            float4 *__restrict__ force4, int task,
                                            float4 *tile, unsigned long long *trace,
@@ -1690,7 +1713,7 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
 
 template <int MODE, int NQ, bool ALLP>
 __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restrict__ cell_start,
-                                               const float4 *__restrict__ snap4,
+                                               const SnapSoa snap4,
                                                const float *__restrict__ snap_soa,
                                                const float *__restrict__ snap_age,
                                                const int *__restrict__ sorted_id,
@@ -1774,7 +1797,7 @@ struct TileGroups {
 // NG: how many groups the code is built for (1: an ordinary task, nothing per-group left in it; 4: a pack)
 template <int MODE, int NQ, int NG, bool ONE_T>
 __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *__restrict__ cell_start,
-                                                const float4 *__restrict__ snap4, float4 *__restrict__ force4,
+                                                const SnapSoa snap4, float4 *__restrict__ force4,
                                                 const TileGroups &G, float *tile, const int *__restrict__ active_list,
                                                 int k0, int k1, int *ready, FrameScalars *fs)
 {
@@ -1898,7 +1921,7 @@ __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *_
 //      2: scalar-load walk for the ordinary tasks, tile walk for the packs, all in one balanced list.
 template <int MODE, int NQ>
 __device__ __forceinline__ void merged_pack_task(const DevParams &P, const int *__restrict__ cell_start,
-                                                 const float4 *__restrict__ snap4,
+                                                 const SnapSoa snap4,
                                                  const int *__restrict__ active_list,
                                                  const int *__restrict__ active_count,
                                                  const int4 *__restrict__ merged_tasks,
@@ -1912,7 +1935,7 @@ __device__ __forceinline__ void merged_pack_task(const DevParams &P, const int *
 // and the stage took 0.1 ms longer.)
 template <int MODE, int NQ, int WALK>
 __global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : 4) void k_pairs_balanced(DevParams P, const int *__restrict__ cell_start,
-                                                        const float4 *__restrict__ snap4,
+                                                        const SnapSoa snap4,
                                                         const float *__restrict__ snap_soa,
                                                         const float *__restrict__ snap_age,
                                                         const int *__restrict__ sorted_id,
@@ -1988,7 +2011,7 @@ __global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : 4) void k_p
 
 template <int MODE, int NQ>
 __device__ __forceinline__ void merged_pack_task(const DevParams &P, const int *__restrict__ cell_start,
-                                                 const float4 *__restrict__ snap4,
+                                                 const SnapSoa snap4,
                                                  const int *__restrict__ active_list,
                                                  const int *__restrict__ active_count,
                                                  const int4 *__restrict__ merged_tasks,
@@ -2085,7 +2108,7 @@ __device__ __forceinline__ void merged_pack_task(const DevParams &P, const int *
 
 template <int MODE, int NQ>
 __global__ __launch_bounds__(256, 6) void k_pairs_merged(DevParams P, const int *__restrict__ cell_start,
-                                                      const float4 *__restrict__ snap4,
+                                                      const SnapSoa snap4,
                                                       const int *__restrict__ active_list,
                                                       const int *__restrict__ active_count,
                                                       const int4 *__restrict__ merged_tasks,
@@ -3078,7 +3101,7 @@ __global__ __launch_bounds__(1024) void k_halo_prefix_out(DevParams P, HaloOut2 
 // one workgroup per cell of the messages; the first one also closes the rank's status record (everything
 // the build stage can raise has been raised by now)
 __global__ __launch_bounds__(256) void k_halo_bodies_out(DevParams P, HaloOut2 H, const int *__restrict__ cell_start,
-                                                          const float4 *__restrict__ snap4,
+                                                          const SnapSoa snap4,
                                                           const float *__restrict__ snap_age, const int *__restrict__ sorted_id,
                                                           int *__restrict__ status_out, const FrameScalars *__restrict__ fs)
 {
@@ -3151,7 +3174,7 @@ __global__ __launch_bounds__(1024) void k_halo_prefix_in(DevParams P, HaloIn2 H,
 }
 
 __global__ __launch_bounds__(256) void k_halo_bodies_in(DevParams P, HaloIn2 H,
-                                                         const int *__restrict__ cell_start, float4 *__restrict__ snap4,
+                                                         const int *__restrict__ cell_start,
                                                          float *__restrict__ snap_soa, float *__restrict__ snap_age,
                                                          int *__restrict__ sorted_id, int *__restrict__ snap_cid)
 {
@@ -3168,7 +3191,6 @@ __global__ __launch_bounds__(256) void k_halo_bodies_in(DevParams P, HaloIn2 H,
         const float x = body[src + e], y = body[cap + src + e], z = body[2 * cap + src + e], w = body[3 * cap + src + e],
                     age = body[4 * cap + src + e];
         const int id = reinterpret_cast<const int *>(body)[5 * cap + src + e];
-        snap4[dst + e] = make_float4(x, y, z, w);
         snap_soa[dst + e] = x; snap_soa[sc + dst + e] = y; snap_soa[2 * sc + dst + e] = z; snap_soa[3 * sc + dst + e] = w;
         snap_age[dst + e] = age;
         sorted_id[dst + e] = id;
@@ -3180,7 +3202,7 @@ __global__ __launch_bounds__(256) void k_halo_bodies_in(DevParams P, HaloIn2 H,
 // does for the own cells.  One workgroup per remote cell: the local cells [lo[i], hi[i]) of up to three regions.
 struct CellRanges3 { int lo[3], hi[3]; };
 __global__ __launch_bounds__(256) void k_remote_halo_lists(DevParams P, CellRanges3 R, const int *__restrict__ cell_start,
-                                                           const float4 *__restrict__ snap4, const int *__restrict__ snap_cid,
+                                                           const SnapSoa snap4, const int *__restrict__ snap_cid,
                                                            int *__restrict__ halo_count, float *__restrict__ halo_f,
                                                            int *__restrict__ halo_id)
 {
@@ -3551,11 +3573,15 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[2], st);
     k_scatter_lds<<<nwg + (P.world == 1 ? P.num_chunks : 0), 1024, 0, st>>>(P, nwg, d.cell, d.cursor, d.sorted_id, d.chunk_count, d.celltab,
-                                                                             d.chunk_segs, d.chunk_skip);
+                                                                             d.chunk_segs, d.chunk_skip, d.pos4, d.vel4, d.tdata);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[3], st);
-    k_sort_cells<<<P.n_own_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
-                                               d.pflags, d.snap4, d.snap_soa, d.snap_age, d.tdata, d.rank_of_slot, d.op_keys, d.op_args, d.ops_cap,
+    k_sort_cells<1024><<<P.n_own_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
+                                               d.pflags, d.snap_soa, d.snap_age, d.tdata, d.rank_of_slot, d.op_keys, d.op_args, d.ops_cap,
+                                               P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.snap_cid, d.status_out, d.fs, d.ctr);
+    PS_LAUNCH_CHECK();
+    k_sort_cells<SORT_MAX><<<P.n_own_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
+                                               d.pflags, d.snap_soa, d.snap_age, d.tdata, d.rank_of_slot, d.op_keys, d.op_args, d.ops_cap,
                                                P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.snap_cid, d.status_out, d.fs, d.ctr);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[4], st);
@@ -3576,7 +3602,7 @@ hipError_t launch_pack_halos(hipStream_t st, const DevParams &P, const DeviceSta
         PS_LAUNCH_CHECK();
     }
     const int blocks = std::max(1, H.h[0].ncell + (H.n > 1 ? H.h[1].ncell : 0));
-    k_halo_bodies_out<<<blocks, 256, 0, st>>>(P, H, d.cell_start, d.snap4, d.snap_age, d.sorted_id, d.status_out, d.fs);
+    k_halo_bodies_out<<<blocks, 256, 0, st>>>(P, H, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_age, d.sorted_id, d.status_out, d.fs);
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -3605,10 +3631,10 @@ hipError_t launch_unpack_halos(hipStream_t st, const DevParams &P, const DeviceS
     k_halo_prefix_in<<<H.n, 1024, 0, st>>>(P, H, d.cell_start, d.task_list, d.fs);
     PS_LAUNCH_CHECK();
     const int cells = H.h[0].ncell + H.h[1].ncell;
-    k_halo_bodies_in<<<cells, 256, 0, st>>>(P, H, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, d.snap_cid);
+    k_halo_bodies_in<<<cells, 256, 0, st>>>(P, H, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.snap_cid);
     PS_LAUNCH_CHECK();
     if (P.two_pass) {
-        k_remote_halo_lists<<<cells, 256, 0, st>>>(P, R, d.cell_start, d.snap4, d.snap_cid, d.halo_count, d.halo_f, d.halo_id);
+        k_remote_halo_lists<<<cells, 256, 0, st>>>(P, R, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_cid, d.halo_count, d.halo_f, d.halo_id);
         PS_LAUNCH_CHECK();
     }
     return hipSuccess;
@@ -3700,7 +3726,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
         constexpr int M = MODE == 0 ? 1 : MODE;
         // the packs of partly filled slices (merge): the first nmb workgroups of the same launch
         const int nmb = merge ? (((ncomp + 3) / 4 + 7) & ~7) : 0;
-#define PS_BALANCED(W) k_pairs_balanced<M, NQ, W><<<nmb + nw / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, \
+#define PS_BALANCED(W) k_pairs_balanced<M, NQ, W><<<nmb + nw / 4, 256, 0, st>>>(P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_soa, d.snap_age, d.sorted_id, task_list, \
                                                                      d.force4, d.fs, d.trace, active_list, active_count, d.wave_unit, task_ready, d.merged_tasks, nmb)
         if (tile) PS_BALANCED(1); else if (packs_in_list) PS_BALANCED(2); else PS_BALANCED(0);
 #undef PS_BALANCED
@@ -3717,15 +3743,15 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
         if (MODE != 0 && (P.flags & PSAMD_FLAG_ALL_PAIRS)) {
             // (two == true here: all-pairs contexts are created only with the two-pass pair stage)
             const int items = std::min(tasks, d.part_tasks) * ALLP_PARTS;
-            k_pairs<MODE, NQ, MODE != 0><<<(items + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
+            k_pairs<MODE, NQ, MODE != 0><<<(items + 3) / 4, 256, 0, st>>>(P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
                                                                         d.fs, d.trace, active_list, active_count, far, far_buf, far_start, far_n);
             k_allpairs_combine<<<(std::min(tasks, d.part_tasks) * 64 + 255) / 256, 256, 0, st>>>(P, d.cell_start, task_list, active_list, active_count, far, d.force4, d.fs);
         } else
-            k_pairs<MODE, NQ, false><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap4, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
+            k_pairs<MODE, NQ, false><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
                                                                       d.fs, d.trace, active_list, active_count, far, nullptr, nullptr, nullptr);
         // (unbalanced pass, A/B runs only: the packs as a kernel of their own behind it)
         if (merge) k_pairs_merged<MODE == 0 ? 1 : MODE, NQ><<<(ncomp + 3) / 4, 256, 0, st>>>(
-                P, d.cell_start, d.snap4, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
+                P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
     }
     return hipGetLastError();
 }

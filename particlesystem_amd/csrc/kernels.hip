@@ -1574,6 +1574,8 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
                     qz[i] = v2f{sz[jj + 2 * i], sz[jj + 2 * i + 1]};
                     qw[i] = v2f{sw[jj + 2 * i], sw[jj + 2 * i + 1]};
                 }
+                // (The compiler lets the masses' load sink to its use, behind the reciprocal square roots; pinned up
+                // here with the coordinates' loads -- four in one batch -- the pass took the same time, 2.13 ms.)
                 if (MODE == 1)
                     pairsN_exact_lean<NQ>(P, ctx, qx, qy, qz, qw, nb + jj, snap_age, sorted_id, ax, ay, az, flag);
                 else

@@ -517,3 +517,20 @@ def test_single_walk_pair_stage_still_matches(monkeypatch):
     assert np.array_equal(g.download_force_counts(), g.download_cellgrid()[:, 0])   # every particle's sum is evaluated
     g.calc_forces_apply()
     g.close(); o.close()
+
+
+def test_many_queue_records_grid_40():
+    """A 40^3 grid (10 x 10 x 10 chunks of 4^3 cells): 64 000 cells and 9261 queue records -- more than
+    the prefix arrays of the force pass's plan and the life cycle's per-workgroup scan of the queue census
+    hold in LDS, so the global-memory forms of both run (k_plan_force's fallback, k_ops_scan +
+    k_ops_scatter<false>).  Fast particles, three steps, every byte against the oracle."""
+    n = 60000
+    rng = np.random.default_rng(151)
+    xyz = rng.uniform(-99.0, 99.0, (n, 3)).astype(np.float32)
+    v = rng.uniform(-120, 120, (n, 3)).astype(np.float32)
+    age = rng.uniform(2.2, 7.0, n).astype(np.float32)
+    g, o = make_pair(xyz, age=age, fert=1e6, vxyz=v, chunk_factor=10)
+    for k in range(3):
+        g.step(1); o.step(1)
+        compare_all(g, o, "40^3 grid step %d" % (k + 1))
+    assert g.counters["relocations"] > 10000

@@ -42,7 +42,7 @@ struct DevParams {
     float slow_below;        // max(eps_f32_from, just above coll_d2_gate): closer pairs take the slow branch
     float halo_reach;        // bodies this close to a cell face are collision candidates of the cell beyond it
     float coll_d2_max;       // (double)sqrtf(d2) > COLLISION_RADIUS  <=>  d2 > coll_d2_max (bisection at creation)
-    int32_t two_pass;        // 1: collision flags first (k_collide), forces only for the particles that move
+    int32_t two_pass;        // 1: collision flags first (k_collide_cell), forces only for the particles that move
     float pad_f;
     // ---- slab partition (partition.hpp); world == 1: one region, one slot range, the identity ----
     // Cells are addressed by LOCAL index: four regions of whole cell layers, each followed by one

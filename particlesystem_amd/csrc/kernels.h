@@ -42,7 +42,7 @@ struct DeviceState {
     float *halo_f = nullptr;      // [3][num_cells * HALO_CAP] x, y, z of those candidates
     int *halo_id = nullptr;       // [num_cells * HALO_CAP] their slot ids
     int *snap_cid = nullptr;      // [container] sorted order: slot id, or -1 for a body that can never collide
-    int *active_list = nullptr;   // [container] per cell (at cell_start[c]): sorted indices of the particles that need a force (written by k_collide)
+    int *active_list = nullptr;   // [container] per cell (at cell_start[c]): sorted indices of the particles that need a force (written by k_collide_cell)
     int *active_count = nullptr;  // [num_cells] zeroed with the frame
     int *task_list2 = nullptr;    // [num_cells * slices]
     // balanced force pass: every wave walks the same number of bodies; a task may be cut at a stencil-cell boundary

@@ -517,7 +517,7 @@ struct SnapSoa {
     __device__ __forceinline__ float4 operator[](int i) const { return make_float4(p[i], p[cap + i], p[2 * cap + i], p[3 * cap + i]); }
 };
 
-// Collision candidates of the neighbour cells (k_collide): a body within HALO_REACH of a
+// Collision candidates of the neighbour cells (k_collide_cell): a body within HALO_REACH of a
 // face, edge or corner of its cell is listed in the halo of the cell(s) beyond it.  Two
 // bodies in different cells can only collide (distance <= COLLISION_RADIUS < HALO_REACH) if
 // each is in the other's halo.  Called by all threads of a workgroup for one cell whose `kept`
@@ -1047,7 +1047,7 @@ __device__ __forceinline__ void pair1_exact_lean(const DevParams &P, const PairC
 // only if there was none (ps.cpp:1182-1263): a particle that dies or "survives" a collision
 // this step is not integrated and its acceleration is never looked at.  In a dense cloud
 // that is a large share (42 % in the first step of the N = 2^20 benchmark cloud).  The lean
-// modes do the same: k_collide settles every particle's flag from the few bodies that can
+// modes do the same: k_collide_cell settles every particle's flag from the few bodies that can
 // reach it -- its own cell and the neighbours' bodies near the shared faces (the halo lists
 // k_sort_cells filled) -- then k_build_active lists, per cell, the particles that still need
 // a force, and the force pass walks the 27-cell stencil for those only.
@@ -1112,101 +1112,209 @@ __device__ __forceinline__ void collide_scan(const DevParams &P, float xi, float
     }
 }
 
-// One wave per (cell, 64-particle slice) of the ordinary task list.  Writes the flag of every
-// particle and, for those that will not be integrated or feel no force (kids), the final
-// force4 record.
-// (A workgroup per cell that brings the cell's ~400 bodies into LDS once and reads them back as broadcast
-// 16-byte rows was built and measured in round 3: 133 us against this kernel's 123 -- a broadcast
-// ds_read_b128 still occupies the LDS pipe for its 64 lanes, and 6.5 M of them per launch are more than
-// the scalar cache's misses cost.)
-__global__ __launch_bounds__(256) void k_collide(DevParams P, const int *__restrict__ cell_start,
-                                                 const float *__restrict__ snap_soa, const float *__restrict__ snap_age,
-                                                 const int *__restrict__ sorted_id, const int *__restrict__ snap_cid,
-                                                 const int *__restrict__ task_list, const int *__restrict__ task_start,
-                                                 const int *__restrict__ halo_count, const float *__restrict__ halo_f,
-                                                 const int *__restrict__ halo_id, int *__restrict__ active_list,
-                                                 int *__restrict__ active_count, int *__restrict__ task_cost,
-                                                 float4 *__restrict__ force4, const FrameScalars *__restrict__ fs)
+// The collision flags of every particle of the computed cells and, for the particles that will not be
+// integrated or feel no force (kids), the final force4 record.  One workgroup per cell, with the
+// candidates culled first.  A collision needs the two within COLLISION_RADIUS (0.4 against a 5.0 cell): of
+// the ~400 bodies a cell's particle could meet (its cell's and the halo list's) a handful are near enough
+// to be worth the arithmetic.  The workgroup bins those bodies (the ones that can collide at all: cid >= 0)
+// on a grid of up to 10^3 bins over the cell's box grown by the halo reach -- a counting sort in LDS:
+// census with the body's rank in its bin from the atomic's return, prefix, scatter of (x, y, z, id) rows,
+// the bodies held in registers between the passes -- and a particle then tests the bodies of its bin and
+// the bins around it only: nine runs (a row of three bins along x is one run of the sorted rows), nine
+// bodies in all at the benchmark's density.  A bin is wider than the reach, so two bodies within it of
+// each other are never more than one bin apart on any axis (the bin coordinate is a monotone function of
+// the position, clamped into the grid); the test itself is the arithmetic of collide_scan on the same
+// operands, and "any hit with a higher / a lower id" does not depend on the order the candidates come
+// in: the flags are the same bits.  A cell with more bodies than the LDS rows hold, or whose halo list
+// overflowed, takes collide_scan over everything.
+// (Until round 3 this was one wave per 64-particle slice running collide_scan over all ~400 bodies, 123 us
+// at N = 2^20; a workgroup per cell with the 400 bodies in LDS read back as broadcast rows was 133 us --
+// a broadcast ds_read_b128 still occupies the LDS pipe for its 64 lanes.  With the bins: 41 us, of which
+// the runs are 18.  Steps on the way, flags + plan: 146 us -> 98 (bins) -> 91 (bodies kept in registers,
+// run bounds read in one batch) -> 69 (two bodies a turn, ids by max / min instead of a branch at a hit)
+// -> 67 (the particle's own position and id from the binning registers); profiles/r3_ab_collide.txt.)
+constexpr int COLL_NB = 10;
+template <int CAP>
+__global__ __launch_bounds__(256, CAP <= 1024 ? 7 : 3) void k_collide_cell(DevParams P, const int *__restrict__ cell_start,
+                                                      const float *__restrict__ snap_soa, const float *__restrict__ snap_age,
+                                                      const int *__restrict__ sorted_id, const int *__restrict__ snap_cid,
+                                                      const int *__restrict__ halo_count, const float *__restrict__ halo_f,
+                                                      const int *__restrict__ halo_id, int *__restrict__ active_list,
+                                                      int *__restrict__ active_count, int *__restrict__ task_cost,
+                                                      float4 *__restrict__ force4)
 {
-    // (readfirstlane: the wave index is uniform but the compiler cannot know; with uniform
-    // ranges the body loads below become scalar loads)
-    int slot = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // the collide work list: own cells' slices cell-major (prefix task_start), then the lent
-    // cells' slices (appended when their snapshot arrived); this pass takes its ranges' part
-    int at = -1;
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        if (at >= 0 || P.comp_hi[r] <= P.comp_lo[r]) continue;
-        const bool lent = P.comp_lo[r] >= P.n_own_cells;
-        const int t0 = lent ? task_start[P.n_own_cells] : task_start[P.comp_lo[r]];
-        const int t1 = lent ? fs->n_tasks : task_start[P.comp_hi[r]];
-        if (slot < t1 - t0) at = t0 + slot; else slot -= t1 - t0;
-    }
-    if (at < 0) return;
-    const int task = task_list[at];
-    const int c = task / P.slices, slice = task - c * P.slices;
+    constexpr int KB = CAP / 256;                                 // bodies a thread bins (held in registers between the passes)
+    __shared__ float4 s_body[CAP];
+    __shared__ int s_bin[COLL_NB * COLL_NB * COLL_NB + 1];
+    __shared__ int s_wtot[4];
+    const int c = comp_cell(P, blockIdx.x);
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int base = __builtin_amdgcn_readfirstlane(cell_start[c]);
     const int cnt = __builtin_amdgcn_readfirstlane(min(cell_start[c + 1] - base, P.max_per_cell));
-    const int first = slice * 64;
-    if (first >= cnt) return;
-    const int lane = threadIdx.x & 63;
-    const bool valid = lane < cnt - first;
-    const int gi = base + first + (valid ? lane : 0);
-    const size_t cap = (size_t)P.sorted_cap;
-    const float xi = snap_soa[gi], yi = snap_soa[cap + gi], zi = snap_soa[2 * cap + gi];
-    const float age_i = snap_age[gi];
-    const int id_i = sorted_id[gi];
-    const bool dead = age_i > P.life_thr, kid = age_i < P.kid_thr;
-    const bool scan = valid && !dead && !kid;
-    unsigned long long hi_mask = 0, lo_mask = 0;
-    // own cell
-    collide_scan(P, xi, yi, zi, id_i, scan, snap_soa + base, snap_soa + cap + base, snap_soa + 2 * cap + base,
-                 snap_cid + base, cnt, hi_mask, lo_mask);
+    if (cnt <= 0) return;
     const int nh = __builtin_amdgcn_readfirstlane(halo_count[c]);
-    if (nh <= HALO_CAP) {
-        const size_t at = (size_t)c * HALO_CAP, plane = (size_t)P.n_local_cells * HALO_CAP;
-        collide_scan(P, xi, yi, zi, id_i, scan, halo_f + at, halo_f + plane + at, halo_f + 2 * plane + at, halo_id + at, nh,
-                     hi_mask, lo_mask);
-    } else {
-        // the halo list overflowed (denser than the container admits in steady state): whole stencil
-        int i1, i2, i3;
-        cell_coords(P, c, i1, i2, i3);
-        for (int k = 1; k < 27; k++) {
-            const int nc = __builtin_amdgcn_readfirstlane(local_cell(P, i3 + c_stencil[k][2], i1 + c_stencil[k][1], i2 + c_stencil[k][0]));
-            if (nc < 0) continue;
-            const int nb = __builtin_amdgcn_readfirstlane(cell_start[nc]);
-            const int n = __builtin_amdgcn_readfirstlane(min(cell_start[nc + 1] - nb, P.max_per_cell));
-            collide_scan(P, xi, yi, zi, id_i, scan, snap_soa + nb, snap_soa + cap + nb, snap_soa + 2 * cap + nb, snap_cid + nb, n,
-                         hi_mask, lo_mask);
-        }
-    }
-    const bool met_higher = (hi_mask >> lane) & 1ull, met_lower = (lo_mask >> lane) & 1ull;
-    int flag = met_higher ? 2 : met_lower ? 1 : 0;
-    if (dead) flag = 2;                                          // ps.cpp:1183
-    if (valid) force4[gi] = make_float4(0.f, 0.f, 0.f, __int_as_float(flag));   // final unless the force pass overwrites it
-    // The particles the force pass has to visit (flag 0 and not a kid: a kid moves, but every force
-    // term is skipped for it), packed at active_list[cell_start[c] ...] in whatever order the cell's
-    // waves arrive (a particle's sum is its own lane's chain, so the grouping into tasks is free);
-    // active_count is zeroed with the frame.
-    const bool on = valid && flag == 0 && !kid;
-    const unsigned long long m = __ballot(on);
-    if (m) {
-        int off = 0;
-        if (lane == 0) off = atomicAdd(&active_count[c], __popcll(m));
-        off = __builtin_amdgcn_readfirstlane(off);
-        if (on) active_list[base + off + __popcll(m & ((1ull << lane) - 1ull))] = gi;
-    }
-    // what one force task of this cell walks: the population of its stencil (the cell's first slice reports it)
-    if (slice == 0) {
+    const size_t cap = (size_t)P.sorted_cap;
+    const size_t hat = (size_t)c * HALO_CAP, hplane = (size_t)P.n_local_cells * HALO_CAP;
+    int i1, i2, i3;
+    cell_coords(P, c, i1, i2, i3);
+    // the bins: nb per axis over [-reach, cell + reach) in the cell's own coordinates
+    const float cs = (float)P.cell_size, reach = P.halo_reach * 1.01f + 1e-3f, box = cs + 2.0f * reach;
+    const int nb = max(1, min(COLL_NB, (int)(box / (reach * 1.05f))));
+    const float per_unit = (float)nb / box;
+    const float ox = ((float)i2 - (float)(P.G / 2)) * cs - reach, oy = ((float)(P.G / 2) - (float)i1) * cs + reach,
+                oz = ((float)(P.G / 2) - (float)i3) * cs + reach;      // u = x - ox, oy - y, oz - z: offsets into the grown box
+    auto bin1 = [&](float u) { return max(0, min(nb - 1, (int)(u * per_unit))); };
+    const bool binned = nh <= HALO_CAP && cnt + nh <= CAP;
+    const int nbins = nb * nb * nb;
+    // what one force task of this cell walks: the population of its stencil (the last wave, while the others' loads fly)
+    if (wv == 3) {
         int n = 0;
         if (lane < STENCIL) {
-            int i1, i2, i3;
-            cell_coords(P, c, i1, i2, i3);
             const int nc = local_cell(P, i3 + c_stencil[lane][2], i1 + c_stencil[lane][1], i2 + c_stencil[lane][0]);
             if (nc >= 0) n = min(cell_start[nc + 1] - cell_start[nc], P.max_per_cell);
         }
         n = wave_incl_scan(n);
         if (lane == 63) task_cost[c] = n;
+    }
+    float4 q[KB];
+    if (binned) {
+        const int nbody = cnt + nh;
+        int bin[KB], rank[KB];
+        // all the loads in one batch (the coordinates do not wait for the ids), the bins zeroed meanwhile
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+            const int e = tid + 256 * k;
+            const bool own = e < cnt;
+            q[k] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            if (e < nbody) {
+                q[k].w = __int_as_float(own ? snap_cid[base + e] : halo_id[hat + (e - cnt)]);
+                q[k].x = own ? snap_soa[base + e] : halo_f[hat + (e - cnt)];
+                q[k].y = own ? snap_soa[cap + base + e] : halo_f[hplane + hat + (e - cnt)];
+                q[k].z = own ? snap_soa[2 * cap + base + e] : halo_f[2 * hplane + hat + (e - cnt)];
+            }
+        }
+        for (int b = tid; b <= nbins; b += 256) s_bin[b] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+            bin[k] = -1; rank[k] = 0;
+            if (__float_as_int(q[k].w) >= 0) {
+                bin[k] = (bin1(oz - q[k].z) * nb + bin1(oy - q[k].y)) * nb + bin1(q[k].x - ox);
+                rank[k] = atomicAdd(&s_bin[bin[k]], 1);
+            }
+        }
+        __syncthreads();
+        // exclusive prefix over the bins: a run of bins per thread, the runs' totals through the waves
+        const int per = (nbins + 255) / 256;
+        const int b0 = min(nbins, tid * per), b1 = min(nbins, b0 + per);
+        int mine = 0;
+        for (int b = b0; b < b1; b++) mine += s_bin[b];
+        const int incl = wave_incl_scan(mine);
+        if (lane == 63) s_wtot[wv] = incl;
+        __syncthreads();
+        int run = incl - mine;
+        for (int k = 0; k < wv; k++) run += s_wtot[k];
+        for (int b = b0; b < b1; b++) { const int n = s_bin[b]; s_bin[b] = run; run += n; }
+        if (tid == 255) s_bin[nbins] = run;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KB; k++)
+            if (bin[k] >= 0) s_body[s_bin[bin[k]] + rank[k]] = q[k];
+        __syncthreads();
+    }
+    const float dmax = P.coll_d2_max;
+    // the flag, the final force4 record of the particles the force pass does not visit, and the list of the ones it does
+    // (flag 0 and not a kid), packed at active_list[cell_start[c] ...] in whatever order the cell's waves arrive
+    auto finish = [&](bool valid, int gi, bool dead, bool kid, bool met_higher, bool met_lower) {
+        int flag = met_higher ? 2 : met_lower ? 1 : 0;
+        if (dead) flag = 2;                                          // ps.cpp:1183
+        if (valid) force4[gi] = make_float4(0.f, 0.f, 0.f, __int_as_float(flag));   // final unless the force pass overwrites it
+        const bool on = valid && flag == 0 && !kid;
+        const unsigned long long m = __ballot(on);
+        if (m) {
+            int off = 0;
+            if (lane == 0) off = atomicAdd(&active_count[c], __popcll(m));
+            off = __builtin_amdgcn_readfirstlane(off);
+            if (on) active_list[base + off + __popcll(m & ((1ull << lane) - 1ull))] = gi;
+        }
+    };
+    if (binned) {
+        // thread tid's k-th body is the cell's particle tid + 256 k (the cell's own come first): position and id are
+        // in registers already; only a particle that cannot collide needs its age looked up (dead or kid?)
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+            const int first = wv * 64 + 256 * k;
+            if (first >= cnt) break;
+            const bool valid = lane < cnt - first;
+            const int gi = base + first + (valid ? lane : 0);
+            const int id_i = __float_as_int(q[k].w);
+            const bool scan = valid && id_i >= 0;
+            bool dead = false, kid = false, met_higher = false, met_lower = false;
+            if (valid && id_i < 0) { const float age_i = snap_age[gi]; dead = age_i > P.life_thr; kid = age_i < P.kid_thr; }
+            if (scan) {
+                const float xi = q[k].x, yi = q[k].y, zi = q[k].z;
+                const unsigned uid = (unsigned)id_i;
+                const int bx = bin1(xi - ox), by = bin1(oy - yi), bz = bin1(oz - zi);
+                const int x0 = max(bx - 1, 0), x1 = min(bx + 1, nb - 1);
+                // the nine runs' bounds first (one batch of LDS reads), then the runs
+                int j0[9], j1[9];
+#pragma unroll
+                for (int r = 0; r < 9; r++) {
+                    const int z = bz + r / 3 - 1, y = by + r % 3 - 1;
+                    const bool in = z >= 0 && z < nb && y >= 0 && y < nb;
+                    const int row = (z * nb + y) * nb;
+                    j0[r] = in ? s_bin[row + x0] : 0;
+                    j1[r] = in ? s_bin[row + x1 + 1] : 0;
+                }
+                // two bodies a turn (an odd run's last body twice: the result is an OR over the hits), no branch
+                // at a hit: the highest id met as a signed number and the lowest as an unsigned one say, against
+                // the particle's own, whether there was one above and one below (a miss counts as id -1: neither)
+                const v2f x2 = {xi, xi}, y2 = {yi, yi}, z2 = {zi, zi};
+                int hi = -1;
+                unsigned lo = ~0u;
+#pragma unroll
+                for (int r = 0; r < 9; r++)
+                    for (int j = j0[r]; j < j1[r]; j += 2) {
+                        const float4 qa = s_body[j], qb = s_body[min(j + 1, j1[r] - 1)];
+                        const v2f rx = v2f{qa.x, qb.x} - x2, ry = v2f{qa.y, qb.y} - y2, rz = v2f{qa.z, qb.z} - z2;
+                        const v2f d2 = rx * rx + ry * ry + rz * rz;
+                        const int ca = !(d2.x > dmax) ? __float_as_int(qa.w) : -1, cb = !(d2.y > dmax) ? __float_as_int(qb.w) : -1;
+                        hi = max(hi, max(ca, cb));
+                        lo = min(lo, min((unsigned)ca, (unsigned)cb));
+                    }
+                met_higher = hi > id_i;
+                met_lower = lo < uid;
+            }
+            finish(valid, gi, dead, kid, met_higher, met_lower);
+        }
+    } else {
+        for (int first = wv * 64; first < cnt; first += 256) {
+            const bool valid = lane < cnt - first;
+            const int gi = base + first + (valid ? lane : 0);
+            const float xi = snap_soa[gi], yi = snap_soa[cap + gi], zi = snap_soa[2 * cap + gi];
+            const float age_i = snap_age[gi];
+            const int id_i = sorted_id[gi];
+            const bool dead = age_i > P.life_thr, kid = age_i < P.kid_thr;
+            const bool scan = valid && !dead && !kid;
+            unsigned long long hi_mask = 0, lo_mask = 0;
+            collide_scan(P, xi, yi, zi, id_i, scan, snap_soa + base, snap_soa + cap + base, snap_soa + 2 * cap + base,
+                         snap_cid + base, cnt, hi_mask, lo_mask);
+            if (nh <= HALO_CAP) {
+                collide_scan(P, xi, yi, zi, id_i, scan, halo_f + hat, halo_f + hplane + hat, halo_f + 2 * hplane + hat, halo_id + hat, nh,
+                             hi_mask, lo_mask);
+            } else {
+                // the halo list overflowed (denser than the container admits in steady state): whole stencil
+                for (int k = 1; k < 27; k++) {
+                    const int nc = __builtin_amdgcn_readfirstlane(local_cell(P, i3 + c_stencil[k][2], i1 + c_stencil[k][1], i2 + c_stencil[k][0]));
+                    if (nc < 0) continue;
+                    const int nbase = __builtin_amdgcn_readfirstlane(cell_start[nc]);
+                    const int n = __builtin_amdgcn_readfirstlane(min(cell_start[nc + 1] - nbase, P.max_per_cell));
+                    collide_scan(P, xi, yi, zi, id_i, scan, snap_soa + nbase, snap_soa + cap + nbase, snap_soa + 2 * cap + nbase, snap_cid + nbase, n,
+                                 hi_mask, lo_mask);
+                }
+            }
+            finish(valid, gi, dead, kid, (hi_mask >> lane) & 1ull, (lo_mask >> lane) & 1ull);
+        }
     }
 }
 
@@ -3712,8 +3820,12 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     if (tile) merge = false;                  // no separate merged kernel beside a tile-walk pass
     if (two) {
         // collision flags and the per-cell lists of the particles that need a force, then the plan of the force pass
-        k_collide<<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.snap_cid, d.task_list, d.task_start,
-                                                   d.halo_count, d.halo_f, d.halo_id, d.active_list, d.active_count, d.task_cost, d.force4, d.fs);
+        if (P.max_per_cell + HALO_CAP / 2 <= 1024)
+            k_collide_cell<1024><<<ncomp, 256, 0, st>>>(P, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.snap_cid, d.halo_count, d.halo_f,
+                                                        d.halo_id, d.active_list, d.active_count, d.task_cost, d.force4);
+        else
+            k_collide_cell<2560><<<ncomp, 256, 0, st>>>(P, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.snap_cid, d.halo_count, d.halo_f,
+                                                        d.halo_id, d.active_list, d.active_count, d.task_cost, d.force4);
         k_plan_force<<<8, 1024, 0, st>>>(P, balanced ? nw : 0, packs_in_list ? 2 : merge ? 1 : 0, d.cell_start, d.active_count, d.task_cost,
                                          d.task_list2, d.ctask_start, d.cost_start, d.merged_tasks, d.wave_pos, d.fs, d.trace);
         if (balanced) k_resolve_steps<<<(nw + 1 + 3) / 4, 256, 0, st>>>(P, nw, d.cell_start, d.task_list2, d.wave_pos, d.wave_unit);

@@ -509,7 +509,8 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.op_args_sorted, (size_t)d.ops_cap));
     PS_HIP(c, sort_ops_tmp_bytes((size_t)d.ops_cap, P.key_bits, &d.sort_tmp_bytes));
     { char *tmp = nullptr; PS_HIP(c, dev_alloc(c, &tmp, d.sort_tmp_bytes)); d.sort_tmp = tmp; }
-    PS_HIP(c, hipHostMalloc((void **)&c->h_fs, sizeof(FrameScalars), hipHostMallocDefault));
+    PS_HIP(c, hipHostMalloc((void **)&c->h_fs, sizeof(FrameScalars), hipHostMallocMapped));
+    PS_HIP(c, hipHostGetDevicePointer((void **)&c->d.fs_host, c->h_fs, 0));
     PS_HIP(c, dev_alloc(c, &d.moves, (size_t)d.moves_cap));
     PS_HIP(c, dev_alloc(c, &d.stage, 3 * (size_t)d.moves_cap));
     PS_HIP(c, dev_alloc(c, &d.ctr, (size_t)COUNTER_COPIES));
@@ -1038,10 +1039,10 @@ static int do_lifecycle(psamd_ctx *c)
                           + (c->P.world > 1 ? (int64_t)c->P.world * STATUS_KILL_CAP : 0);
     PS_HIP(c, launch_ops_bucket(c->stream, c->P, c->d, c->geo.queue_infos, bound));
     // one small read-back per step, as the reference's driver does for hostGridMax
-    // (ps.cpp:1878-1900): live count, sticky errors and the sizes of the op lists.  The rest of the
-    // life cycle is enqueued behind it without waiting (the kernels size themselves from
+    // (ps.cpp:1878-1900): live count, sticky errors and the sizes of the op lists -- written into the
+    // pinned host record by the census kernels themselves (publish_scalars), read after this event.  The
+    // rest of the life cycle is enqueued behind it without waiting (the kernels size themselves from
     // the same scalars on the device), so the GPU is busy while the host catches up.
-    PS_HIP(c, hipMemcpyAsync(c->h_fs, c->d.fs, sizeof(FrameScalars), hipMemcpyDeviceToHost, c->stream));
     PS_HIP(c, hipEventRecord(c->ev_scalars, c->stream));
     PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos, bound));
     c->host_queues_valid = false;

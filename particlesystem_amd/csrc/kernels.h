@@ -33,6 +33,7 @@ struct DeviceState {
     uint8_t *chunk_skip = nullptr;   // [slots] 1: not in its chunk's (capped) list this frame; valid for the slots of over-cap chunks only
     int2 *chunk_segs = nullptr;      // [num_chunks * 27] (first slot, slots) of the segments a chunk's particles live in, in slot order
     FrameScalars *fs = nullptr;
+    FrameScalars *fs_host = nullptr;  // the host's pinned copy as the device sees it (written by the queue-census kernels)
     int *cell_start = nullptr;    // [num_cells+1]
     int *cursor = nullptr;        // [num_cells]
     int *task_start = nullptr;    // [num_cells+1] prefix of 64-particle slices per cell

@@ -608,8 +608,12 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
     __shared__ __attribute__((aligned(16))) int ids[CAP + 4];
     __shared__ int ordered[CAP];
     __shared__ int s_halo[27], s_halo_base[27];    // bodies this cell lists in each neighbour's halo
+    constexpr int BITMAP_WORDS = 512;              // the ids' span the bitmap ranking covers: 16384 slots
+    __shared__ unsigned bitmap[BITMAP_WORDS];
+    __shared__ int s_lo, s_hi, s_wt[4];
     const int c = blockIdx.x, tid = threadIdx.x;
     if (tid < 27) s_halo[tid] = 0;
+    if (tid == 0) { s_lo = 0x7fffffff; s_hi = -1; }
     const int start = cell_start[c];
     int n = cell_start[c + 1] - start;
     if (n == 0 || (CAP == SMALL ? n > SMALL : n <= SMALL)) return;       // (empty, or the other instance's)
@@ -680,22 +684,62 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
         for (int e = tid; e < n; e += 256) ids[e] = sorted_id[start + e];
     }
     __syncthreads();
-    // pad to a multiple of 4 with INT_MAX so the ranking reads whole 16-byte LDS words
-    for (int e = n + tid; e < ((n + 3) & ~3); e += 256) ids[e] = 0x7fffffff;
+    // The ids in ascending order.  A cell's particles live in the slots of one segment, so the ids span a few
+    // thousand values: a bitmap of the span in LDS (one atomicOr per id), a prefix of the words' population
+    // counts, and every thread writes out the ids of its two words.  (Before: every id counted the smaller ones
+    // among all of them, n/4 16-byte broadcast reads per thread -- at 256 ids per cell the LDS pipe's
+    // 14 us of the kernel.)  Ids spread wider than the bitmap holds are ranked by counting as before.
+    int lo = 0x7fffffff, hi = -1;
+    for (int e = tid; e < n; e += 256) { const int v = ids[e]; lo = min(lo, v); hi = max(hi, v); }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) { lo = min(lo, __shfl_xor(lo, sft)); hi = max(hi, __shfl_xor(hi, sft)); }
+    if ((tid & 63) == 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
     __syncthreads();
-    for (int e = tid; e < n; e += 256) {
-        const int mine = ids[e];
-        int rank = 0;
-        const int4 *v = reinterpret_cast<const int4 *>(ids);
+    const int id_base = s_lo, span = s_hi - id_base + 1;
+    if (span <= BITMAP_WORDS * 32) {
+        const int words = (span + 31) >> 5;
+        for (int w = tid; w < words; w += 256) bitmap[w] = 0;
+        __syncthreads();
+        for (int e = tid; e < n; e += 256) { const int b = ids[e] - id_base; atomicOr(&bitmap[b >> 5], 1u << (b & 31)); }
+        __syncthreads();
+        constexpr int WPT = BITMAP_WORDS / 256;                 // words per thread
+        unsigned w[WPT];
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < WPT; i++) { w[i] = (WPT * tid + i < words) ? bitmap[WPT * tid + i] : 0u; cnt += __popc(w[i]); }
+        const int incl = wave_incl_scan(cnt);
+        if ((tid & 63) == 63) s_wt[tid >> 6] = incl;
+        __syncthreads();
+        int pos = incl - cnt;
+        for (int k = 0; k < (tid >> 6); k++) pos += s_wt[k];
+#pragma unroll
+        for (int i = 0; i < WPT; i++)
+            for (unsigned m = w[i]; m; m &= m - 1) ordered[pos++] = id_base + (WPT * tid + i) * 32 + (__ffs(m) - 1);
+    } else {
+        // pad to a multiple of 4 with INT_MAX so the ranking reads whole 16-byte LDS words
+        for (int e = n + tid; e < ((n + 3) & ~3); e += 256) ids[e] = 0x7fffffff;
+        __syncthreads();
+        for (int e = tid; e < n; e += 256) {
+            const int mine = ids[e];
+            int rank = 0;
+            const int4 *v = reinterpret_cast<const int4 *>(ids);
 #pragma unroll 4
-        for (int j = 0; j < (n + 3) / 4; j++) {
-            const int4 q = v[j];
-            rank += (q.x < mine) + (q.y < mine) + (q.z < mine) + (q.w < mine);
+            for (int j = 0; j < (n + 3) / 4; j++) {
+                const int4 q = v[j];
+                rank += (q.x < mine) + (q.y < mine) + (q.z < mine) + (q.w < mine);
+            }
+            ordered[rank] = mine;
         }
-        ordered[rank] = mine;
     }
     __syncthreads();
-    for (int e = tid; e < n; e += 256) {
+    // (the small instance keeps what the halo lists need -- position, collision id, face bits -- in registers
+    // instead of reading the rows back and redoing the three divisions)
+    constexpr int KR = CAP == SMALL ? SMALL / 256 : 1;
+    float hx[KR], hy[KR], hz[KR];
+    int hid[KR], hm3[KR];
+#pragma unroll
+    for (int k = 0; k < KR; k++) hm3[k] = 0;
+    auto row = [&](int e, int k) {
         const int id = ordered[e], si = slot_index(P, id);
         // the particle's T_DATA row (written by the scatter pass for every live slot, before the overflow
         // check as in ps.cpp:1495-1500): x, y, z, w, age in one 24-byte read
@@ -722,6 +766,7 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
                     const int dir = halo_dir_of_subset(m3, m);
                     if (dir >= 0) atomicAdd(&s_halo[dir], 1);
                 }
+                if (CAP == SMALL) { hx[k] = p.x; hy[k] = p.y; hz[k] = p.z; hid[k] = id; hm3[k] = m3; }
             }
         } else {
             sorted_id[start + e] = -1;
@@ -742,10 +787,46 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
                 else atomicOr(&fs->error, ERR_REMOTE_RECORD0);
             }
         }
+    };
+    if (CAP == SMALL) {
+#pragma unroll
+        for (int k = 0; k < KR; k++) { const int e = tid + 256 * k; if (e < n) row(e, k); }
+    } else {
+        for (int e = tid; e < n; e += 256) row(e, 0);
     }
     if (!halo_count) return;
-    __syncthreads();                                     // the snapshot rows of this cell are in memory
-    list_in_neighbour_halos(P, c, start, min(n, P.max_per_cell), SnapSoa{snap_soa, (size_t)P.sorted_cap}, snap_cid, halo_count, halo_f, halo_id, s_halo, s_halo_base, true);
+    __syncthreads();                                     // the snapshot rows of this cell are in memory, the directions counted
+    if (CAP != SMALL) {
+        list_in_neighbour_halos(P, c, start, min(n, P.max_per_cell), SnapSoa{snap_soa, (size_t)P.sorted_cap}, snap_cid, halo_count, halo_f, halo_id, s_halo, s_halo_base, true);
+        return;
+    }
+    // room in each neighbour's list with one global atomic per direction, then the bodies (as list_in_neighbour_halos)
+    if (tid < 27) {
+        int base = -1;
+        const int cnt = s_halo[tid];
+        if (cnt > 0) {
+            const int nc = halo_neighbour(P, ci1, ci2, ci3, tid);
+            if (nc >= 0) base = atomicAdd(&halo_count[nc], cnt);
+        }
+        s_halo_base[tid] = base;
+        s_halo[tid] = 0;
+    }
+    __syncthreads();
+    const size_t plane = (size_t)P.n_local_cells * HALO_CAP;
+#pragma unroll
+    for (int k = 0; k < KR; k++) {
+        if (!hm3[k]) continue;
+        for (int m = 1; m < 8; m++) {
+            const int dir = halo_dir_of_subset(hm3[k], m);
+            if (dir < 0 || s_halo_base[dir] < 0) continue;
+            const int kk = s_halo_base[dir] + atomicAdd(&s_halo[dir], 1);
+            if (kk < HALO_CAP) {
+                const size_t at = (size_t)halo_neighbour(P, ci1, ci2, ci3, dir) * HALO_CAP + kk;
+                halo_f[at] = hx[k]; halo_f[plane + at] = hy[k]; halo_f[2 * plane + at] = hz[k];
+                halo_id[at] = hid[k];
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ pair kernel
@@ -2717,10 +2798,26 @@ __global__ __launch_bounds__(1024) void k_ops_hist(const uint64_t *__restrict__ 
     }
 }
 
+// The step's scalars for the host (live count, sticky errors, the sizes of the operation lists): the
+// workgroup that settles the last of them, the longest bucket, writes the record straight into the
+// host's pinned copy -- the host reads it after the event behind this kernel.  (It was a 100-byte
+// device-to-host copy command between this kernel and the replay: a launch of its own on the
+// step's critical path.)
+__device__ __forceinline__ void publish_scalars(const FrameScalars *fs, FrameScalars *fs_host, int longest)
+{
+    constexpr int WORDS = (int)(sizeof(FrameScalars) / sizeof(int)), SKIP = (int)(offsetof(FrameScalars, max_bucket) / sizeof(int));
+    static_assert(sizeof(FrameScalars) % sizeof(int) == 0, "copied word by word");
+    const int *src = reinterpret_cast<const int *>(fs);
+    int *dst = reinterpret_cast<int *>(fs_host);
+    for (int i = threadIdx.x; i < WORDS; i += blockDim.x)
+        dst[i] = i == SKIP ? longest : src[i];              // (max_bucket is being written by this very workgroup)
+    __threadfence_system();
+}
+
 // exclusive prefix of rec_count and its maximum, for configurations with more queue records than
 // k_ops_scatter scans for itself in LDS
 __global__ __launch_bounds__(1024) void k_ops_scan(int nrec, const int *__restrict__ rec_count,
-                                                    int *__restrict__ rec_start, FrameScalars *fs)
+                                                    int *__restrict__ rec_start, FrameScalars *fs, FrameScalars *fs_host)
 {
     __shared__ int wave_tot[16];
     __shared__ int carry_s, max_s;
@@ -2746,6 +2843,7 @@ __global__ __launch_bounds__(1024) void k_ops_scan(int nrec, const int *__restri
     atomicMax(&max_s, mymax);
     __syncthreads();
     if (tid == 0) { rec_start[nrec] = carry_s; fs->max_bucket = max_s; }
+    publish_scalars(fs, fs_host, max_s);
 }
 
 // The life-cycle kernels below are launched BEFORE the host has read the step's counts back
@@ -2761,7 +2859,7 @@ __device__ __forceinline__ bool lifecycle_deferred(const FrameScalars *fs) { ret
 // the live count, whatever the step really produced is covered.
 template <bool SCAN>
 __global__ __launch_bounds__(1024) void k_ops_scatter(const uint64_t *__restrict__ keys, const int *__restrict__ args,
-                                                       FrameScalars *fs, int ops_cap, int rec_shift, int nrec,
+                                                       FrameScalars *fs, FrameScalars *fs_host, int ops_cap, int rec_shift, int nrec,
                                                        const int *__restrict__ rec_count, int *__restrict__ rec_start,
                                                        int *__restrict__ rec_cursor,
                                                        uint64_t *__restrict__ keys_out, int *__restrict__ args_out)
@@ -2772,7 +2870,10 @@ __global__ __launch_bounds__(1024) void k_ops_scatter(const uint64_t *__restrict
     __shared__ int max_s;
     const int n = min(fs->n_ops, ops_cap);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if ((long long)blockIdx.x * SLOTS_PER_WG >= n && (!SCAN || blockIdx.x != 0)) return;
+    // (SCAN: the last workgroup -- as a rule one with no operations of its own, the grid is sized from a bound --
+    // stays for the scan and hands the step's scalars to the host, see publish_scalars)
+    const bool publisher = SCAN && blockIdx.x == gridDim.x - 1;
+    if ((long long)blockIdx.x * SLOTS_PER_WG >= n && (!SCAN || (blockIdx.x != 0 && !publisher))) return;
     const int *start = rec_start;
     if (SCAN) {
         if (tid == 0) max_s = 0;
@@ -2793,6 +2894,7 @@ __global__ __launch_bounds__(1024) void k_ops_scatter(const uint64_t *__restrict
             for (int r = tid; r <= nrec; r += 1024) rec_start[r] = s_start[r];
             if (tid == 0) fs->max_bucket = longest;
         }
+        if (publisher) publish_scalars(fs, fs_host, longest);
         if (longest > BUCKET_MAX) return;                       // (lifecycle_deferred, from this workgroup's own scan)
         start = s_start;
     } else if (lifecycle_deferred(fs)) return;
@@ -3921,12 +4023,12 @@ hipError_t launch_ops_bucket(hipStream_t st, const DevParams &P, const DeviceSta
     k_ops_hist<<<std::min(nwg, 512), 1024, 0, st>>>(d.op_keys, d.fs, d.ops_cap, P.key_rec_shift, nrec, d.rec_count);
     PS_LAUNCH_CHECK();
     if (nrec <= LDS_CELLS)
-        k_ops_scatter<true><<<nwg, 1024, 0, st>>>(d.op_keys, d.op_args, d.fs, d.ops_cap, P.key_rec_shift, nrec, d.rec_count, d.rec_start,
+        k_ops_scatter<true><<<nwg, 1024, 0, st>>>(d.op_keys, d.op_args, d.fs, d.fs_host, d.ops_cap, P.key_rec_shift, nrec, d.rec_count, d.rec_start,
                                                   d.rec_cursor, d.op_keys_sorted, d.op_args_sorted);
     else {
-        k_ops_scan<<<1, 1024, 0, st>>>(nrec, d.rec_count, d.rec_start, d.fs);
+        k_ops_scan<<<1, 1024, 0, st>>>(nrec, d.rec_count, d.rec_start, d.fs, d.fs_host);
         PS_LAUNCH_CHECK();
-        k_ops_scatter<false><<<nwg, 1024, 0, st>>>(d.op_keys, d.op_args, d.fs, d.ops_cap, P.key_rec_shift, nrec, d.rec_count, d.rec_start,
+        k_ops_scatter<false><<<nwg, 1024, 0, st>>>(d.op_keys, d.op_args, d.fs, nullptr, d.ops_cap, P.key_rec_shift, nrec, d.rec_count, d.rec_start,
                                                    d.rec_cursor, d.op_keys_sorted, d.op_args_sorted);
     }
     PS_LAUNCH_CHECK();

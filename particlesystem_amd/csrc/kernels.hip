@@ -352,18 +352,35 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
     };
     long long mine = 0;
     int mymax = 0;
-    for (int c = c0; c < c1; c++) {
+    // (a thread's first KEEP counts stay in registers for the second pass, their loads -- and then the cell table's --
+    // go out as one batch each: the kernel is one workgroup's chain of round trips, nothing else)
+    constexpr int KEEP = 8;
+    int kept[KEEP];
+    CellInfo kci[KEEP];
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) kept[k] = (c0 + k < c1) ? cell_count[c0 + k] : 0;
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) if (kept[k] > 0) kci[k] = celltab[c0 + k + cell_off];
+    auto census = [&](int c, int v, const CellInfo &ci) {
+        if (chunks_in_lds) atomicAdd(&chunk_s[ci.chunk], v);
+        else atomicAdd(&chunk_count[ci.chunk], v);
+        // slab: a particle lives in the segment of its cell, so this is also the census of the chunk's
+        // particles per segment type held here, for the other ranks (status record, zeroed with the frame)
+        if (P.world > 1) atomicAdd(&status_out[STATUS_CHUNK_OFF + 4 * ci.chunk + (ci.seg_type == 1 ? 0 : ci.seg_type == 2 ? 1 : ci.seg_type == 4 ? 2 : 3)], v);
+    };
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) {
+        const int c = c0 + k, v = kept[k];
+        if (c >= c1) continue;
+        mymax = max(mymax, min(v, P.max_per_cell));
+        mine += word(c, v);
+        if (v > 0) census(c, v, kci[k]);
+    }
+    for (int c = c0 + KEEP; c < c1; c++) {
         const int v = cell_count[c];
         mymax = max(mymax, min(v, P.max_per_cell));
         mine += word(c, v);
-        if (v > 0) {
-            const CellInfo ci = celltab[c + cell_off];
-            if (chunks_in_lds) atomicAdd(&chunk_s[ci.chunk], v);
-            else atomicAdd(&chunk_count[ci.chunk], v);
-            // slab: a particle lives in the segment of its cell, so this is also the census of the chunk's
-            // particles per segment type held here, for the other ranks (status record, zeroed with the frame)
-            if (P.world > 1) atomicAdd(&status_out[STATUS_CHUNK_OFF + 4 * ci.chunk + (ci.seg_type == 1 ? 0 : ci.seg_type == 2 ? 1 : ci.seg_type == 4 ? 2 : 3)], v);
-        }
+        if (v > 0) census(c, v, celltab[c + cell_off]);
     }
     long long incl = mine;
     for (int d = 1; d < 64; d <<= 1) {
@@ -375,19 +392,22 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
     __syncthreads();
     long long run = incl - mine, total = 0;
     for (int k = 0; k < 16; k++) { if (k < wv) run += wave_tot[k]; total += wave_tot[k]; }
-    for (int c = c0; c < c1; c++) {
-        const int v = cell_count[c];
+    auto place = [&](int c, int v) {
         const int excl = (int)(run & 0xffffffffll);
         cell_start[c] = excl;
         cursor[c] = excl;
         const int t0 = (int)(run >> 32);
         task_start[c] = t0;
         const long long w = word(c, v);
-        // the collide work list: one entry per non-empty (cell, 64-particle slice) of the own computed
-        // cells (the lent ones are appended when their snapshot has arrived, k_halo_prefix_in)
-        for (int sl = 0; sl < (int)(w >> 32); sl++) task_list[t0 + sl] = c * P.slices + sl;
+        // the work list of the one-pass pair stage: one entry per non-empty (cell, 64-particle slice) of the own
+        // computed cells (the lent ones are appended when their snapshot has arrived, k_halo_prefix_in); the
+        // two-pass stage makes its own list of the particles that need a force (k_plan_force)
+        if (!P.two_pass) for (int sl = 0; sl < (int)(w >> 32); sl++) task_list[t0 + sl] = c * P.slices + sl;
         run += w;
-    }
+    };
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) if (c0 + k < c1) place(c0 + k, kept[k]);
+    for (int c = c0 + KEEP; c < c1; c++) place(c, cell_count[c]);
     if (tid == 0) {
         cell_start[ncell] = (int)(total & 0xffffffffll);     // the gap cell after region 0: end of the own bodies
         task_start[ncell] = (int)(total >> 32);

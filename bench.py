@@ -610,7 +610,7 @@ def main():
                        "particles_with_a_force_term": int(fcounts1.sum()),
                        "relocations": ctr["relocations"], "relocations_lost": ctr["relocations_lost"],
                        "cell_overflow_kills": ctr["cell_overflow_kills"]},
-            "roofline": {"kernel": "k_pairs_balanced (+ k_pairs_merged beside it on one GPU: the interval brackets both)", "bound": "valu", "achieved": ach_tflops, "peak": VALU_PEAK_TFLOPS,
+            "roofline": {"kernel": ("k_pairs + k_allpairs_combine (all-pairs walk)" if args.all_pairs else "k_pairs_balanced (the packs of partly filled slices are workgroups of the same launch)"), "bound": "valu", "achieved": ach_tflops, "peak": VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach_tflops / VALU_PEAK_TFLOPS, "traffic": traffic_pairs,
                          "traffic_source": TRAFFIC_FILE if traffic_pairs is not None else None,
                          "pairs_per_launch": pairs_rank, "flop_per_pair": FLOP_PER_PAIR, "us_per_launch": us_pairs},

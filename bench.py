@@ -458,6 +458,12 @@ def main():
         # layer's population (n / G) is what it sends, measured; a message that did not fit is a loud error
         G = args.chunk_factor * args.chunk_dim
         cfg_over["xfer_cap"] = max(4096, int(args.n / G / 8) + 1024)
+    if args.all_pairs and (world > 1 or args.sim_world):
+        # all-pairs forces pull the whole uniform cloud inwards by the step's clamp (MAX_DX = one cell): in the
+        # replayed step up to a whole cell layer (n / G particles) changes owner across a cut; the library's
+        # default message has room for a quarter of a layer's capacity (half its mean population here)
+        G = args.chunk_factor * args.chunk_dim
+        cfg_over["xfer_cap"] = int(1.25 * args.n / G) + 4096
     flags = (ps.FLAG_FAST_MATH if args.fast_math else 0) | (ps.FLAG_ALL_PAIRS if args.all_pairs else 0)
     if args.sim_world:
         print(json.dumps(sim_world(args, ps, cfg_over, flags)))

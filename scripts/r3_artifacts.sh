@@ -32,6 +32,11 @@ python bench.py --no-cpu --no-side-runs --steps 30 --warmup 5 --n 4194304 --chun
 python bench.py --sim-world 8 --steps 30 --warmup 5 --n 4194304 --chunk-factor 6 > $out/sim8_n22_grid24.json 2> $out/sim8_n22.err
 python bench.py --no-cpu --no-side-runs --steps 10 --warmup 3 --n 4194304 > $out/one_n22_grid16.json 2> /dev/null
 python bench.py --sim-world 8 --all-pairs --steps 5 --warmup 2 > $out/sim8_allpairs.json 2> $out/sim8_allpairs.err
+say "all-pairs at N=2^20 and N=2^22 (BASELINE configs[3]: 8 ranks, all-gather of the snapshot)"
+python bench.py --all-pairs --n 1048576 --no-cpu --no-side-runs --steps 3 --warmup 1 > $out/ap_n20_one.json 2> /dev/null
+python bench.py --sim-world 8 --all-pairs --n 1048576 --steps 3 --warmup 1 > $out/ap_n20_sim8.json 2> $out/ap_n20_sim8.err
+python bench.py --all-pairs --n 4194304 --no-cpu --no-side-runs --steps 2 --warmup 1 > $out/ap_n22_one.json 2> /dev/null
+python bench.py --sim-world 8 --all-pairs --n 4194304 --steps 2 --warmup 1 > $out/ap_n22_sim8.json 2> $out/ap_n22_sim8.err
 say "rocprof of the 8-rank projection"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r3art_sim8 -o sim -- python3 bench.py --sim-world 8 --steps 10 --warmup 3 > $out/sim8_prof.json 2> $out/sim8_prof.err
 say "done"

@@ -13,6 +13,9 @@ last $a/sim4_n20.json > $p/r3_sim_world4.json
 last $a/sim8_n20.json > $p/r3_sim_world8.json
 last $a/sim8_n22_grid24.json > $p/r3_sim_world8_n22_grid24.json
 last $a/sim8_allpairs.json > $p/r3_sim_world8_allpairs.json
+for f in ap_n20_one:r3_allpairs_n20_line ap_n20_sim8:r3_sim_world8_allpairs_n20 ap_n22_one:r3_allpairs_n22_line ap_n22_sim8:r3_sim_world8_allpairs_n22; do
+    [ -f $a/${f%%:*}.json ] && last $a/${f%%:*}.json > $p/${f##*:}.json
+done
 cp $g/prof_r3art_exact/bench_kernel_stats.csv $p/r3_bench_kernel_stats.csv
 last $g/prof_r3art_exact/bench_stdout.json > $p/r3_bench_under_rocprof.json
 cp $g/prof_r3art_fast/bench_kernel_stats.csv $p/r3_fast_kernel_stats.csv

@@ -28,3 +28,24 @@ def test_bench_two_ranks_one_line():
     assert d["value"] > 0 and d["config"]["updates_in_timed_region"] == 4 * 131072
     assert "slabs" in d["config"]["parallelism"] and d["cpu_baseline"] is None
     assert d["roofline"]["frac"] > 0 and d["config"]["message_bytes_rank0"]["halo_up"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("ranks,all_pairs", [(4, False), (2, True)])
+def test_bench_more_ranks_and_all_pairs(ranks, all_pairs):
+    """Four slabs (interior ranks with two neighbours each, the status all-gather over four records), and the
+    all-pairs mode across two ranks (the snapshot all-gather through the process group): the line comes out,
+    every particle was advanced in every timed step."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    n = 32768 if all_pairs else 131072
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--n", str(n),
+           "--steps", "3", "--warmup", "1", "--settle-seconds", "0.05"] + (["--all-pairs"] if all_pairs else [])
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=860)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == ranks and d["steps"] == 3
+    assert d["value"] > 0 and d["config"]["updates_in_timed_region"] == 3 * n
+    assert ("all-pairs" in d["metric"]) == all_pairs

@@ -62,6 +62,8 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel-times", action="store_true", help="HIP events between all stage kernels, not only around the "
                     "pair pass / apply / life cycle (costs ~40 us of idle GPU per step)")
+    ap.add_argument("--timing-period", type=int, default=8, help="record the HIP events that time the force pass / apply / life cycle on every "
+                    "n-th step of the timed region (an event between two kernels idles the GPU for ~6 us; 1: every step)")
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--chunk-factor", type=int, default=4, help="grid = (chunk_factor*chunk_dim)^3 cells (reference: 4)")
     ap.add_argument("--chunk-dim", type=int, default=4)
@@ -236,7 +238,7 @@ def force_terms(n, f, G, all_pairs):
     return pair_count(n, f, G)
 
 
-def side_run(ps, cfg_over, device, xyz, age, fert, flags, steps, restore, warm=10, all_pairs=False, **cfg_extra):
+def side_run(ps, cfg_over, device, xyz, age, fert, flags, steps, restore, warm=10, all_pairs=False, timing_period=1, **cfg_extra):
     """A second, short measurement on a fresh context: the same timed loop with other flags (fast
     math), other constants (life cycle off) or free-running (restore=False).  Never the headline.
     Returns updates, seconds, live counts per step, and -- from HIP events on the context's stream
@@ -252,7 +254,7 @@ def side_run(ps, cfg_over, device, xyz, age, fert, flags, steps, restore, warm=1
             g.snapshot_restore(); g.step(1)
     G = g.sizes.grid_dim
     n0, f0 = pass_counts(g, restore) if restore else (None, None)
-    g.set_timing(True)
+    g.set_timing(True, period=timing_period)
     g.synchronize()
     p0 = g.counters["particles_processed"]
     t0 = time.perf_counter()
@@ -559,7 +561,10 @@ def main():
         counts0 = fcounts0 = mine0 = None
     else:
         counts0, fcounts0, mine0 = frame_counts()
-    g.set_timing(True, every_stage=args.kernel_times)
+    # the events that time the kernels go in on every timing_period-th step (each costs ~6 us of idle GPU
+    # between two kernels); kernel_us_per_step and the rooflines are means over those steps
+    period = 1 if args.kernel_times else max(1, min(args.timing_period, args.steps))
+    g.set_timing(True, every_stage=args.kernel_times, period=period)
     sync()
     processed0 = g.counters["particles_processed"]
     t0 = time.perf_counter()
@@ -625,6 +630,7 @@ def main():
                                    "traffic_source": TRAFFIC_FILE if traffic_apply is not None else None,
                                    "bytes_per_update": APPLY_BYTES_PER_UPDATE, "us_per_launch": us_apply},
             "kernel_us_per_step": {k: v / max(launches, 1) for k, v in tim.items() if v > 0},
+            "kernel_times_from": "HIP events on the context's stream on %d of the %d timed steps (every %d%s)" % (launches, args.steps, period, "th" if period > 1 else "st"),
         }
         if world > 1:
             out["config"]["halo_cap_cell"] = int(args.halo_cap_cell)
@@ -638,14 +644,14 @@ def main():
             if not args.fast_math and not args.evolve and not args.no_side_runs and not args.all_pairs:
                 # SURVEY 8(d)'s lifecycle-off mode: collision radius 0 (and no births, no deaths of age in these
                 # steps), so every one of the N particles goes through the force loop and is integrated
-                d, t, _, roof, kt = side_run(ps, cfg_over, local_rank, xyz, age, fert, flags, 50, True, collision_radius=0.0)
+                d, t, _, roof, kt = side_run(ps, cfg_over, local_rank, xyz, age, fert, flags, 50, True, timing_period=min(5, period), collision_radius=0.0)
                 out["lifecycle_off"] = {
                     "what": "the same cloud and step with COLLISION_RADIUS = 0: nothing collides, all %d particles get a force and are "
                             "integrated (the headline's step, at the reference's radius 0.4, integrates the particles the "
                             "reference integrates: config.particles_with_a_force_term)" % args.n,
                     "value": d / t, "unit": "particle-updates/s", "ms_per_step": 1e3 * t / 50, "steps": 50,
                     "roofline": roof, "kernel_us_per_step": kt}
-                d, t, _, roof, kt = side_run(ps, cfg_over, local_rank, xyz, age, fert, ps.FLAG_FAST_MATH, 50, True)
+                d, t, _, roof, kt = side_run(ps, cfg_over, local_rank, xyz, age, fert, ps.FLAG_FAST_MATH, 50, True, timing_period=min(5, period))
                 out["within_tolerance_mode"] = {
                     "arithmetic": "PSAMD_FLAG_FAST_MATH (FMA + v_rsq): accelerations deviate from the oracle's by the amounts "
                                   "tests/test_gpu_fast.py measures and bounds (also at this density); not the headline",

@@ -324,9 +324,13 @@ int psamd_selftest_math(psamd_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, uint
  * sort, pairs (the force pass), apply, lifecycle, frame reset, collide (collision flags and the
  * lists of the particles that need a force: the two-pass prologue of the pair stage).  level 0: off; 1: collide, pairs, apply and lifecycle
  * only (four events per step); 2: every stage (an event between two kernels costs a few
- * microseconds of idle GPU, so this is for diagnosis).  Never makes a step wait. */
+ * microseconds of idle GPU, so this is for diagnosis).  Never makes a step wait.
+ * psamd_set_timing_period(ctx, n): record the events on every n-th step only (n >= 1; default 1) --
+ * the accumulated times and `launches` then count those steps; what a long timed run uses so that
+ * the events' idle gaps (four to six per step at level 1) do not weigh on the steps in between. */
 #define PSAMD_NUM_TIMERS 9
 int psamd_set_timing(psamd_ctx *ctx, int level);
+int psamd_set_timing_period(psamd_ctx *ctx, int every);
 int psamd_get_timing(psamd_ctx *ctx, double us_out[PSAMD_NUM_TIMERS], int64_t *launches);
 
 #ifdef __cplusplus

@@ -163,6 +163,7 @@ ABI = [
     ("psamd_debug_wave_trace", C.c_int, [_vp, _vp, _i64]),
     ("psamd_selftest_math", C.c_int, [_vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("psamd_set_timing", C.c_int, [_vp, C.c_int]),
+    ("psamd_set_timing_period", C.c_int, [_vp, C.c_int]),
     ("psamd_get_timing", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
 ]
 
@@ -460,9 +461,11 @@ class ParticleSystem:
         self._ck(self.lib.psamd_selftest_math(self.h, lo_bits, hi_bits, out))
         return list(out)
 
-    def set_timing(self, on=True, every_stage=False):
+    def set_timing(self, on=True, every_stage=False, period=1):
         """HIP-event timing of the step's kernels: pair pass, apply and life cycle, or every
-        stage (an event between every two kernels costs ~6 us of idle GPU each)."""
+        stage (an event between two kernels costs ~6 us of idle GPU each); period n: on every
+        n-th step only."""
+        self._ck(self.lib.psamd_set_timing_period(self.h, int(period)))
         self._ck(self.lib.psamd_set_timing(self.h, (2 if every_stage else 1) if on else 0))
 
     def timing(self):

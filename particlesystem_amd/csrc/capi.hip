@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -76,9 +77,12 @@ struct psamd_ctx {
     int64_t live_bound = 0, snapshot_live_bound = 0;
     // timing
     int timing = 0;                    // 0 off, 1 pair pass / apply / life cycle, 2 every stage
+    int timing_period = 1;             // events are recorded on every timing_period-th step since set_timing
+    int64_t timing_steps = 0;          // steps since set_timing
+    int timing_now = 0;                // the level in force for the step being run (0 on the steps in between)
+    int scalars_seq = 0;               // number of the last step whose scalars were asked for (h_fs->seq follows it)
     hipEvent_t ev[14]{};               // 10 frame reset | 0 hist 1 scan 2 scatter 3 sort 4 | 5 collide 13 force pass 6 | 7 apply 8,11 | life cycle 9,12
     bool lifecycle_pending[2] = {false, false};   // ev[8|11] -> ev[9|12] recorded, not yet read
-    hipEvent_t ev_scalars = nullptr;   // the per-step read-back of FrameScalars has landed
     bool ev_made = false;
     double t_us[PSAMD_NUM_TIMERS]{};
     int64_t t_launches = 0;
@@ -339,7 +343,6 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, hipSetDevice(cfg->device));
     PS_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    PS_HIP(c, hipEventCreateWithFlags(&c->ev_scalars, hipEventDisableTiming));
     PS_HIP(c, hipStreamCreateWithFlags(&c->d.side_stream, hipStreamNonBlocking));
     PS_HIP(c, hipEventCreateWithFlags(&c->d.ev_fork, hipEventDisableTiming));
     PS_HIP(c, hipEventCreateWithFlags(&c->d.ev_join, hipEventDisableTiming));
@@ -656,7 +659,6 @@ int psamd_destroy(psamd_ctx *c)
     if (c->staging) (void)hipFree(c->staging);
     if (c->h_fs) (void)hipHostFree(c->h_fs);
     if (c->ev_made) for (auto &e : c->ev) (void)hipEventDestroy(e);
-    if (c->ev_scalars) (void)hipEventDestroy(c->ev_scalars);
     if (c->d.ev_fork) (void)hipEventDestroy(c->d.ev_fork);
     if (c->d.ev_join) (void)hipEventDestroy(c->d.ev_join);
     if (c->d.side_stream) (void)hipStreamDestroy(c->d.side_stream);
@@ -983,7 +985,9 @@ static int slab_only(psamd_ctx *c, const char *what)
 
 static int do_init_iframe(psamd_ctx *c)
 {
-    if (c->timing >= 2) { make_events(c); (void)hipEventRecord(c->ev[10], c->stream); }
+    // (an event between two kernels costs ~6 us of idle GPU: a long timed run records them on every n-th step)
+    c->timing_now = (c->timing && c->timing_steps++ % c->timing_period == 0) ? c->timing : 0;
+    if (c->timing_now >= 2) { make_events(c); (void)hipEventRecord(c->ev[10], c->stream); }
     // cell / chunk / queue-record counts and the per-frame scalars (the sticky error word stays)
     PS_HIP(c, launch_frame_reset(c->stream, c->d, c->frame_ints, c->P.world > 1 ? 4 * c->geo.num_chunks : 0));
     c->frame_reset = true; c->grid_built = false; c->pairs_done = false;
@@ -993,8 +997,8 @@ static int do_init_iframe(psamd_ctx *c)
 static int do_build_grid(psamd_ctx *c)
 {
     if (!c->frame_reset) return fail(c, PSAMD_ERR_STATE, "build_grid needs init_iframe first");
-    if (c->timing) make_events(c);
-    PS_HIP(c, launch_build_grid(c->stream, c->P, c->d, c->timing >= 2 ? c->ev : nullptr));
+    if (c->timing_now) make_events(c);
+    PS_HIP(c, launch_build_grid(c->stream, c->P, c->d, c->timing_now >= 2 ? c->ev : nullptr));
     c->frame_reset = false; c->grid_built = true; c->pairs_done = false;
     c->live_at_build = -1;
     return PSAMD_OK;
@@ -1003,15 +1007,15 @@ static int do_build_grid(psamd_ctx *c)
 static int do_pairs(psamd_ctx *c, const DevParams &P, bool last = true, bool first = true)
 {
     if (!c->grid_built) return fail(c, PSAMD_ERR_STATE, "calc_forces needs build_grid first");
-    if (c->timing && first) (void)hipEventRecord(c->ev[5], c->stream);
+    if (c->timing_now && first) (void)hipEventRecord(c->ev[5], c->stream);
     // size of the balanced force pass: the tasks of the last step this context ran (the
     // read-back of its scalars is on the host already), else the bound of the live count
     // (a pass over part of the cells gets its share of the hint)
     int64_t tasks_hint = (c->steps_total > 0 && c->tasks_last > 0) ? c->tasks_last
                          : (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) / 64 + comp_count(c->P);
     tasks_hint = tasks_hint * comp_count(P) / std::max(1, comp_count(c->P));
-    PS_HIP(c, launch_pairs(c->stream, P, c->d, (c->timing && first) ? c->ev[13] : nullptr, tasks_hint, first ? 0 : 1));
-    if (c->timing && last) (void)hipEventRecord(c->ev[6], c->stream);
+    PS_HIP(c, launch_pairs(c->stream, P, c->d, (c->timing_now && first) ? c->ev[13] : nullptr, tasks_hint, first ? 0 : 1));
+    if (c->timing_now && last) (void)hipEventRecord(c->ev[6], c->stream);
     c->pairs_done = last;
     return PSAMD_OK;
 }
@@ -1021,10 +1025,30 @@ static int do_pairs(psamd_ctx *c, const DevParams &P, bool last = true, bool fir
 static int do_apply(psamd_ctx *c)
 {
     if (!c->grid_built || !c->pairs_done) return fail(c, PSAMD_ERR_STATE, "apply needs build_grid and the pair pass first");
-    if (c->timing) (void)hipEventRecord(c->ev[7], c->stream);
+    if (c->timing_now) (void)hipEventRecord(c->ev[7], c->stream);
     PS_HIP(c, launch_apply(c->stream, c->P, c->S, c->d, c->step));
     if (c->P.world > 1)
         PS_HIP(c, launch_outbox_close(c->stream, c->P, c->d, c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total, c->xfer_out));
+    return PSAMD_OK;
+}
+
+// Wait until the step's scalars are in the host's record: the publishing workgroup stores the step's
+// number last.  The stream is looked at now and then so that a failed launch cannot leave the host spinning.
+static int wait_scalars(psamd_ctx *c, int seq)
+{
+    volatile int32_t *word = &c->h_fs->seq;
+    for (uint64_t spins = 1; *word != seq; spins++) {
+        __builtin_ia32_pause();
+        if ((spins & 0x3fff) == 0) {
+            const hipError_t e = hipStreamQuery(c->stream);
+            if (e == hipSuccess) {
+                if (*word == seq) break;
+                return fail(c, PSAMD_ERR_STATE, "the step's scalars never arrived on the host");
+            }
+            if (e != hipErrorNotReady) return hip_fail(c, e, "waiting for the step's scalars");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
     return PSAMD_OK;
 }
 
@@ -1032,21 +1056,22 @@ static int do_apply(psamd_ctx *c)
 static int do_lifecycle(psamd_ctx *c)
 {
     const int par = (int)(c->steps_total & 1);   // not c->step: a snapshot restore rewinds that
-    if (c->timing) (void)hipEventRecord(c->ev[par ? 11 : 8], c->stream);
+    if (c->timing_now) { collect_lifecycle_time(c, par); (void)hipEventRecord(c->ev[par ? 11 : 8], c->stream); }
     if (c->P.world > 1) PS_HIP(c, launch_inbox_merge(c->stream, c->P, c->d, c->xfer_in));
     // live_bound < 0: unknown (state was uploaded) -> size for every owned slot; arrivals on top
     const int64_t bound = (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) + 2 * (int64_t)c->P.xfer_cap + 2 * (int64_t)c->P.xfer2_cap
                           + (c->P.world > 1 ? (int64_t)c->P.world * STATUS_KILL_CAP : 0);
-    PS_HIP(c, launch_ops_bucket(c->stream, c->P, c->d, c->geo.queue_infos, bound));
+    const int seq = ++c->scalars_seq;
+    PS_HIP(c, launch_ops_bucket(c->stream, c->P, c->d, c->geo.queue_infos, bound, seq));
     // one small read-back per step, as the reference's driver does for hostGridMax
     // (ps.cpp:1878-1900): live count, sticky errors and the sizes of the op lists -- written into the
-    // pinned host record by the census kernels themselves (publish_scalars), read after this event.  The
+    // pinned host record by the census kernels themselves (publish_scalars) with the step's number behind
+    // them, which the host polls: no copy command, no event.  The
     // rest of the life cycle is enqueued behind it without waiting (the kernels size themselves from
     // the same scalars on the device), so the GPU is busy while the host catches up.
-    PS_HIP(c, hipEventRecord(c->ev_scalars, c->stream));
     PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos, bound));
     c->host_queues_valid = false;
-    PS_HIP(c, hipEventSynchronize(c->ev_scalars));
+    { const int st = wait_scalars(c, seq); if (st != PSAMD_OK) return st; }
     c->live_at_build = c->h_fs->live;
     const int64_t tasks_now = (int64_t)c->h_fs->n_tasks2 + c->h_fs->n_merged;       // ordinary tasks + packs of partial slices
     c->tasks_last = c->interior_ran ? tasks_now * comp_count(c->P) / std::max(1, comp_count(c->P_rest)) : tasks_now;
@@ -1063,7 +1088,7 @@ static int do_lifecycle(psamd_ctx *c)
     if (c->P.world > 1 ? c->h_fs->status_error != 0 : c->h_fs->error != 0) return check_device_errors(c);
     if (c->h_fs->max_bucket > BUCKET_MAX)      // rare: the kernels above stood down
         PS_HIP(c, launch_lifecycle_sorted(c->stream, c->P, c->d, c->step, c->geo.queue_infos, c->h_fs->n_ops, c->h_fs->n_moves));
-    if (c->timing) {
+    if (c->timing_now) {
         // No wait for the end of the step: everything up to `apply` was complete when the
         // scalars landed; the life-cycle interval is read one step later (or by get_timing).
         (void)hipEventRecord(c->ev[par ? 12 : 9], c->stream);
@@ -1071,8 +1096,8 @@ static int do_lifecycle(psamd_ctx *c)
         collect_lifecycle_time(c, par ^ 1);
         // slots: hist scan scatter sort | force pass, apply | frame reset | flags + active lists (two-pass prologue)
         const int a[] = {0, 1, 2, 3, 13, 7, 10, 5}, b[] = {1, 2, 3, 4, 6, par ? 11 : 8, 0, 13}, slot[] = {0, 1, 2, 3, 4, 5, 7, 8};
-        for (int k = (c->timing >= 2 ? 0 : 4); k < 8; k++) {
-            if (c->timing < 2 && k == 6) continue;
+        for (int k = (c->timing_now >= 2 ? 0 : 4); k < 8; k++) {
+            if (c->timing_now < 2 && k == 6) continue;
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, c->ev[a[k]], c->ev[b[k]]) == hipSuccess) c->t_us[slot[k]] += 1000.0 * ms;
         }
@@ -1434,10 +1459,19 @@ int psamd_set_timing(psamd_ctx *c, int enabled)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
     c->timing = enabled < 0 ? 0 : enabled > 2 ? 2 : enabled;
+    c->timing_steps = 0; c->timing_now = 0;
     if (c->timing) make_events(c);
     for (double &v : c->t_us) v = 0.0;
     c->t_launches = 0;
     c->lifecycle_pending[0] = c->lifecycle_pending[1] = false;
+    return PSAMD_OK;
+}
+
+int psamd_set_timing_period(psamd_ctx *c, int every)
+{
+    if (!c || every < 1) return PSAMD_ERR_INVALID_ARG;
+    c->timing_period = every;
+    c->timing_steps = 0;
     return PSAMD_OK;
 }
 

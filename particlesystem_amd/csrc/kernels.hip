@@ -2820,24 +2820,28 @@ __global__ __launch_bounds__(1024) void k_ops_hist(const uint64_t *__restrict__ 
 
 // The step's scalars for the host (live count, sticky errors, the sizes of the operation lists): the
 // workgroup that settles the last of them, the longest bucket, writes the record straight into the
-// host's pinned copy -- the host reads it after the event behind this kernel.  (It was a 100-byte
-// device-to-host copy command between this kernel and the replay: a launch of its own on the
-// step's critical path.)
-__device__ __forceinline__ void publish_scalars(const FrameScalars *fs, FrameScalars *fs_host, int longest)
+// host's pinned copy, and the step's number behind it once the record is out -- the host polls that
+// word.  (It was a 100-byte device-to-host copy command and an event between this kernel and the replay:
+// a launch of its own and an idle gap of ~6 us on the step's critical path.)  Called by all threads of
+// one workgroup.
+__device__ __forceinline__ void publish_scalars(const FrameScalars *fs, FrameScalars *fs_host, int longest, int seq)
 {
-    constexpr int WORDS = (int)(sizeof(FrameScalars) / sizeof(int)), SKIP = (int)(offsetof(FrameScalars, max_bucket) / sizeof(int));
+    constexpr int WORDS = (int)(sizeof(FrameScalars) / sizeof(int)), SKIP = (int)(offsetof(FrameScalars, max_bucket) / sizeof(int)),
+                  SEQ = (int)(offsetof(FrameScalars, seq) / sizeof(int));
     static_assert(sizeof(FrameScalars) % sizeof(int) == 0, "copied word by word");
     const int *src = reinterpret_cast<const int *>(fs);
     int *dst = reinterpret_cast<int *>(fs_host);
     for (int i = threadIdx.x; i < WORDS; i += blockDim.x)
-        dst[i] = i == SKIP ? longest : src[i];              // (max_bucket is being written by this very workgroup)
+        if (i != SEQ) dst[i] = i == SKIP ? longest : src[i];              // (max_bucket is being written by this very workgroup)
     __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&fs_host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // exclusive prefix of rec_count and its maximum, for configurations with more queue records than
 // k_ops_scatter scans for itself in LDS
 __global__ __launch_bounds__(1024) void k_ops_scan(int nrec, const int *__restrict__ rec_count,
-                                                    int *__restrict__ rec_start, FrameScalars *fs, FrameScalars *fs_host)
+                                                    int *__restrict__ rec_start, FrameScalars *fs, FrameScalars *fs_host, int seq)
 {
     __shared__ int wave_tot[16];
     __shared__ int carry_s, max_s;
@@ -2863,7 +2867,7 @@ __global__ __launch_bounds__(1024) void k_ops_scan(int nrec, const int *__restri
     atomicMax(&max_s, mymax);
     __syncthreads();
     if (tid == 0) { rec_start[nrec] = carry_s; fs->max_bucket = max_s; }
-    publish_scalars(fs, fs_host, max_s);
+    publish_scalars(fs, fs_host, max_s, seq);
 }
 
 // The life-cycle kernels below are launched BEFORE the host has read the step's counts back
@@ -2879,7 +2883,7 @@ __device__ __forceinline__ bool lifecycle_deferred(const FrameScalars *fs) { ret
 // the live count, whatever the step really produced is covered.
 template <bool SCAN>
 __global__ __launch_bounds__(1024) void k_ops_scatter(const uint64_t *__restrict__ keys, const int *__restrict__ args,
-                                                       FrameScalars *fs, FrameScalars *fs_host, int ops_cap, int rec_shift, int nrec,
+                                                       FrameScalars *fs, FrameScalars *fs_host, int seq, int ops_cap, int rec_shift, int nrec,
                                                        const int *__restrict__ rec_count, int *__restrict__ rec_start,
                                                        int *__restrict__ rec_cursor,
                                                        uint64_t *__restrict__ keys_out, int *__restrict__ args_out)
@@ -2914,7 +2918,7 @@ __global__ __launch_bounds__(1024) void k_ops_scatter(const uint64_t *__restrict
             for (int r = tid; r <= nrec; r += 1024) rec_start[r] = s_start[r];
             if (tid == 0) fs->max_bucket = longest;
         }
-        if (publisher) publish_scalars(fs, fs_host, longest);
+        if (publisher) publish_scalars(fs, fs_host, longest, seq);
         if (longest > BUCKET_MAX) return;                       // (lifecycle_deferred, from this workgroup's own scan)
         start = s_start;
     } else if (lifecycle_deferred(fs)) return;
@@ -4036,19 +4040,19 @@ hipError_t launch_outbox_close(hipStream_t st, const DevParams &P, const DeviceS
 // back at that point), replay the queues with the first relocation phase riding along, commit.
 // `live_bound` >= live particles of the step (arrivals from the neighbour ranks included): at most 3
 // queue operations and 2 move records each.
-hipError_t launch_ops_bucket(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_bound)
+hipError_t launch_ops_bucket(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_bound, int seq)
 {
     const int64_t max_ops = std::max<int64_t>(1, std::min<int64_t>(d.ops_cap, 3 * live_bound));
     const int nwg = (int)std::min<int64_t>((max_ops + SLOTS_PER_WG - 1) / SLOTS_PER_WG, 2048);    // (grid-stride beyond)
     k_ops_hist<<<std::min(nwg, 512), 1024, 0, st>>>(d.op_keys, d.fs, d.ops_cap, P.key_rec_shift, nrec, d.rec_count);
     PS_LAUNCH_CHECK();
     if (nrec <= LDS_CELLS)
-        k_ops_scatter<true><<<nwg, 1024, 0, st>>>(d.op_keys, d.op_args, d.fs, d.fs_host, d.ops_cap, P.key_rec_shift, nrec, d.rec_count, d.rec_start,
+        k_ops_scatter<true><<<nwg, 1024, 0, st>>>(d.op_keys, d.op_args, d.fs, d.fs_host, seq, d.ops_cap, P.key_rec_shift, nrec, d.rec_count, d.rec_start,
                                                   d.rec_cursor, d.op_keys_sorted, d.op_args_sorted);
     else {
-        k_ops_scan<<<1, 1024, 0, st>>>(nrec, d.rec_count, d.rec_start, d.fs, d.fs_host);
+        k_ops_scan<<<1, 1024, 0, st>>>(nrec, d.rec_count, d.rec_start, d.fs, d.fs_host, seq);
         PS_LAUNCH_CHECK();
-        k_ops_scatter<false><<<nwg, 1024, 0, st>>>(d.op_keys, d.op_args, d.fs, nullptr, d.ops_cap, P.key_rec_shift, nrec, d.rec_count, d.rec_start,
+        k_ops_scatter<false><<<nwg, 1024, 0, st>>>(d.op_keys, d.op_args, d.fs, nullptr, 0, d.ops_cap, P.key_rec_shift, nrec, d.rec_count, d.rec_start,
                                                    d.rec_cursor, d.op_keys_sorted, d.op_args_sorted);
     }
     PS_LAUNCH_CHECK();

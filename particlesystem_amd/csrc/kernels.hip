@@ -495,8 +495,19 @@ __device__ __forceinline__ void chunk_cap_block(const DevParams &P, int ch, cons
 // (set_pos_t, app.cu:117-158).  halo_dirs packs, two bits per axis (i2, i1, i3), whether a
 // body lies within P.halo_reach of the low (1) or high (2) face of cell (i1, i2, i3) on that
 // axis; an axis whose neighbour would be outside the grid reports 0 (the stencil is not periodic).
+// A body whose position is not a number (a child born with the direction (0, 0, 0): 0/0, ps.cpp:1306-1333; the
+// reference files it under one fixed cell from then on, see the conversion in k_apply) is a candidate of EVERY neighbour: the reference's test `dist > COLLISION_RADIUS`
+// does not fail for it, so once it is no kid every adult that scans it collides with it (app_common.cu:269-301).
+constexpr int HALO_ALL = 0x40;
+__device__ __forceinline__ bool finite3(float x, float y, float z)
+{
+    return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u && (__float_as_uint(y) & 0x7f800000u) != 0x7f800000u &&
+           (__float_as_uint(z) & 0x7f800000u) != 0x7f800000u;
+}
+
 __device__ __forceinline__ int halo_dirs(const DevParams &P, int i1, int i2, int i3, float x, float y, float z)
 {
+    if (!finite3(x, y, z)) return HALO_ALL;
     const int G = P.G;
     const float cs = (float)P.cell_size, half = (float)(G / 2), reach = P.halo_reach;
     const float u2 = (x / cs + half - (float)i2) * cs, u1 = (-y / cs + half - (float)i1) * cs,
@@ -519,6 +530,14 @@ __device__ __forceinline__ int halo_dir_of_subset(int dirs, int m)
     const int d2 = (m & 1) ? (n2 == 1 ? -1 : 1) : 0, d1 = (m & 2) ? (n1 == 1 ? -1 : 1) : 0,
               d3 = (m & 4) ? (n3 == 1 ? -1 : 1) : 0;
     return (d3 + 1) * 9 + (d1 + 1) * 3 + (d2 + 1);
+}
+
+// The neighbours a body with face bits `dirs` is listed with: target t of halo_targets(dirs), or -1.
+__device__ __forceinline__ int halo_targets(int dirs) { return dirs == HALO_ALL ? 27 : 8; }
+__device__ __forceinline__ int halo_target(int dirs, int t)
+{
+    if (dirs == HALO_ALL) return t == 13 ? -1 : t;
+    return t == 0 ? -1 : halo_dir_of_subset(dirs, t);
 }
 
 // local index of the neighbour in direction `dir`, -1 if this rank does not hold it
@@ -561,8 +580,8 @@ __device__ __forceinline__ void list_in_neighbour_halos(const DevParams &P, int 
             const float4 q = snap4[start + e];
             const int m3 = halo_dirs(P, i1, i2, i3, q.x, q.y, q.z);
             if (!m3) continue;
-            for (int m = 1; m < 8; m++) {
-                const int dir = halo_dir_of_subset(m3, m);
+            for (int t = 0; t < halo_targets(m3); t++) {
+                const int dir = halo_target(m3, t);
                 if (dir >= 0) atomicAdd(&s_halo[dir], 1);
             }
         }
@@ -585,8 +604,8 @@ __device__ __forceinline__ void list_in_neighbour_halos(const DevParams &P, int 
         const float4 q = snap4[start + e];
         const int m3 = halo_dirs(P, i1, i2, i3, q.x, q.y, q.z);
         if (!m3) continue;
-        for (int m = 1; m < 8; m++) {
-            const int dir = halo_dir_of_subset(m3, m);
+        for (int t = 0; t < halo_targets(m3); t++) {
+            const int dir = halo_target(m3, t);
             if (dir < 0 || s_halo_base[dir] < 0) continue;
             const int k = s_halo_base[dir] + atomicAdd(&s_halo[dir], 1);
             if (k < HALO_CAP) {
@@ -765,8 +784,14 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
         // check as in ps.cpp:1495-1500): x, y, z, w, age in one 24-byte read
         const uint2 *t = reinterpret_cast<const uint2 *>(tdata + (size_t)6 * si);
         const uint2 t0 = t[0], t1 = t[1], t2 = t[2];
-        const float4 p = make_float4(__uint_as_float(t0.y), __uint_as_float(t1.x), __uint_as_float(t1.y), __uint_as_float(t2.x));
+        float4 p = make_float4(__uint_as_float(t0.y), __uint_as_float(t1.x), __uint_as_float(t1.y), __uint_as_float(t2.x));
         const float age = __uint_as_float(t2.y);
+        // A kid is skipped by the reference's force loop and never collides (app_common.cu:240-243, 284-287);
+        // here it stays in the lists with mass 0, so that r * 0 = +-0 leaves every sum as it was -- which needs r
+        // to be a number.  A child born with the direction (0, 0, 0) has a velocity and, a step later, a position
+        // that is not one (0/0, ps.cpp:1306-1333): in the snapshot a kid's position is the origin (its T_DATA row
+        // and its own state keep what the reference has).
+        if (age < P.kid_thr) p.x = p.y = p.z = 0.0f;
         if (e < P.max_per_cell) {
             sorted_id[start + e] = id;
             rank_of_slot[si] = start + e;
@@ -782,8 +807,8 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
             snap_cid[start + e] = collides ? id : -1;
             const int m3 = (halo_count && collides) ? halo_dirs(P, ci1, ci2, ci3, p.x, p.y, p.z) : 0;
             if (m3) {
-                for (int m = 1; m < 8; m++) {
-                    const int dir = halo_dir_of_subset(m3, m);
+                for (int t = 0; t < halo_targets(m3); t++) {
+                    const int dir = halo_target(m3, t);
                     if (dir >= 0) atomicAdd(&s_halo[dir], 1);
                 }
                 if (CAP == SMALL) { hx[k] = p.x; hy[k] = p.y; hz[k] = p.z; hid[k] = id; hm3[k] = m3; }
@@ -836,8 +861,8 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
 #pragma unroll
     for (int k = 0; k < KR; k++) {
         if (!hm3[k]) continue;
-        for (int m = 1; m < 8; m++) {
-            const int dir = halo_dir_of_subset(hm3[k], m);
+        for (int t = 0; t < halo_targets(hm3[k]); t++) {
+            const int dir = halo_target(hm3[k], t);
             if (dir < 0 || s_halo_base[dir] < 0) continue;
             const int kk = s_halo_base[dir] + atomicAdd(&s_halo[dir], 1);
             if (kk < HALO_CAP) {
@@ -1031,13 +1056,24 @@ __device__ __forceinline__ void pairs_finish_exact(const DevParams &P, const Pai
 {
     constexpr int H = NQ / 2;
     v2f e[H];
-    if (__any(r.dm < P.slow_below)) {
+    // One-pass stage (c.scan; a compile-time false in the two-pass force pass): a distance that is not a number --
+    // the particle's own position or a body's is not one -- passes the reference's collision test, but the
+    // group's minimum does not see it (fminf drops it): such a group takes the branch with the exact rule too.
+    bool wild = false;
+    if (c.scan) {
+        v2f t = r.d[0];
+#pragma unroll
+        for (int i = 1; i < H; i++) t = t + r.d[i];
+        const float tt = t.x + t.y;
+        wild = tt != tt;
+    }
+    if (__any(r.dm < P.slow_below) || __any(wild)) {
 #pragma unroll
         for (int i = 0; i < H; i++) {
             e[i].x = (float)((double)r.d[i].x + P.eps2);
             e[i].y = (float)((double)r.d[i].y + P.eps2);
         }
-        if (c.scan && !(r.dm > P.coll_d2_gate)) {
+        if (c.scan && (wild || !(r.dm > P.coll_d2_gate))) {
 #pragma unroll
             for (int i = 0; i < NQ; i++) {
                 const float di = (i & 1) ? r.d[i >> 1].y : r.d[i >> 1].x;
@@ -1153,6 +1189,29 @@ __device__ __forceinline__ void pair1_exact_lean(const DevParams &P, const PairC
 // k_sort_cells filled) -- then k_build_active lists, per cell, the particles that still need
 // a force, and the force pass walks the 27-cell stencil for those only.
 //
+// Bodies in the stencil of local cell (i1, i2, i3) that are no kids, counted by one wave.  For the particle
+// whose own position is not a number: the lean force walks let a particle meet itself and the kids because
+// r * 0 adds nothing -- not so when r is no number.  The reference skips both (ps.cpp:1258,
+// app_common.cu:240-243): with no other body in the stencil the particle's sum is +0 (this count is 1:
+// itself), with one it is no number either way.
+__device__ __forceinline__ int stencil_adults(const DevParams &P, int i1, int i2, int i3, const int *__restrict__ cell_start,
+                                              const float *__restrict__ snap_age)
+{
+    const int lane = threadIdx.x & 63;
+    int total = 0;
+    for (int k = 0; k < STENCIL; k++) {
+        const int nc = __builtin_amdgcn_readfirstlane(local_cell(P, i3 + c_stencil[k][2], i1 + c_stencil[k][1], i2 + c_stencil[k][0]));
+        if (nc < 0) continue;
+        const int b = __builtin_amdgcn_readfirstlane(cell_start[nc]);
+        const int n = __builtin_amdgcn_readfirstlane(min(cell_start[nc + 1] - b, P.max_per_cell));
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            total += __popcll(__ballot(j < n && !(snap_age[b + (j < n ? j : 0)] < P.kid_thr)));
+        }
+    }
+    return total;
+}
+
 // One particle against `n` bodies given as arrays (wave-uniform pointers, so the loads are
 // scalar loads).  bodyBodyCollision (app_common.cu:269-301) without a branch: the reference's
 // test (double)sqrtf(r.r) > COLLISION_RADIUS is, sqrtf being correctly rounded and monotone,
@@ -1265,7 +1324,7 @@ __global__ __launch_bounds__(256, CAP <= 1024 ? 7 : 3) void k_collide_cell(DevPa
     const float ox = ((float)i2 - (float)(P.G / 2)) * cs - reach, oy = ((float)(P.G / 2) - (float)i1) * cs + reach,
                 oz = ((float)(P.G / 2) - (float)i3) * cs + reach;      // u = x - ox, oy - y, oz - z: offsets into the grown box
     auto bin1 = [&](float u) { return max(0, min(nb - 1, (int)(u * per_unit))); };
-    const bool binned = nh <= HALO_CAP && cnt + nh <= CAP;
+    bool binned = nh <= HALO_CAP && cnt + nh <= CAP;
     const int nbins = nb * nb * nb;
     // what one force task of this cell walks: the population of its stencil (the last wave, while the others' loads fly)
     if (wv == 3) {
@@ -1280,7 +1339,6 @@ __global__ __launch_bounds__(256, CAP <= 1024 ? 7 : 3) void k_collide_cell(DevPa
     float4 q[KB];
     if (binned) {
         const int nbody = cnt + nh;
-        int bin[KB], rank[KB];
         // all the loads in one batch (the coordinates do not wait for the ids), the bins zeroed meanwhile
 #pragma unroll
         for (int k = 0; k < KB; k++) {
@@ -1294,8 +1352,16 @@ __global__ __launch_bounds__(256, CAP <= 1024 ? 7 : 3) void k_collide_cell(DevPa
                 q[k].z = own ? snap_soa[2 * cap + base + e] : halo_f[2 * hplane + hat + (e - cnt)];
             }
         }
+        // A candidate whose position is not a number passes the reference's distance test against every particle
+        // that scans it (halo_dirs): no bins for this cell, collide_scan meets it with everything.
+        bool wild = false;
+#pragma unroll
+        for (int k = 0; k < KB; k++) wild |= __float_as_int(q[k].w) >= 0 && !finite3(q[k].x, q[k].y, q[k].z);
         for (int b = tid; b <= nbins; b += 256) s_bin[b] = 0;
-        __syncthreads();
+        if (__syncthreads_or(wild)) binned = false;
+    }
+    if (binned) {
+        int bin[KB], rank[KB];
 #pragma unroll
         for (int k = 0; k < KB; k++) {
             bin[k] = -1; rank[k] = 0;
@@ -1326,11 +1392,11 @@ __global__ __launch_bounds__(256, CAP <= 1024 ? 7 : 3) void k_collide_cell(DevPa
     const float dmax = P.coll_d2_max;
     // the flag, the final force4 record of the particles the force pass does not visit, and the list of the ones it does
     // (flag 0 and not a kid), packed at active_list[cell_start[c] ...] in whatever order the cell's waves arrive
-    auto finish = [&](bool valid, int gi, bool dead, bool kid, bool met_higher, bool met_lower) {
+    auto finish = [&](bool valid, int gi, bool dead, bool kid, bool met_higher, bool met_lower, bool alone = false) {
         int flag = met_higher ? 2 : met_lower ? 1 : 0;
         if (dead) flag = 2;                                          // ps.cpp:1183
         if (valid) force4[gi] = make_float4(0.f, 0.f, 0.f, __int_as_float(flag));   // final unless the force pass overwrites it
-        const bool on = valid && flag == 0 && !kid;
+        const bool on = valid && flag == 0 && !kid && !alone;       // (alone: stencil_adults)
         const unsigned long long m = __ballot(on);
         if (m) {
             int off = 0;
@@ -1400,7 +1466,9 @@ __global__ __launch_bounds__(256, CAP <= 1024 ? 7 : 3) void k_collide_cell(DevPa
             unsigned long long hi_mask = 0, lo_mask = 0;
             collide_scan(P, xi, yi, zi, id_i, scan, snap_soa + base, snap_soa + cap + base, snap_soa + 2 * cap + base,
                          snap_cid + base, cnt, hi_mask, lo_mask);
-            if (nh <= HALO_CAP) {
+            // (a particle whose own position is not a number passes the distance test against EVERY body of its
+            // stencil, not only the ones near the faces: its wave walks the whole stencil)
+            if (nh <= HALO_CAP && !__any(scan && !finite3(xi, yi, zi))) {
                 collide_scan(P, xi, yi, zi, id_i, scan, halo_f + hat, halo_f + hplane + hat, halo_f + 2 * hplane + hat, halo_id + hat, nh,
                              hi_mask, lo_mask);
             } else {
@@ -1414,7 +1482,13 @@ __global__ __launch_bounds__(256, CAP <= 1024 ? 7 : 3) void k_collide_cell(DevPa
                                  hi_mask, lo_mask);
                 }
             }
-            finish(valid, gi, dead, kid, (hi_mask >> lane) & 1ull, (lo_mask >> lane) & 1ull);
+            // (a particle whose position is not a number and that has no other adult in its stencil: its sum is +0)
+            bool alone = false;
+            if (__any(scan && !finite3(xi, yi, zi))) {
+                const int adults = stencil_adults(P, i1, i2, i3, cell_start, snap_age);   // (all lanes: the count is a wave's work)
+                alone = scan && !finite3(xi, yi, zi) && adults <= 1;
+            }
+            finish(valid, gi, dead, kid, (hi_mask >> lane) & 1ull, (lo_mask >> lane) & 1ull, alone);
         }
     }
 }
@@ -1880,21 +1954,24 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
             have = k < 27;
             // issued after the fences (they drain outstanding loads), consumed a tile later
             if (have && lane < min(64, ncnt - t0)) pre = snap4[nb + t0 + lane];
-            float dmin = 3.0e38f;
+            float dmin = 3.0e38f, dsum = 0.0f;          // (dsum: a distance that is not a number passes the collision test; fminf drops it)
 #pragma unroll 4
             for (int jj = 0; jj < n; jj++) {
                 if (c_nb + c_t0 + jj == gi) continue;
                 const float4 q = tile[jj];
                 if (q.w == 0.0f) {                     // kid (or massless) neighbour: no force term, still a distance
                     const float rx = q.x - me.x, ry = q.y - me.y, rz = q.z - me.z;
-                    dmin = fminf(dmin, rx * rx + ry * ry + rz * rz);
+                    const float d2 = rx * rx + ry * ry + rz * rz;
+                    dmin = fminf(dmin, d2); dsum += d2;
                     continue;
                 }
-                dmin = fminf(dmin, pair_exact(me.x, me.y, me.z, q, P.eps2, ax, ay, az));
+                const float d2 = pair_exact(me.x, me.y, me.z, q, P.eps2, ax, ay, az);
+                dmin = fminf(dmin, d2); dsum += d2;
             }
             // rare: someone in this tile is within the collision gate of one of my lanes
-            if (__any(scan && !(dmin > P.coll_d2_gate))) {
-                if (scan && !(dmin > P.coll_d2_gate)) {
+            const bool close = scan && (!(dmin > P.coll_d2_gate) || dsum != dsum);
+            if (__any(close)) {
+                if (close) {
                     for (int jj = 0; jj < n; jj++) {
                         const float4 q = tile[jj];
                         const float rx = q.x - me.x, ry = q.y - me.y, rz = q.z - me.z;
@@ -1918,6 +1995,15 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
     }
     if (dead) flag = 2;
     if (kid) { ax = 0.f; ay = 0.f; az = 0.f; }   // every term is skipped for a kid (app_common.cu:240)
+    if (MODE != 0 && !SETTLED) {
+        // one-pass lean stage: a particle whose own position is not a number met itself and the kids (stencil_adults;
+        // the two-pass stage settles this in k_collide_cell, the generic mode skips both explicitly)
+        const bool lost = valid && !kid && !finite3(me.x, me.y, me.z);
+        if (__any(lost)) {
+            const int adults = stencil_adults(P, i1, i2, i3, cell_start, snap_age);       // (all lanes: the count is a wave's work)
+            if (lost && adults <= 1) { ax = 0.f; ay = 0.f; az = 0.f; }
+        }
+    }
     if (valid) force4[gi] = make_float4(ax, ay, az, __int_as_float(flag));
     PS_TRACE_END();
 }
@@ -2466,9 +2552,13 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
         // set_pos_t, app.cu:117-158: double floor, periodic wrap one grid length at a time
         const int G = P.G;
         const double cs = P.cell_size;
-        int i1 = (int)(floor((-1.0 * (double)ry) / cs) + (double)(G / 2));
-        int i2 = (int)(floor((1.0 * (double)rx) / cs) + (double)(G / 2));
-        int i3 = (int)(floor((-1.0 * (double)rz) / cs) + (double)(G / 2));
+        // (the reference's host path converts with cvttsd2si: a value that is no number, or out of int's range, comes
+        // out as INT_MIN there -- 0 on this hardware -- and the wrap loop below then walks it to (2^31 mod G
+        // related) cell indices: 0 for G = 16, 4 for G = 12, 7 for G = 15.  Same arithmetic here.)
+        auto to_int = [](double d) { return (d >= -2147483648.0 && d < 2147483648.0) ? (int)d : (int)0x80000000; };
+        int i1 = to_int(floor((-1.0 * (double)ry) / cs) + (double)(G / 2));
+        int i2 = to_int(floor((1.0 * (double)rx) / cs) + (double)(G / 2));
+        int i3 = to_int(floor((-1.0 * (double)rz) / cs) + (double)(G / 2));
         for (int guard = 0; guard < 64 &&
              !((i1 >= 0 && i1 < G) && (i2 >= 0 && i2 < G) && (i3 >= 0 && i3 < G)); guard++) {
             if (!(i1 >= 0 && i1 < G)) { const int o = i1; i1 = (i1 + G) % G; ry = (float)((double)ry + (-1.0 * (double)(i1 - o) * cs)); }
@@ -2521,7 +2611,8 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
     const int GG = P.G * P.G;
     const int layers_up = ((new_cell / GG) - (old_cell / GG) + P.G) % P.G;
     bool up_ = remote_ && (layers_up == 1 || layers_up == 2);
-    if (remote_ && !up_ && layers_up < P.G - 2) atomicOr(&fs->error, ERR_FOREIGN_CELL);     // not a neighbour's: cannot happen with MAX_DX
+    // (A jump of more layers than that -- a particle whose position stopped being a number is filed under cell 0
+    // wherever it was -- is routed by who holds the record, below; no route: ERR_FOREIGN_CELL.)
     // Whose queue is it?  The neighbour's in the direction of travel as a rule; the OTHER neighbour's in a
     // ring of two or three (the same rank, or the rank two further round); and when a two-layer jump flies
     // over a rank whose whole state is one layer, the rank beyond it: that record travels in the hop-two

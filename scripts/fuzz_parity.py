@@ -88,10 +88,22 @@ def draw_case(rng, sizes, max_steps=6, worlds=(1, 1, 2, 3, 4)):
     interior = bool(world > 1 and rng.random() < 0.3)
     reupload = bool(world == 1 and not births and rng.random() < 0.4)   # hand the state to a fresh context half way
     # (not with births: the birth RNG is keyed on the context's step counter, which a fresh context restarts)
-    return dict(n=n, xyz=xyz, v=v, age=age, fert=fert, w=w, births=births, over=over, world=world, steps=int(rng.integers(2, max_steps + 1)),
-                cuts=cuts, interior=interior, reupload=reupload, replay=bool(rng.random() < 0.35),
-                desc="n=%d G=%d half=%.1f vmax=%g births=%d masses=%d world=%d cuts=%r interior=%d reupload=%d %r" %
-                     (n, G, half, vmax, births, w is not None, world, cuts, interior, reupload, over))
+    steps = int(rng.integers(2, max_steps + 1))
+    replay = bool(rng.random() < 0.35)
+    # (last draw, so that the cases of earlier campaigns keep their other draws) now and then two particles whose
+    # velocity is not a number -- what a child born with the direction (0, 0, 0) gets (0/0, ps.cpp:1306-1333): a kid and
+    # an adult; a step later their position is not a number either and the reference files them under cell 0
+    if rng.random() < 0.15:
+        if v is None:
+            v = np.zeros((n, 3), np.float32)
+        pick = rng.choice(n, 2, replace=False)
+        v[pick] = np.nan
+        age[pick[0]] = np.float32(0.3 * kid)
+        age[pick[1]] = np.float32(0.4 * life)
+    return dict(n=n, xyz=xyz, v=v, age=age, fert=fert, w=w, births=births, over=over, world=world, steps=steps,
+                cuts=cuts, interior=interior, reupload=reupload, replay=replay,
+                desc="n=%d G=%d half=%.1f vmax=%g births=%d masses=%d world=%d cuts=%r interior=%d reupload=%d nan=%d %r" %
+                     (n, G, half, vmax, births, w is not None, world, cuts, interior, reupload, int(v is not None and bool(np.isnan(v).any())), over))
 
 
 def run_case(c, seed):
@@ -147,7 +159,11 @@ def run_case(c, seed):
             # smaller than what a fast dense cloud sends (halo_cap_cell, xfer_cap, the hop-two messages' 1024 records).
             # (Served since round 3, no longer refusals: the chunk-list capacity rule across ranks, a two-layer jump
             # over a rank whose state is a single layer.)
-            if W > 1 and ("status message" in str(e) or "had no room" in str(e)):
+            # ... and a particle whose position is not a number, which the reference files under cell 0, on a rank that is not
+            # within two layers of layer 0: its record has no route to rank 0
+            far_nan = (W >= 4 and (c["births"] or (c["v"] is not None and bool(np.isnan(c["v"]).any())))
+                       and ("holds no state for" in str(e) or "does not match the receiver" in str(e)))
+            if W > 1 and ("status message" in str(e) or "had no room" in str(e) or far_nan):
                 for g in ranks:
                     g.close()
                 o.close()

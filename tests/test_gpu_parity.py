@@ -534,3 +534,33 @@ def test_many_queue_records_grid_40():
         g.step(1); o.step(1)
         compare_all(g, o, "40^3 grid step %d" % (k + 1))
     assert g.counters["relocations"] > 10000
+
+
+@pytest.mark.parametrize("steps,radius", [(4, 0.4), (3, 2.0)])
+def test_particles_whose_position_is_not_a_number(steps, radius):
+    """A child born with the direction (0, 0, 0) gets the velocity 0/0 (ps.cpp:1306-1333) and, a step later, a
+    position that is not a number; the reference files it under cell 0 from then on.  While it is a kid it is
+    skipped by the force loop and the collision test (here: mass 0 in the snapshot, position replaced); once it
+    is an adult, `dist > COLLISION_RADIUS` does not fail for it and every adult of its stencil that scans it
+    collides with it -- and it, scanning, with every adult body of ITS stencil.  Two such particles (a kid and an
+    adult) start among a dense crowd in the corner cells (0..1)^3; every byte against the oracle.  (Radius 2.0: the
+    one-pass pair stage, where flags and forces come from the same walk.)"""
+    rng = np.random.default_rng(171)
+    n = 1500
+    corner = np.stack([rng.uniform(-39.9, -30.1, n), rng.uniform(30.1, 39.9, n), rng.uniform(30.1, 39.9, n)], axis=1).astype(np.float32)
+    rest = cloud(2000, 172)
+    xyz = np.concatenate([corner, rest]).astype(np.float32)
+    m = len(xyz)
+    age = rng.uniform(2.0, 9.0, m).astype(np.float32)
+    v = rng.uniform(-3, 3, (m, 3)).astype(np.float32)
+    # the kid (its velocity is not a number from birth) and the adult, both well inside the box so that the first
+    # step files them under cell 0 from somewhere else
+    xyz[0] = (1.0, 2.0, 3.0); age[0] = 0.05; v[0] = np.nan
+    xyz[1] = (-7.0, 4.0, -9.0); age[1] = 4.0; v[1] = np.nan
+    g, o = make_pair(xyz, age=age, fert=1e6, vxyz=v, collision_radius=radius)
+    for k in range(steps):
+        g.step(1); o.step(1)
+        compare_all(g, o, "not-a-number particles, step %d" % (k + 1))
+    p = o.particles
+    assert np.isnan(p["x"][p["cell"] >= 0]).sum() >= 1 and (p["cell"] == 0).sum() >= 1
+    assert o.counters["deaths_collision"] + o.counters["survives"] > 100          # the crowd met the adult

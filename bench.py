@@ -553,6 +553,7 @@ def main():
             ring.exchange("force")
             g.slab_apply()
             ring.exchange("xfer")
+            ring.finish_far(ring.gather_far())
             g.slab_finish()
             n, f = allsum(n), allsum(mine)
         return n, f, mine

@@ -136,18 +136,21 @@ int exchange(const std::vector<Slab> &local, int world, bool loopback, Phase ph,
     return 0;
 }
 
-int gather_status(const std::vector<Slab> &local, int world, bool loopback, ncclComm_t comm, hipStream_t st)
+// an all-gathered buffer pair: the status records (far == false), or the far outboxes of the transfer phase
+int gather(const std::vector<Slab> &local, int world, bool loopback, bool far, ncclComm_t comm, hipStream_t st)
 {
-    if (world == 1 || !local[0].b.status_bytes) return 0;
-    const size_t nb = (size_t)local[0].b.status_bytes;
+    auto out_of = [&](const Slab &s) { return far ? s.b.far_out : s.b.status_out; };
+    auto in_of = [&](const Slab &s) { return far ? s.b.far_in : s.b.status_in; };
+    const size_t nb = (size_t)(far ? local[0].b.far_bytes : local[0].b.status_bytes);
+    if (world == 1 || !nb) return 0;
     if (!loopback) {
-        NCCL_OK(ncclAllGather(local[0].b.status_out, local[0].b.status_in, nb, ncclInt8, comm, st));
+        NCCL_OK(ncclAllGather(out_of(local[0]), in_of(local[0]), nb, ncclInt8, comm, st));
         return 0;
     }
     // a communicator of one rank: its all-gather is a copy; every slab's record into every slab's block
     for (const Slab &src : local)
         for (const Slab &dst : local)
-            NCCL_OK(ncclAllGather(src.b.status_out, (char *)dst.b.status_in + (size_t)src.rank * nb, nb, ncclInt8, comm, st));
+            NCCL_OK(ncclAllGather(out_of(src), (char *)in_of(dst) + (size_t)src.rank * nb, nb, ncclInt8, comm, st));
     return 0;
 }
 
@@ -260,11 +263,12 @@ int main(int argc, char **argv)
     for (int it = 0; it < iters; it++) {      // DoParallelProcess, ps.cpp:1843-1928, one slab per GPU
         for (Slab &s : local) PS_OK(s.ctx, psamd_slab_build(s.ctx));
         if (exchange(local, world, loopback, HALO, comm, st, &moved)) return 1;
-        if (gather_status(local, world, loopback, comm, st)) return 1;
+        if (gather(local, world, loopback, false, comm, st)) return 1;
         for (Slab &s : local) PS_OK(s.ctx, psamd_slab_pairs(s.ctx));
         if (exchange(local, world, loopback, FORCE, comm, st, &moved)) return 1;
         for (Slab &s : local) PS_OK(s.ctx, psamd_slab_apply(s.ctx));
         if (exchange(local, world, loopback, XFER, comm, st, &moved)) return 1;
+        if (gather(local, world, loopback, true, comm, st)) return 1;        // (births on, four or more ranks)
         for (Slab &s : local) PS_OK(s.ctx, psamd_slab_finish(s.ctx));
     }
     for (Slab &s : local) PS_OK(s.ctx, psamd_synchronize(s.ctx));

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PSAMD_ABI_VERSION 3
+#define PSAMD_ABI_VERSION 4
 
 #define PSAMD_MAX_RANKS 64
 
@@ -272,13 +272,19 @@ typedef struct psamd_slab_buffers {
                                               out[1] -> rank+2's in[0].  Only in worlds (>= 4 ranks) where some rank's whole state is one
                                               cell layer, which a particle crossing two layers in a step can fly over; else 0 bytes */
     int64_t xfer2_bytes;
+    void   *far_out, *far_in;              /* ALL-GATHERED in the transfer phase (with xfer_*): records for a rank further away than the
+                                              neighbour messages reach; far_in = world blocks of far_bytes, by rank.  A particle whose
+                                              position stopped being a number is filed under one fixed cell wherever it was (the
+                                              reference's conversion): only births make such particles, so the buffers exist in worlds
+                                              of >= 4 ranks with PSAMD_FLAG_EXPLOSIONS; else 0 bytes */
+    int64_t far_bytes;
 } psamd_slab_buffers;
 int psamd_slab_buffers_get(psamd_ctx *ctx, psamd_slab_buffers *out);
 
 /* One step = build, [exchange halo_out -> neighbours' halo_in; start the all-gather of
  * status_out into every rank's status_in; with PSAMD_FLAG_ALL_PAIRS the all-gather of allg_out into
  * allg_in, which must have landed], pairs, [force_out -> rank-1's force_in; the status gather must
- * have landed], apply, [xfer_out -> neighbours' xfer_in], finish.  The status record carries a rank's
+ * have landed], apply, [xfer_out -> neighbours' xfer_in; where they exist xfer2_* likewise and the all-gather of far_out into far_in], finish.  The status record carries a rank's
  * sticky error bits, the slots the cell-overflow rule killed, which the reference frees into queue
  * record 0 wherever they were (ps.cpp:1523-1526), and the rank's part of every chunk's particle count
  * per segment type, from which all ranks reproduce the chunk lists' capacity rule (ps.cpp:1502-1508)
@@ -297,7 +303,7 @@ int psamd_slab_finish(psamd_ctx *ctx);  /* merges xfer_in; queue replay and relo
 /* Transport through host memory (tests, two processes sharing one GPU): copy message buffer
  * `which` to / from the host.  which: 0/1 halo_out[0/1], 2/3 halo_in[0/1], 4 force_out,
  * 5 force_in, 6/7 xfer_out[0/1], 8/9 xfer_in[0/1], 10 status_out, 11 status_in, 12 allg_out, 13 allg_in,
- * 14/15 xfer2_out[0/1], 16/17 xfer2_in[0/1]. */
+ * 14/15 xfer2_out[0/1], 16/17 xfer2_in[0/1], 18 far_out, 19 far_in. */
 int psamd_slab_msg_download(psamd_ctx *ctx, int which, void *host, int64_t bytes);
 int psamd_slab_msg_upload(psamd_ctx *ctx, int which, const void *host, int64_t bytes);
 

@@ -94,13 +94,15 @@ class SlabBuffers(C.Structure):
                 ("xfer_out", C.c_void_p * 2), ("xfer_in", C.c_void_p * 2), ("xfer_bytes", C.c_int64),
                 ("status_out", C.c_void_p), ("status_in", C.c_void_p), ("status_bytes", C.c_int64),
                 ("allg_out", C.c_void_p), ("allg_in", C.c_void_p), ("allg_bytes", C.c_int64),
-                ("xfer2_out", C.c_void_p * 2), ("xfer2_in", C.c_void_p * 2), ("xfer2_bytes", C.c_int64)]
+                ("xfer2_out", C.c_void_p * 2), ("xfer2_in", C.c_void_p * 2), ("xfer2_bytes", C.c_int64),
+                ("far_out", C.c_void_p), ("far_in", C.c_void_p), ("far_bytes", C.c_int64)]
 
 
 # psamd_slab_msg_download / _upload `which`
 MSG_HALO_OUT, MSG_HALO_IN, MSG_FORCE_OUT, MSG_FORCE_IN, MSG_XFER_OUT, MSG_XFER_IN, MSG_STATUS_OUT, MSG_STATUS_IN = 0, 2, 4, 5, 6, 8, 10, 11
 MSG_ALLG_OUT, MSG_ALLG_IN = 12, 13
 MSG_XFER2_OUT, MSG_XFER2_IN = 14, 16
+MSG_FAR_OUT, MSG_FAR_IN = 18, 19
 
 
 class PsamdError(RuntimeError):
@@ -400,7 +402,8 @@ class ParticleSystem:
             self._msg_bytes = [b.halo_out_bytes[0], b.halo_out_bytes[1], b.halo_in_bytes[0], b.halo_in_bytes[1],
                                b.force_out_bytes, b.force_in_bytes] + [b.xfer_bytes] * 4 + \
                               [b.status_bytes, b.status_bytes * max(1, self.cfg.world),
-                               b.allg_bytes, b.allg_bytes * max(1, self.cfg.world)] + [b.xfer2_bytes] * 4
+                               b.allg_bytes, b.allg_bytes * max(1, self.cfg.world)] + [b.xfer2_bytes] * 4 + \
+                              [b.far_bytes, b.far_bytes * max(1, self.cfg.world)]
         return self._msg_bytes[which]
 
     def msg_download(self, which, nbytes=None):

@@ -42,8 +42,8 @@ struct psamd_ctx {
     int halo_out_c0[2] = {0, 0}, halo_out_cells[2] = {0, 0}, halo_in_cells[2] = {0, 0};
     int *force_out = nullptr, *force_in = nullptr;
     size_t force_out_bytes = 0, force_in_bytes = 0;
-    int *xfer_out[4] = {nullptr, nullptr, nullptr, nullptr}, *xfer_in[4] = {nullptr, nullptr, nullptr, nullptr};   // [2], [3]: two ranks below / above
-    size_t xfer_bytes = 0, xfer2_bytes = 0;
+    int *xfer_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, *xfer_in[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [2], [3]: two ranks below / above; [4]: the far outbox and the world's far outboxes, all-gathered
+    size_t xfer_bytes = 0, xfer2_bytes = 0, far_bytes = 0;
     int *status_out = nullptr, *status_in = nullptr;   // status_in: world records, all-gathered
     size_t status_bytes = 0;
     int *allg_out = nullptr, *allg_in = nullptr;       // all-pairs across ranks: own snapshot block, all ranks' blocks (all-gathered)
@@ -386,6 +386,10 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
                 if (w >= 0) for (int t = 0; t < 4; t++) { P.nbr_rec_lo[w][t] = pr.rec_lo[t]; P.nbr_rec_hi[w][t] = pr.rec_hi[t]; }
         }
         P.xfer2_cap = (single && cfg->world >= 4) ? 1024 : 0;       // (a ring of two or three has no rank beyond the neighbours)
+        // A record for a rank further away: only a particle whose position stopped being a number travels that far (it is
+        // filed under one fixed cell wherever it was), and only births make such particles (a child with the direction
+        // (0, 0, 0)): with births on, a world of four or more all-gathers a small far outbox in the transfer phase.
+        P.far_cap = (cfg->world >= 4 && (cfg->flags & PSAMD_FLAG_EXPLOSIONS)) ? 16 : 0;
     }
     if ((cfg->flags & PSAMD_FLAG_ALL_PAIRS) && cfg->world > 1) {
         // every rank's block of the all-gathered snapshot has the same size: room for the rank with the most cells / slots
@@ -441,7 +445,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     const size_t C = (size_t)P.slots_total;          // owned slots
     const size_t SC = (size_t)P.sorted_cap + 64;     // sorted-order arrays (+ slack: scalar loads fetch whole groups)
     const size_t LC = (size_t)P.n_local_cells;
-    const size_t xf = (size_t)P.xfer_cap + (size_t)P.xfer2_cap;
+    const size_t xf = (size_t)P.xfer_cap + (size_t)P.xfer2_cap + (size_t)P.far_cap * (size_t)std::max(1, P.world) / 2 + 1;
     d.ops_cap = (int)std::min<size_t>(3 * C + 2 * xf + 64 + (P.world > 1 ? (size_t)P.world * STATUS_KILL_CAP : 0), (size_t)INT32_MAX / 2);
     d.moves_cap = (int)std::min<size_t>(2 * C + 2 * xf + 64, (size_t)INT32_MAX / 2);
     int *frame = nullptr;
@@ -565,6 +569,14 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
             PS_HIP(c, hipMemsetAsync(c->xfer_out[k], 0, bytes, c->stream));
             PS_HIP(c, hipMemsetAsync(c->xfer_in[k], 0, bytes, c->stream));
             d.xfer_out[k] = reinterpret_cast<XferRec *>(c->xfer_out[k] + MSG_HEADER_WORDS);
+        }
+        if (P.far_cap > 0) {
+            c->far_bytes = ((size_t)MSG_HEADER_WORDS + (size_t)P.far_cap * (sizeof(XferRec) / sizeof(int))) * sizeof(int);
+            PS_HIP(c, dev_alloc(c, &c->xfer_out[4], c->far_bytes / sizeof(int)));
+            PS_HIP(c, dev_alloc(c, &c->xfer_in[4], c->far_bytes / sizeof(int) * (size_t)P.world));
+            PS_HIP(c, hipMemsetAsync(c->xfer_out[4], 0, c->far_bytes, c->stream));
+            PS_HIP(c, hipMemsetAsync(c->xfer_in[4], 0, c->far_bytes * (size_t)P.world, c->stream));
+            d.xfer_out[4] = reinterpret_cast<XferRec *>(c->xfer_out[4] + MSG_HEADER_WORDS);
         }
         if (P.flags & PSAMD_FLAG_ALL_PAIRS) {
             c->allg_bytes = (size_t)P.allg_block * sizeof(int);
@@ -1059,7 +1071,7 @@ static int do_lifecycle(psamd_ctx *c)
     if (c->timing_now) { collect_lifecycle_time(c, par); (void)hipEventRecord(c->ev[par ? 11 : 8], c->stream); }
     if (c->P.world > 1) PS_HIP(c, launch_inbox_merge(c->stream, c->P, c->d, c->xfer_in));
     // live_bound < 0: unknown (state was uploaded) -> size for every owned slot; arrivals on top
-    const int64_t bound = (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) + 2 * (int64_t)c->P.xfer_cap + 2 * (int64_t)c->P.xfer2_cap
+    const int64_t bound = (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) + 2 * (int64_t)c->P.xfer_cap + 2 * (int64_t)c->P.xfer2_cap + (int64_t)c->P.far_cap * c->P.world
                           + (c->P.world > 1 ? (int64_t)c->P.world * STATUS_KILL_CAP : 0);
     const int seq = ++c->scalars_seq;
     PS_HIP(c, launch_ops_bucket(c->stream, c->P, c->d, c->geo.queue_infos, bound, seq));
@@ -1262,6 +1274,7 @@ int psamd_slab_buffers_get(psamd_ctx *c, psamd_slab_buffers *o)
     }
     for (int k = 0; k < 2; k++) { o->xfer2_out[k] = c->xfer_out[2 + k]; o->xfer2_in[k] = c->xfer_in[2 + k]; }
     o->xfer2_bytes = (int64_t)c->xfer2_bytes;
+    o->far_out = c->xfer_out[4]; o->far_in = c->xfer_in[4]; o->far_bytes = (int64_t)c->far_bytes;
     o->force_out = c->force_out; o->force_in = c->force_in;
     o->force_out_bytes = (int64_t)c->force_out_bytes; o->force_in_bytes = (int64_t)c->force_in_bytes;
     o->xfer_bytes = (int64_t)c->xfer_bytes;
@@ -1285,6 +1298,8 @@ static bool slab_msg(psamd_ctx *c, int which, int *&ptr, size_t &bytes)
     case 13: ptr = c->allg_in; bytes = c->allg_bytes * (size_t)std::max(1, c->P.world); return true;
     case 14: case 15: ptr = c->xfer_out[which - 12]; bytes = c->xfer2_bytes; return true;
     case 16: case 17: ptr = c->xfer_in[which - 14]; bytes = c->xfer2_bytes; return true;
+    case 18: ptr = c->xfer_out[4]; bytes = c->far_bytes; return true;
+    case 19: ptr = c->xfer_in[4]; bytes = c->far_bytes * (size_t)std::max(1, c->P.world); return true;
     }
     return false;
 }

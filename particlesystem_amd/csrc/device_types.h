@@ -80,6 +80,7 @@ struct DevParams {
     // the ring neighbours' QUEUE_INFO records (0: the rank below, 1: above): which of them a departing record is for
     int32_t nbr_rec_lo[2][4], nbr_rec_hi[2][4];
     int32_t xfer2_cap;       // records per step and direction that may go TWO ranks away (0: no rank of this world can be flown over)
+    int32_t far_cap;         // records per step that may go to a rank further away still, through the all-gathered far outbox (0: none)
 };
 
 
@@ -196,7 +197,7 @@ struct FrameScalars {
     int32_t n_tasks;        // non-empty (cell, slice) tasks of the pair kernel this frame
     int32_t n_tasks2;       // two-pass mode: (cell, 64-slice) tasks over the particles that need a force
     int32_t n_merged;       // ... and merged tasks (up to four cells' partly filled last slices in one wave)
-    int32_t n_out[4];       // slab mode: relocation / birth records leaving for the rank below [0] / above [1], two ranks below [2] / above [3]
+    int32_t n_out[5];       // slab mode: relocation / birth records leaving for the rank below [0] / above [1], two ranks below [2] / above [3], any other rank [4] (the all-gathered far outbox)
     int32_t n_lent;         // slab mode: bodies in the lent-in region this frame
     int32_t chunk_over;     // a chunk's count passed MAX_PARTICLES_PER_CHUNK this frame: the tail of its list is skipped (k_chunk_cap)
     int32_t status_error;   // slab mode: OR of the error bits in this step's all-gathered status records (every rank sees the same word)
@@ -243,6 +244,7 @@ constexpr int MOVE_IN = 0x200;       // arrived from a neighbour rank: state alr
 constexpr int MOVE_OUT = 0x400;      // leaves for a neighbour rank (whose queue hands out the slot); | MOVE_UP: the rank above
 constexpr int MOVE_UP = 0x800;
 constexpr int MOVE_HOP2 = 0x1000;    // ... two ranks away (a two-layer jump over a rank whose state is a single layer)
+constexpr int MOVE_FAR = 0x2000;     // ... any rank further away: the record goes into the far outbox, which every rank receives
 
 // One particle on its way to a segment another rank owns (relocation or birth): the queue
 // operation's key in the reference's serial order, and the state to place.  64 bytes.

@@ -75,7 +75,7 @@ struct DeviceState {
     MoveRec *moves = nullptr;
     int moves_cap = 0;
     float4 *stage = nullptr;      // 3 float4 per move
-    XferRec *xfer_out[4] = {nullptr, nullptr, nullptr, nullptr};   // slab mode: records leaving for the rank below / above, two ranks below / above (inside the messages)
+    XferRec *xfer_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // slab mode: records leaving for the rank below / above, two ranks below / above (inside the messages)
     int *status_out = nullptr;    // slab mode: [0] cell-overflow kills this frame, [1] error bits, [2] live, [16..] the killed slot ids
     // all-pairs across ranks: the gathered snapshot blocks (inside the context's message buffer) and their index by global cell
     const int *allg_in = nullptr;
@@ -119,8 +119,8 @@ hipError_t launch_pack_halos(hipStream_t st, const DevParams &P, const DeviceSta
 hipError_t launch_unpack_halos(hipStream_t st, const DevParams &P, const DeviceState &d, int ncell_below, const int *msg_below,
                                int *off_below, int ncell_above, const int *msg_above, int *off_above);
 hipError_t launch_pack_force(hipStream_t st, const DevParams &P, const DeviceState &d, int *msg, int cap_bodies);
-hipError_t launch_outbox_close(hipStream_t st, const DevParams &P, const DeviceState &d, int64_t live_bound, int *const msgs[4]);
-hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *const msgs[4]);
+hipError_t launch_outbox_close(hipStream_t st, const DevParams &P, const DeviceState &d, int64_t live_bound, int *const msgs[5]);
+hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *const msgs[5]);
 hipError_t launch_allg_pack(hipStream_t st, const DevParams &P, const DeviceState &d, int *msg);
 hipError_t launch_allg_index(hipStream_t st, const DevParams &P, const DeviceState &d);
 // status records of all ranks (error bits, cell-overflow kills, chunk counts) + the force records of the lent-out layers (force_msg, may be null)

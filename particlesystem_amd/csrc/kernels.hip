@@ -2420,8 +2420,8 @@ __global__ __launch_bounds__(256, 6) void k_pairs_merged(DevParams P, const int 
 
 // ------------------------------------------------------------------ apply
 // the four outboxes of a slab: records for the rank below [0] / above [1] (xfer_cap each), two ranks below [2] / above [3] (xfer2_cap)
-struct Outboxes { XferRec *o[4]; };
-struct OutboxMsgs { int *m[4]; };        // the messages the outboxes live in (their headers), null where there is none
+struct Outboxes { XferRec *o[5]; };         // below, above, two below, two above, far (all-gathered)
+struct OutboxMsgs { int *m[5]; };        // the messages the outboxes live in (their headers), null where there is none
 
 __device__ __forceinline__ float clamp_mag(float v, float lim)   // ps.cpp:1279-1281, 1294-1296
 {
@@ -2617,15 +2617,20 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
     // ring of two or three (the same rank, or the rank two further round); and when a two-layer jump flies
     // over a rank whose whole state is one layer, the rank beyond it: that record travels in the hop-two
     // outbox, straight to rank +-2 (the reference relocates to any segment, ps.cpp:1335-1374).
-    bool hop2_ = false;
+    // A record for a rank further away than that -- a particle whose position stopped being a number is filed under
+    // one fixed cell wherever it was (see the conversion below) -- goes into the far outbox, which every rank
+    // receives (an all-gather in the transfer phase; worlds of four or more with births on).
+    bool hop2_ = false, far_ = false;
     if (remote_ && !nbr_owns_record(P, up_ ? 1 : 0, new_rec)) {
+        const bool near2 = layers_up == 1 || layers_up == 2 || layers_up >= P.G - 2;
         if (nbr_owns_record(P, up_ ? 0 : 1, new_rec)) up_ = !up_;
-        else if (P.xfer2_cap > 0) hop2_ = true;
+        else if (P.xfer2_cap > 0 && (near2 || P.far_cap <= 0)) hop2_ = true;
+        else if (P.far_cap > 0) far_ = true;
         else atomicOr(&fs->error, ERR_FOREIGN_CELL);
     }
 
         em[it].id = id; em[it].new_cell = new_cell; em[it].new_rec = new_rec; em[it].old_chunk = old_ci.chunk;
-        em[it].bits = (killed ? 1u : 0u) | (born ? 2u : 0u) | (relocate ? 4u : 0u) | (remote_ ? 8u : 0u) | (up_ ? 16u : 0u) | (hop2_ ? 32u : 0u);
+        em[it].bits = (killed ? 1u : 0u) | (born ? 2u : 0u) | (relocate ? 4u : 0u) | (remote_ ? 8u : 0u) | (up_ ? 16u : 0u) | (hop2_ ? 32u : 0u) | (far_ ? 64u : 0u);
         n_op += (killed ? 1 : 0) + ((born && !remote_) ? 1 : 0) + (relocate ? (remote_ ? 1 : 2) : 0);
         n_mv += (born ? 1 : 0) + (relocate ? 1 : 0);
         cnt_moved += (unsigned)__popcll(__ballot(moved)); cnt_surv += (unsigned)__popcll(__ballot(survived));
@@ -2672,18 +2677,18 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
 #pragma unroll
     for (int it = 0; it < ITEMS; it++) {
         const unsigned bits = (room && (n_op || n_mv)) ? em[it].bits : 0u;
-        const bool killed = bits & 1u, born = bits & 2u, relocate = bits & 4u, remote = bits & 8u, up = bits & 16u, hop2 = bits & 32u;
+        const bool killed = bits & 1u, born = bits & 2u, relocate = bits & 4u, remote = bits & 8u, up = bits & 16u, hop2 = bits & 32u, far = bits & 64u;
         const int id = em[it].id, new_cell = em[it].new_cell;
         const int own_r = segment_record_of_slot(S, id);
-        const int box = (up ? 1 : 0) + (hop2 ? 2 : 0);          // which outbox a departure of this particle goes to
+        const int box = far ? 4 : (up ? 1 : 0) + (hop2 ? 2 : 0);          // which outbox a departure of this particle goes to
         // Outbox entries are reserved per wave and direction: one atomic on the message's counter for all
         // of a wave's departures (a rank whose layer empties into its neighbour -- the box surface on the
         // last rank -- made tens of thousands of same-address atomics here, one per particle: 80 us).
         int out_base[2] = {0, 0};               // this lane's outbox entry for [0] a relocation, [1] a birth
         if (P.world > 1) {
 #pragma unroll
-            for (int dir = 0; dir < 4; dir++) {
-                if (dir >= 2 && P.xfer2_cap <= 0) continue;
+            for (int dir = 0; dir < 5; dir++) {
+                if (dir >= 2 && (dir == 4 ? P.far_cap : P.xfer2_cap) <= 0) continue;
                 const bool mine = remote && box == dir;
                 const int want = mine ? ((born ? 1 : 0) + (relocate ? 1 : 0)) : 0;
                 if (__any(want > 0)) {
@@ -2702,14 +2707,14 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
         // a departure: reserve its outbox entry and put the key there; k_moves_stage adds the state
         auto depart = [&](int kind, uint64_t sub) -> int {
             const int o = out_base[kind];
-            if (o >= (hop2 ? P.xfer2_cap : P.xfer_cap)) { atomicOr(&fs->error, ERR_HALO_OVERFLOW); return -1; }
+            if (o >= (far ? P.far_cap : hop2 ? P.xfer2_cap : P.xfer_cap)) { atomicOr(&fs->error, ERR_HALO_OVERFLOW); return -1; }
             XferRec *x = out.o[box] + o;
             x->key = dst_rec | key | sub; x->new_cell = new_cell; x->kind = kind;
             return o;
         };
         if (killed) { op_keys[k] = own_rec | key | 2ull; op_args[k] = id; k++; }
         if (born) {
-            if (remote) moves[m] = {id, depart(1, 0ull), 1 | MOVE_OUT | (up ? MOVE_UP : 0) | (hop2 ? MOVE_HOP2 : 0), new_cell};
+            if (remote) moves[m] = {id, depart(1, 0ull), 1 | MOVE_OUT | (up ? MOVE_UP : 0) | (hop2 ? MOVE_HOP2 : 0) | (far ? MOVE_FAR : 0), new_cell};
             else {
                 moves[m] = {id, -1, 1, new_cell};
                 op_keys[k] = dst_rec | key | 0ull; op_args[k] = m;
@@ -2718,7 +2723,7 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
             m++;
         }
         if (relocate) {
-            if (remote) moves[m] = {id, depart(0, 1ull), 0 | MOVE_OUT | (up ? MOVE_UP : 0) | (hop2 ? MOVE_HOP2 : 0), new_cell};
+            if (remote) moves[m] = {id, depart(0, 1ull), 0 | MOVE_OUT | (up ? MOVE_UP : 0) | (hop2 ? MOVE_HOP2 : 0) | (far ? MOVE_FAR : 0), new_cell};
             else {
                 moves[m] = {id, -1, 0, new_cell};
                 op_keys[k] = dst_rec | key | 1ull; op_args[k] = m;
@@ -3290,9 +3295,9 @@ __global__ void k_moves_stage(DevParams P, MoveRec *moves, int n_host, const Fra
                               const uint8_t *pflags, float4 *stage, Outboxes out, OutboxMsgs msgs)
 {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < 4 && msgs.m[m]) {          // slab, closing the outboxes: the headers of the relocation messages
+    if (m < 5 && msgs.m[m]) {          // slab, closing the outboxes: the headers of the relocation messages
         int *h = msgs.m[m];
-        h[0] = min(fs->n_out[m], m < 2 ? P.xfer_cap : P.xfer2_cap); h[1] = 0; h[2] = fs->error;
+        h[0] = min(fs->n_out[m], m < 2 ? P.xfer_cap : m < 4 ? P.xfer2_cap : P.far_cap); h[1] = 0; h[2] = fs->error;
     }
     if (n_host < 0 && lifecycle_deferred(fs)) return;
     const int n = n_host < 0 ? fs->n_moves : n_host;
@@ -3302,7 +3307,7 @@ __global__ void k_moves_stage(DevParams P, MoveRec *moves, int n_host, const Fra
     const int si = slot_index(P, r.src);
     if (r.kind & MOVE_OUT) {
         if (r.dst < 0) return;                          // the outbox was full (error already raised)
-        XferRec *x = out.o[((r.kind & MOVE_UP) ? 1 : 0) + ((r.kind & MOVE_HOP2) ? 2 : 0)] + r.dst;
+        XferRec *x = out.o[(r.kind & MOVE_FAR) ? 4 : ((r.kind & MOVE_UP) ? 1 : 0) + ((r.kind & MOVE_HOP2) ? 2 : 0)] + r.dst;
         const float4 p = pos4[si], v = vel4[si], a = acc4[si];
         x->pos[0] = p.x; x->pos[1] = p.y; x->pos[2] = p.z; x->pos[3] = p.w;
         x->vel[0] = v.x; x->vel[1] = v.y; x->vel[2] = v.z; x->vel[3] = v.w;
@@ -3575,12 +3580,15 @@ __device__ __forceinline__ void unpack_force_block(const DevParams &P, int b, in
 
 // Arrivals: every record a neighbour sent becomes a MoveRec whose state is staged already,
 // plus the remove operation on this rank's queue, keyed as the sender keyed it.
+// far_stride > 0: msg0 is the all-gathered far outbox, world messages far_stride ints apart; a record is taken by the
+// rank that holds its queue and passed over by the others (and the own message holds nothing for oneself).
 __global__ void k_inbox_merge(DevParams P, const int *__restrict__ msg0, const int *__restrict__ msg1, int blocks_each, int cap,
                               uint64_t *op_keys, int *op_args, int ops_cap,
-                              MoveRec *moves, int moves_cap, float4 *stage, FrameScalars *fs)
+                              MoveRec *moves, int moves_cap, float4 *stage, FrameScalars *fs, int far_stride)
 {
     // (the message from the rank below and the one from the rank above in one launch)
-    const int *msg = (int)blockIdx.x < blocks_each ? msg0 : msg1;
+    const int *msg = far_stride > 0 ? msg0 + (size_t)((int)blockIdx.x / blocks_each) * far_stride : (int)blockIdx.x < blocks_each ? msg0 : msg1;
+    if (far_stride > 0 && (int)blockIdx.x / blocks_each == P.rank) return;
     const int n = min(msg[0], cap);
     const XferRec *in = reinterpret_cast<const XferRec *>(msg + MSG_HEADER_WORDS);
     const int i = ((int)blockIdx.x % blocks_each) * blockDim.x + threadIdx.x;
@@ -3589,7 +3597,7 @@ __global__ void k_inbox_merge(DevParams P, const int *__restrict__ msg0, const i
     const XferRec x = in[i];
     // the record names the queue it is for: it must be one of this rank's (anything else would be
     // replayed on a queue array this rank does not hold)
-    if (!owns_record(P, (int)(x.key >> P.key_rec_shift))) { atomicOr(&fs->error, ERR_SLAB_MISMATCH); return; }
+    if (!owns_record(P, (int)(x.key >> P.key_rec_shift))) { if (far_stride <= 0) atomicOr(&fs->error, ERR_SLAB_MISMATCH); return; }
     const unsigned long long old = atomicAdd((unsigned long long *)&fs->n_ops, (1ull << 32) | 1ull);
     const int k = (int)(old & 0xffffffffull), m = (int)(old >> 32);
     if (k >= ops_cap || m >= moves_cap) { atomicOr(&fs->error, ERR_OPS_OVERFLOW); return; }
@@ -3977,15 +3985,21 @@ hipError_t launch_pack_force(hipStream_t st, const DevParams &P, const DeviceSta
 }
 
 // the inboxes: from the ring neighbours, and (msgs[2], msgs[3]; null where no rank of this world can be flown over) from two ranks away
-hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *const msgs[4])
+hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *const msgs[5])
 {
     if (P.xfer_cap <= 0) return hipSuccess;
     const int nb = (P.xfer_cap + 255) / 256;
-    k_inbox_merge<<<2 * nb, 256, 0, st>>>(P, msgs[0], msgs[1], nb, P.xfer_cap, d.op_keys, d.op_args, d.ops_cap, d.moves, d.moves_cap, d.stage, d.fs);
+    k_inbox_merge<<<2 * nb, 256, 0, st>>>(P, msgs[0], msgs[1], nb, P.xfer_cap, d.op_keys, d.op_args, d.ops_cap, d.moves, d.moves_cap, d.stage, d.fs, 0);
     PS_LAUNCH_CHECK();
     if (P.xfer2_cap > 0 && msgs[2] && msgs[3]) {
         const int nb2 = (P.xfer2_cap + 255) / 256;
-        k_inbox_merge<<<2 * nb2, 256, 0, st>>>(P, msgs[2], msgs[3], nb2, P.xfer2_cap, d.op_keys, d.op_args, d.ops_cap, d.moves, d.moves_cap, d.stage, d.fs);
+        k_inbox_merge<<<2 * nb2, 256, 0, st>>>(P, msgs[2], msgs[3], nb2, P.xfer2_cap, d.op_keys, d.op_args, d.ops_cap, d.moves, d.moves_cap, d.stage, d.fs, 0);
+        PS_LAUNCH_CHECK();
+    }
+    if (P.far_cap > 0 && msgs[4]) {          // the all-gathered far outboxes of all ranks
+        const int nbf = (P.far_cap + 255) / 256;
+        const int stride = MSG_HEADER_WORDS + P.far_cap * (int)(sizeof(XferRec) / sizeof(int));
+        k_inbox_merge<<<P.world * nbf, 256, 0, st>>>(P, msgs[4], nullptr, nbf, P.far_cap, d.op_keys, d.op_args, d.ops_cap, d.moves, d.moves_cap, d.stage, d.fs, stride);
         PS_LAUNCH_CHECK();
     }
     return hipSuccess;
@@ -4104,7 +4118,7 @@ hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, 
     // slots per thread: one (PSAMD_APPLY_ITEMS: the measurement quoted at the kernel)
 #define PS_APPLY(I) k_apply<I><<<(P.slots_total + I * 1024 - 1) / (I * 1024), 1024, 0, st>>>(P, S, step, d.rank_of_slot, d.force4, d.pos4, \
         d.vel4, d.acc4, d.cell, d.pflags, d.celltab, d.op_keys, d.op_args, d.ops_cap, \
-        d.moves, d.moves_cap, Outboxes{{d.xfer_out[0], d.xfer_out[1], d.xfer_out[2], d.xfer_out[3]}}, d.chunk_count, d.chunk_skip, d.fs, d.ctr)
+        d.moves, d.moves_cap, Outboxes{{d.xfer_out[0], d.xfer_out[1], d.xfer_out[2], d.xfer_out[3], d.xfer_out[4]}}, d.chunk_count, d.chunk_skip, d.fs, d.ctr)
     static const int items_env = std::getenv("PSAMD_APPLY_ITEMS") ? std::atoi(std::getenv("PSAMD_APPLY_ITEMS")) : 0;
     const int items = items_env ? items_env : 1;
     if (items >= 4) PS_APPLY(4); else if (items >= 2) PS_APPLY(2); else PS_APPLY(1);
@@ -4115,12 +4129,12 @@ hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, 
 
 // slab mode, right after apply: the state of the departing particles goes into the outboxes
 // (the rest of the staging waits for the queue replay) and the two messages get their headers
-hipError_t launch_outbox_close(hipStream_t st, const DevParams &P, const DeviceState &d, int64_t live_bound, int *const msgs[4])
+hipError_t launch_outbox_close(hipStream_t st, const DevParams &P, const DeviceState &d, int64_t live_bound, int *const msgs[5])
 {
     const int64_t max_moves = std::min<int64_t>(d.moves_cap, 2 * live_bound);
     const int nb = std::max(1, (int)((max_moves + 255) / 256));
     k_moves_stage<<<nb, 256, 0, st>>>(P, d.moves, -2, d.fs, d.pos4, d.vel4, d.acc4, d.pflags, d.stage,
-                                      Outboxes{{d.xfer_out[0], d.xfer_out[1], d.xfer_out[2], d.xfer_out[3]}}, OutboxMsgs{{msgs[0], msgs[1], msgs[2], msgs[3]}});
+                                      Outboxes{{d.xfer_out[0], d.xfer_out[1], d.xfer_out[2], d.xfer_out[3], d.xfer_out[4]}}, OutboxMsgs{{msgs[0], msgs[1], msgs[2], msgs[3], msgs[4]}});
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -4181,7 +4195,7 @@ hipError_t launch_lifecycle_sorted(hipStream_t st, const DevParams &P, const Dev
     if (n_moves > 0) {
         const int nb = (n_moves + 255) / 256;
         k_moves_stage<<<nb, 256, 0, st>>>(P, d.moves, n_moves, d.fs, d.pos4, d.vel4, d.acc4, d.pflags, d.stage,
-                                          Outboxes{{d.xfer_out[0], d.xfer_out[1], d.xfer_out[2], d.xfer_out[3]}}, OutboxMsgs{{nullptr, nullptr, nullptr, nullptr}});
+                                          Outboxes{{d.xfer_out[0], d.xfer_out[1], d.xfer_out[2], d.xfer_out[3], d.xfer_out[4]}}, OutboxMsgs{{nullptr, nullptr, nullptr, nullptr}});
         PS_LAUNCH_CHECK();
         k_moves_reset<<<nb, 256, 0, st>>>(P, d.moves, n_moves, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags);
         PS_LAUNCH_CHECK();

@@ -28,6 +28,7 @@ import numpy as np
 HALO_OUT, HALO_IN, FORCE_OUT, FORCE_IN, XFER_OUT, XFER_IN, STATUS_OUT, STATUS_IN = 0, 2, 4, 5, 6, 8, 10, 11
 ALLG_OUT, ALLG_IN = 12, 13          # all-pairs forces only: every rank's snapshot block, all-gathered between build and pairs
 XFER2_OUT, XFER2_IN = 14, 16        # particles changing owner to a rank TWO away (worlds where a single-layer rank can be flown over)
+FAR_OUT, FAR_IN = 18, 19            # ... to any other rank: a small outbox, all-gathered in the transfer phase (births on, world >= 4)
 BELOW, ABOVE = 0, 1
 
 
@@ -76,17 +77,21 @@ def step_local(ranks, overlap_interior=False):
         for s in ranks:
             s.slab_pairs_interior()   # (in a real run: while the halo travels)
     deliver("halo")
-    for out_slot, in_slot in ((STATUS_OUT, STATUS_IN), (ALLG_OUT, ALLG_IN)):      # the "all-gathers"
+    def gather(out_slot, in_slot):                                                # the "all-gathers"
         if world > 1 and _bytes(ranks[0], out_slot):
             every = np.concatenate([s.msg_download(out_slot) for s in ranks])
             for s in ranks:
                 s.msg_upload(in_slot, every)
+
+    gather(STATUS_OUT, STATUS_IN)
+    gather(ALLG_OUT, ALLG_IN)
     for s in ranks:
         s.slab_pairs()
     deliver("force")
     for s in ranks:
         s.slab_apply()
     deliver("xfer")
+    gather(FAR_OUT, FAR_IN)
     for s in ranks:
         s.slab_finish()
 
@@ -160,6 +165,13 @@ class HostRing(_Ring):
     def finish_snapshot(self, work):
         pass
 
+    def gather_far(self):
+        """the far outboxes (records for ranks beyond the neighbour messages' reach), with the transfer phase"""
+        self._gather(FAR_OUT, FAR_IN)
+
+    def finish_far(self, work):
+        pass
+
     def step(self):
         s = self.s
         s.slab_build()
@@ -170,6 +182,7 @@ class HostRing(_Ring):
         self.exchange("force")
         s.slab_apply()
         self.exchange("xfer")
+        self.gather_far()
         s.slab_finish()
 
 
@@ -200,7 +213,8 @@ class DeviceRing(_Ring):
                 STATUS_OUT: (b.status_out, b.status_bytes), STATUS_IN: (b.status_in, b.status_bytes * world),
                 ALLG_OUT: (b.allg_out, b.allg_bytes), ALLG_IN: (b.allg_in, b.allg_bytes * world),
                 XFER2_OUT + 0: (b.xfer2_out[0], b.xfer2_bytes), XFER2_OUT + 1: (b.xfer2_out[1], b.xfer2_bytes),
-                XFER2_IN + 0: (b.xfer2_in[0], b.xfer2_bytes), XFER2_IN + 1: (b.xfer2_in[1], b.xfer2_bytes)}
+                XFER2_IN + 0: (b.xfer2_in[0], b.xfer2_bytes), XFER2_IN + 1: (b.xfer2_in[1], b.xfer2_bytes),
+                FAR_OUT: (b.far_out, b.far_bytes), FAR_IN: (b.far_in, b.far_bytes * world)}
         self.t = {slot: torch.as_tensor(_DevPtr(p, n), device="cuda") for slot, (p, n) in ptrs.items() if p and n}
         self.stream = torch_stream
         sysr.set_stream(torch_stream.cuda_stream)
@@ -254,6 +268,16 @@ class DeviceRing(_Ring):
 
     finish_snapshot = finish_status
 
+    def gather_far(self):
+        """start the all-gather of the far outboxes (beside the transfer messages; slab_finish needs it)"""
+        import torch
+        if self.dist is None or FAR_OUT not in self.t or self.world == 1:
+            return None
+        with torch.cuda.stream(self.stream):
+            return self.dist.all_gather_into_tensor(self.t[FAR_IN], self.t[FAR_OUT], async_op=True)
+
+    finish_far = finish_status
+
     def step(self):
         import torch
         s = self.s
@@ -270,7 +294,10 @@ class DeviceRing(_Ring):
             self.exchange("force")
             self.finish_status(status)         # slab_apply merges the status records (chunk counts over all ranks, error bits)
             s.slab_apply()
-            self.exchange("xfer")
+            xfer = self.start("xfer")
+            far = self.gather_far()            # births on, four or more ranks: records for ranks the messages do not reach
+            self.finish(xfer)
+            self.finish_far(far)
             s.slab_finish()
 
 

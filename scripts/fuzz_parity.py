@@ -107,7 +107,8 @@ def draw_case(rng, sizes, max_steps=6, worlds=(1, 1, 2, 3, 4)):
 
 
 def run_case(c, seed):
-    flags = ps.FLAG_EXPLOSIONS if c["births"] else 0
+    has_nan = c["v"] is not None and bool(np.isnan(c["v"]).any())
+    flags = ps.FLAG_EXPLOSIONS if (c["births"] or has_nan) else 0      # (births on: the far outbox exists in worlds of four or more)
     extra = dict(seed=seed) if c["births"] else {}
     W = c["world"]
     if c["cuts"]:

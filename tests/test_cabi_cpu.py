@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_defaults(lib):
-    assert lib.psamd_abi_version() == 3
+    assert lib.psamd_abi_version() == 4
     cfg = ps.default_config()
     assert (cfg.max_particles_num, cfg.x_factor, cfg.chunk_factor, cfg.chunk_dim) == (1 << 20, 2, 4, 4)
     assert (cfg.cell_size, cfg.eps2, cfg.collision_radius, cfg.dt) == (5.0, 0.2, 0.4, 0.05)

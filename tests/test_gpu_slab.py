@@ -391,3 +391,51 @@ def test_slab_two_layer_jump_over_a_single_layer_rank():
     assert flew >= n // 2 - 5, "the records must have gone two ranks up in one hop"
     for g in ranks:
         g.close()
+
+
+@pytest.mark.parametrize("world,grid", [(8, {}), (6, dict(chunk_factor=3, chunk_dim=4))])
+def test_slab_far_relocation_of_a_particle_that_is_no_number(world, grid):
+    """A particle whose velocity is not a number (what a child born with the direction (0, 0, 0) gets: 0/0,
+    ps.cpp:1306-1333) has, a step later, a position that is not one, and the reference files it under one fixed
+    cell wherever it was: (0,0,0) in the default 16^3 grid, (4,4,4) for G = 12.  On slabs its record must reach the
+    rank that holds that cell's segment, possibly across the ring: it travels in the far outbox
+    (psamd_slab_buffers.far_*), all-gathered in the transfer phase when births are on, and takes its slot from that
+    rank's queue in the reference's serial order.  A kid and an adult start in the middle of the box, among a
+    crowd; every byte of the merged ranks against the oracle.  (Until round 3: a refusal, ERR_FOREIGN_CELL.)"""
+    rng = np.random.default_rng(191)
+    over = dict(grid)
+    G = over.get("chunk_factor", 4) * over.get("chunk_dim", 4)
+    L = 0.5 * G * 5.0 * 0.99
+    n = 6000
+    xyz = rng.uniform(-L, L, (n, 3)).astype(np.float32)
+    # a crowd around the cell the two will be filed under, so that the adult meets somebody there
+    home = 0 if G == 16 else 4
+    lo = -0.5 * G * 5.0
+    c0 = np.array([lo + 5.0 * home, -(lo + 5.0 * home) - 10.0, -(lo + 5.0 * home) - 10.0], np.float32)      # x up, y and z down
+    xyz[:600] = (c0 + rng.uniform(0.2, 9.8, (600, 3))).astype(np.float32)
+    age = rng.uniform(2.0, 9.0, n).astype(np.float32)
+    v = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    # the two start in layers of ranks at least two away on the ring from the one that holds the home cell
+    # (16^3, 8 ranks: layers 7 and 8, ranks 3 and 4, home on rank 0; 12^3, 6 ranks: layers 10 and 0, ranks 5 and 0, home on rank 2)
+    z_a, z_b = (1.5, -3.5) if G == 16 else (-20.0, -27.0)
+    xyz[1000] = (1.0, 2.0, z_a); age[1000] = 0.05; v[1000] = np.nan
+    xyz[1001] = (-7.0, 4.0, z_b); age[1001] = 4.0; v[1001] = np.nan
+    fert = (1e6 + np.arange(n)).astype(np.float32)
+    ranks = [ps.ParticleSystem(ps.default_config(rank=r, world=world, flags=ps.FLAG_EXPLOSIONS, **over)) for r in range(world)]
+    assert ranks[0].msg_bytes(ps.MSG_FAR_OUT) > 0 and ranks[0].msg_bytes(ps.MSG_FAR_IN) == world * ranks[0].msg_bytes(ps.MSG_FAR_OUT)
+    o = O.System(oracle_cfg_from(ranks[0].cfg))
+    ids = o.fill(xyz, age=age, fert_age=fert)
+    p = o.particles
+    p["vx"][ids], p["vy"][ids], p["vz"][ids] = v.T
+    for g in ranks:
+        g.fill_particles(xyz, age=age, fert_age=fert, vxyz=v)
+    far = 0
+    for step in range(4):
+        step_local(ranks); o.step(1)
+        compare_world(ranks, o, "far relocation, world %d, step %d" % (world, step + 1))
+        far += sum(int(g.msg_download(ps.MSG_FAR_OUT)[0]) for g in ranks)
+    live = o.particles["cell"] >= 0
+    assert np.isnan(o.particles["x"][live]).sum() >= 1
+    assert far >= 1, "a record must have travelled in the far outbox"       # (the other may start next to the home rank: the state cuts follow the segments)
+    for g in ranks:
+        g.close()

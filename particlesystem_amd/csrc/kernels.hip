@@ -505,9 +505,16 @@ __device__ __forceinline__ bool finite3(float x, float y, float z)
            (__float_as_uint(z) & 0x7f800000u) != 0x7f800000u;
 }
 
+__device__ __forceinline__ int halo_dirs_of_numbers(const DevParams &P, int i1, int i2, int i3, float x, float y, float z);
 __device__ __forceinline__ int halo_dirs(const DevParams &P, int i1, int i2, int i3, float x, float y, float z)
 {
     if (!finite3(x, y, z)) return HALO_ALL;
+    return halo_dirs_of_numbers(P, i1, i2, i3, x, y, z);
+}
+
+// (x, y, z numbers; anything else reports 0)
+__device__ __forceinline__ int halo_dirs_of_numbers(const DevParams &P, int i1, int i2, int i3, float x, float y, float z)
+{
     const int G = P.G;
     const float cs = (float)P.cell_size, half = (float)(G / 2), reach = P.halo_reach;
     const float u2 = (x / cs + half - (float)i2) * cs, u1 = (-y / cs + half - (float)i1) * cs,
@@ -532,12 +539,21 @@ __device__ __forceinline__ int halo_dir_of_subset(int dirs, int m)
     return (d3 + 1) * 9 + (d1 + 1) * 3 + (d2 + 1);
 }
 
-// The neighbours a body with face bits `dirs` is listed with: target t of halo_targets(dirs), or -1.
-__device__ __forceinline__ int halo_targets(int dirs) { return dirs == HALO_ALL ? 27 : 8; }
-__device__ __forceinline__ int halo_target(int dirs, int t)
+// Calls fn(dir) for every neighbour a body with face bits `dirs` is listed with: the (up to seven) neighbours
+// beyond the faces it is near -- the loop every body takes, unrolled -- or all 26 for HALO_ALL.
+template <class F>
+__device__ __forceinline__ void for_each_halo_dir(int dirs, F fn)
 {
-    if (dirs == HALO_ALL) return t == 13 ? -1 : t;
-    return t == 0 ? -1 : halo_dir_of_subset(dirs, t);
+    if (dirs != HALO_ALL) {
+#pragma unroll
+        for (int m = 1; m < 8; m++) {
+            const int dir = halo_dir_of_subset(dirs, m);
+            if (dir >= 0) fn(dir);
+        }
+    } else {
+        for (int dir = 0; dir < 27; dir++)
+            if (dir != 13) fn(dir);
+    }
 }
 
 // local index of the neighbour in direction `dir`, -1 if this rank does not hold it
@@ -580,10 +596,7 @@ __device__ __forceinline__ void list_in_neighbour_halos(const DevParams &P, int 
             const float4 q = snap4[start + e];
             const int m3 = halo_dirs(P, i1, i2, i3, q.x, q.y, q.z);
             if (!m3) continue;
-            for (int t = 0; t < halo_targets(m3); t++) {
-                const int dir = halo_target(m3, t);
-                if (dir >= 0) atomicAdd(&s_halo[dir], 1);
-            }
+            for_each_halo_dir(m3, [&](int dir) { atomicAdd(&s_halo[dir], 1); });
         }
     }
     __syncthreads();
@@ -604,16 +617,15 @@ __device__ __forceinline__ void list_in_neighbour_halos(const DevParams &P, int 
         const float4 q = snap4[start + e];
         const int m3 = halo_dirs(P, i1, i2, i3, q.x, q.y, q.z);
         if (!m3) continue;
-        for (int t = 0; t < halo_targets(m3); t++) {
-            const int dir = halo_target(m3, t);
-            if (dir < 0 || s_halo_base[dir] < 0) continue;
+        for_each_halo_dir(m3, [&](int dir) {
+            if (s_halo_base[dir] < 0) return;
             const int k = s_halo_base[dir] + atomicAdd(&s_halo[dir], 1);
             if (k < HALO_CAP) {
                 const size_t at = (size_t)halo_neighbour(P, i1, i2, i3, dir) * HALO_CAP + k, plane = (size_t)P.n_local_cells * HALO_CAP;
                 halo_f[at] = q.x; halo_f[plane + at] = q.y; halo_f[2 * plane + at] = q.z;
                 halo_id[at] = id;
             }
-        }
+        });
     }
 }
 
@@ -778,6 +790,7 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
     int hid[KR], hm3[KR];
 #pragma unroll
     for (int k = 0; k < KR; k++) hm3[k] = 0;
+    bool wild_any = false;
     auto row = [&](int e, int k) {
         const int id = ordered[e], si = slot_index(P, id);
         // the particle's T_DATA row (written by the scatter pass for every live slot, before the overflow
@@ -805,13 +818,19 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
             // collision id: the slot id, or -1 for a body that can never collide (kid, over age)
             const bool collides = !(age < P.kid_thr) && !(age > P.life_thr);
             snap_cid[start + e] = collides ? id : -1;
-            const int m3 = (halo_count && collides) ? halo_dirs(P, ci1, ci2, ci3, p.x, p.y, p.z) : 0;
+            // (small instance: a candidate whose position is no number -- HALO_ALL -- is left to a pass of its own
+            // below, so that the loop every body takes knows nothing of it: with the 26-neighbour case in here
+            // the kernel took 10 us more, measured)
+            const int m3 = !(halo_count && collides) ? 0 : CAP == SMALL ? halo_dirs_of_numbers(P, ci1, ci2, ci3, p.x, p.y, p.z)
+                                                                        : halo_dirs(P, ci1, ci2, ci3, p.x, p.y, p.z);
+            if (CAP == SMALL && halo_count && collides && !finite3(p.x, p.y, p.z)) wild_any = true;
             if (m3) {
-                for (int t = 0; t < halo_targets(m3); t++) {
-                    const int dir = halo_target(m3, t);
-                    if (dir >= 0) atomicAdd(&s_halo[dir], 1);
-                }
-                if (CAP == SMALL) { hx[k] = p.x; hy[k] = p.y; hz[k] = p.z; hid[k] = id; hm3[k] = m3; }
+                if (CAP == SMALL) {
+#pragma unroll
+                    for (int m = 1; m < 8; m++) { const int dir = halo_dir_of_subset(m3, m); if (dir >= 0) atomicAdd(&s_halo[dir], 1); }
+                    hx[k] = p.x; hy[k] = p.y; hz[k] = p.z; hid[k] = id; hm3[k] = m3;
+                } else
+                    for_each_halo_dir(m3, [&](int dir) { atomicAdd(&s_halo[dir], 1); });
             }
         } else {
             sorted_id[start + e] = -1;
@@ -840,10 +859,23 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
         for (int e = tid; e < n; e += 256) row(e, 0);
     }
     if (!halo_count) return;
-    __syncthreads();                                     // the snapshot rows of this cell are in memory, the directions counted
+    const bool wild_cell = __syncthreads_or(wild_any);   // the snapshot rows of this cell are in memory, the directions counted
     if (CAP != SMALL) {
         list_in_neighbour_halos(P, c, start, min(n, P.max_per_cell), SnapSoa{snap_soa, (size_t)P.sorted_cap}, snap_cid, halo_count, halo_f, halo_id, s_halo, s_halo_base, true);
         return;
+    }
+    // the candidates whose position is no number: listed with all 26 neighbours (read back from the rows)
+    auto for_each_wild = [&](auto fn) {
+        const size_t cap = (size_t)P.sorted_cap;
+        for (int e = tid; e < min(n, P.max_per_cell); e += 256) {
+            const int id = snap_cid[start + e];
+            const float x = snap_soa[start + e], y = snap_soa[cap + start + e], z = snap_soa[2 * cap + start + e];
+            if (id >= 0 && !finite3(x, y, z)) fn(id, x, y, z);
+        }
+    };
+    if (wild_cell) {
+        for_each_wild([&](int, float, float, float) { for (int dir = 0; dir < 27; dir++) if (dir != 13) atomicAdd(&s_halo[dir], 1); });
+        __syncthreads();
     }
     // room in each neighbour's list with one global atomic per direction, then the bodies (as list_in_neighbour_halos)
     if (tid < 27) {
@@ -861,8 +893,9 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
 #pragma unroll
     for (int k = 0; k < KR; k++) {
         if (!hm3[k]) continue;
-        for (int t = 0; t < halo_targets(hm3[k]); t++) {
-            const int dir = halo_target(hm3[k], t);
+#pragma unroll
+        for (int m = 1; m < 8; m++) {
+            const int dir = halo_dir_of_subset(hm3[k], m);
             if (dir < 0 || s_halo_base[dir] < 0) continue;
             const int kk = s_halo_base[dir] + atomicAdd(&s_halo[dir], 1);
             if (kk < HALO_CAP) {
@@ -872,6 +905,18 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
             }
         }
     }
+    if (wild_cell)
+        for_each_wild([&](int id, float x, float y, float z) {
+            for (int dir = 0; dir < 27; dir++) {
+                if (dir == 13 || s_halo_base[dir] < 0) continue;
+                const int kk = s_halo_base[dir] + atomicAdd(&s_halo[dir], 1);
+                if (kk < HALO_CAP) {
+                    const size_t at = (size_t)halo_neighbour(P, ci1, ci2, ci3, dir) * HALO_CAP + kk;
+                    halo_f[at] = x; halo_f[plane + at] = y; halo_f[2 * plane + at] = z;
+                    halo_id[at] = id;
+                }
+            }
+        });
 }
 
 // ------------------------------------------------------------------ pair kernel
@@ -1295,7 +1340,7 @@ __device__ __forceinline__ void collide_scan(const DevParams &P, float xi, float
 // -> 67 (the particle's own position and id from the binning registers); profiles/r3_ab_collide.txt.)
 constexpr int COLL_NB = 10;
 template <int CAP>
-__global__ __launch_bounds__(256, CAP <= 1024 ? 7 : 3) void k_collide_cell(DevParams P, const int *__restrict__ cell_start,
+__global__ __launch_bounds__(256, CAP <= 1024 ? 6 : 3) void k_collide_cell(DevParams P, const int *__restrict__ cell_start,
                                                       const float *__restrict__ snap_soa, const float *__restrict__ snap_age,
                                                       const int *__restrict__ sorted_id, const int *__restrict__ snap_cid,
                                                       const int *__restrict__ halo_count, const float *__restrict__ halo_f,

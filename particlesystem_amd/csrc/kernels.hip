@@ -2465,6 +2465,7 @@ __global__ __launch_bounds__(256, 6) void k_pairs_merged(DevParams P, const int 
 
 // ------------------------------------------------------------------ apply
 // the four outboxes of a slab: records for the rank below [0] / above [1] (xfer_cap each), two ranks below [2] / above [3] (xfer2_cap)
+constexpr int FAR_MAGIC = 0x21524146;       // "FAR!": header word 3 of a far outbox that was closed this step
 struct Outboxes { XferRec *o[5]; };         // below, above, two below, two above, far (all-gathered)
 struct OutboxMsgs { int *m[5]; };        // the messages the outboxes live in (their headers), null where there is none
 
@@ -3343,6 +3344,7 @@ __global__ void k_moves_stage(DevParams P, MoveRec *moves, int n_host, const Fra
     if (m < 5 && msgs.m[m]) {          // slab, closing the outboxes: the headers of the relocation messages
         int *h = msgs.m[m];
         h[0] = min(fs->n_out[m], m < 2 ? P.xfer_cap : m < 4 ? P.xfer2_cap : P.far_cap); h[1] = 0; h[2] = fs->error;
+        if (m == 4) h[3] = FAR_MAGIC;      // (the receivers take it off again: a far outbox that was not all-gathered this step is noticed)
     }
     if (n_host < 0 && lifecycle_deferred(fs)) return;
     const int n = n_host < 0 ? fs->n_moves : n_host;
@@ -3633,7 +3635,15 @@ __global__ void k_inbox_merge(DevParams P, const int *__restrict__ msg0, const i
 {
     // (the message from the rank below and the one from the rank above in one launch)
     const int *msg = far_stride > 0 ? msg0 + (size_t)((int)blockIdx.x / blocks_each) * far_stride : (int)blockIdx.x < blocks_each ? msg0 : msg1;
-    if (far_stride > 0 && (int)blockIdx.x / blocks_each == P.rank) return;
+    if (far_stride > 0) {
+        if ((int)blockIdx.x / blocks_each == P.rank) return;
+        // every rank's outbox must have arrived THIS step (a caller that does not know the far outbox would lose records
+        // silently): the sender's mark is taken off once seen
+        if ((int)blockIdx.x % blocks_each == 0 && threadIdx.x == 0) {
+            if (msg[3] != FAR_MAGIC) atomicOr(&fs->error, ERR_SLAB_MISMATCH);
+            const_cast<int *>(msg)[3] = 0;
+        }
+    }
     const int n = min(msg[0], cap);
     const XferRec *in = reinterpret_cast<const XferRec *>(msg + MSG_HEADER_WORDS);
     const int i = ((int)blockIdx.x % blocks_each) * blockDim.x + threadIdx.x;

@@ -439,3 +439,30 @@ def test_slab_far_relocation_of_a_particle_that_is_no_number(world, grid):
     assert far >= 1, "a record must have travelled in the far outbox"       # (the other may start next to the home rank: the state cuts follow the segments)
     for g in ranks:
         g.close()
+
+
+def test_slab_far_outbox_left_out_is_loud():
+    """A caller that exchanges the neighbour messages but not the far outboxes (an older transport) would lose the
+    records in them: every rank checks that every rank's far outbox arrived this step."""
+    world = 4
+    rng = np.random.default_rng(193)
+    xyz = rng.uniform(-39, 39, (2000, 3)).astype(np.float32)
+    age = rng.uniform(2.0, 9.0, 2000).astype(np.float32)
+    fert = (1e6 + np.arange(2000)).astype(np.float32)
+    ranks = [ps.ParticleSystem(ps.default_config(rank=r, world=world, flags=ps.FLAG_EXPLOSIONS)) for r in range(world)]
+    for g in ranks:
+        g.fill_particles(xyz, age=age, fert_age=fert)
+    step_local(ranks)                                          # with the far all-gather: fine
+    from particlesystem_amd import slab
+    far_out = slab.FAR_OUT
+    slab.FAR_OUT = 99                                          # (no such message: step_local skips the all-gather)
+    try:
+        with pytest.raises(ps.PsamdError, match="does not match"):
+            for _ in range(2):                                 # (raised in finish, reported collectively with the next step's status)
+                step_local(ranks)
+                for g in ranks:
+                    g.synchronize()
+    finally:
+        slab.FAR_OUT = far_out
+    for g in ranks:
+        g.close()

@@ -21,6 +21,7 @@
 // does this, except where an fp32 form is proven bit-identical (see k_pairs).
 // Citations: ps.cpp = source/code/src/particleSystem.cpp of the reference.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <algorithm>
 #include <cstdlib>
@@ -3191,40 +3192,74 @@ __global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, i
     QueueInfo q = qinfo[rec];
     const bool in_lds = q.seg_size <= WINDOW_SLOTS;
     queue += slot_index(P, q.rloc) - q.rloc;           // owned segments only, back to back
-    for (int e = tid; e < n; e += NT) { kbuf[e] = keys[start + e]; abuf[e] = args[start + e]; }
+    // Inside one bucket the record bits of the keys are all the same: what is sorted is (chunk, id, sub) with the
+    // operation's place in the bucket packed in below it -- one 8-byte word per operation, its argument fetched
+    // through that place once the order is known.  (With the arguments carried along as a second array every
+    // exchange moved 24 bytes instead of 16; the sort is bound by LDS bandwidth, five workgroups to a CU.)
+    constexpr int IDX_BITS = CAP == RANK_MAX ? 11 : 13;
+    static_assert((1 << IDX_BITS) >= CAP, "an operation's place in the bucket must fit");
+    const bool packed_keys = P.key_rec_shift + IDX_BITS <= 64;              // (else, a geometry with > 2^51 (chunk, id) pairs: keys and arguments side by side)
+    const uint64_t low_mask = P.key_rec_shift >= 64 ? ~0ull : ((1ull << P.key_rec_shift) - 1ull);
+    for (int e = tid; e < n; e += NT) {
+        const uint64_t k = keys[start + e];
+        kbuf[e] = packed_keys ? (((k & low_mask) << IDX_BITS) | (uint64_t)e) : k;
+        abuf[e] = args[start + e];
+    }
     if (tid == 0) s_bad = 0;
     __syncthreads();
     RT();
-    // bitonic sort of (key, arg) in LDS, padded to a power of two with +inf keys.  (Ranking by counting --
+    // bitonic sort in LDS, padded to a power of two with +inf keys.  (Ranking by counting --
     // every thread compares its keys with all of them, two per 16-byte broadcast read, no barriers -- was
     // tried for the short lists: LDS-bandwidth-bound, 65 us against the network's 36 for the usual step.)
     int np = 2;
     while (np < n) np <<= 1;
     for (int e = n + tid; e < np; e += NT) { kbuf[e] = ~0ull; abuf[e] = -1; }
     __syncthreads();
-    for (int k = 2; k <= np; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (np >> 1); t += NT) {
-                // t-th compare-exchange pair of this stage: e has bit j clear
-                const int e = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int partner = e | j;
-                const uint64_t a = kbuf[e], b = kbuf[partner];
-                const bool up = (e & k) == 0;
-                if ((a > b) == up) {
-                    kbuf[e] = b; kbuf[partner] = a;
-                    const int x = abuf[e]; abuf[e] = abuf[partner]; abuf[partner] = x;
+    auto sort = [&](auto with_args) {
+        for (int k = 2; k <= np; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (np >> 1); t += NT) {
+                    // t-th compare-exchange pair of this stage: e has bit j clear
+                    const int e = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int partner = e | j;
+                    const uint64_t a = kbuf[e], b = kbuf[partner];
+                    const bool up = (e & k) == 0;
+                    if ((a > b) == up) {
+                        kbuf[e] = b; kbuf[partner] = a;
+                        if (decltype(with_args)::value) { const int x = abuf[e]; abuf[e] = abuf[partner]; abuf[partner] = x; }
+                    }
                 }
+                // For j <= 64 both elements of pair p lie in the 128-element chunk p >> 6, and all 64
+                // pairs of a chunk belong to one wave (p = t + m * NT, NT a multiple of 64): such
+                // stages need no workgroup barrier, only the wave's own order -- 56 of the 66 stages
+                // at 2048 operations, and the barriers were what a long list cost.
+                const int next_j = j > 1 ? (j >> 1) : k;              // the next k starts at j = k
+                if (j > 64 || next_j > 64) __syncthreads();
+                else PS_WAVE_SYNC();
             }
-            // For j <= 64 both elements of pair p lie in the 128-element chunk p >> 6, and all 64
-            // pairs of a chunk belong to one wave (p = t + m * NT, NT a multiple of 64): such
-            // stages need no workgroup barrier, only the wave's own order -- 56 of the 66 stages
-            // at 2048 operations, and the barriers were what a long list cost.
-            const int next_j = j > 1 ? (j >> 1) : k;              // the next k starts at j = k
-            if (j > 64 || next_j > 64) __syncthreads();
-            else PS_WAVE_SYNC();
-        }
+    };
+    if (packed_keys) sort(std::false_type{}); else sort(std::true_type{});
     __syncthreads();
-    for (int e = tid; e < n; e += NT) s_sub[e] = (unsigned char)(kbuf[e] & 3ull);
+    if (packed_keys) {
+        // the arguments into the order of the keys: through registers, the array is permuted in place
+        constexpr int PER = CAP / NT;
+        int av[PER];
+#pragma unroll
+        for (int m = 0; m < PER; m++) {
+            const int e = tid + m * NT;
+            av[m] = 0;
+            if (e < n) {
+                const uint64_t k = kbuf[e];
+                av[m] = abuf[(int)(k & ((1ull << IDX_BITS) - 1ull))];
+                s_sub[e] = (unsigned char)((k >> IDX_BITS) & 3ull);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < PER; m++) { const int e = tid + m * NT; if (e < n) abuf[e] = av[m]; }
+    } else {
+        for (int e = tid; e < n; e += NT) s_sub[e] = (unsigned char)(kbuf[e] & 3ull);
+    }
     __syncthreads();
     const int *s_arg = abuf;
     RT();

@@ -202,6 +202,7 @@ struct FrameScalars {
     int32_t chunk_over;     // a chunk's count passed MAX_PARTICLES_PER_CHUNK this frame: the tail of its list is skipped (k_chunk_cap)
     int32_t status_error;   // slab mode: OR of the error bits in this step's all-gathered status records (every rank sees the same word)
     int32_t seq;            // host copy only: the number of the step whose scalars these are, written last (the host polls it)
+    int32_t max_cell_raw;   // most ids any own cell received this frame, uncapped (gridmax[1] is capped at the list capacity)
     long long cost_total;   // two-pass mode: sum over the force pass's tasks of the bodies each walks (its stencil's population)
 };
 

@@ -337,12 +337,12 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
     // Each thread owns a contiguous run of cells, so the whole scan needs one pass and two barriers.
     constexpr int LDS_CHUNKS = 4096;
     __shared__ long long wave_tot[16];
-    __shared__ int maxcell_s;
+    __shared__ int maxcell_s, maxraw_s;
     __shared__ int chunk_s[LDS_CHUNKS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool chunks_in_lds = P.num_chunks <= LDS_CHUNKS;
     const int ncell = P.n_own_cells, cell_off = P.reg_first[0] * P.G * P.G;
-    if (tid == 0) maxcell_s = 0;
+    if (tid == 0) { maxcell_s = 0; maxraw_s = 0; }
     if (chunks_in_lds) for (int ch = tid; ch < P.num_chunks; ch += 1024) chunk_s[ch] = 0;
     __syncthreads();
     const int per = (ncell + 1023) / 1024;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
         return ((long long)(computed ? (min(v, P.max_per_cell) + 63) >> 6 : 0) << 32) | (long long)v;
     };
     long long mine = 0;
-    int mymax = 0;
+    int mymax = 0, myraw = 0;
     // (a thread's first KEEP counts stay in registers for the second pass, their loads -- and then the cell table's --
     // go out as one batch each: the kernel is one workgroup's chain of round trips, nothing else)
     constexpr int KEEP = 8;
@@ -373,13 +373,13 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
     for (int k = 0; k < KEEP; k++) {
         const int c = c0 + k, v = kept[k];
         if (c >= c1) continue;
-        mymax = max(mymax, min(v, P.max_per_cell));
+        mymax = max(mymax, min(v, P.max_per_cell)); myraw = max(myraw, v);
         mine += word(c, v);
         if (v > 0) census(c, v, kci[k]);
     }
     for (int c = c0 + KEEP; c < c1; c++) {
         const int v = cell_count[c];
-        mymax = max(mymax, min(v, P.max_per_cell));
+        mymax = max(mymax, min(v, P.max_per_cell)); myraw = max(myraw, v);
         mine += word(c, v);
         if (v > 0) census(c, v, celltab[c + cell_off]);
     }
@@ -390,6 +390,7 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
     }
     if (lane == 63) wave_tot[wv] = incl;
     if (mymax) atomicMax(&maxcell_s, mymax);
+    if (myraw > P.max_per_cell || myraw > 1024) atomicMax(&maxraw_s, myraw);       // (only a crowded cell bothers)
     __syncthreads();
     long long run = incl - mine, total = 0;
     for (int k = 0; k < 16; k++) { if (k < wv) run += wave_tot[k]; total += wave_tot[k]; }
@@ -415,6 +416,7 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
         fs->live = (int)(total & 0xffffffffll);
         fs->n_tasks = (int)(total >> 32);
         fs->gridmax[1] = maxcell_s;
+        fs->max_cell_raw = max(maxraw_s, maxcell_s);
     }
     // chunk totals: complete after the barrier above (every thread added its cells before it)
     int cm = 0;
@@ -643,7 +645,7 @@ __device__ __forceinline__ void list_in_neighbour_halos(const DevParams &P, int 
 // per cell, not a stream) serves the cells with up to 1024 ids, CAP = SORT_MAX (33 KB: four cells per
 // CU) the fuller ones; a workgroup leaves at once where the cell is the other instance's.
 template <int CAP>
-__global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__restrict__ cell_start,
+__device__ __forceinline__ void sort_cell(const DevParams &P, const int c, const int *__restrict__ cell_start,
                                                      int *__restrict__ sorted_id,
                                                      float4 *pos4, float4 *vel4, float4 *acc4,
                                                      int *cell_arr, uint8_t *pflags,
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
     constexpr int BITMAP_WORDS = 512;              // the ids' span the bitmap ranking covers: 16384 slots
     __shared__ unsigned bitmap[BITMAP_WORDS];
     __shared__ int s_lo, s_hi, s_wt[4];
-    const int c = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     if (tid < 27) s_halo[tid] = 0;
     if (tid == 0) { s_lo = 0x7fffffff; s_hi = -1; }
     const int start = cell_start[c];
@@ -918,6 +920,32 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__re
                 }
             }
         });
+}
+
+// The instance for ordinary cells runs one workgroup per cell; the one for crowded cells (more than 1024 ids: a
+// collapsing cloud) is launched every step too, with a few workgroups that leave at once unless the frame has
+// such a cell (max_cell_raw, from k_scan) and otherwise stride over the cells.
+template <int CAP>
+__global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__restrict__ cell_start, int *__restrict__ sorted_id,
+                                                     float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr, uint8_t *pflags,
+                                                     float *__restrict__ snap_soa, float *__restrict__ snap_age,
+                                                     const uint32_t *__restrict__ tdata, int *__restrict__ rank_of_slot,
+                                                     uint64_t *op_keys, int *op_args, int ops_cap,
+                                                     int *__restrict__ halo_count, float *__restrict__ halo_f,
+                                                     int *__restrict__ halo_id, int *__restrict__ snap_cid,
+                                                     int *__restrict__ status_out, FrameScalars *fs, DevCounters *ctr)
+{
+    if (CAP == 1024) {
+        sort_cell<CAP>(P, (int)blockIdx.x, cell_start, sorted_id, pos4, vel4, acc4, cell_arr, pflags, snap_soa, snap_age, tdata, rank_of_slot,
+                       op_keys, op_args, ops_cap, halo_count, halo_f, halo_id, snap_cid, status_out, fs, ctr);
+        return;
+    }
+    if (fs->max_cell_raw <= 1024) return;
+    for (int c = blockIdx.x; c < P.n_own_cells; c += gridDim.x) {
+        sort_cell<CAP>(P, c, cell_start, sorted_id, pos4, vel4, acc4, cell_arr, pflags, snap_soa, snap_age, tdata, rank_of_slot,
+                       op_keys, op_args, ops_cap, halo_count, halo_f, halo_id, snap_cid, status_out, fs, ctr);
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------ pair kernel
@@ -3146,7 +3174,7 @@ __device__ __forceinline__ void moves_stage_reset(const DevParams &P, int m, Mov
 // network) the longer lists -- its workgroups leave at once where there is none.  (One instance sized
 // for the longest list ran one workgroup per CU for every queue: 66 us instead of 36 for the usual step.)
 template <int CAP>
-__global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, int nrec, const int *__restrict__ rec_start,
+__device__ __forceinline__ void replay_record(const DevParams &P, const int rec, const int *__restrict__ rec_start,
                                                         const uint64_t *__restrict__ keys,
                                                         const int *__restrict__ args,
                                                         QueueInfo *qinfo, int *queue, MoveRec *moves,
@@ -3155,10 +3183,6 @@ __global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, i
                                                         float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr, uint8_t *pflags,
                                                         float4 *stage)
 {
-    if ((int)blockIdx.x >= nrec) {
-        moves_stage_reset(P, ((int)blockIdx.x - nrec) * REPLAY_THREADS + (int)threadIdx.x, moves, fs, pos4, vel4, acc4, cell_arr, pflags, stage);
-        return;
-    }
 #ifdef PSAMD_REPLAY_TRACE
     unsigned long long tk[6]; int ti = 0;
 #define RT() do { if (threadIdx.x == 0 && ti < 6) tk[ti++] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -3184,7 +3208,7 @@ __global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, i
     constexpr int NT = REPLAY_THREADS;
     __shared__ int wave_tot[NT / 64];
     __shared__ int s_bad;
-    const int rec = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (lifecycle_deferred(fs)) return;
     const int start = rec_start[rec];
     const int n = min(rec_start[rec + 1] - start, BUCKET_MAX);
@@ -3364,6 +3388,33 @@ __global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, i
     if (threadIdx.x == 0) { for (int i = 0; i < 6; i++) trace[(size_t)8 * rec + i] = tk[i]; trace[(size_t)8 * rec + 6] = (unsigned long long)n; }
 #endif
 #undef RT
+}
+
+// The instance for the usual lists runs one workgroup per queue record (and the first relocation phase in the
+// workgroups past them); the one for long lists is launched every step too, with a few workgroups that leave at
+// once unless some queue got more than 2048 operations this step (max_bucket) and otherwise stride over the records.
+template <int CAP>
+__global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, int nrec, const int *__restrict__ rec_start,
+                                                        const uint64_t *__restrict__ keys, const int *__restrict__ args,
+                                                        QueueInfo *qinfo, int *queue, MoveRec *moves,
+                                                        DevCounters *ctr, const FrameScalars *__restrict__ fs,
+                                                        unsigned long long *trace,
+                                                        float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr, uint8_t *pflags,
+                                                        float4 *stage)
+{
+    if (CAP == 2048) {
+        if ((int)blockIdx.x >= nrec) {
+            moves_stage_reset(P, ((int)blockIdx.x - nrec) * REPLAY_THREADS + (int)threadIdx.x, moves, fs, pos4, vel4, acc4, cell_arr, pflags, stage);
+            return;
+        }
+        replay_record<CAP>(P, (int)blockIdx.x, rec_start, keys, args, qinfo, queue, moves, ctr, fs, trace, pos4, vel4, acc4, cell_arr, pflags, stage);
+        return;
+    }
+    if (fs->max_bucket <= 2048) return;
+    for (int rec = blockIdx.x; rec < nrec; rec += gridDim.x) {
+        replay_record<CAP>(P, rec, rec_start, keys, args, qinfo, queue, moves, ctr, fs, trace, pos4, vel4, acc4, cell_arr, pflags, stage);
+        __syncthreads();
+    }
 }
 
 // Relocation phase 1a: read every moving particle (copy_particle, ps.cpp:1363) and
@@ -4005,7 +4056,7 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
                                                d.pflags, d.snap_soa, d.snap_age, d.tdata, d.rank_of_slot, d.op_keys, d.op_args, d.ops_cap,
                                                P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.snap_cid, d.status_out, d.fs, d.ctr);
     PS_LAUNCH_CHECK();
-    k_sort_cells<SORT_MAX><<<P.n_own_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
+    k_sort_cells<SORT_MAX><<<std::min(P.n_own_cells, 512), 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
                                                d.pflags, d.snap_soa, d.snap_age, d.tdata, d.rank_of_slot, d.op_keys, d.op_args, d.ops_cap,
                                                P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.snap_cid, d.status_out, d.fs, d.ctr);
     PS_LAUNCH_CHECK();
@@ -4261,7 +4312,7 @@ hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceStat
     k_replay_bucket<2048><<<nrec + nb, REPLAY_THREADS, 0, st>>>(P, nrec, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
                                           d.moves, d.ctr, d.fs, d.trace, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
     PS_LAUNCH_CHECK();
-    k_replay_bucket<BUCKET_MAX><<<nrec, REPLAY_THREADS, 0, st>>>(P, nrec, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
+    k_replay_bucket<BUCKET_MAX><<<std::min(nrec, 256), REPLAY_THREADS, 0, st>>>(P, nrec, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
                                           d.moves, d.ctr, d.fs, d.trace, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
     PS_LAUNCH_CHECK();
     if (nb > 0) {

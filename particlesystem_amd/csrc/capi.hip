@@ -1081,7 +1081,7 @@ static int do_lifecycle(psamd_ctx *c)
     // them, which the host polls: no copy command, no event.  The
     // rest of the life cycle is enqueued behind it without waiting (the kernels size themselves from
     // the same scalars on the device), so the GPU is busy while the host catches up.
-    PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos, bound));
+    PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos, bound, 0, false));
     c->host_queues_valid = false;
     { const int st = wait_scalars(c, seq); if (st != PSAMD_OK) return st; }
     c->live_at_build = c->h_fs->live;
@@ -1098,8 +1098,10 @@ static int do_lifecycle(psamd_ctx *c)
     // record and stops every rank there; returning it now would leave the ranks that have not heard
     // of it waiting in the next exchange.  (psamd_synchronize reports whatever is pending.)
     if (c->P.world > 1 ? c->h_fs->status_error != 0 : c->h_fs->error != 0) return check_device_errors(c);
-    if (c->h_fs->max_bucket > BUCKET_MAX)      // rare: the kernels above stood down
+    if (c->h_fs->max_bucket > BUCKET_MAX)      // rare: the replay above stood down
         PS_HIP(c, launch_lifecycle_sorted(c->stream, c->P, c->d, c->step, c->geo.queue_infos, c->h_fs->n_ops, c->h_fs->n_moves));
+    else                                       // the long lists' instance if there is one, and the commit (the replay above is still running)
+        PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos, bound, 1, c->h_fs->max_bucket > 2048));
     if (c->timing_now) {
         // No wait for the end of the step: everything up to `apply` was complete when the
         // scalars landed; the life-cycle interval is read one step later (or by get_timing).

@@ -4305,16 +4305,25 @@ hipError_t launch_ops_bucket(hipStream_t st, const DevParams &P, const DeviceSta
     return hipSuccess;
 }
 
-hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec, int64_t live_bound)
+// part 0: the replay of the usual lists (with the first relocation phase), enqueued without waiting for the host;
+// part 1, once the host has the step's scalars (they are out before part 0 starts running): the instance for
+// long lists only if some queue got more than 2048 operations (`long_lists`), and the commit.  (The long-list
+// instance used to be launched every step and leave at once: ~4.5 us on the timeline for nothing.)
+hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec, int64_t live_bound, int part, bool long_lists)
 {
     const int64_t max_moves = std::min<int64_t>(d.moves_cap, 2 * live_bound);
     const int nb = (int)((max_moves + REPLAY_THREADS - 1) / REPLAY_THREADS);
-    k_replay_bucket<2048><<<nrec + nb, REPLAY_THREADS, 0, st>>>(P, nrec, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
-                                          d.moves, d.ctr, d.fs, d.trace, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
-    PS_LAUNCH_CHECK();
-    k_replay_bucket<BUCKET_MAX><<<std::min(nrec, 256), REPLAY_THREADS, 0, st>>>(P, nrec, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
-                                          d.moves, d.ctr, d.fs, d.trace, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
-    PS_LAUNCH_CHECK();
+    if (part == 0) {
+        k_replay_bucket<2048><<<nrec + nb, REPLAY_THREADS, 0, st>>>(P, nrec, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
+                                              d.moves, d.ctr, d.fs, d.trace, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
+        PS_LAUNCH_CHECK();
+        return hipSuccess;
+    }
+    if (long_lists) {
+        k_replay_bucket<BUCKET_MAX><<<std::min(nrec, 256), REPLAY_THREADS, 0, st>>>(P, nrec, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
+                                              d.moves, d.ctr, d.fs, d.trace, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
+        PS_LAUNCH_CHECK();
+    }
     if (nb > 0) {
         k_moves_commit<<<(int)((max_moves + 255) / 256), 256, 0, st>>>(P, step, d.moves, -1, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
         PS_LAUNCH_CHECK();

@@ -69,6 +69,29 @@ def test_set_pos_random():
     assert a.tobytes() == b.tobytes()
 
 
+def test_set_pos_of_what_is_no_number():
+    """A position that is not a number (a child born with the direction (0, 0, 0) has one a step later): the
+    reference's set_pos_t converts floor(NaN) + G/2 to int -- INT_MIN on this host's cvttsd2si -- and its wrap loop
+    walks that to cell index 0 on each axis of the default 16^3 grid (2^31 is a multiple of 16).  The oracle, the
+    reference's compiled code and, through them, the kernels' conversion (k_apply) agree; so do +-inf and values far
+    outside the box."""
+    c = O.default_config()
+    d = O.derive(c)
+    L, R = O.lib(), O.ref()
+    nan, inf = float("nan"), float("inf")
+    cases = [(nan, nan, nan), (nan, 1.0, -2.0), (3.0, nan, 7.0), (1.0, 2.0, nan), (inf, 0.0, 0.0), (0.0, -inf, 0.0), (1e30, -1e30, 5.0)]
+    a, b = _blank(len(cases)), _blank(len(cases))
+    a["seg_type"] = b["seg_type"] = 1
+    a["seg_tid"] = b["seg_tid"] = 0
+    for k, pos in enumerate(cases):
+        R.ref_set_pos_x(a[k:k + 1].ctypes.data, *pos)
+        L.pso_set_pos_x(C.byref(c), C.byref(d), b[k:k + 1].ctypes.data, *pos)
+    for f in ("cell", "chunk", "seg_type", "seg_tid", "seg_fault"):
+        assert np.array_equal(a[f], b[f]), (f, a[f], b[f])
+    assert np.array_equal(bits(np.stack([a["x"], a["y"], a["z"]])), bits(np.stack([b["x"], b["y"], b["z"]])))
+    assert a["cell"][0] == 0 and (a["cell"] >= 0).all() and (a["cell"] < 4096).all()
+
+
 def test_neighbour_gather_matches_reference():
     """fill_cells + fill_particles over a real cell grid == the oracle's gather order."""
     rng = np.random.default_rng(11)

@@ -461,6 +461,16 @@ def test_timing_levels_report_without_stalling_steps():
     g.set_timing(False)
     g.step(1)
     assert g.timing()[1] == 0
+    # every fourth step only (what bench.py's timed region does): steps 0, 4, 8 of ten carry the events
+    g.set_timing(True, period=4)
+    g.step(10)
+    t, n = g.timing()
+    assert n == 3 and t["pairs"] > 0 and t["lifecycle"] > 0
+    per_step = t["pairs"] / n
+    g.set_timing(True, period=1)
+    g.step(4)
+    t1, n1 = g.timing()
+    assert n1 == 4 and 0.3 * per_step < t1["pairs"] / n1 < 3.0 * per_step
     g.close()
 
 

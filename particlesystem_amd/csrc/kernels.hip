@@ -84,15 +84,24 @@ __global__ void k_unpack_aos(DevParams P, const uint32_t *__restrict__ aos, int 
     // the pair arithmetic is validated for in-box distances only
     if ((int)r[1] >= 0) {
         const float x = __uint_as_float(r[9]), y = __uint_as_float(r[10]), z = __uint_as_float(r[11]);
-        bool bad = (int)r[1] >= P.num_cells_global || !(fabsf(x) <= half_box) || !(fabsf(y) <= half_box) || !(fabsf(z) <= half_box);
+        bool bad = (int)r[1] >= P.num_cells_global;
         if (!bad) {
             // ... and inside the cell it claims (set_pos_t derives the cell from the position, app.cu:126-157;
             // the two-pass collision stage relies on it).  A wrapped position is rounded to float after the
-            // cell was fixed, so allow it a sliver beyond the faces.
+            // cell was fixed, so allow it a sliver beyond the faces.  A coordinate that is no number (a child born
+            // with the direction (0, 0, 0), a step later) belongs to the index the reference's conversion gives it:
+            // INT_MIN, walked into the grid by the wrap loop (see k_apply).
             const int c = (int)r[1], G = P.G, i3 = c / (G * G), i1 = (c - i3 * G * G) / G, i2 = c - i3 * G * G - i1 * G;
             const float cs = (float)P.cell_size, tol = 1e-4f * cs, h = (float)(G / 2);
-            const float u2 = x / cs + h - (float)i2, u1 = -y / cs + h - (float)i1, u3 = -z / cs + h - (float)i3;   // in [0, 1) inside
-            bad = !(u1 * cs >= -tol && u1 * cs <= cs + tol && u2 * cs >= -tol && u2 * cs <= cs + tol && u3 * cs >= -tol && u3 * cs <= cs + tol);
+            int lost = (int)0x80000000;
+            for (int guard = 0; guard < 4 && !(lost >= 0 && lost < G); guard++) lost = (lost + G) % G;
+            auto axis_ok = [&](float v, float sign, int idx) {
+                if ((__float_as_uint(v) & 0x7f800000u) == 0x7f800000u) return idx == lost;
+                if (!(fabsf(v) <= half_box)) return false;
+                const float u = (sign * v / cs + h - (float)idx) * cs;                      // in [0, cs) inside
+                return u >= -tol && u <= cs + tol;
+            };
+            bad = !(axis_ok(x, 1.0f, i2) && axis_ok(y, -1.0f, i1) && axis_ok(z, -1.0f, i3));
         }
         if (bad) atomicOr(&fs->error, ERR_BAD_POS);
     }

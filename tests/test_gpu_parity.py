@@ -574,3 +574,10 @@ def test_particles_whose_position_is_not_a_number(steps, radius):
     p = o.particles
     assert np.isnan(p["x"][p["cell"] >= 0]).sum() >= 1 and (p["cell"] == 0).sum() >= 1
     assert o.counters["deaths_collision"] + o.counters["survives"] > 100          # the crowd met the adult
+    # the reference's buffers out of this context and into a fresh one: such a particle is valid state, where it is filed
+    part, (qi, q) = g.download_particles(), g.download_queues()
+    g2 = ps.ParticleSystem(g.cfg)
+    g2.upload_particles(part); g2.upload_queues(qi, q)
+    g2.step(1); o.step(1)
+    assert_same_particles(g2.download_particles(), o.particles, "after the upload into a fresh context")
+    g2.close()

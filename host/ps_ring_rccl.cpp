@@ -1,27 +1,35 @@
 // ps_ring_rccl.cpp -- the multi-GPU step in C++: libpsamd.so's four slab stage calls with the
 // messages moved by RCCL (ncclSend / ncclRecv / ncclAllGather) straight between the contexts'
-// device buffers, on the stream the stage kernels run on.  No Python, no torch: include/psamd.h,
-// the HIP runtime and rccl.h.  This is what the reference's pmlib layer does for it between
-// nodes (subscriptions to segments, ps.cpp:380-487); here one process drives one GPU.
+// device buffers.  No Python, no torch: include/psamd.h, the HIP runtime and rccl.h.  This is
+// what the reference's pmlib layer does for it between nodes (subscriptions to segments,
+// ps.cpp:380-487; the stage loop, ps.cpp:1843-1928); here one process drives one GPU.
 //
-//   one process per GPU (what a node runs):
-//       ps_ring_rccl --world W --rank r --id-file /tmp/id --job J [--n N] [--iters K] [--seed S]
+//   one process per GPU (what a node runs; bench.py --gpus N starts these):
+//       ps_ring_rccl --world W --rank r --device d --id-file /tmp/id --job J [--bench ...]
 //     rank 0 writes the communicator's ncclUniqueId to the file (tagged with the job's nonce J), the others wait for it.
 //   all slabs in ONE process on GPU 0 (what a one-GPU test box can run):
-//       ps_ring_rccl --world W --loopback [--n N] [--iters K] [--seed S]
+//       ps_ring_rccl --world W --loopback [--n N] [--iters K] [--seed S] [--all-pairs] [--births]
 //     The communicator has a single rank; every message is an ncclSend to self matched by
 //     an ncclRecv from self in the same group -- RCCL moves every byte, between the buffers of
 //     different contexts.  This mode also runs the whole system in one plain context and
 //     requires the union of the slabs to equal it byte for byte (P_DATA_TYPE of every slot).
 //
+// Two HIP streams.  The stage kernels run on the COMPUTE stream -- with --graphs (default) each stage's
+// kernels as one captured hipGraph, so a rank's step is five submissions, not two dozen launches --, every
+// RCCL call on the TRANSFER stream; events order the two: the halo (and the all-pairs snapshot all-gather)
+// waits for slab_build and travels while the compute stream runs the interior pair pass (--overlap-interior)
+// or simply goes ahead; the all-gather of the status records travels beside the whole pair pass; force and
+// transfer messages fork off after slab_pairs / slab_apply and are joined before the stage that reads them.
+//
 // Message routes (particlesystem_amd/slab.py says the same in Python): after slab_build the
 // halo snapshots (rank r's halo_out[above] -> rank r+1's halo_in[below]; halo_out[below] ->
-// rank r-1's halo_in[above]) and the all-gather of the status records; after slab_pairs the
-// force records of lent layers (force_out -> rank r-1's force_in); after slab_apply the
-// particles that change owner, on the ring (xfer_out[below] -> rank (r-1)%W's xfer_in[above],
-// xfer_out[above] -> rank (r+1)%W's xfer_in[below]).  All sizes are fixed by the plan; a
-// message of 0 bytes does not exist.  Between one pair of ranks RCCL matches sends and
-// receives by order, so both sides post them ordered by (peer, direction of travel).
+// rank r-1's halo_in[above]), the all-gather of the status records and -- all-pairs forces -- of the
+// snapshot blocks; after slab_pairs the force records of lent layers (force_out -> rank r-1's force_in);
+// after slab_apply the particles that change owner, on the ring (xfer_out[below] -> rank (r-1)%W's
+// xfer_in[above], xfer_out[above] -> rank (r+1)%W's xfer_in[below]; hop-two and far outboxes where the
+// plan has them).  All sizes are fixed by the plan; a message of 0 bytes does not exist.  Between one
+// pair of ranks RCCL matches sends and receives by order, so both sides post them ordered by
+// (peer, hop, direction of travel).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -59,6 +67,7 @@ struct Slab {
 struct Msg { void *buf; int64_t bytes; int peer; int dir; int hop; };   // dir: 0 travels down the ring, 1 up; hop: 1 to a ring neighbour, 2 to the rank beyond it
 
 enum Phase { HALO, FORCE, XFER };
+enum Gather { G_STATUS, G_SNAPSHOT, G_FAR };
 
 // what slab `s` of `world` sends in a phase: (buffer, bytes, destination rank, direction)
 std::vector<Msg> sends_of(const Slab &s, int world, Phase ph)
@@ -93,23 +102,32 @@ Msg recv_of(const Slab &s, Phase ph, int from, int dir, int hop = 1)
 
 bool by_peer_then_dir(const Msg &a, const Msg &b) { return a.peer != b.peer ? a.peer < b.peer : (a.hop != b.hop ? a.hop < b.hop : a.dir < b.dir); }
 
-// One phase's messages as ONE RCCL group.  `local`: the slabs this process holds (one per
-// process in a real run; all of them in loopback mode, where every peer is comm rank 0).
-int exchange(const std::vector<Slab> &local, int world, bool loopback, Phase ph, ncclComm_t comm, hipStream_t st, int64_t *moved)
+struct Ring {
+    int world = 1;
+    bool loopback = false, side_stream = true, overlap_interior = false;
+    ncclComm_t comm = nullptr;
+    hipStream_t compute = nullptr, transfer = nullptr;      // (transfer == compute without --no-side-stream's opposite)
+    hipEvent_t ev_built = nullptr, ev_halo = nullptr, ev_paired = nullptr, ev_force = nullptr, ev_applied = nullptr, ev_xfer = nullptr;
+    std::vector<Slab> local;            // the slabs this process holds (one per process in a real run; all of them in loopback mode, where every peer is comm rank 0)
+    int64_t moved = 0;
+};
+
+// One phase's messages as ONE RCCL group on the transfer stream.
+int exchange(Ring &R, Phase ph)
 {
     std::vector<Msg> sends, recvs;
-    if (loopback) {
+    if (R.loopback) {
         // k-th receive from self = k-th send to self: enumerate the routes once for both lists
-        for (const Slab &s : local)
-            for (const Msg &m : sends_of(s, world, ph)) {
-                const Msg r = recv_of(local[(size_t)m.peer], ph, s.rank, m.dir, m.hop);
+        for (const Slab &s : R.local)
+            for (const Msg &m : sends_of(s, R.world, ph)) {
+                const Msg r = recv_of(R.local[(size_t)m.peer], ph, s.rank, m.dir, m.hop);
                 if (r.bytes != m.bytes) { std::fprintf(stderr, "message size mismatch %lld vs %lld\n", (long long)m.bytes, (long long)r.bytes); return 1; }
                 sends.push_back({m.buf, m.bytes, 0, m.dir, m.hop});
                 recvs.push_back({r.buf, r.bytes, 0, r.dir, r.hop});
             }
     } else {
-        const Slab &s = local[0];
-        const int r = s.rank;
+        const Slab &s = R.local[0];
+        const int r = s.rank, world = R.world;
         sends = sends_of(s, world, ph);
         // what the neighbours send here (a message exists iff its in-buffer has a size)
         if (ph == HALO) {
@@ -130,40 +148,111 @@ int exchange(const std::vector<Slab> &local, int world, bool loopback, Phase ph,
     }
     if (sends.empty() && recvs.empty()) return 0;
     NCCL_OK(ncclGroupStart());
-    for (const Msg &m : sends) { NCCL_OK(ncclSend(m.buf, (size_t)m.bytes, ncclInt8, m.peer, comm, st)); *moved += m.bytes; }
-    for (const Msg &m : recvs) NCCL_OK(ncclRecv(m.buf, (size_t)m.bytes, ncclInt8, m.peer, comm, st));
+    for (const Msg &m : sends) { NCCL_OK(ncclSend(m.buf, (size_t)m.bytes, ncclInt8, m.peer, R.comm, R.transfer)); R.moved += m.bytes; }
+    for (const Msg &m : recvs) NCCL_OK(ncclRecv(m.buf, (size_t)m.bytes, ncclInt8, m.peer, R.comm, R.transfer));
     NCCL_OK(ncclGroupEnd());
     return 0;
 }
 
-// an all-gathered buffer pair: the status records (far == false), or the far outboxes of the transfer phase
-int gather(const std::vector<Slab> &local, int world, bool loopback, bool far, ncclComm_t comm, hipStream_t st)
+// an all-gathered buffer pair: the status records, the snapshot blocks of an all-pairs run (between slab_build and
+// slab_pairs: SURVEY 8(e)'s "all-gather of positions once per step"), or the far outboxes of the transfer phase
+int gather(Ring &R, Gather what)
 {
-    auto out_of = [&](const Slab &s) { return far ? s.b.far_out : s.b.status_out; };
-    auto in_of = [&](const Slab &s) { return far ? s.b.far_in : s.b.status_in; };
-    const size_t nb = (size_t)(far ? local[0].b.far_bytes : local[0].b.status_bytes);
-    if (world == 1 || !nb) return 0;
-    if (!loopback) {
-        NCCL_OK(ncclAllGather(out_of(local[0]), in_of(local[0]), nb, ncclInt8, comm, st));
+    auto out_of = [&](const Slab &s) { return what == G_FAR ? s.b.far_out : what == G_SNAPSHOT ? s.b.allg_out : s.b.status_out; };
+    auto in_of = [&](const Slab &s) { return what == G_FAR ? s.b.far_in : what == G_SNAPSHOT ? s.b.allg_in : s.b.status_in; };
+    const Slab &s0 = R.local[0];
+    const size_t nb = (size_t)(what == G_FAR ? s0.b.far_bytes : what == G_SNAPSHOT ? s0.b.allg_bytes : s0.b.status_bytes);
+    if (R.world == 1 || !nb) return 0;
+    if (!R.loopback) {
+        NCCL_OK(ncclAllGather(out_of(s0), in_of(s0), nb, ncclInt8, R.comm, R.transfer));
+        R.moved += (int64_t)nb;
         return 0;
     }
     // a communicator of one rank: its all-gather is a copy; every slab's record into every slab's block
-    for (const Slab &src : local)
-        for (const Slab &dst : local)
-            NCCL_OK(ncclAllGather(out_of(src), (char *)in_of(dst) + (size_t)src.rank * nb, nb, ncclInt8, comm, st));
+    for (const Slab &src : R.local)
+        for (const Slab &dst : R.local)
+            NCCL_OK(ncclAllGather(out_of(src), (char *)in_of(dst) + (size_t)src.rank * nb, nb, ncclInt8, R.comm, R.transfer));
+    R.moved += (int64_t)nb * (int64_t)R.local.size();
     return 0;
 }
 
+// `later` waits for everything enqueued on `earlier` so far (nothing to do when they are one stream)
+int order(Ring &R, hipStream_t earlier, hipEvent_t ev, hipStream_t later)
+{
+    if (earlier == later) return 0;
+    HIP_OK(hipEventRecord(ev, earlier));
+    HIP_OK(hipStreamWaitEvent(later, ev, 0));
+    return 0;
+}
+
+// One step of the stage loop (DoParallelProcess, ps.cpp:1843-1928), one slab per GPU.  between(stage): a hook the
+// benchmark's frame census uses to read counts back between two stages (nullptr: none).
+template <typename Hook>
+int ring_step(Ring &R, Hook between)
+{
+    for (Slab &s : R.local) PS_OK(s.ctx, psamd_slab_build(s.ctx));
+    if (between(0)) return 1;
+    if (order(R, R.compute, R.ev_built, R.transfer)) return 1;
+    if (exchange(R, HALO)) return 1;
+    if (gather(R, G_SNAPSHOT)) return 1;                       // all-pairs forces only
+    if (R.transfer != R.compute) HIP_OK(hipEventRecord(R.ev_halo, R.transfer));
+    if (gather(R, G_STATUS)) return 1;                         // travels beside the pair pass; slab_apply needs it
+    if (R.overlap_interior)
+        for (Slab &s : R.local) PS_OK(s.ctx, psamd_slab_pairs_interior(s.ctx));      // cells whose stencil lies in the own layers: no halo needed
+    if (R.transfer != R.compute) HIP_OK(hipStreamWaitEvent(R.compute, R.ev_halo, 0));
+    for (Slab &s : R.local) PS_OK(s.ctx, psamd_slab_pairs(s.ctx));
+    if (between(1)) return 1;
+    if (order(R, R.compute, R.ev_paired, R.transfer)) return 1;
+    if (exchange(R, FORCE)) return 1;
+    if (order(R, R.transfer, R.ev_force, R.compute)) return 1;      // (behind the status gather on the transfer stream: that has landed too)
+    for (Slab &s : R.local) PS_OK(s.ctx, psamd_slab_apply(s.ctx));
+    if (order(R, R.compute, R.ev_applied, R.transfer)) return 1;
+    if (exchange(R, XFER)) return 1;
+    if (gather(R, G_FAR)) return 1;                            // (births on, four or more ranks)
+    if (order(R, R.transfer, R.ev_xfer, R.compute)) return 1;
+    for (Slab &s : R.local) PS_OK(s.ctx, psamd_slab_finish(s.ctx));
+    return 0;
+}
+int no_hook(int) { return 0; }
+
 struct Particle72 { unsigned char bytes[72]; };
+
+// force terms one pair pass evaluates: per visited particle its stencil's population (27 cells, not periodic:
+// app.cu:352-409), or -- all-pairs -- every listed body
+double force_terms(const std::vector<int64_t> &n, const std::vector<int32_t> &f, int G, bool all_pairs)
+{
+    double total = 0;
+    if (all_pairs) {
+        double sn = 0, sf = 0;
+        for (size_t i = 0; i < n.size(); i++) { sn += (double)n[i]; sf += (double)f[i]; }
+        return sn * sf;
+    }
+    for (int i3 = 0; i3 < G; i3++) for (int i1 = 0; i1 < G; i1++) for (int i2 = 0; i2 < G; i2++) {
+        const int fc = f[(size_t)(i3 * G + i1) * G + i2];
+        if (!fc) continue;
+        int64_t nb = 0;
+        for (int a = -1; a <= 1; a++) for (int b = -1; b <= 1; b++) for (int d = -1; d <= 1; d++) {
+            const int j3 = i3 + a, j1 = i1 + b, j2 = i2 + d;
+            if (j3 < 0 || j3 >= G || j1 < 0 || j1 >= G || j2 < 0 || j2 >= G) continue;
+            nb += n[(size_t)(j3 * G + j1) * G + j2];
+        }
+        total += (double)fc * (double)nb;
+    }
+    return total;
+}
 
 }  // namespace
 
 int main(int argc, char **argv)
 {
-    int world = 2, rank = 0, iters = 8;
+    int world = 2, rank = 0, iters = 8, device = -1;
     int64_t n = 60000;
     uint32_t seed = 2026;
-    bool loopback = false, id_only = false;
+    bool loopback = false, id_only = false, all_pairs = false, births = false, graphs = true, bench = false, evolve = false;
+    bool side_stream = true, overlap_interior = false, fast_math = false, launch_check = false;
+    int steps = 200, warmup = 5, chunk_factor = 4, chunk_dim = 4, halo_cap_cell = 0, xfer_cap = 0, timing_period = 8, wait_policy = -1;
+    double settle_seconds = 0.5;
+    int64_t max_particles = 0;
     uint64_t job = 0;
     std::string id_file;
     for (int i = 1; i < argc; i++) {
@@ -171,6 +260,7 @@ int main(int argc, char **argv)
         auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : "0"; };
         if (a == "--world") world = std::atoi(next());
         else if (a == "--rank") rank = std::atoi(next());
+        else if (a == "--device") device = std::atoi(next());
         else if (a == "--iters") iters = std::atoi(next());
         else if (a == "--n") n = std::atoll(next());
         else if (a == "--seed") seed = (uint32_t)std::atoll(next());
@@ -178,21 +268,49 @@ int main(int argc, char **argv)
         else if (a == "--loopback") loopback = true;
         else if (a == "--job") job = (uint64_t)std::strtoull(next(), nullptr, 10);
         else if (a == "--id-only") id_only = true;
+        else if (a == "--launch-check") launch_check = true;
+        else if (a == "--all-pairs") all_pairs = true;
+        else if (a == "--births") births = true;
+        else if (a == "--fast-math") fast_math = true;
+        else if (a == "--graphs") graphs = std::atoi(next()) != 0;
+        else if (a == "--side-stream") side_stream = std::atoi(next()) != 0;
+        else if (a == "--overlap-interior") overlap_interior = true;
+        else if (a == "--wait") wait_policy = std::atoi(next());
+        else if (a == "--bench") bench = true;
+        else if (a == "--evolve") evolve = true;
+        else if (a == "--steps") steps = std::atoi(next());
+        else if (a == "--warmup") warmup = std::atoi(next());
+        else if (a == "--settle-seconds") settle_seconds = std::atof(next());
+        else if (a == "--timing-period") timing_period = std::max(1, std::atoi(next()));
+        else if (a == "--chunk-factor") chunk_factor = std::atoi(next());
+        else if (a == "--chunk-dim") chunk_dim = std::atoi(next());
+        else if (a == "--halo-cap-cell") halo_cap_cell = std::atoi(next());
+        else if (a == "--xfer-cap") xfer_cap = std::atoi(next());
+        else if (a == "--max-particles") max_particles = std::atoll(next());
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     if (world < 1 || rank < 0 || rank >= world || (!loopback && world > 1 && id_file.empty())) {
-        std::fprintf(stderr, "usage: ps_ring_rccl --world W (--loopback | --rank r --id-file F) [--n N] [--iters K] [--seed S]\n");
+        std::fprintf(stderr, "usage: ps_ring_rccl --world W (--loopback | --rank r --id-file F --job J [--device d]) [--n N] [--iters K] [--seed S] "
+                             "[--all-pairs] [--births] [--graphs 0|1] [--side-stream 0|1] [--overlap-interior] [--bench --steps K --warmup W ...]\n");
         return 2;
     }
-    const int device = loopback ? 0 : rank;
-    hipStream_t st = nullptr;
-    if (!id_only) {
+    if (psamd_abi_version() != PSAMD_ABI_VERSION) {
+        std::fprintf(stderr, "libpsamd.so has ABI version %d, this program was built against %d: rebuild one of them\n", psamd_abi_version(), PSAMD_ABI_VERSION);
+        return 2;
+    }
+    if (device < 0) device = loopback ? 0 : rank;
+    const bool no_gpu = id_only || launch_check;
+    Ring R;
+    R.world = world; R.loopback = loopback; R.side_stream = side_stream; R.overlap_interior = overlap_interior;
+    if (!no_gpu) {
         HIP_OK(hipSetDevice(device));
-        HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIP_OK(hipStreamCreateWithFlags(&R.compute, hipStreamNonBlocking));
+        if (side_stream) HIP_OK(hipStreamCreateWithFlags(&R.transfer, hipStreamNonBlocking));
+        else R.transfer = R.compute;
+        for (hipEvent_t *e : {&R.ev_built, &R.ev_halo, &R.ev_paired, &R.ev_force, &R.ev_applied, &R.ev_xfer}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
 
     // the communicator: one rank per process
-    ncclComm_t comm;
     ncclUniqueId id;
     const int comm_world = loopback ? 1 : world, comm_rank = loopback ? 0 : rank;
     // The id file carries the job's nonce (--job, the same on every rank of one job) in front of the id: a file
@@ -201,7 +319,7 @@ int main(int argc, char **argv)
     struct IdFile { uint64_t magic, job; ncclUniqueId id; };
     const uint64_t kMagic = 0x70735f72696e6731ull;        // "ps_ring1"
     if (comm_rank == 0) {
-        if (id_only) { uint64_t x = job * 0x9E3779B97F4A7C15ull + 1; for (size_t i = 0; i < sizeof id; i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; ((char *)&id)[i] = (char)x; } }
+        if (no_gpu) { uint64_t x = job * 0x9E3779B97F4A7C15ull + 1; for (size_t i = 0; i < sizeof id; i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; ((char *)&id)[i] = (char)x; } }
         else NCCL_OK(ncclGetUniqueId(&id));
         if (!id_file.empty()) {
             std::remove(id_file.c_str());
@@ -220,87 +338,246 @@ int main(int argc, char **argv)
             std::this_thread::sleep_for(std::chrono::milliseconds(100));
         }
     }
-    if (id_only) {                      // (test hook: the rendezvous through the file, without a GPU or RCCL transport)
+    if (no_gpu) {                      // (test hooks: the rendezvous through the file, without a GPU or RCCL transport)
         unsigned sum = 0;
         for (size_t i = 0; i < sizeof id; i++) sum = sum * 131u + (unsigned char)((const char *)&id)[i];
-        std::printf("rank %d of %d: communicator id %08x (job %llu)\n", rank, world, sum, (unsigned long long)job);
+        if (id_only) { std::printf("rank %d of %d: communicator id %08x (job %llu)\n", rank, world, sum, (unsigned long long)job); return 0; }
+        // --launch-check: every rank reports in through a file beside the id file; rank 0 waits for all of them and
+        // prints the skeleton of the benchmark record -- proves bench.py's launcher of C++ ranks on a machine without GPUs
+        const std::string mine = id_file + ".in" + std::to_string(rank);
+        { std::ofstream f(mine, std::ios::binary); f << sum << " " << job << "\n"; }
+        if (rank == 0) {
+            int seen = 0;
+            for (int tries = 0; tries < 600 && seen < world; tries++) {
+                seen = 0;
+                for (int r = 0; r < world; r++) {
+                    std::ifstream f(id_file + ".in" + std::to_string(r));
+                    unsigned s2 = 0; unsigned long long j2 = 0;
+                    if (f && (f >> s2 >> j2) && s2 == sum && j2 == job) seen++;
+                }
+                if (seen < world) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            }
+            for (int r = 0; r < world; r++) std::remove((id_file + ".in" + std::to_string(r)).c_str());
+            std::remove(id_file.c_str());
+            if (seen < world) { std::fprintf(stderr, "launch check: %d of %d ranks reported in\n", seen, world); return 1; }
+            std::printf("{\"psamd_ring\": 1, \"launch_check\": true, \"world\": %d, \"steps\": %d, \"warmup\": %d}\n", seen, steps, warmup);
+        }
         return 0;
     }
-    NCCL_OK(ncclCommInitRank(&comm, comm_world, id, comm_rank));
-    g_comm = comm;
+    NCCL_OK(ncclCommInitRank(&R.comm, comm_world, id, comm_rank));
+    g_comm = R.comm;
     if (comm_rank == 0 && !id_file.empty()) std::remove(id_file.c_str());      // every rank has joined: the file has served
 
     // the slabs this process holds, all shown the same particles (each keeps its own segments')
-    std::vector<Slab> local;
     std::vector<float> xyz((size_t)3 * n), age((size_t)n), fert((size_t)n);
+    psamd_config cfg0;
+    psamd_default_config(&cfg0);
+    cfg0.chunk_factor = chunk_factor; cfg0.chunk_dim = chunk_dim;
+    cfg0.max_particles_num = (int32_t)std::max<int64_t>(std::max<int64_t>(n, max_particles), 1 << 20);
+    cfg0.flags = (all_pairs ? PSAMD_FLAG_ALL_PAIRS : 0u) | (births ? PSAMD_FLAG_EXPLOSIONS : 0u) | (fast_math ? PSAMD_FLAG_FAST_MATH : 0u);
+    cfg0.halo_cap_cell = halo_cap_cell; cfg0.xfer_cap = xfer_cap;
+    cfg0.seed = seed;
+    const double life = cfg0.life_steps * cfg0.dt;
     for (int r = 0; r < world; r++) {
         if (!loopback && r != rank) continue;
         Slab s; s.rank = r;
-        psamd_config cfg;
-        psamd_default_config(&cfg);
+        psamd_config cfg = cfg0;
         cfg.device = device; cfg.rank = r; cfg.world = world;
         psamd_ctx *ctx = nullptr;
         PS_OK(ctx, psamd_create(&cfg, &ctx));
         s.ctx = ctx;
-        if (local.empty()) {
+        if (R.local.empty()) {
             PS_OK(ctx, psamd_uniform_cloud(ctx, n, seed, xyz.data()));
             uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
-            for (int64_t i = 0; i < n; i++) {            // ages of adults, no births (a tag as fertility age)
+            for (int64_t i = 0; i < n; i++) {            // ages of adults [MIN_ADULT_AGE, MAX_ADULT_AGE); births: fertility ages they reach within a few steps
                 x ^= x << 13; x ^= x >> 7; x ^= x << 17;
-                age[(size_t)i] = 15.0f / 7.0f + (7.5f - 15.0f / 7.0f) * (float)((x >> 40) * (1.0 / 16777216.0));
-                fert[(size_t)i] = 1.0e6f + (float)i;
+                const double u = (double)(x >> 40) * (1.0 / 16777216.0);
+                age[(size_t)i] = (float)(life / 7.0 + (life / 2.0 - life / 7.0) * u);
+                fert[(size_t)i] = births ? (float)(age[(size_t)i] + cfg0.dt * (double)(1 + (x & 15))) : 1.0e6f + (float)(bench ? 0 : i);
             }
         }
         PS_OK(ctx, psamd_fill_particles(ctx, n, xyz.data(), nullptr, nullptr, age.data(), fert.data(), nullptr, nullptr));
-        PS_OK(ctx, psamd_set_stream(ctx, (void *)st));
+        PS_OK(ctx, psamd_set_stream(ctx, (void *)R.compute));
+        PS_OK(ctx, psamd_set_graphs(ctx, graphs ? 1 : 0));
+        if (wait_policy >= 0) PS_OK(ctx, psamd_set_wait_policy(ctx, wait_policy));
         PS_OK(ctx, psamd_slab_buffers_get(ctx, &s.b));
         PS_OK(ctx, psamd_get_slab_plan(ctx, &s.plan));
-        local.push_back(s);
+        R.local.push_back(s);
+    }
+    psamd_sizes sz;
+    PS_OK(R.local[0].ctx, psamd_get_sizes(R.local[0].ctx, &sz));
+
+    // ---------------------------------------------------------------- benchmark protocol (bench.py --gpus N relays the record)
+    if (bench) {
+        // collectives on host numbers: a device scratch word, RCCL, the transfer stream (a world of one -- loopback -- has nothing to reduce)
+        int64_t *d_red = nullptr;
+        const size_t red_words = (size_t)sz.num_cells + 8;
+        HIP_OK(hipMalloc((void **)&d_red, red_words * sizeof(int64_t)));
+        auto sync_all = [&]() -> int {
+            for (Slab &s : R.local) PS_OK(s.ctx, psamd_synchronize(s.ctx));
+            HIP_OK(hipStreamSynchronize(R.compute));
+            HIP_OK(hipStreamSynchronize(R.transfer));
+            return 0;
+        };
+        auto reduce_i64 = [&](int64_t *host, size_t count, ncclRedOp_t op) -> int {
+            if (comm_world == 1) return 0;
+            HIP_OK(hipMemcpyAsync(d_red, host, count * sizeof(int64_t), hipMemcpyHostToDevice, R.transfer));
+            NCCL_OK(ncclAllReduce(d_red, d_red, count, ncclInt64, op, R.comm, R.transfer));
+            HIP_OK(hipMemcpyAsync(host, d_red, count * sizeof(int64_t), hipMemcpyDeviceToHost, R.transfer));
+            HIP_OK(hipStreamSynchronize(R.transfer));
+            return 0;
+        };
+        auto barrier = [&]() -> int {              // every rank's device work is done, then all ranks meet, then again nothing is in flight
+            if (sync_all()) return 1;
+            int64_t one = 1;
+            if (reduce_i64(&one, 1, ncclSum)) return 1;
+            return 0;
+        };
+        if (!evolve) for (Slab &s : R.local) PS_OK(s.ctx, psamd_snapshot_save(s.ctx));
+        auto one_step = [&]() -> int {
+            if (!evolve) for (Slab &s : R.local) PS_OK(s.ctx, psamd_snapshot_restore(s.ctx));
+            return ring_step(R, no_hook);
+        };
+        // untimed: let the clocks settle; all ranks must take the same number of steps: they decide together, ten at a time
+        int settle = 0;
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(settle_seconds);
+        for (;;) {
+            int64_t go = (!evolve && std::chrono::steady_clock::now() < t_end) ? 1 : 0;
+            if (reduce_i64(&go, 1, ncclMin)) return bail();
+            if (!go) break;
+            for (int k = 0; k < 10; k++) if (one_step()) return bail();
+            settle += 10;
+        }
+        for (int k = 0; k < warmup; k++) if (one_step()) return bail();
+        if (barrier()) return bail();
+        // the frame's census: particles per cell (whole system) and particles the force pass visits per cell (own, and whole system)
+        std::vector<int32_t> cellgrid((size_t)sz.n_cellgrid), fc((size_t)sz.num_cells);
+        std::vector<int64_t> n_cell((size_t)sz.num_cells), f_all((size_t)sz.num_cells);
+        std::vector<int32_t> f_own((size_t)sz.num_cells);
+        auto census = [&](double *terms_own, int64_t *with_force, int64_t *live) -> int {
+            std::fill(n_cell.begin(), n_cell.end(), 0); std::fill(f_own.begin(), f_own.end(), 0);
+            if (!evolve) for (Slab &s : R.local) PS_OK(s.ctx, psamd_snapshot_restore(s.ctx));
+            const size_t stride = 1 + (size_t)sz.max_per_cell;
+            auto hook = [&](int stage) -> int {
+                for (Slab &s : R.local) {
+                    if (stage == 0) {
+                        PS_OK(s.ctx, psamd_download_cellgrid(s.ctx, cellgrid.data()));
+                        for (int c = 0; c < sz.num_cells; c++) n_cell[(size_t)c] += cellgrid[stride * (size_t)c];
+                    } else {
+                        PS_OK(s.ctx, psamd_download_force_counts(s.ctx, fc.data()));
+                        if (&s == &R.local[0]) f_own = fc;
+                        for (int c = 0; c < sz.num_cells; c++) f_all[(size_t)c] += fc[(size_t)c];
+                    }
+                }
+                return 0;
+            };
+            std::fill(f_all.begin(), f_all.end(), 0);
+            if (ring_step(R, hook)) return 1;
+            if (sync_all()) return 1;
+            if (reduce_i64(n_cell.data(), n_cell.size(), ncclSum)) return 1;
+            if (reduce_i64(f_all.data(), f_all.size(), ncclSum)) return 1;
+            *terms_own = force_terms(n_cell, f_own, sz.grid_dim, all_pairs);
+            *with_force = 0; *live = 0;
+            for (int c = 0; c < sz.num_cells; c++) { *with_force += f_all[(size_t)c]; *live += n_cell[(size_t)c]; }
+            return 0;
+        };
+        double terms0 = 0, terms1 = 0;
+        int64_t wf0 = 0, wf1 = 0, live0 = 0, live1 = 0;
+        if (!evolve && census(&terms0, &wf0, &live0)) return bail();
+        psamd_ctx *c0 = R.local[0].ctx;
+        const int period = std::max(1, std::min(timing_period, steps));
+        PS_OK(c0, psamd_set_timing_period(c0, period));
+        PS_OK(c0, psamd_set_timing(c0, 1));
+        psamd_counters cn0{}, cn1{};
+        int64_t processed0 = 0;
+        for (Slab &s : R.local) { PS_OK(s.ctx, psamd_get_counters(s.ctx, &cn0)); processed0 += cn0.particles_processed; }
+        if (barrier()) return bail();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < steps; k++) if (one_step()) return bail();
+        if (barrier()) return bail();
+        double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        double us[PSAMD_NUM_TIMERS];
+        int64_t launches = 0;
+        PS_OK(c0, psamd_get_timing(c0, us, &launches));
+        PS_OK(c0, psamd_set_timing(c0, 0));
+        int64_t processed1 = 0;
+        for (Slab &s : R.local) { PS_OK(s.ctx, psamd_get_counters(s.ctx, &cn1)); processed1 += cn1.particles_processed; }
+        PS_OK(c0, psamd_get_counters(c0, &cn1));
+        const int64_t own_updates = processed1 - processed0;
+        if (census(&terms1, &wf1, &live1)) return bail();
+        if (evolve) { terms0 = terms1; wf0 = wf1; }
+        int64_t red[2] = {own_updates, (int64_t)(elapsed * 1e9)};
+        int64_t upd = own_updates;
+        if (reduce_i64(&upd, 1, ncclSum)) return bail();
+        if (reduce_i64(&red[1], 1, ncclMax)) return bail();
+        elapsed = (double)red[1] * 1e-9;
+        int64_t gl = 0, gc = 0;
+        const int grc = psamd_get_graph_stats(c0, &gl, &gc);
+        if (rank == 0 || loopback) {
+            static const char *names[PSAMD_NUM_TIMERS] = {"hist", "scan", "scatter", "sort_cells", "pairs", "apply", "lifecycle", "init_iframe", "collide"};
+            std::string kt;
+            for (int k = 0; k < PSAMD_NUM_TIMERS; k++)
+                if (us[k] > 0) { char b[96]; std::snprintf(b, sizeof b, "%s\"%s\": %.3f", kt.empty() ? "" : ", ", names[k], us[k] / (double)std::max<int64_t>(launches, 1)); kt += b; }
+            const psamd_slab_buffers &b = R.local[0].b;
+            std::printf("{\"psamd_ring\": 1, \"world\": %d, \"loopback\": %s, \"n\": %lld, \"grid_dim\": %d, \"steps\": %d, \"warmup\": %d, \"settle_steps\": %d, "
+                        "\"elapsed_s\": %.9f, \"updates\": %lld, \"own_updates\": %lld, \"live_after\": %lld, \"particles_with_a_force_term\": %lld, "
+                        "\"pairs_rank0\": %.6e, \"kernel_us\": {%s}, \"timed_launches\": %lld, \"timing_period\": %d, "
+                        "\"relocations\": %lld, \"relocations_lost\": %lld, \"cell_overflow_kills\": %lld, "
+                        "\"message_bytes_rank0\": {\"halo_up\": %lld, \"halo_down\": %lld, \"force_in\": %lld, \"xfer_each\": %lld, \"status\": %lld, \"snapshot_block\": %lld}, "
+                        "\"rccl_mb_rank0\": %.3f, \"graphs\": %s, \"graph_replays\": %lld, \"graph_captures\": %lld, \"side_stream\": %s, \"overlap_interior\": %s, "
+                        "\"all_pairs\": %s, \"fast_math\": %s, \"evolve\": %s, \"halo_cap_cell\": %d, \"xfer_cap\": %d}\n",
+                        world, loopback ? "true" : "false", (long long)n, sz.grid_dim, steps, warmup, settle, elapsed, (long long)upd, (long long)own_updates,
+                        (long long)live1, (long long)wf1, 0.5 * (terms0 + terms1), kt.c_str(), (long long)launches, period,
+                        (long long)cn1.relocations, (long long)cn1.relocations_lost, (long long)cn1.cell_overflow_kills,
+                        (long long)b.halo_out_bytes[1], (long long)b.halo_out_bytes[0], (long long)b.force_in_bytes, (long long)b.xfer_bytes, (long long)b.status_bytes,
+                        (long long)b.allg_bytes, R.moved / 1e6, (graphs && grc == PSAMD_OK) ? "true" : "false", (long long)gl, (long long)gc,
+                        side_stream ? "true" : "false", overlap_interior ? "true" : "false", all_pairs ? "true" : "false", fast_math ? "true" : "false",
+                        evolve ? "true" : "false", halo_cap_cell, xfer_cap);
+            std::fflush(stdout);
+        }
+        if (barrier()) return bail();
+        (void)hipFree(d_red);
+        for (Slab &s : R.local) psamd_destroy(s.ctx);
+        g_comm = nullptr;
+        ncclCommDestroy(R.comm);
+        return 0;
     }
 
-    int64_t moved = 0;
+    // ---------------------------------------------------------------- plain run (and, in loopback mode, the check against one context)
     const auto t0 = std::chrono::steady_clock::now();
-    for (int it = 0; it < iters; it++) {      // DoParallelProcess, ps.cpp:1843-1928, one slab per GPU
-        for (Slab &s : local) PS_OK(s.ctx, psamd_slab_build(s.ctx));
-        if (exchange(local, world, loopback, HALO, comm, st, &moved)) return 1;
-        if (gather(local, world, loopback, false, comm, st)) return 1;
-        for (Slab &s : local) PS_OK(s.ctx, psamd_slab_pairs(s.ctx));
-        if (exchange(local, world, loopback, FORCE, comm, st, &moved)) return 1;
-        for (Slab &s : local) PS_OK(s.ctx, psamd_slab_apply(s.ctx));
-        if (exchange(local, world, loopback, XFER, comm, st, &moved)) return 1;
-        if (gather(local, world, loopback, true, comm, st)) return 1;        // (births on, four or more ranks)
-        for (Slab &s : local) PS_OK(s.ctx, psamd_slab_finish(s.ctx));
-    }
-    for (Slab &s : local) PS_OK(s.ctx, psamd_synchronize(s.ctx));
-    HIP_OK(hipStreamSynchronize(st));
+    for (int it = 0; it < iters; it++)
+        if (ring_step(R, no_hook)) return bail();
+    for (Slab &s : R.local) PS_OK(s.ctx, psamd_synchronize(s.ctx));
+    HIP_OK(hipStreamSynchronize(R.compute));
+    HIP_OK(hipStreamSynchronize(R.transfer));
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
-    psamd_sizes sz;
-    PS_OK(local[0].ctx, psamd_get_sizes(local[0].ctx, &sz));
     std::vector<Particle72> merged((size_t)sz.container_size), part((size_t)sz.container_size);
     std::memset(merged.data(), 0, merged.size() * sizeof(Particle72));
-    int64_t live = 0;
-    for (Slab &s : local) {
+    int64_t live = 0, replays = 0, captures = 0;
+    for (Slab &s : R.local) {
         PS_OK(s.ctx, psamd_download_particles(s.ctx, part.data(), 0, sz.container_size));
         for (int t = 0; t < 4; t++)
             std::memcpy(merged.data() + s.plan.slot_lo[t], part.data() + s.plan.slot_lo[t],
                         (size_t)(s.plan.slot_hi[t] - s.plan.slot_lo[t]) * sizeof(Particle72));
-        int64_t l = 0;
+        int64_t l = 0, a = 0, b = 0;
         PS_OK(s.ctx, psamd_live_count(s.ctx, &l));
-        live += l;
+        PS_OK(s.ctx, psamd_get_graph_stats(s.ctx, &a, &b));       // (an error here: the runtime refused to capture a stage)
+        live += l; replays += a; captures += b;
     }
-    std::printf("rank %d of %d%s: %d steps, %.1f MB through RCCL, %.3f ms per step, %lld live here\n", rank, world,
-                loopback ? " (all slabs in this process)" : "", iters, moved / 1e6, 1e3 * secs / std::max(1, iters), (long long)live);
+    std::printf("rank %d of %d%s: %d steps, %.1f MB through RCCL, %.3f ms per step, %lld live here, %lld graph replays (%lld captures)%s%s\n", rank, world,
+                loopback ? " (all slabs in this process)" : "", iters, R.moved / 1e6, 1e3 * secs / std::max(1, iters), (long long)live,
+                (long long)replays, (long long)captures, side_stream ? ", transfers on a second stream" : "", overlap_interior ? ", interior pass beside the halo" : "");
 
     int rc = 0;
     if (loopback) {
         // the same steps in one plain context: the union of the slabs must be its state
-        psamd_config cfg;
-        psamd_default_config(&cfg);
-        cfg.device = 0;
+        psamd_config cfg = cfg0;
+        cfg.device = device;
         psamd_ctx *one = nullptr;
         PS_OK(one, psamd_create(&cfg, &one));
         PS_OK(one, psamd_fill_particles(one, n, xyz.data(), nullptr, nullptr, age.data(), fert.data(), nullptr, nullptr));
+        PS_OK(one, psamd_set_graphs(one, graphs ? 1 : 0));
         PS_OK(one, psamd_step(one, iters));
         PS_OK(one, psamd_download_particles(one, part.data(), 0, sz.container_size));
         psamd_counters cn;
@@ -309,14 +586,15 @@ int main(int argc, char **argv)
         size_t bad = 0;
         for (size_t i = 0; i < merged.size(); i++)
             if (std::memcmp(&merged[i], &part[i], sizeof(Particle72)) != 0) bad++;
-        std::printf("ring-rccl %s: %zu of %lld records differ from the single context after %d steps (%lld relocations there)\n",
-                    bad ? "MISMATCH" : "ok", bad, (long long)sz.container_size, iters, (long long)cn.relocations);
+        std::printf("ring-rccl %s: %zu of %lld records differ from the single context after %d steps (%lld relocations, %lld births there)\n",
+                    bad ? "MISMATCH" : "ok", bad, (long long)sz.container_size, iters, (long long)cn.relocations, (long long)cn.births);
         rc = bad ? 1 : 0;
         psamd_destroy(one);
     }
-    for (Slab &s : local) psamd_destroy(s.ctx);
+    for (Slab &s : R.local) psamd_destroy(s.ctx);
     g_comm = nullptr;
-    ncclCommDestroy(comm);
-    (void)hipStreamDestroy(st);
+    ncclCommDestroy(R.comm);
+    (void)hipStreamDestroy(R.compute);
+    if (R.transfer != R.compute) (void)hipStreamDestroy(R.transfer);
     return rc;
 }

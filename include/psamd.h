@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PSAMD_ABI_VERSION 4
+#define PSAMD_ABI_VERSION 5
 
 #define PSAMD_MAX_RANKS 64
 
@@ -310,6 +310,20 @@ int psamd_slab_msg_upload(psamd_ctx *ctx, int which, const void *host, int64_t b
 /* Enqueue all further work on the caller's HIP stream (e.g. the one RCCL orders
  * against) instead of the context's own.  NULL restores the context's stream. */
 int psamd_set_stream(psamd_ctx *ctx, void *hip_stream);
+
+/* One submission per stage sequence: with graphs on, the kernels a stage call enqueues (psamd_slab_build / _pairs /
+ * _apply / _finish up to its read-back; psamd_step: init_iframe .. the queue replay) are captured into a hipGraph the
+ * first time a launch shape is met and replayed afterwards -- a rank's step is then four or five submissions instead of
+ * two dozen launches.  The results are the same kernels' (tests compare every byte with graphs on); steps that carry
+ * timing events run eagerly.  Nothing a graph replays depends on the step: sizes, the step's number and the sequence
+ * number of the scalar record live in device memory.  psamd_get_graph_stats: replays and captures so far; returns
+ * PSAMD_ERR_UNSUPPORTED (and says why) if the runtime refused a capture and the context fell back to plain launches. */
+int psamd_set_graphs(psamd_ctx *ctx, int enabled);
+int psamd_get_graph_stats(psamd_ctx *ctx, int64_t *launches, int64_t *captures);
+/* How the calling thread waits for a step's scalars (the one read-back of a step, ps.cpp:1878-1900): 0 spins on the
+ * pinned record (default of a single context: lowest latency), 1 spins for a few microseconds and then sleeps in
+ * 5-us naps (default of a slab: a node's eight ranks do not pin eight cores). */
+int psamd_set_wait_policy(psamd_ctx *ctx, int policy);
 
 /* ---- introspection -------------------------------------------------------- */
 int psamd_get_counters(psamd_ctx *ctx, psamd_counters *out);

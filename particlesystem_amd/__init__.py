@@ -20,6 +20,7 @@ from . import build as _build
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PSAMD_LIB") or os.path.join(HERE, "libpsamd.so")   # PSAMD_LIB: another build, for A/B measurements
 
+ABI_VERSION = 5         # the struct layouts below are include/psamd.h's at this PSAMD_ABI_VERSION
 MAX_RANKS = 64
 FLAG_EXPLOSIONS = 0x1
 FLAG_FAST_MATH = 0x2
@@ -164,6 +165,9 @@ ABI = [
     ("psamd_device_view_get", C.c_int, [_vp, C.POINTER(DeviceView)]),
     ("psamd_debug_wave_trace", C.c_int, [_vp, _vp, _i64]),
     ("psamd_selftest_math", C.c_int, [_vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+    ("psamd_set_graphs", C.c_int, [_vp, C.c_int]),
+    ("psamd_get_graph_stats", C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    ("psamd_set_wait_policy", C.c_int, [_vp, C.c_int]),
     ("psamd_set_timing", C.c_int, [_vp, C.c_int]),
     ("psamd_set_timing_period", C.c_int, [_vp, C.c_int]),
     ("psamd_get_timing", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
@@ -189,6 +193,12 @@ def load():
             fn = getattr(lib, name)  # AttributeError here = a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
+        have = lib.psamd_abi_version()
+        if have != ABI_VERSION:
+            # (PSAMD_LIB may point at another build: a library with other struct layouts would misread the
+            # configuration and hand out garbage message pointers)
+            raise RuntimeError("%s has ABI version %d, this module is written for %d: rebuild it (particlesystem_amd.build(force=True))"
+                               % (LIB_PATH, have, ABI_VERSION))
         _lib = lib
     return _lib
 
@@ -463,6 +473,19 @@ class ParticleSystem:
         out = (C.c_uint64 * 24)()
         self._ck(self.lib.psamd_selftest_math(self.h, lo_bits, hi_bits, out))
         return list(out)
+
+    def set_graphs(self, on=True):
+        """stage sequences as hipGraphs: one submission per stage instead of one per kernel"""
+        self._ck(self.lib.psamd_set_graphs(self.h, 1 if on else 0))
+
+    def graph_stats(self):
+        """(replays, captures); raises if the runtime refused to capture and the context fell back"""
+        a, b = C.c_int64(), C.c_int64()
+        self._ck(self.lib.psamd_get_graph_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_wait_policy(self, policy):
+        self._ck(self.lib.psamd_set_wait_policy(self.h, int(policy)))
 
     def set_timing(self, on=True, every_stage=False, period=1):
         """HIP-event timing of the step's kernels: pair pass, apply and life cycle, or every

@@ -13,10 +13,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <random>
 #include <string>
 #include <vector>
+
+#include <sys/prctl.h>
 
 #include "../../include/psamd.h"
 #include "device_types.h"
@@ -86,6 +89,15 @@ struct psamd_ctx {
     bool ev_made = false;
     double t_us[PSAMD_NUM_TIMERS]{};
     int64_t t_launches = 0;
+    // stage sequences as hipGraphs (psamd_set_graphs): per kind of sequence, the shapes captured so far
+    struct GraphSlot { uint64_t key; hipGraphExec_t exec; uint64_t stamp; };
+    bool graphs = false;
+    std::vector<GraphSlot> gcache[5];
+    uint64_t gstamp = 0;
+    int64_t graph_launches = 0, graph_captures = 0;
+    std::string graph_refused;         // why the runtime would not capture (the context then runs without graphs)
+    int64_t slab_bound = 0;            // the bound slab_apply sized its launches from; slab_finish uses the same
+    int wait_policy = 0;               // how the host waits for the step's scalars: 0 spin, 1 spin briefly, then nap
 };
 
 namespace {
@@ -479,6 +491,9 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.wave_unit, (size_t)MAX_PAIR_WAVES + 1));
     PS_HIP(c, dev_alloc(c, &d.rec_start, (size_t)g.queue_infos + 1));
     PS_HIP(c, dev_alloc(c, &d.fs, 1));
+    PS_HIP(c, dev_alloc(c, &d.st, 1));
+    PS_HIP(c, hipMemsetAsync(d.st, 0, sizeof(StepState), c->stream));
+    c->wait_policy = cfg->world > 1 ? 1 : 0;
     PS_HIP(c, dev_alloc(c, &d.cell_start, LC + 1));
     PS_HIP(c, dev_alloc(c, &d.cursor, LC));
     PS_HIP(c, dev_alloc(c, &d.task_start, LC + 1));
@@ -516,7 +531,11 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.op_args_sorted, (size_t)d.ops_cap));
     PS_HIP(c, sort_ops_tmp_bytes((size_t)d.ops_cap, P.key_bits, &d.sort_tmp_bytes));
     { char *tmp = nullptr; PS_HIP(c, dev_alloc(c, &tmp, d.sort_tmp_bytes)); d.sort_tmp = tmp; }
-    PS_HIP(c, hipHostMalloc((void **)&c->h_fs, sizeof(FrameScalars), hipHostMallocMapped));
+    // the host polls this record (wait_scalars): coherent mapping whatever HIP_HOST_COHERENT says, and zeroed --
+    // hipHostMalloc does not promise zeroed pages, and a recycled page whose seq word happened to hold the number
+    // the first step waits for would be taken for that step's scalars
+    PS_HIP(c, hipHostMalloc((void **)&c->h_fs, sizeof(FrameScalars), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->h_fs, 0, sizeof(FrameScalars));
     PS_HIP(c, hipHostGetDevicePointer((void **)&c->d.fs_host, c->h_fs, 0));
     PS_HIP(c, dev_alloc(c, &d.moves, (size_t)d.moves_cap));
     PS_HIP(c, dev_alloc(c, &d.stage, 3 * (size_t)d.moves_cap));
@@ -667,6 +686,7 @@ int psamd_destroy(psamd_ctx *c)
 {
     if (!c) return PSAMD_OK;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &cache : c->gcache) for (auto &g : cache) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->staging) (void)hipFree(c->staging);
     if (c->h_fs) (void)hipHostFree(c->h_fs);
@@ -988,6 +1008,15 @@ int psamd_get_gridmax(psamd_ctx *c, int32_t out2[2])
 }
 
 // ---- stages ---------------------------------------------------------------------
+//
+// Every stage is a fixed sequence of kernel launches whose arguments do not change from step to step
+// (sizes live on the device; the step's number and the scalar records' sequence number too: StepState).
+// enq_* functions only enqueue; the host-side state machine is advanced by their callers -- so that a
+// sequence can be captured once into a hipGraph and replayed (psamd_set_graphs): one submission per stage
+// instead of one per kernel.  A graph is keyed by what shapes its launches: the size of the balanced force
+// pass (from the last step's task count) and the bound of the live count the life-cycle grids are sized
+// from, rounded up to 64 Ki so that a free-running population does not mean a capture per step.  Steps
+// that carry timing events run eagerly (the events sit between the kernels).
 
 static int slab_only(psamd_ctx *c, const char *what)
 {
@@ -995,63 +1024,157 @@ static int slab_only(psamd_ctx *c, const char *what)
                                                          "_pairs / _apply / _finish and exchange the messages in between");
 }
 
-static int do_init_iframe(psamd_ctx *c)
+// which steps carry timing events is settled when the step begins (before anything is enqueued or replayed)
+static void begin_step(psamd_ctx *c)
 {
     // (an event between two kernels costs ~6 us of idle GPU: a long timed run records them on every n-th step)
     c->timing_now = (c->timing && c->timing_steps++ % c->timing_period == 0) ? c->timing : 0;
-    if (c->timing_now >= 2) { make_events(c); (void)hipEventRecord(c->ev[10], c->stream); }
+    if (c->timing_now) make_events(c);
+}
+
+static int enq_init_iframe(psamd_ctx *c)
+{
+    if (c->timing_now >= 2) (void)hipEventRecord(c->ev[10], c->stream);
     // cell / chunk / queue-record counts and the per-frame scalars (the sticky error word stays)
     PS_HIP(c, launch_frame_reset(c->stream, c->d, c->frame_ints, c->P.world > 1 ? 4 * c->geo.num_chunks : 0));
-    c->frame_reset = true; c->grid_built = false; c->pairs_done = false;
     return PSAMD_OK;
 }
 
-static int do_build_grid(psamd_ctx *c)
+static int enq_build_grid(psamd_ctx *c)
 {
-    if (!c->frame_reset) return fail(c, PSAMD_ERR_STATE, "build_grid needs init_iframe first");
-    if (c->timing_now) make_events(c);
     PS_HIP(c, launch_build_grid(c->stream, c->P, c->d, c->timing_now >= 2 ? c->ev : nullptr));
-    c->frame_reset = false; c->grid_built = true; c->pairs_done = false;
-    c->live_at_build = -1;
     return PSAMD_OK;
 }
 
-static int do_pairs(psamd_ctx *c, const DevParams &P, bool last = true, bool first = true)
+// size of the balanced force pass: the tasks of the last step this context ran (the read-back of its
+// scalars is on the host already), else the bound of the live count (a pass over part of the cells gets
+// its share of the hint)
+static int64_t pairs_hint(const psamd_ctx *c, const DevParams &P)
 {
-    if (!c->grid_built) return fail(c, PSAMD_ERR_STATE, "calc_forces needs build_grid first");
-    if (c->timing_now && first) (void)hipEventRecord(c->ev[5], c->stream);
-    // size of the balanced force pass: the tasks of the last step this context ran (the
-    // read-back of its scalars is on the host already), else the bound of the live count
-    // (a pass over part of the cells gets its share of the hint)
     int64_t tasks_hint = (c->steps_total > 0 && c->tasks_last > 0) ? c->tasks_last
                          : (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) / 64 + comp_count(c->P);
-    tasks_hint = tasks_hint * comp_count(P) / std::max(1, comp_count(c->P));
+    return tasks_hint * comp_count(P) / std::max(1, comp_count(c->P));
+}
+
+static int enq_pairs(psamd_ctx *c, const DevParams &P, int64_t tasks_hint, bool last = true, bool first = true)
+{
+    if (c->timing_now && first) (void)hipEventRecord(c->ev[5], c->stream);
     PS_HIP(c, launch_pairs(c->stream, P, c->d, (c->timing_now && first) ? c->ev[13] : nullptr, tasks_hint, first ? 0 : 1));
     if (c->timing_now && last) (void)hipEventRecord(c->ev[6], c->stream);
-    c->pairs_done = last;
     return PSAMD_OK;
+}
+
+// the live count the life-cycle grids are sized from (live_bound < 0: unknown -- state was uploaded -- every owned slot)
+static int64_t live_bound_of(const psamd_ctx *c)
+{
+    const int64_t b = c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total;
+    return c->graphs ? std::min<int64_t>((b + 65535) & ~(int64_t)65535, std::max<int64_t>(c->P.slots_total, 65536)) : b;
 }
 
 // kill / survive / integrate / explosion for every own particle; in slab mode the particles
-// that leave for a neighbour's segment are in the outboxes when this returns
-static int do_apply(psamd_ctx *c)
+// that leave for a neighbour's segment are in the outboxes when this has run
+static int enq_apply(psamd_ctx *c, int64_t bound)
 {
-    if (!c->grid_built || !c->pairs_done) return fail(c, PSAMD_ERR_STATE, "apply needs build_grid and the pair pass first");
     if (c->timing_now) (void)hipEventRecord(c->ev[7], c->stream);
-    PS_HIP(c, launch_apply(c->stream, c->P, c->S, c->d, c->step));
-    if (c->P.world > 1)
-        PS_HIP(c, launch_outbox_close(c->stream, c->P, c->d, c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total, c->xfer_out));
+    PS_HIP(c, launch_apply(c->stream, c->P, c->S, c->d));
+    if (c->P.world > 1) PS_HIP(c, launch_outbox_close(c->stream, c->P, c->d, bound, c->xfer_out));
     return PSAMD_OK;
 }
 
-// Wait until the step's scalars are in the host's record: the publishing workgroup stores the step's
-// number last.  The stream is looked at now and then so that a failed launch cannot leave the host spinning.
+// arrivals on top of the own particles: what the op lists and move records of a step can hold at most
+static int64_t lifecycle_bound(const psamd_ctx *c, int64_t bound)
+{
+    return bound + 2 * (int64_t)c->P.xfer_cap + 2 * (int64_t)c->P.xfer2_cap + (int64_t)c->P.far_cap * c->P.world
+           + (c->P.world > 1 ? (int64_t)c->P.world * STATUS_KILL_CAP : 0);
+}
+
+// free-slot queues and relocation, the part enqueued without waiting for the host (in slab mode: after the
+// arrivals were merged in): census, bucketing -- the last bucketing workgroup hands the step's scalars to the
+// host's pinned record -- and the replay of the usual lists
+static int enq_lifecycle(psamd_ctx *c, int64_t bound)
+{
+    const int par = (int)(c->steps_total & 1);   // not c->step: a snapshot restore rewinds that
+    if (c->timing_now) { collect_lifecycle_time(c, par); (void)hipEventRecord(c->ev[par ? 11 : 8], c->stream); }
+    if (c->P.world > 1) PS_HIP(c, launch_inbox_merge(c->stream, c->P, c->d, c->xfer_in));
+    PS_HIP(c, launch_ops_bucket(c->stream, c->P, c->d, c->geo.queue_infos, lifecycle_bound(c, bound)));
+    PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->geo.queue_infos, lifecycle_bound(c, bound), 0, false));
+    return PSAMD_OK;
+}
+
+// ---- hipGraph cache ----
+enum { SEG_BUILD = 0, SEG_PAIRS, SEG_APPLY, SEG_FINISH, SEG_STEP, NSEG };
+
+static void drop_graphs(psamd_ctx *c)
+{
+    for (auto &cache : c->gcache) {
+        for (auto &g : cache) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        cache.clear();
+    }
+}
+
+extern "C++" {
+template <typename F>
+static int run_segment(psamd_ctx *c, int seg, uint64_t key, F enqueue)
+{
+    if (!c->graphs || c->timing_now) return enqueue();
+    auto &cache = c->gcache[seg];
+    for (auto &g : cache)
+        if (g.key == key) {
+            g.stamp = ++c->gstamp;
+            PS_HIP(c, hipGraphLaunch(g.exec, c->stream));
+            c->graph_launches++;
+            return PSAMD_OK;
+        }
+    // not seen with this shape: capture the sequence once, then replay it
+    hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed);
+    if (e == hipSuccess) {
+        const int rc = enqueue();
+        hipGraph_t graph = nullptr;
+        e = hipStreamEndCapture(c->stream, &graph);
+        hipGraphExec_t exec = nullptr;
+        if (rc == PSAMD_OK && e == hipSuccess && graph) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (rc != PSAMD_OK) return rc;
+        if (e == hipSuccess && exec) {
+            if (cache.size() >= 8) {                      // the shape that was used longest ago makes room
+                size_t old = 0;
+                for (size_t k = 1; k < cache.size(); k++) if (cache[k].stamp < cache[old].stamp) old = k;
+                (void)hipGraphExecDestroy(cache[old].exec);
+                cache.erase(cache.begin() + (long)old);
+            }
+            cache.push_back({key, exec, ++c->gstamp});
+            c->graph_captures++;
+            PS_HIP(c, hipGraphLaunch(exec, c->stream));
+            c->graph_launches++;
+            return PSAMD_OK;
+        }
+    }
+    // the runtime would not capture this: the context goes on without graphs (nothing was executed so far)
+    (void)hipGetLastError();
+    c->graphs = false;
+    c->graph_refused = std::string(hipGetErrorString(e));
+    return enqueue();
+}
+}  // extern "C++"
+
+// Wait until the step's scalars are in the host's record: the publishing workgroup stores the record's
+// number last.  The stream is looked at now and then so that a failed launch cannot leave the host waiting.
+// Policy 0 spins on the word (lowest latency: one GPU, the step's critical path); policy 1, the default of
+// a slab, spins for a few microseconds and then sleeps in short naps -- eight ranks of a node do not pin
+// eight cores for the whole run (the word arrives while the GPU still has the queue replay to do).
 static int wait_scalars(psamd_ctx *c, int seq)
 {
     volatile int32_t *word = &c->h_fs->seq;
+    const bool naps = c->wait_policy == 1;
     for (uint64_t spins = 1; *word != seq; spins++) {
-        __builtin_ia32_pause();
-        if ((spins & 0x3fff) == 0) {
+        if (naps && spins > 2000) {
+            static thread_local bool slack_set = false;
+            if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); slack_set = true; }   // 1 us: the default 50 us would be the nap
+            struct timespec ts = {0, 5000};
+            (void)nanosleep(&ts, nullptr);
+        } else
+            __builtin_ia32_pause();
+        if ((spins & (naps ? 0x3ff : 0x3fff)) == 0) {
             const hipError_t e = hipStreamQuery(c->stream);
             if (e == hipSuccess) {
                 if (*word == seq) break;
@@ -1064,25 +1187,18 @@ static int wait_scalars(psamd_ctx *c, int seq)
     return PSAMD_OK;
 }
 
-// free-slot queues and relocation (in slab mode: after the arrivals were merged in)
-static int do_lifecycle(psamd_ctx *c)
+// the rest of the step, once enq_lifecycle is enqueued (or replayed): the step's one read-back, the host's
+// bookkeeping, the commit of the relocations
+static int finish_step(psamd_ctx *c, int64_t bound)
 {
-    const int par = (int)(c->steps_total & 1);   // not c->step: a snapshot restore rewinds that
-    if (c->timing_now) { collect_lifecycle_time(c, par); (void)hipEventRecord(c->ev[par ? 11 : 8], c->stream); }
-    if (c->P.world > 1) PS_HIP(c, launch_inbox_merge(c->stream, c->P, c->d, c->xfer_in));
-    // live_bound < 0: unknown (state was uploaded) -> size for every owned slot; arrivals on top
-    const int64_t bound = (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) + 2 * (int64_t)c->P.xfer_cap + 2 * (int64_t)c->P.xfer2_cap + (int64_t)c->P.far_cap * c->P.world
-                          + (c->P.world > 1 ? (int64_t)c->P.world * STATUS_KILL_CAP : 0);
-    const int seq = ++c->scalars_seq;
-    PS_HIP(c, launch_ops_bucket(c->stream, c->P, c->d, c->geo.queue_infos, bound, seq));
+    const int par = (int)(c->steps_total & 1);
+    c->host_queues_valid = false;
     // one small read-back per step, as the reference's driver does for hostGridMax
     // (ps.cpp:1878-1900): live count, sticky errors and the sizes of the op lists -- written into the
-    // pinned host record by the census kernels themselves (publish_scalars) with the step's number behind
-    // them, which the host polls: no copy command, no event.  The
-    // rest of the life cycle is enqueued behind it without waiting (the kernels size themselves from
-    // the same scalars on the device), so the GPU is busy while the host catches up.
-    PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos, bound, 0, false));
-    c->host_queues_valid = false;
+    // pinned host record by the census kernels themselves (publish_scalars) with the record's number behind
+    // them, which the host polls: no copy command, no event.  The replay is enqueued behind it already
+    // (the kernels size themselves from the same scalars on the device), so the GPU is busy while the host catches up.
+    const int seq = ++c->scalars_seq;
     { const int st = wait_scalars(c, seq); if (st != PSAMD_OK) return st; }
     c->live_at_build = c->h_fs->live;
     const int64_t tasks_now = (int64_t)c->h_fs->n_tasks2 + c->h_fs->n_merged;       // ordinary tasks + packs of partial slices
@@ -1099,9 +1215,10 @@ static int do_lifecycle(psamd_ctx *c)
     // of it waiting in the next exchange.  (psamd_synchronize reports whatever is pending.)
     if (c->P.world > 1 ? c->h_fs->status_error != 0 : c->h_fs->error != 0) return check_device_errors(c);
     if (c->h_fs->max_bucket > BUCKET_MAX)      // rare: the replay above stood down
-        PS_HIP(c, launch_lifecycle_sorted(c->stream, c->P, c->d, c->step, c->geo.queue_infos, c->h_fs->n_ops, c->h_fs->n_moves));
-    else                                       // the long lists' instance if there is one, and the commit (the replay above is still running)
-        PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->step, c->geo.queue_infos, bound, 1, c->h_fs->max_bucket > 2048));
+        PS_HIP(c, launch_lifecycle_sorted(c->stream, c->P, c->d, c->geo.queue_infos, c->h_fs->n_ops, c->h_fs->n_moves));
+    else                                       // the long lists' instance if there is one (launched only then: the host's copy of
+                                               // max_bucket is the device's), and the commit (the replay above is still running)
+        PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->geo.queue_infos, lifecycle_bound(c, bound), 1, c->h_fs->max_bucket > 2048));
     if (c->timing_now) {
         // No wait for the end of the step: everything up to `apply` was complete when the
         // scalars landed; the life-cycle interval is read one step later (or by get_timing).
@@ -1126,30 +1243,46 @@ int psamd_init_iframe(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
     if (c->P.world > 1) return slab_only(c, "init_iframe");
-    return do_init_iframe(c);
+    begin_step(c);
+    const int rc = enq_init_iframe(c);
+    if (rc != PSAMD_OK) return rc;
+    c->frame_reset = true; c->grid_built = false; c->pairs_done = false;
+    return PSAMD_OK;
 }
 
 int psamd_build_grid(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
     if (c->P.world > 1) return slab_only(c, "build_grid");
-    return do_build_grid(c);
+    if (!c->frame_reset) return fail(c, PSAMD_ERR_STATE, "build_grid needs init_iframe first");
+    const int rc = enq_build_grid(c);
+    if (rc != PSAMD_OK) return rc;
+    c->frame_reset = false; c->grid_built = true; c->pairs_done = false;
+    c->live_at_build = -1;
+    return PSAMD_OK;
 }
 
 int psamd_calc_forces_pairs(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
     if (c->P.world > 1) return slab_only(c, "calc_forces");
-    return do_pairs(c, c->P);
+    if (!c->grid_built) return fail(c, PSAMD_ERR_STATE, "calc_forces needs build_grid first");
+    const int rc = enq_pairs(c, c->P, pairs_hint(c, c->P));
+    if (rc != PSAMD_OK) return rc;
+    c->pairs_done = true;
+    return PSAMD_OK;
 }
 
 int psamd_calc_forces_apply(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
     if (c->P.world > 1) return slab_only(c, "calc_forces");
-    int rc = do_apply(c);
+    if (!c->grid_built || !c->pairs_done) return fail(c, PSAMD_ERR_STATE, "apply needs build_grid and the pair pass first");
+    const int64_t bound = live_bound_of(c);
+    int rc = enq_apply(c, bound);
+    if (rc == PSAMD_OK) rc = enq_lifecycle(c, bound);
     if (rc != PSAMD_OK) return rc;
-    return do_lifecycle(c);
+    return finish_step(c, bound);
 }
 
 int psamd_calc_forces(psamd_ctx *c)
@@ -1163,10 +1296,23 @@ int psamd_calc_forces(psamd_ctx *c)
 int psamd_step(psamd_ctx *c, int32_t nsteps)
 {
     if (!c || nsteps < 0) return PSAMD_ERR_INVALID_ARG;
+    if (c->P.world > 1 && nsteps > 0) return slab_only(c, "step");
     for (int k = 0; k < nsteps; k++) {
-        int rc = psamd_init_iframe(c);
-        if (rc == PSAMD_OK) rc = psamd_build_grid(c);
-        if (rc == PSAMD_OK) rc = psamd_calc_forces(c);
+        // init_iframe, build_grid, calc_forces up to the step's read-back: one sequence of launches (one graph)
+        begin_step(c);
+        const int64_t hint = pairs_hint(c, c->P), bound = live_bound_of(c);
+        const uint64_t key = launch_pairs_shape(c->P, hint) | ((uint64_t)bound << 20);
+        int rc = run_segment(c, SEG_STEP, key, [&]() {
+            int r = enq_init_iframe(c);
+            if (r == PSAMD_OK) r = enq_build_grid(c);
+            if (r == PSAMD_OK) r = enq_pairs(c, c->P, hint);
+            if (r == PSAMD_OK) r = enq_apply(c, bound);
+            if (r == PSAMD_OK) r = enq_lifecycle(c, bound);
+            return r;
+        });
+        if (rc != PSAMD_OK) return rc;
+        c->frame_reset = false; c->grid_built = true; c->pairs_done = true; c->live_at_build = -1;
+        rc = finish_step(c, bound);
         if (rc != PSAMD_OK) return rc;
     }
     return PSAMD_OK;
@@ -1177,11 +1323,17 @@ int psamd_step(psamd_ctx *c, int32_t nsteps)
 int psamd_slab_build(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
-    int rc = do_init_iframe(c);
-    if (rc == PSAMD_OK) rc = do_build_grid(c);
+    begin_step(c);
+    const int rc = run_segment(c, SEG_BUILD, 0, [&]() {
+        int r = enq_init_iframe(c);
+        if (r == PSAMD_OK) r = enq_build_grid(c);
+        if (r != PSAMD_OK) return r;
+        if (c->allg_out) PS_HIP(c, launch_allg_pack(c->stream, c->P, c->d, c->allg_out));
+        if (c->P.world > 1) PS_HIP(c, launch_pack_halos(c->stream, c->P, c->d, c->halo_out_c0, c->halo_out_cells, c->halo_out, c->pack_off));
+        return (int)PSAMD_OK;
+    });
     if (rc != PSAMD_OK) return rc;
-    if (c->allg_out) PS_HIP(c, launch_allg_pack(c->stream, c->P, c->d, c->allg_out));
-    if (c->P.world > 1) PS_HIP(c, launch_pack_halos(c->stream, c->P, c->d, c->halo_out_c0, c->halo_out_cells, c->halo_out, c->pack_off));
+    c->frame_reset = false; c->grid_built = true; c->pairs_done = false; c->live_at_build = -1;
     c->slab_stage = 1;
     return PSAMD_OK;
 }
@@ -1193,7 +1345,8 @@ int psamd_slab_pairs_interior(psamd_ctx *c)
     if (!c) return PSAMD_ERR_INVALID_ARG;
     if (c->slab_stage != 1) return fail(c, PSAMD_ERR_STATE, "slab_pairs_interior belongs between slab_build and slab_pairs");
     if (!c->have_interior || c->interior_done) return PSAMD_OK;
-    int rc = do_pairs(c, c->P_int, false, true);
+    const int64_t hint = pairs_hint(c, c->P_int);
+    const int rc = run_segment(c, SEG_PAIRS, launch_pairs_shape(c->P_int, hint) | (1ull << 40), [&]() { return enq_pairs(c, c->P_int, hint, false, true); });
     if (rc != PSAMD_OK) return rc;
     c->interior_done = true; c->interior_ran = true;
     return PSAMD_OK;
@@ -1204,15 +1357,23 @@ int psamd_slab_pairs(psamd_ctx *c)
     if (!c) return PSAMD_ERR_INVALID_ARG;
     if (c->slab_stage != 1) return fail(c, PSAMD_ERR_STATE, "slab_pairs needs slab_build (and the halo exchange) first");
     const DevParams &P = c->P;
-    const int GG = P.G * P.G;
-    // from the rank below: halo layer (region 1), then lent layers (region 2); from the rank above: halo layer (region 3)
-    PS_HIP(c, launch_unpack_halos(c->stream, P, c->d, c->halo_in_cells[0], c->halo_in[0], c->unpack_off[0],
-                                  c->halo_in_cells[1], c->halo_in[1], c->unpack_off[1]));
-    if (c->allg_in) PS_HIP(c, launch_allg_index(c->stream, P, c->d));      // all-pairs: the gathered snapshot, by global cell
-    int rc = do_pairs(c, c->interior_done ? c->P_rest : c->P, true, !c->interior_done);
+    const DevParams &Pp = c->interior_done ? c->P_rest : c->P;
+    const bool second = c->interior_done;
+    const int64_t hint = pairs_hint(c, Pp);
+    const int rc = run_segment(c, SEG_PAIRS, launch_pairs_shape(Pp, hint) | (second ? 2ull << 40 : 0ull), [&]() {
+        const int GG = P.G * P.G;
+        // from the rank below: halo layer (region 1), then lent layers (region 2); from the rank above: halo layer (region 3)
+        PS_HIP(c, launch_unpack_halos(c->stream, P, c->d, c->halo_in_cells[0], c->halo_in[0], c->unpack_off[0],
+                                      c->halo_in_cells[1], c->halo_in[1], c->unpack_off[1]));
+        if (c->allg_in) PS_HIP(c, launch_allg_index(c->stream, P, c->d));      // all-pairs: the gathered snapshot, by global cell
+        const int r = enq_pairs(c, Pp, hint, true, !second);
+        if (r != PSAMD_OK) return r;
+        if (c->force_out) PS_HIP(c, launch_pack_force(c->stream, P, c->d, c->force_out, P.reg_layers[2] * GG * P.halo_cap_cell));
+        return (int)PSAMD_OK;
+    });
     c->interior_done = false;
     if (rc != PSAMD_OK) return rc;
-    if (c->force_out) PS_HIP(c, launch_pack_force(c->stream, P, c->d, c->force_out, P.reg_layers[2] * GG * P.halo_cap_cell));
+    c->pairs_done = true;
     c->slab_stage = 2;
     return PSAMD_OK;
 }
@@ -1221,13 +1382,17 @@ int psamd_slab_apply(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
     if (c->slab_stage != 2) return fail(c, PSAMD_ERR_STATE, "slab_apply needs slab_pairs (and the force exchange) first");
-    // the status records of all ranks (all-gathered since slab_build): error bits, cell-overflow kills for the
-    // owner of queue record 0, and the chunks' counts over all ranks -- the chunk lists' capacity rule; in
-    // the same launch the force records of the lent-out layers (the tail of the snapshot that went up)
-    PS_HIP(c, launch_status_merge(c->stream, c->P, c->d, c->status_in, c->halo_out_cells[1] - (c->P.lentout_c1 - c->P.lentout_c0),
-                                  c->force_in, c->pack_off[1]));
-    int rc = do_apply(c);
+    const int64_t bound = live_bound_of(c);
+    const int rc = run_segment(c, SEG_APPLY, (uint64_t)bound, [&]() {
+        // the status records of all ranks (all-gathered since slab_build): error bits, cell-overflow kills for the
+        // owner of queue record 0, and the chunks' counts over all ranks -- the chunk lists' capacity rule; in
+        // the same launch the force records of the lent-out layers (the tail of the snapshot that went up)
+        PS_HIP(c, launch_status_merge(c->stream, c->P, c->d, c->status_in, c->halo_out_cells[1] - (c->P.lentout_c1 - c->P.lentout_c0),
+                                      c->force_in, c->pack_off[1]));
+        return enq_apply(c, bound);
+    });
     if (rc != PSAMD_OK) return rc;
+    c->slab_bound = bound;
     c->slab_stage = 3;
     return PSAMD_OK;
 }
@@ -1237,7 +1402,10 @@ int psamd_slab_finish(psamd_ctx *c)
     if (!c) return PSAMD_ERR_INVALID_ARG;
     if (c->slab_stage != 3) return fail(c, PSAMD_ERR_STATE, "slab_finish needs slab_apply (and the transfer exchange) first");
     c->slab_stage = 0;
-    return do_lifecycle(c);
+    const int64_t bound = c->slab_bound;
+    const int rc = run_segment(c, SEG_FINISH, (uint64_t)bound, [&]() { return enq_lifecycle(c, bound); });
+    if (rc != PSAMD_OK) return rc;
+    return finish_step(c, bound);
 }
 
 int psamd_slab_plan_describe(const psamd_config *cfg, psamd_slab_plan *o)
@@ -1398,7 +1566,6 @@ static size_t snapshot_bytes(const psamd_ctx *c)
 static int snapshot_copy(psamd_ctx *c, bool save)
 {
     const size_t C = (size_t)c->P.slots_total;
-    if (C == 0) return PSAMD_OK;
     char *p = c->snapshot;
     char *s_pos = p, *s_vel = s_pos + C * sizeof(float4), *s_acc = s_vel + C * sizeof(float4);
     char *s_cell = s_acc + C * sizeof(float4);
@@ -1416,7 +1583,7 @@ static int snapshot_copy(psamd_ctx *c, bool save)
         PS_HIP(c, hipMemcpyAsync(s_queue, c->d.queue, C * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
     } else {
         PS_HIP(c, launch_restore(c->stream, (int)C, s_pos, s_vel, s_acc, s_cell, s_flags, s_queue, s_qinfo,
-                                 (int)((size_t)c->geo.queue_infos * sizeof(QueueInfo) / sizeof(int)), c->d));
+                                 (int)((size_t)c->geo.queue_infos * sizeof(QueueInfo) / sizeof(int)), c->step, c->d));
     }
     return PSAMD_OK;
 }
@@ -1469,6 +1636,32 @@ int psamd_selftest_math(psamd_ctx *c, uint32_t lo_bits, uint32_t hi_bits, uint64
     if (e == hipSuccess) e = hipMemcpy(out24, d, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return hip_fail(c, e, "selftest_math");
+    return PSAMD_OK;
+}
+
+int psamd_set_graphs(psamd_ctx *c, int enabled)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    if (!enabled) drop_graphs(c);
+    c->graphs = enabled != 0;
+    c->graph_refused.clear();
+    return PSAMD_OK;
+}
+
+int psamd_get_graph_stats(psamd_ctx *c, int64_t *launches, int64_t *captures)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (launches) *launches = c->graph_launches;
+    if (captures) *captures = c->graph_captures;
+    if (!c->graph_refused.empty()) return fail(c, PSAMD_ERR_UNSUPPORTED, "the HIP runtime would not capture a stage sequence (" + c->graph_refused + "); the context runs without graphs");
+    return PSAMD_OK;
+}
+
+int psamd_set_wait_policy(psamd_ctx *c, int policy)
+{
+    if (!c || policy < 0 || policy > 1) return PSAMD_ERR_INVALID_ARG;
+    c->wait_policy = policy;
     return PSAMD_OK;
 }
 

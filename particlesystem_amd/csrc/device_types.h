@@ -206,6 +206,15 @@ struct FrameScalars {
     long long cost_total;   // two-pass mode: sum over the force pass's tasks of the bodies each walks (its stencil's population)
 };
 
+// What a step needs to know about its own number, kept on the device so that no kernel argument changes from
+// one step to the next (a captured hipGraph replays the arguments it was captured with): `step` keys the
+// explosion RNG (k_apply, k_moves_commit), `seq` counts the scalar records handed to the host.  The workgroup
+// that publishes a step's scalars raises `pending`; the next frame's reset kernel -- nothing reads `step`
+// while it runs -- turns that into step + 1.  snapshot_restore rewinds `step` (k_restore).
+struct StepState {
+    int32_t step, pending, seq, pad;
+};
+
 // Cumulative event counters, mirrors psamd_counters.  Kept in COUNTER_COPIES copies on
 // separate 128-byte lines (workgroup b adds to copy b % COUNTER_COPIES; the host sums
 // them): same-line atomics are served one at a time by the memory side.

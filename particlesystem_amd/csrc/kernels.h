@@ -34,6 +34,7 @@ struct DeviceState {
     int2 *chunk_segs = nullptr;      // [num_chunks * 27] (first slot, slots) of the segments a chunk's particles live in, in slot order
     FrameScalars *fs = nullptr;
     FrameScalars *fs_host = nullptr;  // the host's pinned copy as the device sees it (written by the queue-census kernels)
+    StepState *st = nullptr;          // the step's number and the scalar records' sequence number, device-resident
     int *cell_start = nullptr;    // [num_cells+1]
     int *cursor = nullptr;        // [num_cells]
     int *task_start = nullptr;    // [num_cells+1] prefix of 64-particle slices per cell
@@ -94,7 +95,7 @@ hipError_t launch_place(hipStream_t st, const DevParams &P, int n, const int *id
 hipError_t launch_fill_int(hipStream_t st, int *p, int v, size_t n);
 hipError_t launch_restore(hipStream_t st, int n, const void *s_pos, const void *s_vel, const void *s_acc,
                           const void *s_cell, const void *s_flags, const void *s_queue, const void *s_qinfo, int qinfo_words,
-                          const DeviceState &d);
+                          int step, const DeviceState &d);
 hipError_t launch_validate_eps(hipStream_t st, uint32_t lo_bits, uint32_t hi_bits, double eps2, float eps2f,
                                unsigned long long *out);
 hipError_t launch_selftest_math(hipStream_t st, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out24);
@@ -104,13 +105,15 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
 // tasks_hint: about how many force tasks the pass will have (sizes the balanced force pass)
 // pass: 0 or 1, which of a frame's (up to two) passes of the pair stage this is
 hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint, int pass);
-hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step);
+// what shapes launch_pairs' launches for this hint, as a number below 2^20 (the key of a captured graph)
+uint64_t launch_pairs_shape(const DevParams &P, int64_t tasks_hint);
+hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d);
 hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints, int status_table);   // also clears the status record's header and census table
 // the bucketed life cycle, sized from a bound of the live count: bucket the operations (afterwards the
 // frame scalars are complete), then replay + relocation
-hipError_t launch_ops_bucket(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_bound, int seq);
-hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec, int64_t live_bound, int part, bool long_lists);
-hipError_t launch_lifecycle_sorted(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
+hipError_t launch_ops_bucket(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_bound);
+hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_bound, int part, bool long_lists);
+hipError_t launch_lifecycle_sorted(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec,
                                    int n_ops, int n_moves);
 // slab exchange (messages are int arrays with a 16-word header, see kernels.hip)
 // the snapshots for the rank below (k = 0) / above (k = 1), both in one pair of launches; also closes the status record

@@ -163,10 +163,11 @@ __global__ void k_place(DevParams P, int n, const int *__restrict__ ids, const f
 __global__ void k_restore(int n, const float4 *__restrict__ s_pos, const float4 *__restrict__ s_vel,
                           const float4 *__restrict__ s_acc, const int *__restrict__ s_cell,
                           const uint8_t *__restrict__ s_flags, const int *__restrict__ s_queue,
-                          const int *__restrict__ s_qinfo, int qinfo_words,
+                          const int *__restrict__ s_qinfo, int qinfo_words, int step, StepState *st,
                           float4 *pos4, float4 *vel4, float4 *acc4, int *cell, uint8_t *pflags, int *queue, int *qinfo)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { st->step = step; st->pending = 0; }          // the step the snapshot was taken at
     if (i < qinfo_words) qinfo[i] = s_qinfo[i];
     if (i >= n) return;
     queue[i] = s_queue[i];
@@ -178,12 +179,12 @@ __global__ void k_restore(int n, const float4 *__restrict__ s_pos, const float4 
 
 hipError_t launch_restore(hipStream_t st, int n, const void *s_pos, const void *s_vel, const void *s_acc,
                           const void *s_cell, const void *s_flags, const void *s_queue, const void *s_qinfo, int qinfo_words,
-                          const DeviceState &d)
+                          int step, const DeviceState &d)
 {
-    const int threads = std::max(n, qinfo_words);
+    const int threads = std::max(std::max(n, qinfo_words), 1);
     k_restore<<<(threads + 255) / 256, 256, 0, st>>>(n, (const float4 *)s_pos, (const float4 *)s_vel, (const float4 *)s_acc,
                                                     (const int *)s_cell, (const uint8_t *)s_flags, (const int *)s_queue,
-                                                    (const int *)s_qinfo, qinfo_words, d.pos4, d.vel4, d.acc4,
+                                                    (const int *)s_qinfo, qinfo_words, step, d.st, d.pos4, d.vel4, d.acc4,
                                                     d.cell, d.pflags, d.queue, (int *)d.qinfo);
     return hipGetLastError();
 }
@@ -2554,7 +2555,7 @@ struct ApplyEmit {
 // workgroups 71 us -- neither the per-workgroup list reservation (one same-address atomic each) nor
 // the workgroup count is what bounds it; one slot per thread in 1024-thread workgroups stays.
 template <int ITEMS>
-__global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int step,
+__global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, const StepState *__restrict__ stp,
                                                 const int *__restrict__ rank_of_slot,
                                                 const float4 *__restrict__ force4,
                                                 float4 *pos4, float4 *vel4, float4 *acc4,
@@ -2570,6 +2571,7 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, int st
     __shared__ unsigned int s_cnt[4];
     if (threadIdx.x == 0) { s_ops = 0; s_moves = 0; s_cnt[0] = s_cnt[1] = s_cnt[2] = s_cnt[3] = 0; }
     const int chunk_over = fs->chunk_over;
+    const int step = (P.flags & PSAMD_FLAG_EXPLOSIONS) ? stp->step : 0;       // keys the explosion RNG, nothing else
     int old_cells[ITEMS];
     bool any_active = false;
 #pragma unroll
@@ -3004,7 +3006,7 @@ __global__ __launch_bounds__(1024) void k_ops_hist(const uint64_t *__restrict__ 
 // word.  (It was a 100-byte device-to-host copy command and an event between this kernel and the replay:
 // a launch of its own and an idle gap of ~6 us on the step's critical path.)  Called by all threads of
 // one workgroup.
-__device__ __forceinline__ void publish_scalars(const FrameScalars *fs, FrameScalars *fs_host, int longest, int seq)
+__device__ __forceinline__ void publish_scalars(const FrameScalars *fs, FrameScalars *fs_host, int longest, StepState *st)
 {
     constexpr int WORDS = (int)(sizeof(FrameScalars) / sizeof(int)), SKIP = (int)(offsetof(FrameScalars, max_bucket) / sizeof(int)),
                   SEQ = (int)(offsetof(FrameScalars, seq) / sizeof(int));
@@ -3015,13 +3017,19 @@ __device__ __forceinline__ void publish_scalars(const FrameScalars *fs, FrameSca
         if (i != SEQ) dst[i] = i == SKIP ? longest : src[i];              // (max_bucket is being written by this very workgroup)
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&fs_host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        // the record's number: one more than the last one this context handed out (the host counts along); and the
+        // step this record closes is over as far as its number goes: the next frame's reset makes it step + 1
+        const int seq = st->seq + 1;
+        st->seq = seq; st->pending = 1;
+        __hip_atomic_store(&fs_host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // exclusive prefix of rec_count and its maximum, for configurations with more queue records than
 // k_ops_scatter scans for itself in LDS
 __global__ __launch_bounds__(1024) void k_ops_scan(int nrec, const int *__restrict__ rec_count,
-                                                    int *__restrict__ rec_start, FrameScalars *fs, FrameScalars *fs_host, int seq)
+                                                    int *__restrict__ rec_start, FrameScalars *fs, FrameScalars *fs_host, StepState *st)
 {
     __shared__ int wave_tot[16];
     __shared__ int carry_s, max_s;
@@ -3047,7 +3055,7 @@ __global__ __launch_bounds__(1024) void k_ops_scan(int nrec, const int *__restri
     atomicMax(&max_s, mymax);
     __syncthreads();
     if (tid == 0) { rec_start[nrec] = carry_s; fs->max_bucket = max_s; }
-    publish_scalars(fs, fs_host, max_s, seq);
+    publish_scalars(fs, fs_host, max_s, st);
 }
 
 // The life-cycle kernels below are launched BEFORE the host has read the step's counts back
@@ -3063,7 +3071,7 @@ __device__ __forceinline__ bool lifecycle_deferred(const FrameScalars *fs) { ret
 // the live count, whatever the step really produced is covered.
 template <bool SCAN>
 __global__ __launch_bounds__(1024) void k_ops_scatter(const uint64_t *__restrict__ keys, const int *__restrict__ args,
-                                                       FrameScalars *fs, FrameScalars *fs_host, int seq, int ops_cap, int rec_shift, int nrec,
+                                                       FrameScalars *fs, FrameScalars *fs_host, StepState *st, int ops_cap, int rec_shift, int nrec,
                                                        const int *__restrict__ rec_count, int *__restrict__ rec_start,
                                                        int *__restrict__ rec_cursor,
                                                        uint64_t *__restrict__ keys_out, int *__restrict__ args_out)
@@ -3098,7 +3106,7 @@ __global__ __launch_bounds__(1024) void k_ops_scatter(const uint64_t *__restrict
             for (int r = tid; r <= nrec; r += 1024) rec_start[r] = s_start[r];
             if (tid == 0) fs->max_bucket = longest;
         }
-        if (publisher) publish_scalars(fs, fs_host, longest, seq);
+        if (publisher) publish_scalars(fs, fs_host, longest, st);
         if (longest > BUCKET_MAX) return;                       // (lifecycle_deferred, from this workgroup's own scan)
         start = s_start;
     } else if (lifecycle_deferred(fs)) return;
@@ -3480,7 +3488,7 @@ __global__ void k_moves_reset(DevParams P, const MoveRec *__restrict__ moves, in
 }
 
 // Relocation phase 2: drop each particle into the slot the queue replay assigned.
-__global__ void k_moves_commit(DevParams P, int step, const MoveRec *__restrict__ moves, int n_host, const FrameScalars *__restrict__ fs,
+__global__ void k_moves_commit(DevParams P, const StepState *__restrict__ stp, const MoveRec *__restrict__ moves, int n_host, const FrameScalars *__restrict__ fs,
                                float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr,
                                uint8_t *pflags, const float4 *__restrict__ stage)
 {
@@ -3499,7 +3507,7 @@ __global__ void k_moves_commit(DevParams P, int step, const MoveRec *__restrict_
     } else {
         // create_particle_s (app.cu:189-208): child at the parent's position, opposite
         // velocity, age 0, fresh fertility age from the counter-based RNG
-        const uint64_t h0 = splitmix64(P.seed ^ ((uint64_t)(uint32_t)step << 32) ^ (uint64_t)(uint32_t)r.src);
+        const uint64_t h0 = splitmix64(P.seed ^ ((uint64_t)(uint32_t)stp->step << 32) ^ (uint64_t)(uint32_t)r.src);
         const uint64_t h3 = splitmix64(splitmix64(splitmix64(h0)));
         const double u = (double)(h3 >> 11) * (1.0 / 9007199254740992.0);
         const float fert = (float)((double)P.fert_lo + u * (double)(P.fert_hi - P.fert_lo));
@@ -3940,7 +3948,7 @@ hipError_t launch_place(hipStream_t st, const DevParams &P, int n, const int *id
 
 // init_iframe: zero the per-frame counts (cells, chunks, queue records: one array) and the
 // per-frame scalars; the sticky error word survives
-__global__ void k_frame_reset(int *frame, size_t n, FrameScalars *fs, int *status_out, int status_table)
+__global__ void k_frame_reset(int *frame, size_t n, FrameScalars *fs, StepState *st, int *status_out, int status_table)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) frame[i] = 0;
@@ -3948,6 +3956,7 @@ __global__ void k_frame_reset(int *frame, size_t n, FrameScalars *fs, int *statu
         const int err = fs->error;
         *fs = FrameScalars{};
         fs->error = err;
+        if (st->pending) { st->step += 1; st->pending = 0; }      // the step whose scalars went out last is over
     }
     if (status_out) {
         if (i < (size_t)MSG_HEADER_WORDS) status_out[i] = 0;
@@ -3958,7 +3967,7 @@ __global__ void k_frame_reset(int *frame, size_t n, FrameScalars *fs, int *statu
 hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints, int status_table)
 {
     const size_t n = std::max(frame_ints, (size_t)status_table);
-    k_frame_reset<<<(unsigned)((n + 1023) / 1024), 1024, 0, st>>>(d.cell_count, frame_ints, d.fs, d.status_out, d.status_out ? status_table : 0);
+    k_frame_reset<<<(unsigned)((n + 1023) / 1024), 1024, 0, st>>>(d.cell_count, frame_ints, d.fs, d.st, d.status_out, d.status_out ? status_table : 0);
     return hipGetLastError();
 }
 
@@ -4155,13 +4164,17 @@ hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceSt
     return hipSuccess;
 }
 
-template <int MODE, int NQ>
-static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint, int pass)
+// How one pass of the pair stage is launched, from the hint of its task count: everything that shapes the
+// launches and is not read from device memory by the kernels themselves (what a captured graph is keyed by).
+struct PairShape {
+    bool two, merge, balanced, tile, packs_in_list;
+    int nw;                  // wave slots of the balanced force pass
+};
+
+static PairShape pair_shape(const DevParams &P, bool lean, int64_t tasks_hint)
 {
-    const int ncomp = comp_count(P);
-    if (ncomp <= 0) return hipSuccess;
-    const int tasks = ncomp * P.slices;
-    const bool two = MODE != 0 && P.two_pass;
+    PairShape s{};
+    s.two = lean && P.two_pass;
     // leftover slices of several cells in one wave (k_pairs_merged).  A merged wave is long and
     // stalls on its tile loads; a small share (a slab with fewer than ~3 tasks per SIMD) has too
     // little other work to cover that and it becomes the critical path (measured on 1/4 and 1/8
@@ -4169,18 +4182,17 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     static const bool merge_off = std::getenv("PSAMD_NO_MERGE") != nullptr;
     static const bool balance_off = std::getenv("PSAMD_NO_BALANCE") != nullptr;
     static const int waves_env = std::getenv("PSAMD_WAVES") ? std::atoi(std::getenv("PSAMD_WAVES")) : 0;
-    bool merge = two && !merge_off && (P.world == 1 || tasks_hint >= 3000) && !(P.flags & PSAMD_FLAG_ALL_PAIRS);   // (the merged kernel walks the stencil only)
-    const bool balanced = two && !balance_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS);
+    s.merge = s.two && !merge_off && (P.world == 1 || tasks_hint >= 3000) && !(P.flags & PSAMD_FLAG_ALL_PAIRS);   // (the merged kernel walks the stencil only)
+    s.balanced = s.two && !balance_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS);
     // Balanced pass: a fixed number of waves, all resident, each walking the same number of
     // bodies.  At least four per SIMD when there are that many tasks (fewer cannot cover their
     // scalar-load latency: 1024 / 2048 / 4096 / 6144 waves took 3.73 / 2.54 / 2.27 / 2.29 ms on
     // the N = 2^20 cloud), but not more waves than tasks (a task cut in three or more pieces is
     // a chain of waves that wait for each other).
-    int nw = 0;
-    if (balanced) {
+    if (s.balanced) {
         static const int waves_per_simd = std::getenv("PSAMD_WAVES_PER_SIMD") ? std::atoi(std::getenv("PSAMD_WAVES_PER_SIMD")) : PSAMD_BALANCED_WAVES;      // (A/B runs)
-        nw = 1024 * (int)std::min<int64_t>(waves_per_simd, std::max<int64_t>(1, tasks_hint / 1024));
-        if (waves_env >= 32) nw = std::min(waves_env & ~31, MAX_PAIR_WAVES);
+        s.nw = 1024 * (int)std::min<int64_t>(waves_per_simd, std::max<int64_t>(1, tasks_hint / 1024));
+        if (waves_env >= 32) s.nw = std::min(waves_env & ~31, MAX_PAIR_WAVES);
     }
     // few waves per SIMD (a slab of a multi-GPU run): the scalar-load walk cannot cover its own
     // load latency, bodies come through LDS tiles fetched a tile ahead instead -- and the partly
@@ -4188,7 +4200,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     static const int tile_env = std::getenv("PSAMD_TILE") ? std::atoi(std::getenv("PSAMD_TILE")) : -1;
     static const bool unified_packs = std::getenv("PSAMD_UNIFIED_PACKS") != nullptr;
     static const bool tile_packs = std::getenv("PSAMD_TILE_PACKS") != nullptr;
-    const bool tile = balanced && (tile_env >= 0 ? tile_env != 0 : nw <= 2048);
+    s.tile = s.balanced && (tile_env >= 0 ? tile_env != 0 : s.nw <= 2048);
     // The packs of partly filled last slices as tasks of the balanced pass itself (tile walk).
     // Measured (pair stage, N = 2^20): one GPU, 8200 tasks: beside the pass in k_pairs_merged 2.31 ms,
     // in the list 2.40 (one kernel holding both walks needs 99 VGPRs: 4 waves per SIMD, not 6);
@@ -4196,9 +4208,27 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     // a pass that has only 4 waves per SIMD; an eighth (tile walk): no packs 0.58, packs 0.60 -- a
     // pack's four-group walk costs more than the two tasks it saves.  So: in the list for the slabs
     // that use the scalar walk, beside the pass on one GPU, none with the tile walk.
-    const bool packs_in_list = balanced && !merge_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS) && (tile ? tile_packs : (merge && (unified_packs || P.world > 1)));
-    if (packs_in_list) { merge = false; nw = std::min(nw, 4096); }      // (98 VGPRs with the tile walk in: 4 resident waves per SIMD)
-    if (tile) merge = false;                  // no separate merged kernel beside a tile-walk pass
+    s.packs_in_list = s.balanced && !merge_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS) && (s.tile ? tile_packs : (s.merge && (unified_packs || P.world > 1)));
+    if (s.packs_in_list) { s.merge = false; s.nw = std::min(s.nw, 4096); }      // (98 VGPRs with the tile walk in: 4 resident waves per SIMD)
+    if (s.tile) s.merge = false;                  // no separate merged kernel beside a tile-walk pass
+    return s;
+}
+
+uint64_t launch_pairs_shape(const DevParams &P, int64_t tasks_hint)
+{
+    const PairShape s = pair_shape(P, P.lean_math != 0, tasks_hint);
+    return (uint64_t)(s.nw / 32) | (s.merge ? 1ull << 10 : 0) | (s.tile ? 1ull << 11 : 0) | (s.packs_in_list ? 1ull << 12 : 0) | (s.balanced ? 1ull << 13 : 0);
+}
+
+template <int MODE, int NQ>
+static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint, int pass)
+{
+    const int ncomp = comp_count(P);
+    if (ncomp <= 0) return hipSuccess;
+    const int tasks = ncomp * P.slices;
+    const PairShape shape = pair_shape(P, MODE != 0, tasks_hint);
+    const bool two = shape.two, merge = shape.merge, balanced = shape.balanced, tile = shape.tile, packs_in_list = shape.packs_in_list;
+    const int nw = shape.nw;
     if (two) {
         // collision flags and the per-cell lists of the particles that need a force, then the plan of the force pass
         if (P.max_per_cell + HALO_CAP / 2 <= 1024)
@@ -4262,11 +4292,11 @@ hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d
     return launch_pairs_mode<0, 4>(st, P, d, ev_force, tasks_hint, pass);
 }
 
-hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d, int step)
+hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d)
 {
     if (P.slots_total <= 0) return hipSuccess;
     // slots per thread: one (PSAMD_APPLY_ITEMS: the measurement quoted at the kernel)
-#define PS_APPLY(I) k_apply<I><<<(P.slots_total + I * 1024 - 1) / (I * 1024), 1024, 0, st>>>(P, S, step, d.rank_of_slot, d.force4, d.pos4, \
+#define PS_APPLY(I) k_apply<I><<<(P.slots_total + I * 1024 - 1) / (I * 1024), 1024, 0, st>>>(P, S, d.st, d.rank_of_slot, d.force4, d.pos4, \
         d.vel4, d.acc4, d.cell, d.pflags, d.celltab, d.op_keys, d.op_args, d.ops_cap, \
         d.moves, d.moves_cap, Outboxes{{d.xfer_out[0], d.xfer_out[1], d.xfer_out[2], d.xfer_out[3], d.xfer_out[4]}}, d.chunk_count, d.chunk_skip, d.fs, d.ctr)
     static const int items_env = std::getenv("PSAMD_APPLY_ITEMS") ? std::atoi(std::getenv("PSAMD_APPLY_ITEMS")) : 0;
@@ -4295,19 +4325,19 @@ hipError_t launch_outbox_close(hipStream_t st, const DevParams &P, const DeviceS
 // back at that point), replay the queues with the first relocation phase riding along, commit.
 // `live_bound` >= live particles of the step (arrivals from the neighbour ranks included): at most 3
 // queue operations and 2 move records each.
-hipError_t launch_ops_bucket(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_bound, int seq)
+hipError_t launch_ops_bucket(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_bound)
 {
     const int64_t max_ops = std::max<int64_t>(1, std::min<int64_t>(d.ops_cap, 3 * live_bound));
     const int nwg = (int)std::min<int64_t>((max_ops + SLOTS_PER_WG - 1) / SLOTS_PER_WG, 2048);    // (grid-stride beyond)
     k_ops_hist<<<std::min(nwg, 512), 1024, 0, st>>>(d.op_keys, d.fs, d.ops_cap, P.key_rec_shift, nrec, d.rec_count);
     PS_LAUNCH_CHECK();
     if (nrec <= LDS_CELLS)
-        k_ops_scatter<true><<<nwg, 1024, 0, st>>>(d.op_keys, d.op_args, d.fs, d.fs_host, seq, d.ops_cap, P.key_rec_shift, nrec, d.rec_count, d.rec_start,
+        k_ops_scatter<true><<<nwg, 1024, 0, st>>>(d.op_keys, d.op_args, d.fs, d.fs_host, d.st, d.ops_cap, P.key_rec_shift, nrec, d.rec_count, d.rec_start,
                                                   d.rec_cursor, d.op_keys_sorted, d.op_args_sorted);
     else {
-        k_ops_scan<<<1, 1024, 0, st>>>(nrec, d.rec_count, d.rec_start, d.fs, d.fs_host, seq);
+        k_ops_scan<<<1, 1024, 0, st>>>(nrec, d.rec_count, d.rec_start, d.fs, d.fs_host, d.st);
         PS_LAUNCH_CHECK();
-        k_ops_scatter<false><<<nwg, 1024, 0, st>>>(d.op_keys, d.op_args, d.fs, nullptr, 0, d.ops_cap, P.key_rec_shift, nrec, d.rec_count, d.rec_start,
+        k_ops_scatter<false><<<nwg, 1024, 0, st>>>(d.op_keys, d.op_args, d.fs, nullptr, nullptr, d.ops_cap, P.key_rec_shift, nrec, d.rec_count, d.rec_start,
                                                    d.rec_cursor, d.op_keys_sorted, d.op_args_sorted);
     }
     PS_LAUNCH_CHECK();
@@ -4318,7 +4348,7 @@ hipError_t launch_ops_bucket(hipStream_t st, const DevParams &P, const DeviceSta
 // part 1, once the host has the step's scalars (they are out before part 0 starts running): the instance for
 // long lists only if some queue got more than 2048 operations (`long_lists`), and the commit.  (The long-list
 // instance used to be launched every step and leave at once: ~4.5 us on the timeline for nothing.)
-hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec, int64_t live_bound, int part, bool long_lists)
+hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_bound, int part, bool long_lists)
 {
     const int64_t max_moves = std::min<int64_t>(d.moves_cap, 2 * live_bound);
     const int nb = (int)((max_moves + REPLAY_THREADS - 1) / REPLAY_THREADS);
@@ -4334,7 +4364,7 @@ hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceStat
         PS_LAUNCH_CHECK();
     }
     if (nb > 0) {
-        k_moves_commit<<<(int)((max_moves + 255) / 256), 256, 0, st>>>(P, step, d.moves, -1, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
+        k_moves_commit<<<(int)((max_moves + 255) / 256), 256, 0, st>>>(P, d.st, d.moves, -1, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
         PS_LAUNCH_CHECK();
     }
     return hipSuccess;
@@ -4342,7 +4372,7 @@ hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceStat
 
 // A queue with a very long list (e.g. record 0 during a collapse; the kernels above stood
 // down): global sort + serial walk, sized by the counts the host has read back.
-hipError_t launch_lifecycle_sorted(hipStream_t st, const DevParams &P, const DeviceState &d, int step, int nrec,
+hipError_t launch_lifecycle_sorted(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec,
                                    int n_ops, int n_moves)
 {
     if (n_ops > 0) {
@@ -4358,7 +4388,7 @@ hipError_t launch_lifecycle_sorted(hipStream_t st, const DevParams &P, const Dev
         PS_LAUNCH_CHECK();
         k_moves_reset<<<nb, 256, 0, st>>>(P, d.moves, n_moves, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags);
         PS_LAUNCH_CHECK();
-        k_moves_commit<<<nb, 256, 0, st>>>(P, step, d.moves, n_moves, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
+        k_moves_commit<<<nb, 256, 0, st>>>(P, d.st, d.moves, n_moves, d.fs, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
         PS_LAUNCH_CHECK();
     }
     return hipSuccess;

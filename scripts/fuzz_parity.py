@@ -19,7 +19,8 @@ from particlesystem_amd.slab import merge_owned, step_local   # noqa: E402
 from util import assert_same_particles, explosion_rng, oracle_cfg_from   # noqa: E402
 
 
-def draw_case(rng, sizes, max_steps=6, worlds=(1, 1, 2, 3, 4)):
+def draw_case(rng, sizes, max_steps=6, worlds=(1, 1, 2, 3, 4), nan_draw=True):
+    """nan_draw=False: the draws as they were before the not-a-number particles were added (campaigns up to seed 3303 keep their cases)"""
     n = int(rng.choice(sizes))
     geo = [{}, {}, {"chunk_factor": 2, "chunk_dim": 6}, {"chunk_factor": 3, "chunk_dim": 4}, {"chunk_factor": 5, "chunk_dim": 4},
            {"chunk_factor": 4, "chunk_dim": 3, "cell_size": 2.5}, {"chunk_factor": 5, "chunk_dim": 3}][int(rng.integers(0, 7))]
@@ -93,7 +94,7 @@ def draw_case(rng, sizes, max_steps=6, worlds=(1, 1, 2, 3, 4)):
     # (last draw, so that the cases of earlier campaigns keep their other draws) now and then two particles whose
     # velocity is not a number -- what a child born with the direction (0, 0, 0) gets (0/0, ps.cpp:1306-1333): a kid and
     # an adult; a step later their position is not a number either and the reference files them under cell 0
-    if rng.random() < 0.15:
+    if nan_draw and rng.random() < 0.15:
         if v is None:
             v = np.zeros((n, 3), np.float32)
         pick = rng.choice(n, 2, replace=False)
@@ -106,7 +107,8 @@ def draw_case(rng, sizes, max_steps=6, worlds=(1, 1, 2, 3, 4)):
                      (n, G, half, vmax, births, w is not None, world, cuts, interior, reupload, int(v is not None and bool(np.isnan(v).any())), over))
 
 
-def run_case(c, seed):
+def run_case(c, seed, graphs=False):
+    """graphs: the contexts replay their stage sequences as hipGraphs (psamd_set_graphs)"""
     has_nan = c["v"] is not None and bool(np.isnan(c["v"]).any())
     flags = ps.FLAG_EXPLOSIONS if (c["births"] or has_nan) else 0      # (births on: the far outbox exists in worlds of four or more)
     extra = dict(seed=seed) if c["births"] else {}
@@ -114,6 +116,11 @@ def run_case(c, seed):
     if c["cuts"]:
         extra["cuts"] = c["cuts"]
     mk = lambda r: ps.ParticleSystem(ps.default_config(rank=r, world=W, flags=flags, **extra, **c["over"]))
+    def mk(r, mk0=mk):
+        g = mk0(r)
+        if graphs:
+            g.set_graphs(True)
+        return g
     try:
         ranks = [mk(r) for r in range(W)]
     except ps.PsamdError as e:
@@ -160,11 +167,9 @@ def run_case(c, seed):
             # smaller than what a fast dense cloud sends (halo_cap_cell, xfer_cap, the hop-two messages' 1024 records).
             # (Served since round 3, no longer refusals: the chunk-list capacity rule across ranks, a two-layer jump
             # over a rank whose state is a single layer.)
-            # ... and a particle whose position is not a number, which the reference files under cell 0, on a rank that is not
-            # within two layers of layer 0: its record has no route to rank 0
-            far_nan = (W >= 4 and (c["births"] or (c["v"] is not None and bool(np.isnan(c["v"]).any())))
-                       and ("holds no state for" in str(e) or "does not match the receiver" in str(e)))
-            if W > 1 and ("status message" in str(e) or "had no room" in str(e) or far_nan):
+            # (Served since round 3 too: a particle whose position is not a number on a rank far from the cell the
+            # reference files it under -- the far outbox.  ERR_SLAB_MISMATCH / ERR_FOREIGN_CELL are failures again.)
+            if W > 1 and ("status message" in str(e) or "had no room" in str(e)):
                 for g in ranks:
                     g.close()
                 o.close()
@@ -199,6 +204,8 @@ def run_case(c, seed):
     for k, v in cnt.items():
         assert v == twice * o.counters[k], (k, v, o.counters[k], twice)
     cnt = {k: v // twice for k, v in cnt.items()}
+    if graphs:
+        cnt["graph_replays"] = sum(g.graph_stats()[0] for g in ranks)       # (raises if the runtime refused a capture)
     for g in ranks:
         g.close()
     o.close()
@@ -213,6 +220,7 @@ def main():
     ap.add_argument("--sizes", default="3000,12000,40000,90000", help="particle counts to draw from")
     ap.add_argument("--max-steps", type=int, default=6)
     ap.add_argument("--worlds", default="1,1,2,3,4", help="world sizes to draw from (capped at half the grid's layers)")
+    ap.add_argument("--graphs", action="store_true", help="every other case with the stage sequences as hipGraphs")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     log = open(a.log, "a") if a.log else sys.stdout
@@ -223,7 +231,7 @@ def main():
             print("start case %d [%s]" % (i, c["desc"]), file=log, flush=True)
         t = time.time()
         try:
-            res = run_case(c, 1000 + i)
+            res = run_case(c, 1000 + i, graphs=a.graphs and i % 2 == 1)
         except AssertionError as e:
             res = "MISMATCH %s" % str(e)[:300]
             bad += 1

@@ -34,11 +34,24 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_defaults(lib):
-    assert lib.psamd_abi_version() == 4
+    # the header, the library and the python mirror agree on the layout version
+    header = int(re.search(r"#define PSAMD_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "psamd.h")).read()).group(1))
+    assert lib.psamd_abi_version() == header == ps.ABI_VERSION
     cfg = ps.default_config()
     assert (cfg.max_particles_num, cfg.x_factor, cfg.chunk_factor, cfg.chunk_dim) == (1 << 20, 2, 4, 4)
     assert (cfg.cell_size, cfg.eps2, cfg.collision_radius, cfg.dt) == (5.0, 0.2, 0.4, 0.05)
     assert lib.psamd_status_string(2).decode().startswith("no usable HIP device")
+
+
+def test_a_library_of_another_abi_version_is_refused(tmp_path, monkeypatch):
+    """PSAMD_LIB may point at another build (A/B runs): struct layouts of another version must not be bound."""
+    monkeypatch.setattr(ps, "ABI_VERSION", ps.ABI_VERSION + 1)
+    monkeypatch.setattr(ps, "_lib", None)
+    with pytest.raises(RuntimeError, match="ABI version"):
+        ps.load()
+    monkeypatch.undo()
+    ps._lib = None
+    ps.load()
 
 
 def test_null_arguments_are_rejected(lib):

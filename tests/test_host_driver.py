@@ -58,21 +58,58 @@ def test_driver_ends_in_the_oracle_state(fetch_back):
     assert out.count(">>>>>>>>>>> Execution time of iteration (sec):") == 10    # the reference's per-iteration print
 
 
+RING_CASES = [
+    (2, []), (3, ["--overlap-interior"]), (4, ["--births"]), (8, []),
+    (2, ["--all-pairs"]), (4, ["--all-pairs"]), (8, ["--all-pairs", "--n", "30000"]),
+    (3, ["--graphs", "0", "--side-stream", "0"]),              # the round-3 form: plain launches, RCCL on the compute stream
+    (4, ["--births", "--overlap-interior", "--wait", "0"]),
+]
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [2, 3])
-def test_cpp_ring_moves_every_message_with_rccl(world):
+@pytest.mark.parametrize("world,extra", RING_CASES, ids=["w%d%s" % (w, "".join(a for a in e if not a.isdigit())) for w, e in RING_CASES])
+def test_cpp_ring_moves_every_message_with_rccl(world, extra):
     """host/ps_ring_rccl --loopback: all slabs in one C++ process on this GPU, a communicator of one
     rank, every halo / force / transfer message an ncclSend to self matched by an ncclRecv from self
-    on the contexts' stream, the status records by ncclAllGather.  The program itself requires the
+    on the TRANSFER stream (events order it against the compute stream, where every stage runs as one
+    captured hipGraph), the status records -- and, with --all-pairs, the snapshot blocks: SURVEY 8(e)'s
+    all-gather of positions once per step -- by ncclAllGather.  The program itself requires the
     union of the slabs to equal the single-context run byte for byte (which the parity tests tie to
-    the oracle) and exits non-zero otherwise."""
+    the oracle) and exits non-zero otherwise.  Stage loop: ps.cpp:1843-1928; what a rank subscribes
+    to: ps.cpp:380-487."""
     exe = psbuild.build_ring()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run([exe, "--loopback", "--world", str(world), "--n", "60000", "--iters", "8"], env=env,
+    p = subprocess.run([exe, "--loopback", "--world", str(world), "--n", "60000", "--iters", "8"] + extra, env=env,
                        capture_output=True, text=True, timeout=560)
     print(p.stdout)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
-    m = re.search(r"ring-rccl ok: 0 of \d+ records differ from the single context after 8 steps \((\d+) relocations", p.stdout)
+    m = re.search(r"ring-rccl ok: 0 of \d+ records differ from the single context after 8 steps \((\d+) relocations, (\d+) births", p.stdout)
     assert m and int(m.group(1)) > 0, p.stdout
+    assert (int(m.group(2)) > 0) == ("--births" in extra), p.stdout
     assert float(re.search(r"([0-9.]+) MB through RCCL", p.stdout).group(1)) > 1.0
+    replays = int(re.search(r"(\d+) graph replays", p.stdout).group(1))
+    if "--graphs" in extra:
+        assert replays == 0
+    else:
+        assert replays >= world * 8 * 3, p.stdout        # four stage sequences per rank and step, less the captures
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_cpp_ring_bench_record_in_loopback():
+    """The benchmark protocol of the C++ host (what bench.py --gpus N relays from rank 0), all four slabs in one
+    process: settle, warm up, time K restored steps between barriers, census of the frame -- one JSON record."""
+    import json
+    exe = psbuild.build_ring()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([exe, "--loopback", "--world", "4", "--bench", "--n", "131072", "--steps", "6", "--warmup", "2",
+                        "--settle-seconds", "0.05", "--timing-period", "2"], env=env, capture_output=True, text=True, timeout=560)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    recs = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{") and '"psamd_ring"' in l]
+    assert len(recs) == 1, p.stdout
+    r = recs[0]
+    assert r["world"] == 4 and r["steps"] == 6 and r["updates"] == 6 * 131072 and r["elapsed_s"] > 0
+    assert r["graphs"] is True and r["graph_replays"] > 0 and r["side_stream"] is True
+    assert r["pairs_rank0"] > 0 and r["kernel_us"]["pairs"] > 0 and r["timed_launches"] == 3
+    assert r["message_bytes_rank0"]["halo_up"] > 0 and r["particles_with_a_force_term"] > 0

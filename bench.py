@@ -22,8 +22,13 @@ N > 1 starts one process per GPU (python -m torch.distributed.run; or is started
 the caller) and runs the SLAB-PARTITIONED path: every rank holds only the segments of its
 cell layers -- slots, particles, free-slot queues -- and exchanges, with its two ring
 neighbours over RCCL send/recv, the snapshot of its boundary layers, the force records of
-lent layers and the particles that change owner (particlesystem_amd/slab.py).  Total work is
-fixed at N = 2^20 as the GPU count grows => "scaling": "strong".
+lent layers and the particles that change owner.  The ranks that do the work are C++ programs
+(host/ps_ring_rccl: libpsamd.so's stage calls, RCCL on a second HIP stream, every stage's kernels
+as one hipGraph): each Python rank starts its own as a child process before anything here touches
+a GPU, and rank 0 relays its record as the one JSON line.  --backend nccl / gloo runs the same
+step from Python over torch.distributed instead (particlesystem_amd/slab.py), which is also
+what the ranks fall back to, together, if a C++ rank fails.  Total work is fixed at N = 2^20
+as the GPU count grows => "scaling": "strong".
 """
 import argparse
 import json
@@ -77,8 +82,17 @@ def parse_args():
                     "print the line's skeleton (no GPU work): proves the --gpus N launcher on a machine without GPUs")
     ap.add_argument("--overlap-interior", action="store_true", help="multi-GPU: a pass of its own for the cells that need no halo, "
                     "run while the halo travels (measured slower than the single pass it splits; see DESIGN.md)")
-    ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL; gloo: messages staged "
-                    "through host memory, for rehearsals on one GPU)")
+    ap.add_argument("--backend", default="ring", help="--gpus > 1: ring = one C++ rank per GPU (host/ps_ring_rccl: RCCL on a second HIP stream, "
+                    "stage sequences as hipGraphs; the default); nccl = the same step from Python over torch.distributed (RCCL); gloo: "
+                    "messages staged through host memory, for rehearsals on one GPU")
+    ap.add_argument("--graphs", action="store_true", help="one GPU / --sim-world / torch ranks: stage sequences as hipGraphs (psamd_set_graphs)")
+    ap.add_argument("--wait-policy", type=int, default=-1, help="how the host waits for a step's scalars: 0 spin, 1 short spin then naps (default: the library's)")
+    ap.add_argument("--ring-graphs", type=int, default=1, help="C++ ranks: stage sequences as hipGraphs (0: plain launches)")
+    ap.add_argument("--ring-side-stream", type=int, default=1, help="C++ ranks: RCCL on a second HIP stream (0: on the compute stream)")
+    ap.add_argument("--ring-timeout", type=float, default=0.0, help="seconds a C++ rank may take before it is ended and the ranks fall back (0: from --steps)")
+    ap.add_argument("--sustained-steps", type=int, default=200, help="one GPU: when --steps is shorter than this, a second timed region of this "
+                    "many steps is reported beside the line's figure (the chip is power-bound: a region of seconds runs at a lower clock "
+                    "than one of tens of milliseconds); 0: none")
     return ap.parse_args()
 
 
@@ -296,6 +310,10 @@ def sim_world(args, ps, cfg_over, flags):
     for g in ranks:
         g.fill_particles(xyz, age=age, fert_age=fert)
         g.snapshot_save()
+        if args.graphs:
+            g.set_graphs(True)
+        if args.wait_policy >= 0:
+            g.set_wait_policy(args.wait_policy)
     rings = [DeviceRing(g, None, r, W, stream) for r, g in enumerate(ranks)]
     stages = ("build", "pairs_interior", "pairs", "apply", "finish")
     ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in stages] for _ in range(W)]
@@ -381,6 +399,138 @@ def sim_world(args, ps, cfg_over, flags):
         g.close()
     return out
 
+def ring_paths():
+    """the id file of this job's C++ ranks and the job's nonce: the same on every rank of one launch (the ranks share a
+    parent -- torch.distributed.run's agent, or bench.py's own launcher -- and MASTER_PORT), different from any other's"""
+    port = int(os.environ.get("MASTER_PORT", "0") or 0)
+    job = (port % 100000) * 10000000 + os.getppid() % 10000000
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "psamd_ring_%d" % job), job
+
+
+def ring_args(args, world, rank, local_rank, cfg_over):
+    exe = os.path.join(ROOT, "host", "ps_ring_rccl")
+    id_file, job = ring_paths()
+    cmd = [exe, "--world", str(world), "--rank", str(rank), "--device", str(local_rank), "--id-file", id_file, "--job", str(job)]
+    if os.environ.get("PSAMD_BENCH_RING_BREAK"):
+        cmd.append("--no-such-option")          # (test hook: every C++ rank fails at once; the ranks must fall back together)
+    if args.launch_check:
+        return cmd + ["--launch-check", "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    cmd += ["--bench", "--n", str(args.n), "--seed", str(args.seed), "--steps", str(args.steps), "--warmup", str(args.warmup),
+            "--settle-seconds", str(args.settle_seconds), "--timing-period", str(args.timing_period),
+            "--chunk-factor", str(args.chunk_factor), "--chunk-dim", str(args.chunk_dim),
+            "--halo-cap-cell", str(args.halo_cap_cell), "--xfer-cap", str(cfg_over.get("xfer_cap", 0)),
+            "--max-particles", str(cfg_over["max_particles_num"]),
+            "--graphs", str(args.ring_graphs), "--side-stream", str(args.ring_side_stream)]
+    for flag, on in (("--all-pairs", args.all_pairs), ("--fast-math", args.fast_math), ("--evolve", args.evolve),
+                     ("--overlap-interior", args.overlap_interior)):
+        if on:
+            cmd.append(flag)
+    return cmd
+
+
+def run_ring_rank(args, world, rank, local_rank, cfg_over):
+    """Start this rank's C++ program as a child process (nothing in this process has touched a GPU), wait for it --
+    not for ever: a rank that hangs is ended by its exact PID --, tell the other ranks how it went through a file beside
+    the id file, and hear from them.  Returns (every rank succeeded, rank 0's record or None, what went wrong)."""
+    id_file, _ = ring_paths()
+    mine = "%s.rc%d" % (id_file, rank)
+    if os.path.exists(mine):
+        os.remove(mine)
+    limit = args.ring_timeout or (240.0 + 0.05 * (args.steps + args.warmup) * max(1, args.n >> 20) * (40 if args.all_pairs else 1))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    rec, err = None, ""
+    try:
+        p = subprocess.Popen(ring_args(args, world, rank, local_rank, cfg_over), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            out, errtxt = p.communicate(timeout=limit)
+            rc = p.returncode
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, errtxt = p.communicate()
+            rc, errtxt = -9, (errtxt or "") + "\n(ended after %.0f s)" % limit
+        lines = [l for l in out.splitlines() if l.startswith("{") and '"psamd_ring"' in l]     # (librccl prints its banner on stdout too)
+        if rc == 0 and (lines or rank != 0):
+            rec = json.loads(lines[-1]) if lines else None
+        else:
+            err = "rank %d: exit %s: %s" % (rank, rc, (errtxt or out)[-400:].strip())
+            rc = rc or 1
+    except OSError as e:
+        rc, err = 127, "rank %d: %s" % (rank, e)
+    with open(mine + ".tmp", "w") as f:
+        f.write("%d\n" % rc)
+    os.replace(mine + ".tmp", mine)
+    # how did the others do?  (they write their file when their child has ended: within the same limit)
+    codes = {}
+    t_end = time.time() + limit + 30.0
+    while len(codes) < world and time.time() < t_end:
+        for r in range(world):
+            if r not in codes:
+                try:
+                    with open("%s.rc%d" % (id_file, r)) as f:
+                        codes[r] = int(f.read().strip() or "1")
+                except (OSError, ValueError):
+                    pass
+        if len(codes) < world:
+            time.sleep(0.05)
+    ok = len(codes) == world and all(v == 0 for v in codes.values())
+    if not ok and not err:
+        err = "ranks %s failed or never reported" % sorted(set(range(world)) - {r for r, v in codes.items() if v == 0})
+    if rank == 0:
+        time.sleep(1.0)                      # (every rank has read the files by now, or will not)
+        for r in range(world):
+            try:
+                os.remove("%s.rc%d" % (id_file, r))
+            except OSError:
+                pass
+    return ok, rec, err
+
+
+def line_from_ring_record(args, r):
+    """the driver's JSON line from the record rank 0's C++ program printed"""
+    world, G, steps = r["world"], r["grid_dim"], r["steps"]
+    elapsed = r["elapsed_s"]
+    kt = r["kernel_us"]
+    us_pairs, us_apply = kt.get("pairs", 0.0), kt.get("apply", 0.0)
+    ach_tflops = r["pairs_rank0"] * FLOP_PER_PAIR / (us_pairs * 1e-6) / 1e12 if us_pairs > 0 else 0.0
+    ach_gbs = r["own_updates"] / steps * APPLY_BYTES_PER_UPDATE / (us_apply * 1e-6) / 1e9 if us_apply > 0 else 0.0
+    host = ("C++ ranks (host/ps_ring_rccl on include/psamd.h): RCCL send/recv/all-gather %s, %s" %
+            ("on a second HIP stream, ordered against the stage kernels by events" if r["side_stream"] else "on the compute stream",
+             "every stage's kernels as one hipGraph (%d replays, %d captures on rank 0)" % (r["graph_replays"], r["graph_captures"])
+             if r["graphs"] else "plain kernel launches"))
+    out = {
+        "metric": "particle-updates/sec at N=2^20" if not args.all_pairs else "particle-updates/sec, all-pairs forces (BASELINE configs[1]), N=%d" % args.n,
+        "value": r["updates"] / elapsed, "unit": "particle-updates/s",
+        "n_gpus": world, "steps": steps, "warmup": r["warmup"],
+        "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": ("BASELINE configs[1]: N=%d uniform cloud, %d^3 cells x 5.0, ALL-PAIRS gravity (every particle against every "
+                                "body: the 27-cell stencil in the reference's order, then every other cell; not in the reference, parity "
+                                "unpinned) + reference collisions/integrate/wrap/relocation, %s" if args.all_pairs else
+                                "BASELINE configs[2]: N=%d uniform cloud, %d^3 cells x 5.0, 27-cell cutoff gravity "
+                                "+ reference collisions/integrate/wrap/relocation, all constants at reference defaults, "
+                                "%s") % (args.n, G, "free-running" if args.evolve else "each step = one pass over the same cloud (restored in HBM)"),
+                   "arithmetic": "fast-math" if args.fast_math else "reference-exact fp32 (bitwise parity mode)",
+                   "parallelism": "%d slabs of cell layers, one per GPU (state partitioned by segment); halo / force / transfer messages between ring "
+                                  "neighbours, the status records%s all-gathered: RCCL over xGMI" % (world, " and the snapshot blocks" if args.all_pairs else ""),
+                   "host": host,
+                   "updates_in_timed_region": r["updates"], "live_after": r["live_after"], "settle_steps_before_warmup": r["settle_steps"],
+                   "particles_with_a_force_term": r["particles_with_a_force_term"],
+                   "relocations": r["relocations"], "relocations_lost": r["relocations_lost"], "cell_overflow_kills": r["cell_overflow_kills"],
+                   "halo_cap_cell": r["halo_cap_cell"], "message_bytes_rank0": r["message_bytes_rank0"], "rccl_mb_rank0": r["rccl_mb_rank0"]},
+        "roofline": {"kernel": "k_pairs_balanced of rank 0 (its own share of the pairs against its own launch time)" if not args.all_pairs else
+                               "k_pairs (all-pairs walk: stencil in the reference's order, then every other cell, summed per cell) of rank 0",
+                     "bound": "valu", "achieved": ach_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / VALU_PEAK_TFLOPS,
+                     "traffic": None, "traffic_source": None, "pairs_per_launch": r["pairs_rank0"], "flop_per_pair": FLOP_PER_PAIR, "us_per_launch": us_pairs},
+        "roofline_streaming": {"kernel": "k_apply of rank 0", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                               "bytes_per_update": APPLY_BYTES_PER_UPDATE, "us_per_launch": us_apply},
+        "kernel_us_per_step": kt,
+        "kernel_times_from": "HIP events on rank 0's compute stream on %d of the %d timed steps (every %d%s; those steps run as plain launches)" %
+                             (r["timed_launches"], steps, r["timing_period"], "th" if r["timing_period"] > 1 else "st"),
+        "cpu_baseline": None,
+    }
+    return out
+
 
 def main():
     args = parse_args()
@@ -397,9 +547,28 @@ def main():
 
     if os.environ.get("PSAMD_BENCH_FAIL_RANK") == str(rank) and world > 1:
         sys.exit(3)                     # (test hook: a rank that dies before the rendezvous)
+    if args.launch_check and args.backend == "ring" and world > 1:
+        # the launcher of the C++ ranks, without a GPU: every rank's program meets the others through the id file
+        import particlesystem_amd as ps
+        if rank == 0:
+            ps.build()
+            ps._build.build_ring()
+        else:
+            for _ in range(600):
+                if not ps._build.needs_build() and os.path.exists(ps._build.RING) and os.path.getmtime(ps._build.RING) >= os.path.getmtime(ps._build.LIB):
+                    break
+                time.sleep(0.5)
+        ok, rec, err = run_ring_rank(args, world, rank, local_rank, {})
+        if not ok:
+            sys.stderr.write("launch check of the C++ ranks failed: %s\n" % err)
+            sys.exit(1)
+        if rank == 0:
+            print(json.dumps({"metric": "particle-updates/sec at N=2^20", "launch_check": True, "n_gpus": rec["world"], "steps": rec["steps"],
+                              "warmup": rec["warmup"], "host": "C++ ranks (host/ps_ring_rccl)"}))
+        return
     if args.launch_check:
         import torch.distributed as dist
-        dist.init_process_group(args.backend if args.backend != "nccl" else "gloo")
+        dist.init_process_group(args.backend if args.backend not in ("nccl", "ring") else "gloo")
         import torch
         t = torch.ones(1, dtype=torch.int64)
         dist.all_reduce(t)
@@ -418,6 +587,48 @@ def main():
             if not ps._build.needs_build():
                 break
             time.sleep(0.5)
+    cfg_over = dict(chunk_factor=args.chunk_factor, chunk_dim=args.chunk_dim,
+                    max_particles_num=max(args.n, 1 << 20))
+    if args.halo_cap_cell == 0 and not args.evolve and not args.all_pairs and (world > 1 or args.sim_world):
+        # Slab messages have a fixed size, cells x halo_cap_cell bodies (the library's default is the
+        # cell capacity, 2x the mean density at the reference's settings).  The replayed step never
+        # changes the cloud, so size them for it: 1.5x the mean density of the uniform cloud + 64
+        # (mean + 4 sigma of a boundary layer's fullest cell is well below; a message that did not
+        # fit would be a loud error, not a truncation).  A free-running cloud (--evolve) keeps the default.
+        cells = (args.chunk_factor * args.chunk_dim) ** 3
+        args.halo_cap_cell = int(1.5 * args.n / cells) + 64
+        # likewise the transfer messages (particles changing owner per step and direction): the library's
+        # default has room for a quarter of what a layer can hold (a fast, dense cloud); this cloud's busiest
+        # face is the box surface, whose layer implodes by up to a cell in the replayed step: an eighth of a
+        # layer's population (n / G) is what it sends, measured; a message that did not fit is a loud error
+        G = args.chunk_factor * args.chunk_dim
+        cfg_over["xfer_cap"] = max(4096, int(args.n / G / 8) + 1024)
+    if args.all_pairs and (world > 1 or args.sim_world):
+        # all-pairs forces pull the whole uniform cloud inwards by the step's clamp (MAX_DX = one cell): in the
+        # replayed step up to a whole cell layer (n / G particles) changes owner across a cut; the library's
+        # default message has room for a quarter of a layer's capacity (half its mean population here)
+        G = args.chunk_factor * args.chunk_dim
+        cfg_over["xfer_cap"] = int(1.25 * args.n / G) + 4096
+    flags = (ps.FLAG_FAST_MATH if args.fast_math else 0) | (ps.FLAG_ALL_PAIRS if args.all_pairs else 0)
+    if world > 1 and args.backend == "ring":
+        # The ranks that do the work are C++ programs: this rank's is started as a child process (nothing here has
+        # touched a GPU), rank 0 relays its record.  If any rank's program fails, all ranks hear of it (files beside the
+        # id file) and run the step from Python over torch.distributed instead -- the line then says so.
+        if rank == 0:
+            ps._build.build_ring()
+        else:
+            for _ in range(600):
+                if os.path.exists(ps._build.RING) and os.path.getmtime(ps._build.RING) >= os.path.getmtime(ps._build.LIB):
+                    break
+                time.sleep(0.5)
+        ok, rec, err = run_ring_rank(args, world, rank, local_rank, cfg_over)
+        if ok:
+            if rank == 0:
+                print(json.dumps(line_from_ring_record(args, rec)))
+            return
+        sys.stderr.write("bench.py rank %d: the C++ ranks failed (%s); falling back to the torch.distributed ranks\n" % (rank, err))
+        args.backend = os.environ.get("PSAMD_BENCH_FALLBACK_BACKEND", "nccl")      # (gloo: rehearsals on one GPU)
+        args.ring_failed = err
     import torch
     dist = None
     if world > 1:
@@ -444,29 +655,6 @@ def main():
             os.dup2(saved, 1)
             os.close(saved)
 
-    cfg_over = dict(chunk_factor=args.chunk_factor, chunk_dim=args.chunk_dim,
-                    max_particles_num=max(args.n, 1 << 20))
-    if args.halo_cap_cell == 0 and not args.evolve and not args.all_pairs and (world > 1 or args.sim_world):
-        # Slab messages have a fixed size, cells x halo_cap_cell bodies (the library's default is the
-        # cell capacity, 2x the mean density at the reference's settings).  The replayed step never
-        # changes the cloud, so size them for it: 1.5x the mean density of the uniform cloud + 64
-        # (mean + 4 sigma of a boundary layer's fullest cell is well below; a message that did not
-        # fit would be a loud error, not a truncation).  A free-running cloud (--evolve) keeps the default.
-        cells = (args.chunk_factor * args.chunk_dim) ** 3
-        args.halo_cap_cell = int(1.5 * args.n / cells) + 64
-        # likewise the transfer messages (particles changing owner per step and direction): the library's
-        # default has room for a quarter of what a layer can hold (a fast, dense cloud); this cloud's busiest
-        # face is the box surface, whose layer implodes by up to a cell in the replayed step: an eighth of a
-        # layer's population (n / G) is what it sends, measured; a message that did not fit is a loud error
-        G = args.chunk_factor * args.chunk_dim
-        cfg_over["xfer_cap"] = max(4096, int(args.n / G / 8) + 1024)
-    if args.all_pairs and (world > 1 or args.sim_world):
-        # all-pairs forces pull the whole uniform cloud inwards by the step's clamp (MAX_DX = one cell): in the
-        # replayed step up to a whole cell layer (n / G particles) changes owner across a cut; the library's
-        # default message has room for a quarter of a layer's capacity (half its mean population here)
-        G = args.chunk_factor * args.chunk_dim
-        cfg_over["xfer_cap"] = int(1.25 * args.n / G) + 4096
-    flags = (ps.FLAG_FAST_MATH if args.fast_math else 0) | (ps.FLAG_ALL_PAIRS if args.all_pairs else 0)
     if args.sim_world:
         print(json.dumps(sim_world(args, ps, cfg_over, flags)))
         return
@@ -476,6 +664,10 @@ def main():
     xyz, age, fert = make_inputs(g, args.n, args.seed)
     g.fill_particles(xyz, age=age, fert_age=fert)       # a slab rank keeps the particles of its own segments
     G = g.sizes.grid_dim
+    if args.graphs:
+        g.set_graphs(True)
+    if args.wait_policy >= 0:
+        g.set_wait_policy(args.wait_policy)
 
     ring = None
     if world > 1:
@@ -577,6 +769,18 @@ def main():
     g.set_timing(False)
     ctr = g.counters
     own_updates = float(ctr["particles_processed"] - processed0)
+    sustained = None
+    if world == 1 and not args.evolve and 0 < args.steps < args.sustained_steps:
+        # The chip is power-bound under this load: a timed region of tens of milliseconds (the driver's --steps 20) runs at
+        # a higher clock than one of seconds.  The same loop again, long enough to show the sustained figure beside it.
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.sustained_steps):
+            one_step()
+        sync()
+        sustained = {"steps": args.sustained_steps, "ms_per_step": 1e3 * (time.perf_counter() - t1) / args.sustained_steps,
+                     "what": "the same timed loop over %d steps, run right after the line's %d (no timing events): the clock a long run holds"
+                             % (args.sustained_steps, args.steps)}
     counts1, fcounts1, mine1 = frame_counts()
     if counts0 is None:
         counts0, fcounts0, mine0 = counts1, fcounts1, mine1
@@ -618,6 +822,7 @@ def main():
                        "parallelism": ("%d slabs of cell layers, one per GPU (state partitioned by segment); halo / force / "
                                        "transfer messages between ring neighbours over %s" % (world, "RCCL send/recv" if args.backend == "nccl" else args.backend))
                                       if world > 1 else "single GPU",
+                       "graphs": ("stage sequences as hipGraphs: %d replays, %d captures" % g.graph_stats()) if args.graphs else None,
                        "updates_in_timed_region": updates, "live_after": live, "settle_steps_before_warmup": settle,
                        "particles_with_a_force_term": int(fcounts1.sum()),
                        "relocations": ctr["relocations"], "relocations_lost": ctr["relocations_lost"],
@@ -630,10 +835,13 @@ def main():
                                    "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic_apply,
                                    "traffic_source": TRAFFIC_FILE if traffic_apply is not None else None,
                                    "bytes_per_update": APPLY_BYTES_PER_UPDATE, "us_per_launch": us_apply},
+            "sustained": sustained,
             "kernel_us_per_step": {k: v / max(launches, 1) for k, v in tim.items() if v > 0},
             "kernel_times_from": "HIP events on the context's stream on %d of the %d timed steps (every %d%s)" % (launches, args.steps, period, "th" if period > 1 else "st"),
         }
         if world > 1:
+            out["config"]["host"] = "Python ranks over torch.distributed (particlesystem_amd/slab.py)" + \
+                (": FALLBACK, the C++ ranks failed (%s)" % args.ring_failed if getattr(args, "ring_failed", None) else "")
             out["config"]["halo_cap_cell"] = int(args.halo_cap_cell)
             out["config"]["message_bytes_rank0"] = {name: int(g.msg_bytes(k)) for name, k in
                                                     (("halo_up", 1), ("halo_down", 0), ("force_in", 5), ("xfer_each", 6))}

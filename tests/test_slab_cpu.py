@@ -243,6 +243,30 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["launch_check"] and d["steps"] == 7 and d["warmup"] == 3
+    assert d["host"].startswith("C++ ranks")       # the default: every Python rank started its C++ program (host/ps_ring_rccl)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("backend", ["ring", "gloo"])
+def test_bench_under_the_drivers_launcher(backend):
+    """As the driver starts it for N > 1: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N.  With the
+    default backend each rank starts its C++ program, the programs meet through the id file (nonce from MASTER_PORT and
+    the launcher's pid) and rank 0's record comes back as the one line; --backend gloo: the torch.distributed ranks."""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check", "--steps", "5", "--warmup", "2",
+                        "--backend", backend], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["launch_check"] and d["steps"] == 5 and d["warmup"] == 2
+    assert ("host" in d) == (backend == "ring")
 
 
 @pytest.mark.timeout(120)

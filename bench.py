@@ -23,8 +23,7 @@ the caller) and runs the SLAB-PARTITIONED path: every rank holds only the segmen
 cell layers -- slots, particles, free-slot queues -- and exchanges, with its two ring
 neighbours over RCCL send/recv, the snapshot of its boundary layers, the force records of
 lent layers and the particles that change owner.  The ranks that do the work are C++ programs
-(host/ps_ring_rccl: libpsamd.so's stage calls, RCCL on a second HIP stream, every stage's kernels
-as one hipGraph): each Python rank starts its own as a child process before anything here touches
+(host/ps_ring_rccl: libpsamd.so's stage calls, RCCL on a second HIP stream): each Python rank starts its own as a child process before anything here touches
 a GPU, and rank 0 relays its record as the one JSON line.  --backend nccl / gloo runs the same
 step from Python over torch.distributed instead (particlesystem_amd/slab.py), which is also
 what the ranks fall back to, together, if a C++ rank fails.  Total work is fixed at N = 2^20
@@ -87,7 +86,8 @@ def parse_args():
                     "messages staged through host memory, for rehearsals on one GPU")
     ap.add_argument("--graphs", action="store_true", help="one GPU / --sim-world / torch ranks: stage sequences as hipGraphs (psamd_set_graphs)")
     ap.add_argument("--wait-policy", type=int, default=-1, help="how the host waits for a step's scalars: 0 spin, 1 short spin then naps (default: the library's)")
-    ap.add_argument("--ring-graphs", type=int, default=1, help="C++ ranks: stage sequences as hipGraphs (0: plain launches)")
+    ap.add_argument("--ring-graphs", type=int, default=0, help="C++ ranks: stage sequences as hipGraphs (default 0, plain launches: a graph launch costs "
+                    "~10 us on the GPU's timeline, four of them a step -- profiles/r4_ab_graphs.txt)")
     ap.add_argument("--ring-side-stream", type=int, default=1, help="C++ ranks: RCCL on a second HIP stream (0: on the compute stream)")
     ap.add_argument("--ring-timeout", type=float, default=0.0, help="seconds a C++ rank may take before it is ended and the ranks fall back (0: from --steps)")
     ap.add_argument("--sustained-steps", type=int, default=200, help="one GPU: when --steps is shorter than this, a second timed region of this "

@@ -14,9 +14,10 @@
 //     different contexts.  This mode also runs the whole system in one plain context and
 //     requires the union of the slabs to equal it byte for byte (P_DATA_TYPE of every slot).
 //
-// Two HIP streams.  The stage kernels run on the COMPUTE stream -- with --graphs (default) each stage's
-// kernels as one captured hipGraph, so a rank's step is five submissions, not two dozen launches --, every
-// RCCL call on the TRANSFER stream; events order the two: the halo (and the all-pairs snapshot all-gather)
+// Two HIP streams.  The stage kernels run on the COMPUTE stream -- with --graphs 1 each stage's kernels as
+// one captured hipGraph, so a rank's step is five submissions, not two dozen launches (measured: a graph
+// launch costs ~10 us on the GPU's timeline, the plain launches of a host that runs ahead cost nothing:
+// profiles/r4_ab_graphs.txt; off by default) --, every RCCL call on the TRANSFER stream; events order the two: the halo (and the all-pairs snapshot all-gather)
 // waits for slab_build and travels while the compute stream runs the interior pair pass (--overlap-interior)
 // or simply goes ahead; the all-gather of the status records travels beside the whole pair pass; force and
 // transfer messages fork off after slab_pairs / slab_apply and are joined before the stage that reads them.
@@ -248,7 +249,7 @@ int main(int argc, char **argv)
     int world = 2, rank = 0, iters = 8, device = -1;
     int64_t n = 60000;
     uint32_t seed = 2026;
-    bool loopback = false, id_only = false, all_pairs = false, births = false, graphs = true, bench = false, evolve = false;
+    bool loopback = false, id_only = false, all_pairs = false, births = false, graphs = false, bench = false, evolve = false;
     bool side_stream = true, overlap_interior = false, fast_math = false, launch_check = false;
     int steps = 200, warmup = 5, chunk_factor = 4, chunk_dim = 4, halo_cap_cell = 0, xfer_cap = 0, timing_period = 8, wait_policy = -1;
     double settle_seconds = 0.5;

@@ -62,7 +62,7 @@ def test_bench_line_from_the_cpp_ranks_record():
     exe = ps._build.build_ring()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([exe, "--loopback", "--world", "4", "--bench", "--n", "131072", "--steps", "4", "--warmup", "1", "--settle-seconds", "0.05",
-                        "--timing-period", "2"], env=env, capture_output=True, text=True, timeout=560)
+                        "--timing-period", "2", "--graphs", "1"], env=env, capture_output=True, text=True, timeout=560)
     assert p.returncode == 0, p.stderr[-2000:]
     rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{") and '"psamd_ring"' in l][-1])
     args = argparse.Namespace(all_pairs=False, fast_math=False, evolve=False, n=131072)

@@ -58,11 +58,12 @@ def test_driver_ends_in_the_oracle_state(fetch_back):
     assert out.count(">>>>>>>>>>> Execution time of iteration (sec):") == 10    # the reference's per-iteration print
 
 
+G1 = ["--graphs", "1"]       # every stage's kernels as one hipGraph (off by default: profiles/r4_ab_graphs.txt)
 RING_CASES = [
-    (2, []), (3, ["--overlap-interior"]), (4, ["--births"]), (8, []),
-    (2, ["--all-pairs"]), (4, ["--all-pairs"]), (8, ["--all-pairs", "--n", "30000"]),
-    (3, ["--graphs", "0", "--side-stream", "0"]),              # the round-3 form: plain launches, RCCL on the compute stream
-    (4, ["--births", "--overlap-interior", "--wait", "0"]),
+    (2, []), (3, ["--overlap-interior"] + G1), (4, ["--births"] + G1), (8, G1),
+    (2, ["--all-pairs"] + G1), (4, ["--all-pairs"]), (8, ["--all-pairs", "--n", "30000"]),
+    (3, ["--side-stream", "0"]),                               # the round-3 form: plain launches, RCCL on the compute stream
+    (4, ["--births", "--overlap-interior", "--wait", "0"]), (8, ["--births"]),
 ]
 
 
@@ -89,7 +90,7 @@ def test_cpp_ring_moves_every_message_with_rccl(world, extra):
     assert (int(m.group(2)) > 0) == ("--births" in extra), p.stdout
     assert float(re.search(r"([0-9.]+) MB through RCCL", p.stdout).group(1)) > 1.0
     replays = int(re.search(r"(\d+) graph replays", p.stdout).group(1))
-    if "--graphs" in extra:
+    if "--graphs" not in extra:
         assert replays == 0
     else:
         assert replays >= world * 8 * 3, p.stdout        # four stage sequences per rank and step, less the captures
@@ -104,7 +105,7 @@ def test_cpp_ring_bench_record_in_loopback():
     exe = psbuild.build_ring()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([exe, "--loopback", "--world", "4", "--bench", "--n", "131072", "--steps", "6", "--warmup", "2",
-                        "--settle-seconds", "0.05", "--timing-period", "2"], env=env, capture_output=True, text=True, timeout=560)
+                        "--settle-seconds", "0.05", "--timing-period", "2", "--graphs", "1"], env=env, capture_output=True, text=True, timeout=560)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
     recs = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{") and '"psamd_ring"' in l]
     assert len(recs) == 1, p.stdout

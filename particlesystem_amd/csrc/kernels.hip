@@ -1217,115 +1217,6 @@ __device__ __forceinline__ void pairs_finish_fast(const PairRows<NQ> &r, const v
     }
 }
 
-// ---- the DPP walk: bodies broadcast inside the arithmetic -------------------------------------------------
-// A third way to bring a neighbour body to all 64 lanes (besides scalar loads into SGPR operands and broadcast reads
-// of an LDS tile): every ROW of 16 lanes holds the same 16 consecutive bodies of the list in four VGPRs (lane l: body
-// l & 15, one 4-byte vector load per coordinate, issued a tile ahead), and the instruction that first uses a body's
-// coordinate takes it through DPP row_newbcast:j -- `v_sub_f32_dpp rx, tile_x, xi row_newbcast:j` is r = x_j - x_i for
-// all 64 lanes, the broadcast costs no instruction, no LDS access and no SGPR.  Likewise the product with the mass.
-// Same operands, same roundings (a plain v_sub / v_mul rounds like a half of the packed form), same order: same bits.
-// All 64 lanes must be active while a tile is consumed (DPP reads a disabled lane as 0): the walk has no divergent
-// branch, lanes without a particle compute along and store nothing.
-template <int L>
-__device__ __forceinline__ float row_bcast(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + L, 0xf, 0xf, true));   // row_newbcast:L
-}
-// lane `l` (a constant once the caller's loop is unrolled) of every row
-__device__ __forceinline__ float row_bcast_at(float v, int l)
-{
-    switch (l & 15) {
-    case 0: return row_bcast<0>(v); case 1: return row_bcast<1>(v); case 2: return row_bcast<2>(v); case 3: return row_bcast<3>(v);
-    case 4: return row_bcast<4>(v); case 5: return row_bcast<5>(v); case 6: return row_bcast<6>(v); case 7: return row_bcast<7>(v);
-    case 8: return row_bcast<8>(v); case 9: return row_bcast<9>(v); case 10: return row_bcast<10>(v); case 11: return row_bcast<11>(v);
-    case 12: return row_bcast<12>(v); case 13: return row_bcast<13>(v); case 14: return row_bcast<14>(v); default: return row_bcast<15>(v);
-    }
-}
-
-struct RowTile { float x, y, z, w; };       // this lane's body of the current 16-body tile
-
-// pairs_dist for bodies base .. base + NQ - 1 of the tile (base: 0 or 8)
-template <int NQ, bool SOFTENED>
-__device__ __forceinline__ void pairs_dist_dpp(const PairCtx &c, const RowTile &t, int base, float eps2, PairRows<NQ> &r)
-{
-    const v2f eps = {eps2, eps2};
-    r.dm = 3.0e38f;
-#pragma unroll
-    for (int i = 0; i < NQ / 2; i++) {
-        const int a = base + 2 * i, b = a + 1;
-        r.rx[i] = v2f{row_bcast_at(t.x, a) - c.xi, row_bcast_at(t.x, b) - c.xi};
-        r.ry[i] = v2f{row_bcast_at(t.y, a) - c.yi, row_bcast_at(t.y, b) - c.yi};
-        r.rz[i] = v2f{row_bcast_at(t.z, a) - c.zi, row_bcast_at(t.z, b) - c.zi};
-        if (SOFTENED)
-            r.d[i] = __builtin_elementwise_fma(r.rz[i], r.rz[i], __builtin_elementwise_fma(r.ry[i], r.ry[i], __builtin_elementwise_fma(r.rx[i], r.rx[i], eps)));
-        else
-            r.d[i] = r.rx[i] * r.rx[i] + r.ry[i] * r.ry[i] + r.rz[i] * r.rz[i];
-        r.dm = fminf(fminf(r.dm, r.d[i].x), r.d[i].y);
-    }
-}
-
-// pairs_finish_exact with the flags settled (the balanced force pass): the masses come through DPP too
-template <int NQ, bool ONE_T>
-__device__ __forceinline__ void pairs_finish_exact_dpp(const DevParams &P, const PairRows<NQ> &r, const RowTile &t, int base,
-                                                       float &ax, float &ay, float &az)
-{
-    constexpr int H = NQ / 2;
-    v2f e[H];
-    if (__any(r.dm < P.slow_below)) {
-#pragma unroll
-        for (int i = 0; i < H; i++) {
-            e[i].x = (float)((double)r.d[i].x + P.eps2);
-            e[i].y = (float)((double)r.d[i].y + P.eps2);
-        }
-    } else {
-        const v2f eps = {P.eps2f, P.eps2f};
-#pragma unroll
-        for (int i = 0; i < H; i++) e[i] = r.d[i] + eps;
-    }
-    v2f sc[H];
-    if (!ONE_T) {
-#pragma unroll
-        for (int i = 0; i < H; i++) sc[i] = inv_sqrt_selected2(e[i] * e[i] * e[i]);
-    } else {
-        bool tie = false;
-#pragma unroll
-        for (int i = 0; i < H; i++) {
-            sc[i] = inv_sqrt_guarded2(e[i] * e[i] * e[i], tie);
-            asm volatile("" : "+v"(sc[i]));             // (as in pairs_finish_exact: keeps the step's last fma above the rare branch)
-        }
-        if (__any(tie)) {                               // about one group in 500
-#pragma unroll
-            for (int i = 0; i < H; i++) sc[i] = inv_sqrt_selected2(e[i] * e[i] * e[i]);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < H; i++) sc[i] = v2f{row_bcast_at(t.w, base + 2 * i) * sc[i].x, row_bcast_at(t.w, base + 2 * i + 1) * sc[i].y};
-#pragma unroll
-    for (int i = 0; i < H; i++) {                       // sums in list order
-        const v2f px = r.rx[i] * sc[i], py = r.ry[i] * sc[i], pz = r.rz[i] * sc[i];
-        ax += px.x; ay += py.x; az += pz.x;
-        ax += px.y; ay += py.y; az += pz.y;
-    }
-}
-
-template <int NQ>
-__device__ __forceinline__ void pairs_finish_fast_dpp(const PairRows<NQ> &r, const RowTile &t, int base, float &ax, float &ay, float &az)
-{
-    constexpr int H = NQ / 2;
-    v2f sc[H];
-#pragma unroll
-    for (int i = 0; i < H; i++) {
-        v2f q; q.x = __builtin_amdgcn_rsqf(r.d[i].x); q.y = __builtin_amdgcn_rsqf(r.d[i].y);
-        q = q * q * q;
-        sc[i] = v2f{row_bcast_at(t.w, base + 2 * i) * q.x, row_bcast_at(t.w, base + 2 * i + 1) * q.y};
-    }
-#pragma unroll
-    for (int i = 0; i < H; i++) {
-        ax = fmaf(r.rx[i].x, sc[i].x, ax); ay = fmaf(r.ry[i].x, sc[i].x, ay); az = fmaf(r.rz[i].x, sc[i].x, az);
-        ax = fmaf(r.rx[i].y, sc[i].y, ax); ay = fmaf(r.ry[i].y, sc[i].y, ay); az = fmaf(r.rz[i].y, sc[i].y, az);
-    }
-}
-
 #if defined(PSAMD_TWO_TRANSCENDENTALS)      // (A/B builds)
 constexpr bool ONE_T_DEFAULT = false;
 #else
@@ -1908,15 +1799,16 @@ __global__ __launch_bounds__(256) void k_resolve_steps(DevParams P, int nw, cons
 // pairs as operands: no LDS, no vector registers for the bodies.  (An LDS tile read with
 // ds_read_b128 by four waves per CU kept the LDS pipe ~70 % busy -- 16 cycles per wave
 // read, scripts/microbench/lds_groups.hip -- and cost 4 % more time.)
+// (Round 4 tried a third way -- every row of 16 lanes holds 16 bodies in VGPRs and the arithmetic takes them through
+// DPP, `v_sub_f32_dpp rx, tile_x, xi row_newbcast:j`: no LDS, no scalar loads, the compiler fuses every broadcast.
+// Bit-identical and 9-17 % slower everywhere: a DPP-modified v_sub / v_mul issues at half rate on gfx950.
+// profiles/r4_ab_dpp_walk.txt, commit 2592be9.)
 // Mode 0, the fallback for softening lengths outside the lean range, streams 64-body
 // tiles through 1 KiB of LDS per wave.  No s_barrier: a wave only ever touches its own
 // tile, and a wave's LDS operations complete in issue order, so a compiler-level fence
 // is all the ordering needed.
 #ifndef PSAMD_BALANCED_WAVES
 #define PSAMD_BALANCED_WAVES 7      // resident waves per SIMD the scalar-walk force pass is built for (70 VGPRs; measured, exact / tolerance arithmetic: 6 waves 2.15 / 1.25 ms, 7 waves 2.11 / 1.22 ms)
-#endif
-#ifndef PSAMD_DPP_WAVES
-#define PSAMD_DPP_WAVES 6           // resident waves per SIMD the DPP-walk force pass is built for
 #endif
 #define PS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
@@ -2204,89 +2096,6 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
     PS_TRACE_END();
 }
 
-// Stencil steps [k0, k1) of an ordinary task of the settled (two-pass) force pass with the DPP walk: the bodies of
-// the stencil's cells as a stream of 16-body tiles, the next tile's four loads in flight while the current one is
-// worked through (vector loads retire in order: `vmcnt` waits for exactly the tile that is needed).  A list's last tile
-// is padded with massless bodies far outside the box (r * 0 = +-0 leaves a sum that started at +0 as it was, as for
-// kids); its second half is skipped when it holds padding only.  Hand-off as in pairs_task.
-template <int MODE>
-__device__ __forceinline__ void pairs_task_dpp(const DevParams &P, const int *__restrict__ cell_start,
-                                               const SnapSoa snap4, const float *__restrict__ snap_soa,
-                                               float4 *__restrict__ force4, int task,
-                                               const int *__restrict__ active_list, const int *__restrict__ active_count,
-                                               int k0, int k1, int *ready, FrameScalars *fs)
-{
-    constexpr int NQ = 8;
-    const int c = task / P.slices, slice = task - c * P.slices;
-    const int base = cell_start[c];
-    const int cnt = active_count[c];
-    const int first = slice * 64;
-    if (first >= cnt) return;
-    const int nvalid = min(64, cnt - first);
-    const int lane = threadIdx.x & 63, l16 = lane & 15;
-    const bool valid = lane < nvalid;
-    const int gi = active_list[base + first + (valid ? lane : 0)];
-    const float4 me = snap4[gi];
-    int i1, i2, i3;
-    cell_coords(P, c, i1, i2, i3);
-    float ax = 0.f, ay = 0.f, az = 0.f;
-    int flag = 0;
-    const float eps2f = (float)P.eps2;
-    int my_nb = 0, my_cnt = 0;
-    if (lane < 27) {
-        const int nc = local_cell(P, i3 + c_stencil[lane][2], i1 + c_stencil[lane][1], i2 + c_stencil[lane][0]);
-        if (nc >= 0) {
-            my_nb = cell_start[nc];
-            my_cnt = min(cell_start[nc + 1] - my_nb, P.max_per_cell);
-        }
-    }
-    const PairCtx ctx = {me.x, me.y, me.z, 0.f, 0, gi, false};
-    const size_t cap = (size_t)P.sorted_cap;
-    if (k0 > 0 && !handoff_consume(force4 + gi, ax, ay, az, flag, valid, ready, k0)) {
-        if (lane == 0) atomicOr(&fs->error, ERR_HANDOFF_TIMEOUT);
-    }
-    const float far = 1.0e6f;                                       // padding body, mass 0
-    auto fetch = [&](int nb, int n, int t0) -> RowTile {
-        RowTile t = {far, far, far, 0.f};
-        if (l16 < n - t0) {
-            const float *px = snap_soa + (size_t)nb + t0 + l16;
-            t.x = px[0]; t.y = px[cap]; t.z = px[2 * cap]; t.w = px[3 * cap];
-        }
-        return t;
-    };
-    // the stream of tiles: (stencil step k, row t0 of its list), empty cells skipped
-    int k = k0, nb = 0, n = 0, t0 = 0;
-    auto next_cell = [&]() { while (k < k1) { nb = __builtin_amdgcn_readlane(my_nb, k); n = __builtin_amdgcn_readlane(my_cnt, k); if (n > 0) break; k++; } t0 = 0; };
-    next_cell();
-    RowTile nxt = {far, far, far, 0.f};
-    if (k < k1) nxt = fetch(nb, n, 0);
-    while (k < k1) {
-        const RowTile cur = nxt;
-        const int left = n - t0;                       // bodies from this tile on (> 0)
-        t0 += 16;
-        if (t0 >= n) { k++; next_cell(); }
-        if (k < k1) nxt = fetch(nb, n, t0);            // in flight while `cur` is worked through
-        PairRows<NQ> r;
-        if (MODE == 1) {
-            pairs_dist_dpp<NQ, false>(ctx, cur, 0, 0.f, r);
-            pairs_finish_exact_dpp<NQ, ONE_T_DEFAULT>(P, r, cur, 0, ax, ay, az);
-            if (left > 8) {
-                pairs_dist_dpp<NQ, false>(ctx, cur, 8, 0.f, r);
-                pairs_finish_exact_dpp<NQ, ONE_T_DEFAULT>(P, r, cur, 8, ax, ay, az);
-            }
-        } else {
-            pairs_dist_dpp<NQ, true>(ctx, cur, 0, eps2f, r);
-            pairs_finish_fast_dpp<NQ>(r, cur, 0, ax, ay, az);
-            if (left > 8) {
-                pairs_dist_dpp<NQ, true>(ctx, cur, 8, eps2f, r);
-                pairs_finish_fast_dpp<NQ>(r, cur, 8, ax, ay, az);
-            }
-        }
-    }
-    if (k1 < STENCIL) { handoff_publish(force4 + gi, ax, ay, az, flag, valid, ready, k1); return; }
-    if (valid) force4[gi] = make_float4(ax, ay, az, __int_as_float(flag));
-}
-
 template <int MODE, int NQ, bool ALLP>
 __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restrict__ cell_start,
                                                const SnapSoa snap4,
@@ -2494,8 +2303,7 @@ __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *_
 // dispatched no later (block b - 8) or is the same workgroup.
 // WALK 0: scalar-load walk, ordinary tasks only (packs, if any, run in k_pairs_merged beside it);
 //      1: tile walk for everything, packs of partial slices included (few waves per SIMD);
-//      2: scalar-load walk for the ordinary tasks, tile walk for the packs, all in one balanced list;
-//      3: DPP walk (pairs_task_dpp) for the ordinary tasks, packs as in 0.
+//      2: scalar-load walk for the ordinary tasks, tile walk for the packs, all in one balanced list.
 template <int MODE, int NQ>
 __device__ __forceinline__ void merged_pack_task(const DevParams &P, const int *__restrict__ cell_start,
                                                  const SnapSoa snap4,
@@ -2511,7 +2319,7 @@ __device__ __forceinline__ void merged_pack_task(const DevParams &P, const int *
 // needed a head start to get that: forked at the same moment as the balanced pass they ended with it,
 // and the stage took 0.1 ms longer.)
 template <int MODE, int NQ, int WALK>
-__global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : WALK == 3 ? PSAMD_DPP_WAVES : 4) void k_pairs_balanced(DevParams P, const int *__restrict__ cell_start,
+__global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : 4) void k_pairs_balanced(DevParams P, const int *__restrict__ cell_start,
                                                         const SnapSoa snap4,
                                                         const float *__restrict__ snap_soa,
                                                         const float *__restrict__ snap_age,
@@ -2525,7 +2333,7 @@ __global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : WALK == 3 ?
 {
     __shared__ __attribute__((aligned(16))) float tiles[4][4 * MERGE_TILE];   // up to four 1-KiB tiles per wave
     const int wave = threadIdx.x >> 6;
-    if ((WALK == 0 || WALK == 3) && (int)blockIdx.x < nmb) {
+    if (WALK == 0 && (int)blockIdx.x < nmb) {
         const int pack = blockIdx.x * 4 + wave;
         if (pack < fs->n_merged) merged_pack_task<MODE, (NQ > 4 ? 4 : NQ)>(P, cell_start, snap4, active_list, active_count, merged_tasks, force4, pack, tiles[wave]);   // (4 bodies per group: the 8-wide form costs this kernel its sixth wave per SIMD)
         return;
@@ -2570,9 +2378,7 @@ __global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : WALK == 3 ?
             }
             if (t < nord) pairs_task_tile<MODE, NQ, 1, WALK != 1>(P, cell_start, snap4, force4, G, tiles[wave], active_list, k0, k1, task_ready + t, fs);
             else pairs_task_tile<MODE, NQ, 4, WALK != 1>(P, cell_start, snap4, force4, G, tiles[wave], active_list, k0, k1, task_ready + t, fs);
-        } else if (WALK == 3)
-            pairs_task_dpp<MODE>(P, cell_start, snap4, snap_soa, force4, task_list[t], active_list, active_count, k0, k1, task_ready + t, fs);
-        else
+        } else
             pairs_task<MODE, NQ, false, true>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, task_list[t], nullptr, trace,
                                               active_list, active_count, k0, k1, task_ready + t, fs);
     }
@@ -4364,11 +4170,8 @@ hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceSt
 
 // How one pass of the pair stage is launched, from the hint of its task count: everything that shapes the
 // launches and is not read from device memory by the kernels themselves (what a captured graph is keyed by).
-#ifndef PSAMD_DPP_DEFAULT
-#define PSAMD_DPP_DEFAULT(s) false          // (set from the A/B measurements: which shapes take the DPP walk by default)
-#endif
 struct PairShape {
-    bool two, merge, balanced, tile, packs_in_list, dpp;
+    bool two, merge, balanced, tile, packs_in_list;
     int nw;                  // wave slots of the balanced force pass
 };
 
@@ -4412,24 +4215,13 @@ static PairShape pair_shape(const DevParams &P, bool lean, int64_t tasks_hint)
     s.packs_in_list = s.balanced && !merge_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS) && (s.tile ? tile_packs : (s.merge && (unified_packs || P.world > 1)));
     if (s.packs_in_list) { s.merge = false; s.nw = std::min(s.nw, 4096); }      // (98 VGPRs with the tile walk in: 4 resident waves per SIMD)
     if (s.tile) s.merge = false;                  // no separate merged kernel beside a tile-walk pass
-    // the DPP walk (pairs_task_dpp): bodies broadcast inside the arithmetic, no LDS tile, no scalar loads.
-    // PSAMD_DPP: 0 never, 1 always, 2 (default) where it was measured faster -- see launch_pairs_mode
-    static const int dpp_env = std::getenv("PSAMD_DPP") ? std::atoi(std::getenv("PSAMD_DPP")) : 2;
-    static const int dpp_waves = std::getenv("PSAMD_DPP_WAVES_PER_SIMD") ? std::atoi(std::getenv("PSAMD_DPP_WAVES_PER_SIMD")) : PSAMD_DPP_WAVES;
-    s.dpp = s.balanced && (dpp_env == 1 || (dpp_env == 2 && PSAMD_DPP_DEFAULT(s)));
-    if (s.dpp) {
-        s.tile = false; s.packs_in_list = false;
-        s.merge = s.two && !merge_off && (P.world == 1 || tasks_hint >= 3000);
-        s.nw = 1024 * (int)std::min<int64_t>(std::min(dpp_waves, PSAMD_DPP_WAVES), std::max<int64_t>(1, tasks_hint / 1024));
-        if (waves_env >= 32) s.nw = std::min(waves_env & ~31, MAX_PAIR_WAVES);
-    }
     return s;
 }
 
 uint64_t launch_pairs_shape(const DevParams &P, int64_t tasks_hint)
 {
     const PairShape s = pair_shape(P, P.lean_math != 0, tasks_hint);
-    return (uint64_t)(s.nw / 32) | (s.merge ? 1ull << 10 : 0) | (s.tile ? 1ull << 11 : 0) | (s.packs_in_list ? 1ull << 12 : 0) | (s.balanced ? 1ull << 13 : 0) | (s.dpp ? 1ull << 14 : 0);
+    return (uint64_t)(s.nw / 32) | (s.merge ? 1ull << 10 : 0) | (s.tile ? 1ull << 11 : 0) | (s.packs_in_list ? 1ull << 12 : 0) | (s.balanced ? 1ull << 13 : 0);
 }
 
 template <int MODE, int NQ>
@@ -4439,7 +4231,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     if (ncomp <= 0) return hipSuccess;
     const int tasks = ncomp * P.slices;
     const PairShape shape = pair_shape(P, MODE != 0, tasks_hint);
-    const bool two = shape.two, merge = shape.merge, balanced = shape.balanced, tile = shape.tile, packs_in_list = shape.packs_in_list, dpp = shape.dpp;
+    const bool two = shape.two, merge = shape.merge, balanced = shape.balanced, tile = shape.tile, packs_in_list = shape.packs_in_list;
     const int nw = shape.nw;
     if (two) {
         // collision flags and the per-cell lists of the particles that need a force, then the plan of the force pass
@@ -4465,7 +4257,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
         const int nmb = merge ? (((ncomp + 3) / 4 + 7) & ~7) : 0;
 #define PS_BALANCED(W) k_pairs_balanced<M, NQ, W><<<nmb + nw / 4, 256, 0, st>>>(P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_soa, d.snap_age, d.sorted_id, task_list, \
                                                                      d.force4, d.fs, d.trace, active_list, active_count, d.wave_unit, task_ready, d.merged_tasks, nmb)
-        if (dpp) PS_BALANCED(3); else if (tile) PS_BALANCED(1); else if (packs_in_list) PS_BALANCED(2); else PS_BALANCED(0);
+        if (tile) PS_BALANCED(1); else if (packs_in_list) PS_BALANCED(2); else PS_BALANCED(0);
 #undef PS_BALANCED
     }
     else {

@@ -82,7 +82,8 @@ typedef struct psamd_config {
      * layers per rank) overrides the balanced partition when cuts[world] != 0. */
     int32_t  rank;
     int32_t  world;
-    int32_t  halo_cap_cell;      /* bodies per cell a halo message has room for; 0 = MAX_PARTICLES_PER_CELL (never overflows) */
+    int32_t  halo_cap_cell;      /* bodies per cell, ON AVERAGE OVER A CELL LAYER, a halo message has room for (any one cell up to its list
+                                    capacity: the room is pooled); 0 = MAX_PARTICLES_PER_CELL (never overflows) */
     int32_t  xfer_cap;           /* particles per step and direction that may change owner; 0 = a quarter of what a cell layer can hold */
     int32_t  cuts[PSAMD_MAX_RANKS + 1];
     /* Not in the reference (BASELINE.json asks for them; nothing there can pin them): */

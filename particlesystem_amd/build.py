@@ -6,15 +6,16 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpsamd.so")
-SOURCES = ["kernels.hip", "capi.hip", "lifecycle_sort.hip"]
-DEPS = SOURCES + ["kernels.h", "device_types.h", "geometry.hpp", os.path.join("..", "..", "include", "psamd.h")]
+# the step's kernels by stage (kernels_common.hpp holds the map), the host context + C ABI, the radix sort behind long op lists
+SOURCES = ["grid.hip", "pairs.hip", "apply.hip", "lifecycle.hip", "slab.hip", "capi.hip", "lifecycle_sort.hip"]
+DEPS = SOURCES + ["kernels_common.hpp", "kernels.h", "device_types.h", "geometry.hpp", "partition.hpp", os.path.join("..", "..", "include", "psamd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # -ffp-contract=off + correctly rounded fp32 divide/sqrt: the exact kernels must
 # perform the reference's operations one rounding at a time.
 # SLP vectorisation is off because the pair kernel packs its fp32 work by hand; the
 # vectoriser's own packing cost it register shuffles (3.75 v_mov per pair).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
          "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
@@ -31,13 +32,23 @@ def build(force=False, verbose=False, extra=()):
     if not force and not needs_build():
         return LIB
     tmp = LIB + ".tmp"
-    cmd = [HIPCC] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
-    if verbose:
-        print(" ".join(cmd))
     # a failed build must not leave a stale library behind to be tested by mistake
     if os.path.exists(LIB):
         os.remove(LIB)
-    subprocess.check_call(cmd)
+    # the translation units side by side (no device code calls across them), then one link
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src + ".o")
+        cmd = [HIPCC] + FLAGS + list(extra) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((cmd, obj, subprocess.Popen(cmd)))
+    failed = [cmd for cmd, _, p in jobs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj for _, obj, _ in jobs] + ["-o", tmp])
     os.replace(tmp, LIB)
     return LIB
 

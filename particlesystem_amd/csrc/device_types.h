@@ -67,7 +67,7 @@ struct DevParams {
     int32_t slots_total;
     int32_t rec_lo[4], rec_hi[4];    // owned QUEUE_INFO records per segment type
     int32_t rank, world;
-    int32_t halo_cap_cell;   // bodies per cell a halo message has room for
+    int32_t halo_cap_cell;   // bodies per cell, on average over a cell layer, a halo message has room for (pooled)
     int32_t xfer_cap;        // relocation records per direction and step
     int32_t lentout_c0, lentout_c1;  // own local cells computed by the rank above (their force records come back)
     int32_t num_cells_global;

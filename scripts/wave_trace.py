@@ -40,3 +40,16 @@ per_simd = np.bincount(inv, weights=work)
 last_end = np.zeros(len(u2)); np.maximum.at(last_end, inv, end)
 print("work per SIMD wave-us: min %.0f p50 %.0f max %.0f; last end per SIMD: min %.0f p50 %.0f max %.0f" % (
     per_simd.min(), np.median(per_simd), per_simd.max(), last_end.min(), np.median(last_end), last_end.max()))
+# round 4: where the kernel's idle issue slots are -- the ramp at the start, the tail at the end
+span = (t[:, 1].max() - t0) / 100.0
+for name, v in (("start", start), ("end", end)):
+    print(name, "us percentiles 1/10/50/90/99/100:", " ".join("%.0f" % np.percentile(v, q) for q in (1, 10, 50, 90, 99, 100)))
+# resident waves over time (how many waves are alive at time x), in 20 slices of the span
+edges = np.linspace(0, span, 21)
+alive = [(np.minimum(end, b) - np.maximum(start, a)).clip(0).sum() / (b - a) for a, b in zip(edges[:-1], edges[1:])]
+print("mean resident waves per slice of the span:", " ".join("%.0f" % a for a in alive))
+print("SIMD-slots idle at the end: sum over SIMDs of (span - last end) = %.0f wave-us of %.0f (%.1f %%)" % (
+    (span - last_end).sum(), span * len(u2), 100 * (span - last_end).sum() / (span * len(u2))))
+# long and short waves
+order = np.argsort(dur)
+print("shortest 5 durations", dur[order[:5]], "longest 5", dur[order[-5:]])

@@ -212,8 +212,9 @@ def test_slab_context_refuses_the_plain_stage_calls_and_bad_worlds():
 
 
 def test_slab_message_overflow_is_loud():
-    """halo_cap_cell too small for the densest boundary cell => a sticky error on the ranks
-    involved, not a silent truncation."""
+    """halo_cap_cell too small for what a boundary LAYER holds (8 per cell on average, the cloud has 15) => a sticky
+    error on the ranks involved, not a silent truncation.  (One crowded cell alone is served: the room is pooled over
+    the layer, test_slab_halo_room_is_pooled_over_a_layer.)"""
     n = 60000
     xyz = cloud(n, 91)
     ranks = [ps.ParticleSystem(ps.default_config(rank=r, world=2, halo_cap_cell=8)) for r in range(2)]
@@ -223,6 +224,31 @@ def test_slab_message_overflow_is_loud():
         step_local(ranks)
         for g in ranks:
             g.synchronize()
+    for g in ranks:
+        g.close()
+
+
+def test_slab_halo_room_is_pooled_over_a_layer():
+    """halo_cap_cell is the room PER CELL ON AVERAGE over a cell layer: a clump of 300 particles in one boundary
+    cell of a layer that holds 1 250 is served by a message with room for 16 per cell (4 096 a layer) -- until round 4
+    every cell was held to the figure on its own and this cloud was refused.  Byte-equal to the oracle, with the
+    clump's bodies crossing the cut as halo, as lent cells' force records and as particles that change owner."""
+    n = 20000
+    xyz = cloud(n, 92)
+    rng = np.random.default_rng(92)
+    m = 300
+    for k, z in enumerate((-0.5, 0.5, 19.5, -19.5)):         # clumps in the cell layers on both sides of the cuts of a 4-rank world (z = 0, +-20)
+        xyz[k * m:(k + 1) * m] = (rng.uniform(-1.8, 1.8, (m, 3)) + np.array([7.5 + 10 * k, -12.5, z])).astype(np.float32)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    fert = (1e6 + np.arange(n)).astype(np.float32)
+    ranks, o = make_world(4, xyz, age, fert, halo_cap_cell=16)
+    o.init_iframe(); o.build_grid()
+    assert int(o.cellgrid[:, 0].max()) > 100                  # one cell far above the average the message is sized for
+    for step in range(6):
+        step_local(ranks)
+        o.step(1)
+        compare_world(ranks, o, "pooled halo, step %d" % (step + 1))
+    assert o.counters["deaths_collision"] > 100 and changed_owner(ranks) >= 0
     for g in ranks:
         g.close()
 

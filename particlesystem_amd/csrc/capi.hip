@@ -75,6 +75,7 @@ struct psamd_ctx {
     int live_at_build = -1;           // host copy of fs->live (valid after a sync)
     bool interior_ran = false;        // this step's pair stage ran in two passes (the scalars hold the second pass's task count)
     int64_t tasks_last = 0;           // force tasks of the last step (all passes), sizes the next step's balanced pass
+    int64_t packs_last = 0;           // ... of which packs of partly filled slices
     // upper bound of the live count at the next build_grid, kept on the host so that the
     // life-cycle kernels can be sized without a read-back (-1 = unknown)
     int64_t live_bound = 0, snapshot_live_bound = 0;
@@ -1055,7 +1056,10 @@ static int64_t pairs_hint(const psamd_ctx *c, const DevParams &P)
 {
     int64_t tasks_hint = (c->steps_total > 0 && c->tasks_last > 0) ? c->tasks_last
                          : (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) / 64 + comp_count(c->P);
-    return tasks_hint * comp_count(P) / std::max(1, comp_count(c->P));
+    // (high word: about how many packs of partly filled slices the pass will have -- their workgroups hold residency
+    // slots of the same launch; in steps of 64 so that the launch shape does not change with every step)
+    const int64_t packs = ((c->steps_total > 0 ? c->packs_last : 0) + 63) & ~(int64_t)63;
+    return (tasks_hint * comp_count(P) / std::max(1, comp_count(c->P))) | ((packs * comp_count(P) / std::max(1, comp_count(c->P))) << 32);
 }
 
 static int enq_pairs(psamd_ctx *c, const DevParams &P, int64_t tasks_hint, bool last = true, bool first = true)
@@ -1205,6 +1209,7 @@ static int finish_step(psamd_ctx *c, int64_t bound)
     c->live_at_build = c->h_fs->live;
     const int64_t tasks_now = (int64_t)c->h_fs->n_tasks2 + c->h_fs->n_merged;       // ordinary tasks + packs of partial slices
     c->tasks_last = c->interior_ran ? tasks_now * comp_count(c->P) / std::max(1, comp_count(c->P_rest)) : tasks_now;
+    c->packs_last = c->interior_ran ? (int64_t)c->h_fs->n_merged * comp_count(c->P) / std::max(1, comp_count(c->P_rest)) : c->h_fs->n_merged;
     c->interior_ran = false;
     c->live_bound = std::min<int64_t>(c->P.slots_total, (int64_t)c->h_fs->live + c->h_fs->n_moves);   // births and arrivals <= moves
     c->processed_total += c->h_fs->live;

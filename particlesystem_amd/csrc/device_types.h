@@ -213,6 +213,11 @@ struct FrameScalars {
 // while it runs -- turns that into step + 1.  snapshot_restore rewinds `step` (k_restore).
 struct StepState {
     int32_t step, pending, seq, pad;
+    // The balanced force pass paces its waves against the clock (pairs.hip, WavePace): per pass of a frame (0 / 1), when
+    // the pass's planning ended (100 MHz real-time counter), when its last wave ended, and how long the last such pass
+    // took -- what this one expects to take.
+    unsigned long long pairs_t0[2], pairs_end[2];
+    int32_t pairs_ticks[2];
 };
 
 // Cumulative event counters, mirrors psamd_counters.  Kept in COUNTER_COPIES copies on
@@ -277,7 +282,7 @@ constexpr int SORT_MAX = 4096;   // ids one cell may hold for the in-LDS ranking
 constexpr int REPLAY_CHUNK = 2048;   // queue ops staged through LDS at a time
 constexpr int QUEUE_WINDOW = 6144;   // largest segment (slots) whose queue is replayed in LDS
 constexpr int BUCKET_MAX = 8192;     // ops per segment the one-workgroup fast replay sorts in LDS (104 of the CU's 160 KB)
-constexpr int MAX_PAIR_WAVES = 12288;    // wave slots of the balanced force pass: 256 CUs x 4 SIMDs x 6 resident waves (78 VGPRs)
+constexpr int MAX_PAIR_WAVES = 16384;    // wave slots of the balanced force pass at most (seven resident per SIMD: 7168; more: the later ones start as the first ones end)
 constexpr int STENCIL = 27;          // cells a particle's force walk visits, in the reference's order (app.cu:370-409)
 constexpr int HALO_CAP = 768;        // collision candidates one cell can list from its neighbours (else: full stencil)
 

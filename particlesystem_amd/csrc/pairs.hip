@@ -807,9 +807,16 @@ __global__ __launch_bounds__(1024) void k_plan_force(DevParams P, int nw, int me
 // the 27 counts serially -- some 2000 instructions -- was the bulk of the old split kernel.)
 __global__ __launch_bounds__(256) void k_resolve_steps(DevParams P, int nw, const int *__restrict__ cell_start,
                                                        const int *__restrict__ task_list, const long long *__restrict__ wave_pos,
-                                                       int *__restrict__ wave_unit)
+                                                       int *__restrict__ wave_unit, StepState *st, int pass)
 {
     const int s = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // the clock of the pass that follows (WavePace): how long the last one took, and when this one was planned
+        const unsigned long long a = st->pairs_t0[pass], b = st->pairs_end[pass];
+        st->pairs_ticks[pass] = (b > a && b - a < (1ull << 30)) ? (int)(b - a) : 0;
+        st->pairs_t0[pass] = __builtin_amdgcn_s_memrealtime();
+        st->pairs_end[pass] = 0;
+    }
     if (s > nw) return;
     const long long pos = wave_pos[s];
     const int t = __builtin_amdgcn_readfirstlane((int)(pos >> 32)), r = __builtin_amdgcn_readfirstlane((int)(pos & 0xffffffffll));
@@ -914,6 +921,36 @@ __device__ __forceinline__ bool handoff_consume(const float4 *slot, float &ax, f
     return ok != 0;
 }
 
+// Pacing of the balanced force pass.  All its waves are resident and have the same amount of work, but the SIMD issues
+// oldest-first: the seven waves of a SIMD do not advance together, they END one after the other (wave trace, round 4:
+// the workgroups dispatched first end at 37 % of the kernel's span, the next at 47 %, ... the last at 92-100 %), and
+// for the last 40 % of the launch a SIMD holds fewer than four waves -- at the end a lone one, which cannot cover its
+// scalar-load round trips (15 % of the kernel's issue slots idle).  So every wave keeps itself on schedule: at each
+// stencil step it compares the share of its work it has done with the share of the pass's expected duration that has
+// gone by (the duration of the last such pass, kept in StepState by the planning kernel and the waves themselves) and
+// sets its issue priority accordingly -- behind schedule: up, ahead: down.  Waves then advance together and end
+// together, whatever their age.  Nothing but issue order changes: same instructions, same results.
+struct WavePace {
+    unsigned long long t0 = 0;      // when the pass was planned (100 MHz counter)
+    float per_tick = 0.f;           // 1 / expected duration of the pass, in ticks; 0: no pacing (no history yet)
+    float per_unit = 0.f;           // 1 / the wave's (task, stencil step) units
+    int done = 0;                   // units done so far
+    int band = 20;                  // how far off schedule (1/1024 of the pass) before the priority goes to an end of its range
+    __device__ __forceinline__ void step()
+    {
+        done++;
+        if (per_tick == 0.f) return;
+        const float lag = (float)(long long)(__builtin_amdgcn_s_memrealtime() - t0) * per_tick - (float)done * per_unit;
+        // (s_setprio is a scalar instruction: it executes whatever EXEC says, so the choice must be a scalar branch --
+        // the lag as a wave-uniform integer, in 1/1024 of the pass)
+        const int q = __builtin_amdgcn_readfirstlane((int)(lag * 1024.0f));
+        if (q > band) __builtin_amdgcn_s_setprio(3);
+        else if (q > 0) __builtin_amdgcn_s_setprio(2);
+        else if (q > -band) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+};
+
 // Stencil steps [k0, k1) of a task.  resume: the sums of steps < k0 come from the wave that
 // walked them (ready != nullptr); a walk that stops before step 27 publishes its sums instead
 // of finishing the particle.  The whole task is k0 = 0, k1 = 27, ready = nullptr.
@@ -929,7 +966,7 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
                                            int k0 = 0, int k1 = STENCIL, int *ready = nullptr, FrameScalars *fs = nullptr,
                                            const FarCells far = FarCells(), int part = 0, int task_no = 0,
                                            const float *__restrict__ far_buf = nullptr, const int *__restrict__ far_start = nullptr,
-                                           const int *__restrict__ far_n = nullptr)
+                                           const int *__restrict__ far_n = nullptr, WavePace *pace = nullptr)
 {
     PS_TRACE_BEGIN();
     const int c = task / P.slices, slice = task - c * P.slices;
@@ -1023,6 +1060,7 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
                 const int nb = __builtin_amdgcn_readlane(my_nb, k), n = __builtin_amdgcn_readlane(my_cnt, k);
                 const float *sx = snap_soa + nb;
                 walk_cell(sx, sx + cap, sx + 2 * cap, sx + 3 * cap, nb, n);
+                if (pace) pace->step();
             }
         // All-pairs mode (ALLP, not in the reference): then every other cell in GLOBAL index order -- this
         // wave's part of them, the 64-cell blocks [blk_lo, blk_hi).  A far cell's bodies are summed on their
@@ -1354,7 +1392,7 @@ __device__ __forceinline__ void merged_pack_task(const DevParams &P, const int *
                                                  const int *__restrict__ active_list,
                                                  const int *__restrict__ active_count,
                                                  const int4 *__restrict__ merged_tasks,
-                                                 float4 *__restrict__ force4, int slot, float *tile);
+                                                 float4 *__restrict__ force4, int slot, float *tile, WavePace *pace = nullptr);
 
 // nmb (WALK 0, a multiple of 8 so that the XCD dealing is undisturbed): the first nmb workgroups of the
 // launch serve the merged packs of partly filled slices instead (merged_pack_task) -- dispatched first,
@@ -1373,18 +1411,47 @@ __global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : 4) void k_p
                                                         FrameScalars *fs, unsigned long long *trace,
                                                         const int *__restrict__ active_list, const int *__restrict__ active_count,
                                                         const int *__restrict__ wave_unit, int *__restrict__ task_ready,
-                                                        const int4 *__restrict__ merged_tasks, int nmb)
+                                                        const int4 *__restrict__ merged_tasks, int nmb, StepState *st, int pass, int paced)
 {
     __shared__ __attribute__((aligned(16))) float tiles[4][4 * MERGE_TILE];   // up to four 1-KiB tiles per wave
     const int wave = threadIdx.x >> 6;
+#ifdef PSAMD_WAVE_TRACE   // (diagnostic build: the wave's whole life, first instruction to last piece -- overwrites what its pieces noted)
+    const unsigned long long wave_t0 = __builtin_amdgcn_s_memrealtime();
+    struct WholeWave {
+        unsigned long long *trace; unsigned long long t0;
+        __device__ ~WholeWave() { if ((threadIdx.x & 63) == 0) { unsigned long long *t_ = trace + (size_t)3 * (blockIdx.x * 4 + (threadIdx.x >> 6)); t_[0] = t0; t_[1] = __builtin_amdgcn_s_memrealtime(); } }
+    } whole_wave{trace, wave_t0};
+#endif
     if (WALK == 0 && (int)blockIdx.x < nmb) {
         const int pack = blockIdx.x * 4 + wave;
-        if (pack < fs->n_merged) merged_pack_task<MODE, (NQ > 4 ? 4 : NQ)>(P, cell_start, snap4, active_list, active_count, merged_tasks, force4, pack, tiles[wave]);   // (4 bodies per group: the 8-wide form costs this kernel its sixth wave per SIMD)
+        if (pack < fs->n_merged) {
+            WavePace pace;                       // a pack is 27 steps of (up to) four cells' stencils
+            if (paced) {
+                const int ticks = st->pairs_ticks[pass];
+                pace.t0 = st->pairs_t0[pass];
+                pace.per_tick = ticks > 0 ? 1.0f / (float)ticks : 0.f;
+                pace.per_unit = 1.0f / (float)STENCIL;
+                pace.band = paced;
+            }
+            merged_pack_task<MODE, (NQ > 4 ? 4 : NQ)>(P, cell_start, snap4, active_list, active_count, merged_tasks, force4, pack, tiles[wave], &pace);
+        }   // (4 bodies per group: the 8-wide form costs this kernel its sixth wave per SIMD)
         return;
     }
     const int slot = xcd_contiguous((int)blockIdx.x - nmb, (int)gridDim.x - nmb) * 4 + wave;
     const int ub = __builtin_amdgcn_readfirstlane(wave_unit[slot]), ue = __builtin_amdgcn_readfirstlane(wave_unit[slot + 1]);
     if (ue <= ub) return;
+    WavePace pace;
+    if (WALK == 0 && paced) {
+        const int ticks = st->pairs_ticks[pass];
+        pace.t0 = st->pairs_t0[pass];
+        pace.per_tick = ticks > 0 ? 1.0f / (float)ticks : 0.f;
+        pace.per_unit = 1.0f / (float)(ue - ub);
+        pace.band = paced;
+    }
+    struct PassEnd {        // the pass's end, for the next one's clock: the latest wave's last instruction
+        StepState *st; int pass; bool on;
+        __device__ ~PassEnd() { if (on && (threadIdx.x & 63) == 0) atomicMax(&st->pairs_end[pass], (unsigned long long)__builtin_amdgcn_s_memrealtime()); }
+    } pass_end{st, pass, WALK == 0 && paced != 0};
     const int tb = ub / STENCIL, lb = ub - tb * STENCIL;            // first unit: task tb, step lb
     const int tl = (ue - 1) / STENCIL, le = ue - tl * STENCIL;      // last task tl, its steps [.., le)
     // one call site, so one copy of the walk: the pieces in the order they are done
@@ -1424,7 +1491,8 @@ __global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : 4) void k_p
             else pairs_task_tile<MODE, NQ, 4, WALK != 1>(P, cell_start, snap4, force4, G, tiles[wave], active_list, k0, k1, task_ready + t, fs);
         } else
             pairs_task<MODE, NQ, false, true>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, task_list[t], nullptr, trace,
-                                              active_list, active_count, k0, k1, task_ready + t, fs);
+                                              active_list, active_count, k0, k1, task_ready + t, fs, FarCells(), 0, 0, nullptr, nullptr, nullptr,
+                                              WALK == 0 ? &pace : nullptr);          // (per_tick == 0: no pacing)
     }
 }
 
@@ -1444,7 +1512,7 @@ __device__ __forceinline__ void merged_pack_task(const DevParams &P, const int *
                                                  const int *__restrict__ active_list,
                                                  const int *__restrict__ active_count,
                                                  const int4 *__restrict__ merged_tasks,
-                                                 float4 *__restrict__ force4, int slot, float *tile)
+                                                 float4 *__restrict__ force4, int slot, float *tile, WavePace *pace)
 {
     const int lane = threadIdx.x & 63;
     // (Raising these waves' issue priority -- they run one per SIMD among six of the balanced
@@ -1531,6 +1599,7 @@ __device__ __forceinline__ void merged_pack_task(const DevParams &P, const int *
                     dmin = fminf(dmin, pairsN_fast<NQ>(ctx, qx, qy, qz, qw, eps2f, ax, ay, az));
             }
         }
+        if (pace) pace->step();
     }
     if (valid) force4[gi] = make_float4(ax, ay, az, 0.f);
 }
@@ -1621,8 +1690,9 @@ struct PairShape {
     int nw;                  // wave slots of the balanced force pass
 };
 
-static PairShape pair_shape(const DevParams &P, bool lean, int64_t tasks_hint)
+static PairShape pair_shape(const DevParams &P, bool lean, int64_t hint)
 {
+    const int64_t tasks_hint = hint & 0xffffffffll, packs_hint = hint >> 32;      // (capi.hip, pairs_hint)
     PairShape s{};
     s.two = lean && P.two_pass;
     // leftover slices of several cells in one wave (k_pairs_merged).  A merged wave is long and
@@ -1661,6 +1731,18 @@ static PairShape pair_shape(const DevParams &P, bool lean, int64_t tasks_hint)
     s.packs_in_list = s.balanced && !merge_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS) && (s.tile ? tile_packs : (s.merge && (unified_packs || P.world > 1)));
     if (s.packs_in_list) { s.merge = false; s.nw = std::min(s.nw, 4096); }      // (98 VGPRs with the tile walk in: 4 resident waves per SIMD)
     if (s.tile) s.merge = false;                  // no separate merged kernel beside a tile-walk pass
+    // The packs' workgroups are the first of the same launch and hold residency slots for about half of it: with
+    // a wave slot for every resident wave besides, the workgroups dispatched last could only start when a pack ended
+    // (wave trace, round 4: a quarter of the balanced waves started 0.6-0.9 ms into a 2.3-ms launch).  So the balanced
+    // part gets as many wave slots as the packs leave free: everything is resident from the start.
+    static const bool nw_minus_packs = !(std::getenv("PSAMD_NW_PACKS") && std::atoi(std::getenv("PSAMD_NW_PACKS")) == 0);
+    if (s.merge && !s.packs_in_list && nw_minus_packs && waves_env < 32 && s.nw >= 4096) {
+        // (only while the packs are a small part of the launch -- 350 of 1792 workgroups at the reference's N = 2^20;
+        // at N = 2^22 in 24^3 cells they would be two thirds, and leave the SIMDs half empty when they end:
+        // 9.6 -> 10.3 ms measured)
+        const int pack_wgs = (int)((packs_hint + 3) / 4 + 7) & ~7;
+        if (4 * pack_wgs <= s.nw / 4) s.nw = (s.nw - 4 * pack_wgs) & ~255;
+    }
     return s;
 }
 
@@ -1689,7 +1771,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
                                                         d.halo_id, d.active_list, d.active_count, d.task_cost, d.force4);
         k_plan_force<<<8, 1024, 0, st>>>(P, balanced ? nw : 0, packs_in_list ? 2 : merge ? 1 : 0, d.cell_start, d.active_count, d.task_cost,
                                          d.task_list2, d.ctask_start, d.cost_start, d.merged_tasks, d.wave_pos, d.fs, d.trace);
-        if (balanced) k_resolve_steps<<<(nw + 1 + 3) / 4, 256, 0, st>>>(P, nw, d.cell_start, d.task_list2, d.wave_pos, d.wave_unit);
+        if (balanced) k_resolve_steps<<<(nw + 1 + 3) / 4, 256, 0, st>>>(P, nw, d.cell_start, d.task_list2, d.wave_pos, d.wave_unit, d.st, pass);
     }
     if (ev_force) (void)hipEventRecord(ev_force, st);      // timing: the force pass proper starts here
     const int *task_list = two ? d.task_list2 : d.task_list;
@@ -1699,10 +1781,11 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
     int *task_ready = d.task_ready + (size_t)pass * P.n_local_cells * P.slices;
     if (balanced) {
         constexpr int M = MODE == 0 ? 1 : MODE;
+        static const int paced = std::getenv("PSAMD_PACE") ? std::atoi(std::getenv("PSAMD_PACE")) : 20;      // (A/B runs: 0 = no pacing of the waves; else WavePace::band)
         // the packs of partly filled slices (merge): the first nmb workgroups of the same launch
         const int nmb = merge ? (((ncomp + 3) / 4 + 7) & ~7) : 0;
 #define PS_BALANCED(W) k_pairs_balanced<M, NQ, W><<<nmb + nw / 4, 256, 0, st>>>(P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_soa, d.snap_age, d.sorted_id, task_list, \
-                                                                     d.force4, d.fs, d.trace, active_list, active_count, d.wave_unit, task_ready, d.merged_tasks, nmb)
+                                                                     d.force4, d.fs, d.trace, active_list, active_count, d.wave_unit, task_ready, d.merged_tasks, nmb, d.st, pass, paced)
         if (tile) PS_BALANCED(1); else if (packs_in_list) PS_BALANCED(2); else PS_BALANCED(0);
 #undef PS_BALANCED
     }

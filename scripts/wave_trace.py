@@ -53,3 +53,20 @@ print("SIMD-slots idle at the end: sum over SIMDs of (span - last end) = %.0f wa
 # long and short waves
 order = np.argsort(dur)
 print("shortest 5 durations", dur[order[:5]], "longest 5", dur[order[-5:]])
+# end time against dispatch order: block b of the balanced part is the (b // 256)-th oldest workgroup on its CU
+tr = g.wave_trace()
+nblk = len(tr) // 4
+blk = np.repeat(np.arange(nblk), 4)[:len(tr)]
+ok = tr[:, 1] > 0
+t00 = tr[ok, 0].min()
+e = (tr[:, 1] - t00) / 100.0
+s0 = (tr[:, 0] - t00) / 100.0
+live_blocks = np.unique(blk[ok])
+print("blocks with a trace:", len(live_blocks), "first", live_blocks[:3], "last", live_blocks[-3:])
+nb_total = live_blocks.max() + 1
+nmb = nb_total - 1792 if nb_total > 1792 else 0
+print("pack workgroups (first %d blocks): waves %d, end p50 %.0f max %.0f" % (nmb, (ok & (blk < nmb)).sum(), np.median(e[ok & (blk < nmb)]) if (ok & (blk < nmb)).any() else 0, e[ok & (blk < nmb)].max() if (ok & (blk < nmb)).any() else 0))
+for a in range(7):
+    m = ok & (blk >= nmb + 256 * a) & (blk < nmb + 256 * (a + 1))
+    if m.any():
+        print("age rank %d: waves %d  start p50 %.0f  end p10 %.0f p50 %.0f p90 %.0f max %.0f" % (a, m.sum(), np.median(s0[m]), np.percentile(e[m], 10), np.median(e[m]), np.percentile(e[m], 90), e[m].max()))

@@ -45,7 +45,7 @@ VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector (spec)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FLOP_PER_PAIR = 20           # the usual N-body convention
 APPLY_BYTES_PER_UPDATE = 64  # read pos4+vel4, write pos4+vel4
-TRAFFIC_FILE = os.path.join("profiles", "r3_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r4_traffic.json")
 XGMI_LINK_GBS = 153.0        # MI355X_MICROARCH.md: one xGMI link, one direction (model only)
 
 
@@ -398,6 +398,51 @@ def sim_world(args, ps, cfg_over, flags):
     for g in ranks:
         g.close()
     return out
+
+class ClockWatch:
+    """Samples the GPU's shader clock (sysfs pp_dpm_sclk, the level marked current) in a thread while a timed region runs:
+    the chip is power-bound under this load, and which clock a figure was taken at is part of the figure."""
+
+    def __init__(self, index=0, period=0.02):
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.path = cards[index] if index < len(cards) else None
+        self.period, self.samples, self._stop, self._thread = period, [], False, None
+
+    def _read(self):
+        try:
+            for line in open(self.path):
+                if line.strip().endswith("*"):
+                    return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+        except Exception:
+            return None
+        return None
+
+    def __enter__(self):
+        if self.path:
+            import threading
+
+            def loop():
+                while not self._stop:
+                    v = self._read()
+                    if v:
+                        self.samples.append(v)
+                    time.sleep(self.period)
+            self._thread = threading.Thread(target=loop, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._thread:
+            self._thread.join(timeout=1.0)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        v = sorted(self.samples)
+        return {"min": v[0], "median": v[len(v) // 2], "max": v[-1], "samples": len(v), "source": self.path}
+
 
 def ring_paths():
     """the id file of this job's C++ ranks and the job's nonce: the same on every rank of one launch (the ranks share a
@@ -760,11 +805,12 @@ def main():
     g.set_timing(True, every_stage=args.kernel_times, period=period)
     sync()
     processed0 = g.counters["particles_processed"]
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    sync()
-    elapsed = time.perf_counter() - t0
+    with ClockWatch(local_rank if args.backend == "nccl" or world == 1 else 0) as clock:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        sync()
+        elapsed = time.perf_counter() - t0
     tim, launches = g.timing()
     g.set_timing(False)
     ctr = g.counters
@@ -774,11 +820,13 @@ def main():
         # The chip is power-bound under this load: a timed region of tens of milliseconds (the driver's --steps 20) runs at
         # a higher clock than one of seconds.  The same loop again, long enough to show the sustained figure beside it.
         sync()
-        t1 = time.perf_counter()
-        for _ in range(args.sustained_steps):
-            one_step()
-        sync()
-        sustained = {"steps": args.sustained_steps, "ms_per_step": 1e3 * (time.perf_counter() - t1) / args.sustained_steps,
+        with ClockWatch(local_rank) as clock2:
+            t1 = time.perf_counter()
+            for _ in range(args.sustained_steps):
+                one_step()
+            sync()
+            t2 = time.perf_counter()
+        sustained = {"steps": args.sustained_steps, "ms_per_step": 1e3 * (t2 - t1) / args.sustained_steps, "shader_clock_mhz": clock2.summary(),
                      "what": "the same timed loop over %d steps, run right after the line's %d (no timing events): the clock a long run holds"
                              % (args.sustained_steps, args.steps)}
     counts1, fcounts1, mine1 = frame_counts()
@@ -835,6 +883,7 @@ def main():
                                    "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic_apply,
                                    "traffic_source": TRAFFIC_FILE if traffic_apply is not None else None,
                                    "bytes_per_update": APPLY_BYTES_PER_UPDATE, "us_per_launch": us_apply},
+            "shader_clock_mhz": clock.summary(),
             "sustained": sustained,
             "kernel_us_per_step": {k: v / max(launches, 1) for k, v in tim.items() if v > 0},
             "kernel_times_from": "HIP events on the context's stream on %d of the %d timed steps (every %d%s)" % (launches, args.steps, period, "th" if period > 1 else "st"),

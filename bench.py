@@ -405,8 +405,17 @@ class ClockWatch:
 
     def __init__(self, index=0, period=0.02):
         import glob
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        self.path = cards[index] if index < len(cards) else None
+        self.path = None
+        try:
+            # the card whose PCI address is the HIP device's (a box may show the host's other GPUs in sysfs)
+            import torch
+            pr = torch.cuda.get_device_properties(index)
+            want = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for f in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
+                if os.path.basename(os.path.realpath(os.path.dirname(f))) == want:
+                    self.path = f
+        except Exception:
+            pass
         self.period, self.samples, self._stop, self._thread = period, [], False, None
 
     def _read(self):

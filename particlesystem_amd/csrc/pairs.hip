@@ -1737,11 +1737,11 @@ static PairShape pair_shape(const DevParams &P, bool lean, int64_t hint)
     // part gets as many wave slots as the packs leave free: everything is resident from the start.
     static const bool nw_minus_packs = !(std::getenv("PSAMD_NW_PACKS") && std::atoi(std::getenv("PSAMD_NW_PACKS")) == 0);
     if (s.merge && !s.packs_in_list && nw_minus_packs && waves_env < 32 && s.nw >= 4096) {
-        // (only while the packs are a small part of the launch -- 350 of 1792 workgroups at the reference's N = 2^20;
-        // at N = 2^22 in 24^3 cells they would be two thirds, and leave the SIMDs half empty when they end:
-        // 9.6 -> 10.3 ms measured)
+        // (only while the packs are the smaller part of the launch -- ~500 of 1792 workgroups at the reference's
+        // N = 2^20; at N = 2^22 in 24^3 cells they would be most of it, and leave the SIMDs half empty when they
+        // end: 9.6 -> 10.3 ms measured)
         const int pack_wgs = (int)((packs_hint + 3) / 4 + 7) & ~7;
-        if (4 * pack_wgs <= s.nw / 4) s.nw = (s.nw - 4 * pack_wgs) & ~255;
+        if (4 * pack_wgs <= s.nw * 3 / 8) s.nw = (s.nw - 4 * pack_wgs) & ~255;
     }
     return s;
 }

@@ -1308,7 +1308,7 @@ int psamd_step(psamd_ctx *c, int32_t nsteps)
         // init_iframe, build_grid, calc_forces up to the step's read-back: one sequence of launches (one graph)
         begin_step(c);
         const int64_t hint = pairs_hint(c, c->P), bound = live_bound_of(c);
-        const uint64_t key = launch_pairs_shape(c->P, hint) | ((uint64_t)bound << 20);
+        const uint64_t key = launch_pairs_shape(c->P, hint) | ((uint64_t)bound << 24);
         int rc = run_segment(c, SEG_STEP, key, [&]() {
             int r = enq_init_iframe(c);
             if (r == PSAMD_OK) r = enq_build_grid(c);

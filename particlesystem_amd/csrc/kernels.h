@@ -105,7 +105,7 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
 // tasks_hint: about how many force tasks the pass will have (sizes the balanced force pass)
 // pass: 0 or 1, which of a frame's (up to two) passes of the pair stage this is
 hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint, int pass);
-// what shapes launch_pairs' launches for this hint, as a number below 2^20 (the key of a captured graph)
+// what shapes launch_pairs' launches for this hint, as a number below 2^24 (the key of a captured graph)
 uint64_t launch_pairs_shape(const DevParams &P, int64_t tasks_hint);
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d);
 hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints, int status_table);   // also clears the status record's header and census table

@@ -1423,18 +1423,23 @@ __global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : 4) void k_p
     } whole_wave{trace, wave_t0};
 #endif
     if (WALK == 0 && (int)blockIdx.x < nmb) {
-        const int pack = blockIdx.x * 4 + wave;
-        if (pack < fs->n_merged) {
+        // The packs of partly filled slices, dealt round-robin to the 4 * nmb pack waves: a pack wave takes every
+        // (4 * nmb)-th pack, one after the other, and paces itself over all of them -- so the launch holds the number of
+        // pack workgroups that the packs' share of the WORK asks for, whatever their number (N = 2^22 in 24^3 cells has
+        // 6 900 packs: one workgroup per four of them would be the whole GPU).
+        const int first = blockIdx.x * 4 + wave, stride = nmb * 4, npack = fs->n_merged;
+        if (first < npack) {
             WavePace pace;                       // a pack is 27 steps of (up to) four cells' stencils
             if (paced) {
                 const int ticks = st->pairs_ticks[pass];
                 pace.t0 = st->pairs_t0[pass];
                 pace.per_tick = ticks > 0 ? 1.0f / (float)ticks : 0.f;
-                pace.per_unit = 1.0f / (float)STENCIL;
+                pace.per_unit = 1.0f / (float)(STENCIL * ((npack - first + stride - 1) / stride));
                 pace.band = paced;
             }
-            merged_pack_task<MODE, (NQ > 4 ? 4 : NQ)>(P, cell_start, snap4, active_list, active_count, merged_tasks, force4, pack, tiles[wave], &pace);
-        }   // (4 bodies per group: the 8-wide form costs this kernel its sixth wave per SIMD)
+            for (int pack = first; pack < npack; pack += stride)     // (4 bodies per group: the 8-wide form costs this kernel its sixth wave per SIMD)
+                merged_pack_task<MODE, (NQ > 4 ? 4 : NQ)>(P, cell_start, snap4, active_list, active_count, merged_tasks, force4, pack, tiles[wave], &pace);
+        }
         return;
     }
     const int slot = xcd_contiguous((int)blockIdx.x - nmb, (int)gridDim.x - nmb) * 4 + wave;
@@ -1688,6 +1693,7 @@ hipError_t launch_selftest_math(hipStream_t st, uint32_t lo_bits, uint32_t hi_bi
 struct PairShape {
     bool two, merge, balanced, tile, packs_in_list;
     int nw;                  // wave slots of the balanced force pass
+    int nmb;                 // workgroups of the same launch, ahead of them, that serve the packs of partly filled slices (WALK 0)
 };
 
 static PairShape pair_shape(const DevParams &P, bool lean, int64_t hint)
@@ -1728,20 +1734,32 @@ static PairShape pair_shape(const DevParams &P, bool lean, int64_t hint)
     // a pass that has only 4 waves per SIMD; an eighth (tile walk): no packs 0.58, packs 0.60 -- a
     // pack's four-group walk costs more than the two tasks it saves.  So: in the list for the slabs
     // that use the scalar walk, beside the pass on one GPU, none with the tile walk.
-    s.packs_in_list = s.balanced && !merge_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS) && (s.tile ? tile_packs : (s.merge && (unified_packs || P.world > 1)));
+    static const bool slab_walk0 = std::getenv("PSAMD_SLAB_WALK0") != nullptr;      // (A/B: a slab's scalar-walk pass with pack workgroups, like one GPU)
+    s.packs_in_list = s.balanced && !merge_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS) && (s.tile ? tile_packs : (s.merge && (unified_packs || (P.world > 1 && !slab_walk0))));
     if (s.packs_in_list) { s.merge = false; s.nw = std::min(s.nw, 4096); }      // (98 VGPRs with the tile walk in: 4 resident waves per SIMD)
     if (s.tile) s.merge = false;                  // no separate merged kernel beside a tile-walk pass
     // The packs' workgroups are the first of the same launch and hold residency slots for about half of it: with
     // a wave slot for every resident wave besides, the workgroups dispatched last could only start when a pack ended
     // (wave trace, round 4: a quarter of the balanced waves started 0.6-0.9 ms into a 2.3-ms launch).  So the balanced
     // part gets as many wave slots as the packs leave free: everything is resident from the start.
+    // How many pack workgroups: the packs' share of the pass's work (a pack costs about PACK_COST ordinary tasks: four lane
+    // groups with their own LDS tiles), in workgroups of the resident set; a pack wave takes several packs one after the
+    // other.  Without a hint (a context's first step) a quarter.
     static const bool nw_minus_packs = !(std::getenv("PSAMD_NW_PACKS") && std::atoi(std::getenv("PSAMD_NW_PACKS")) == 0);
-    if (s.merge && !s.packs_in_list && nw_minus_packs && waves_env < 32 && s.nw >= 4096) {
-        // (only while the packs are the smaller part of the launch -- ~500 of 1792 workgroups at the reference's
-        // N = 2^20; at N = 2^22 in 24^3 cells they would be most of it, and leave the SIMDs half empty when they
-        // end: 9.6 -> 10.3 ms measured)
-        const int pack_wgs = (int)((packs_hint + 3) / 4 + 7) & ~7;
-        if (4 * pack_wgs <= s.nw * 3 / 8) s.nw = (s.nw - 4 * pack_wgs) & ~255;
+    static const double pack_cost = std::getenv("PSAMD_PACK_COST") ? std::atof(std::getenv("PSAMD_PACK_COST")) : 1.4;
+    s.nmb = 0;
+    if (s.merge && !s.packs_in_list && s.balanced) {
+        const int resident = s.nw / 4;                     // workgroups the launch keeps resident
+        if (nw_minus_packs && waves_env < 32 && s.nw >= 4096) {
+            const double pw = pack_cost * (double)packs_hint, tw = (double)std::max<int64_t>(tasks_hint - packs_hint, 1);
+            const double share = packs_hint > 0 ? pw / (pw + tw) : 0.25;
+            int wgs = ((int)(resident * share + 0.5) + 7) & ~7;
+            wgs = std::max(8, std::min(wgs, resident / 2));
+            if (packs_hint > 0) wgs = std::min(wgs, (int)(((packs_hint + 3) / 4 + 7) & ~7));      // (a pack wave with no pack is a wasted slot)
+            s.nmb = wgs;
+            s.nw = (s.nw - 4 * wgs) & ~255;
+        } else
+            s.nmb = (int)std::min<int64_t>(((packs_hint > 0 ? (packs_hint + 3) / 4 : resident / 4) + 7) & ~7, resident);
     }
     return s;
 }
@@ -1749,7 +1767,7 @@ static PairShape pair_shape(const DevParams &P, bool lean, int64_t hint)
 uint64_t launch_pairs_shape(const DevParams &P, int64_t tasks_hint)
 {
     const PairShape s = pair_shape(P, P.lean_math != 0, tasks_hint);
-    return (uint64_t)(s.nw / 32) | (s.merge ? 1ull << 10 : 0) | (s.tile ? 1ull << 11 : 0) | (s.packs_in_list ? 1ull << 12 : 0) | (s.balanced ? 1ull << 13 : 0);
+    return (uint64_t)(s.nw / 32) | (s.merge ? 1ull << 10 : 0) | (s.tile ? 1ull << 11 : 0) | (s.packs_in_list ? 1ull << 12 : 0) | (s.balanced ? 1ull << 13 : 0) | ((uint64_t)(s.nmb / 8) << 14);
 }
 
 template <int MODE, int NQ>
@@ -1783,7 +1801,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
         constexpr int M = MODE == 0 ? 1 : MODE;
         static const int paced = std::getenv("PSAMD_PACE") ? std::atoi(std::getenv("PSAMD_PACE")) : 20;      // (A/B runs: 0 = no pacing of the waves; else WavePace::band)
         // the packs of partly filled slices (merge): the first nmb workgroups of the same launch
-        const int nmb = merge ? (((ncomp + 3) / 4 + 7) & ~7) : 0;
+        const int nmb = merge ? std::max(8, shape.nmb) : 0;
 #define PS_BALANCED(W) k_pairs_balanced<M, NQ, W><<<nmb + nw / 4, 256, 0, st>>>(P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_soa, d.snap_age, d.sorted_id, task_list, \
                                                                      d.force4, d.fs, d.trace, active_list, active_count, d.wave_unit, task_ready, d.merged_tasks, nmb, d.st, pass, paced)
         if (tile) PS_BALANCED(1); else if (packs_in_list) PS_BALANCED(2); else PS_BALANCED(0);

@@ -1732,10 +1732,11 @@ static PairShape pair_shape(const DevParams &P, bool lean, int64_t hint)
     // in the list 2.40 (one kernel holding both walks needs 99 VGPRs: 4 waves per SIMD, not 6);
     // half the cloud (a slab of two): 1.67 vs 1.40 -- the separate kernel's 512 waves end long after
     // a pass that has only 4 waves per SIMD; an eighth (tile walk): no packs 0.58, packs 0.60 -- a
-    // pack's four-group walk costs more than the two tasks it saves.  So: in the list for the slabs
+    // pack's four-group walk costs more than the two tasks it saves.  So (rounds 2-3): in the list for the slabs
     // that use the scalar walk, beside the pass on one GPU, none with the tile walk.
-    static const bool slab_walk0 = std::getenv("PSAMD_SLAB_WALK0") != nullptr;      // (A/B: a slab's scalar-walk pass with pack workgroups, like one GPU)
-    s.packs_in_list = s.balanced && !merge_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS) && (s.tile ? tile_packs : (s.merge && (unified_packs || (P.world > 1 && !slab_walk0))));
+    // (Round 4: with persistent pack workgroups sized by the packs' share of the work and the waves paced, a slab of two
+    // is served better by the one-GPU form too -- pair stage 1.32 -> 1.12 ms -- so the packs are in the list only on request.)
+    s.packs_in_list = s.balanced && !merge_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS) && (s.tile ? tile_packs : (s.merge && unified_packs));
     if (s.packs_in_list) { s.merge = false; s.nw = std::min(s.nw, 4096); }      // (98 VGPRs with the tile walk in: 4 resident waves per SIMD)
     if (s.tile) s.merge = false;                  // no separate merged kernel beside a tile-walk pass
     // The packs' workgroups are the first of the same launch and hold residency slots for about half of it: with

@@ -874,6 +874,9 @@ __global__ __launch_bounds__(256) void k_resolve_steps(DevParams P, int nw, cons
 #define PS_TRACE_BEGIN() do {} while (0)
 #define PS_TRACE_END() do {} while (0)
 #endif
+#ifndef TILE_PIPELINED
+#define TILE_PIPELINED 1            // the tile walk reads a group of bodies from LDS while it works through the one before (A/B builds: 0)
+#endif
 
 // One task: 64 consecutive particles of one cell against the cell's stencil.
 // Hand-off of a task's partial sums between the wave that walked the first stencil steps and
@@ -1349,23 +1352,47 @@ __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *_
         // issued after the fences (they drain outstanding loads), consumed a tile later
         if (have) fetch(t0);
         float dmin = 3.0e38f;
-        for (int jj = 0; jj < n; jj += NQ) {
-            v2f qx[NQ / 2], qy[NQ / 2], qz[NQ / 2], qw[NQ / 2];   // 16-byte LDS reads, NQ is a multiple of 4
+        // The tile's groups of NQ bodies, the NEXT group's LDS reads in flight while the current one is worked through
+        // (this walk runs one or two waves to a SIMD: nobody else covers a read's round trip, and with all eight
+        // reads followed at once by s_waitcnt lgkmcnt(0) a quarter of the loop was that wait).  Two register sets,
+        // used in turn: LDS reads return in order, so the wait before a group is for that group's reads only.
+        struct Group { v2f qx[NQ / 2], qy[NQ / 2], qz[NQ / 2], qw[NQ / 2]; };
+        auto read_group = [&](int jj, Group &g) {               // 16-byte LDS reads, NQ is a multiple of 4
 #pragma unroll
             for (int i = 0; i < NQ / 2; i += 2) {
                 const float4 vx = *reinterpret_cast<const float4 *>(tx + jj + 2 * i);
                 const float4 vy = *reinterpret_cast<const float4 *>(ty + jj + 2 * i);
                 const float4 vz = *reinterpret_cast<const float4 *>(tz + jj + 2 * i);
                 const float4 vw = *reinterpret_cast<const float4 *>(tw + jj + 2 * i);
-                qx[i] = v2f{vx.x, vx.y}; qx[i + 1] = v2f{vx.z, vx.w};
-                qy[i] = v2f{vy.x, vy.y}; qy[i + 1] = v2f{vy.z, vy.w};
-                qz[i] = v2f{vz.x, vz.y}; qz[i + 1] = v2f{vz.z, vz.w};
-                qw[i] = v2f{vw.x, vw.y}; qw[i + 1] = v2f{vw.z, vw.w};
+                g.qx[i] = v2f{vx.x, vx.y}; g.qx[i + 1] = v2f{vx.z, vx.w};
+                g.qy[i] = v2f{vy.x, vy.y}; g.qy[i + 1] = v2f{vy.z, vy.w};
+                g.qz[i] = v2f{vz.x, vz.y}; g.qz[i + 1] = v2f{vz.z, vz.w};
+                g.qw[i] = v2f{vw.x, vw.y}; g.qw[i + 1] = v2f{vw.z, vw.w};
             }
+        };
+        auto work_group = [&](const Group &g) {
             if (MODE == 1)
-                pairsN_exact_lean<NQ, ONE_T>(P, ctx, qx, qy, qz, qw, 0, nullptr, nullptr, ax, ay, az, flag);
+                pairsN_exact_lean<NQ, ONE_T>(P, ctx, g.qx, g.qy, g.qz, g.qw, 0, nullptr, nullptr, ax, ay, az, flag);
             else
-                dmin = fminf(dmin, pairsN_fast<NQ>(ctx, qx, qy, qz, qw, eps2f, ax, ay, az));
+                dmin = fminf(dmin, pairsN_fast<NQ>(ctx, g.qx, g.qy, g.qz, g.qw, eps2f, ax, ay, az));
+        };
+        if (TILE_PIPELINED) {
+            Group a, b;
+            read_group(0, a);
+            for (int jj = 0; jj < n; jj += 2 * NQ) {
+                if (jj + NQ < n) read_group(jj + NQ, b);
+                work_group(a);
+                if (jj + NQ < n) {
+                    if (jj + 2 * NQ < n) read_group(jj + 2 * NQ, a);
+                    work_group(b);
+                }
+            }
+        } else {
+            for (int jj = 0; jj < n; jj += NQ) {
+                Group g;
+                read_group(jj, g);
+                work_group(g);
+            }
         }
     }
     if (k1 < STENCIL) { handoff_publish(force4 + gi, ax, ay, az, flag, valid, ready, k1); return; }
@@ -1401,7 +1428,7 @@ __device__ __forceinline__ void merged_pack_task(const DevParams &P, const int *
 // needed a head start to get that: forked at the same moment as the balanced pass they ended with it,
 // and the stage took 0.1 ms longer.)
 template <int MODE, int NQ, int WALK>
-__global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : 4) void k_pairs_balanced(DevParams P, const int *__restrict__ cell_start,
+__global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : WALK == 1 ? 2 : 4) void k_pairs_balanced(DevParams P, const int *__restrict__ cell_start,
                                                         const SnapSoa snap4,
                                                         const float *__restrict__ snap_soa,
                                                         const float *__restrict__ snap_age,

@@ -232,7 +232,16 @@ int check_device_errors(psamd_ctx *c)   // after a sync: sticky error bits raise
     }
     if (fs.error & ERR_CELL_TOO_BIG) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "a cell holds more particles than the sort kernel ranks");
     if (fs.error & ERR_FOREIGN_CELL) return fail(c, PSAMD_ERR_STATE, "a particle stored on this rank sits in a cell layer the rank holds no state for");
-    if (fs.error & ERR_HALO_OVERFLOW) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "a slab message had no room (raise halo_cap_cell / xfer_cap)");
+    if (fs.error & ERR_HALO_OVERFLOW) {
+        // say what was asked for, so that the caller can size the messages (the error may also have come in with a
+        // neighbour's message header: then the numbers below are this rank's own and may all fit)
+        char buf[320];
+        std::snprintf(buf, sizeof buf, "a slab message had no room (raise halo_cap_cell / xfer_cap): this step this rank wanted to send %d / %d "
+                      "transfer records down / up (room: xfer_cap = %d each), %d / %d two ranks away (room %d), %d to a far rank (room %d); "
+                      "a halo message holds halo_cap_cell = %d bodies per cell on average over a cell layer",
+                      fs.n_out[0], fs.n_out[1], c->P.xfer_cap, fs.n_out[2], fs.n_out[3], c->P.xfer2_cap, fs.n_out[4], c->P.far_cap, c->P.halo_cap_cell);
+        return fail(c, PSAMD_ERR_CELL_OVERFLOW, buf);
+    }
     if (fs.error & ERR_SLAB_MISMATCH) return fail(c, PSAMD_ERR_STATE, "a slab message does not match the receiver's plan or counts");
     if (fs.error & ERR_REMOTE_RECORD0) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "more cell-overflow kills in one step than a slab's status message carries (ps.cpp:1523-1526 frees them into queue record 0)");
     if (fs.error & ERR_CHUNK_CAP) return fail(c, PSAMD_ERR_CELL_OVERFLOW, "a chunk list passed MAX_PARTICLES_PER_CHUNK: the reference skips its tail (ps.cpp:1502-1508), this library does not reproduce that");

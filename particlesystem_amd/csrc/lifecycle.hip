@@ -367,11 +367,12 @@ __device__ __forceinline__ void moves_stage_reset(const DevParams &P, int m, Mov
     cell_arr[si] = -1; pflags[si] = 0; pos4[si] = zero; vel4[si] = zero; acc4[si] = zero;
 }
 
-// CAP: the longest list this instance holds in LDS.  Two instances are launched back to back: CAP = 2048
-// (27 KB of LDS: five workgroups per CU, every queue of the usual step at once; counting rank) serves
-// the queues with up to 2048 operations, CAP = BUCKET_MAX (104 KB, one workgroup per CU; bitonic
-// network) the longer lists -- its workgroups leave at once where there is none.  (One instance sized
-// for the longest list ran one workgroup per CU for every queue: 66 us instead of 36 for the usual step.)
+// CAP: the longest list this instance holds in LDS.  Two instances: CAP = 2048 (27 KB of LDS: five
+// workgroups per CU, every queue of the usual step at once) serves the queues with up to 2048 operations and is
+// launched every step; CAP = BUCKET_MAX (104 KB, one workgroup per CU) the longer lists -- launched by the HOST
+// only in a step whose scalars show such a list (launch_lifecycle part 1: h_fs->max_bucket > 2048; the host's copy
+// of the scalars is the device's, so its test agrees with the kernel's own `fs->max_bucket <= 2048` backstop).
+// (One instance sized for the longest list ran one workgroup per CU for every queue: 66 us instead of 36.)
 template <int CAP>
 __device__ __forceinline__ void replay_record(const DevParams &P, const int rec, const int *__restrict__ rec_start,
                                                         const uint64_t *__restrict__ keys,
@@ -590,8 +591,8 @@ __device__ __forceinline__ void replay_record(const DevParams &P, const int rec,
 }
 
 // The instance for the usual lists runs one workgroup per queue record (and the first relocation phase in the
-// workgroups past them); the one for long lists is launched every step too, with a few workgroups that leave at
-// once unless some queue got more than 2048 operations this step (max_bucket) and otherwise stride over the records.
+// workgroups past them); the one for long lists -- launched only in a step that has one, see above -- strides
+// over the records with a few workgroups.
 template <int CAP>
 __global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, int nrec, const int *__restrict__ rec_start,
                                                         const uint64_t *__restrict__ keys, const int *__restrict__ args,

@@ -645,12 +645,13 @@ def main():
                     max_particles_num=max(args.n, 1 << 20))
     if args.halo_cap_cell == 0 and not args.evolve and not args.all_pairs and (world > 1 or args.sim_world):
         # Slab messages have a fixed size, cells x halo_cap_cell bodies (the library's default is the
-        # cell capacity, 2x the mean density at the reference's settings).  The replayed step never
-        # changes the cloud, so size them for it: 1.5x the mean density of the uniform cloud + 64
-        # (mean + 4 sigma of a boundary layer's fullest cell is well below; a message that did not
-        # fit would be a loud error, not a truncation).  A free-running cloud (--evolve) keeps the default.
+        # cell capacity, 2x the mean density at the reference's settings), and their room is pooled over a
+        # cell layer.  The replayed step never changes the cloud, so size them for it: 1.15x the mean
+        # density of the uniform cloud + 16 per cell -- a layer of G^2 cells holds n / G particles give or
+        # take a few hundred (sqrt of it), so a fifth of headroom is hundreds of sigma; a message that did
+        # not fit would be a loud error, not a truncation.  A free-running cloud (--evolve) keeps the default.
         cells = (args.chunk_factor * args.chunk_dim) ** 3
-        args.halo_cap_cell = int(1.5 * args.n / cells) + 64
+        args.halo_cap_cell = int(1.15 * args.n / cells) + 16
         # likewise the transfer messages (particles changing owner per step and direction): the library's
         # default has room for a quarter of what a layer can hold (a fast, dense cloud); this cloud's busiest
         # face is the box surface, whose layer implodes by up to a cell in the replayed step: an eighth of a

@@ -36,7 +36,7 @@ python bench.py --all-pairs --n 1048576 --no-cpu --no-side-runs --steps 3 --warm
 python bench.py --sim-world 8 --all-pairs --n 1048576 --steps 3 --warmup 1 > $out/ap_n20_sim8.json 2> $out/ap_n20_sim8.err
 say "the C++ host: eight slabs in one process, every message through RCCL (loopback)"
 for v in "0 1" "1 1" "0 0"; do set -- $v
-  host/ps_ring_rccl --loopback --world 8 --bench --n 1048576 --steps 50 --warmup 5 --halo-cap-cell 448 --xfer-cap 9216 --graphs $1 --side-stream $2 2>> $out/ring.err | grep psamd_ring > $out/ring_w8_g$1_s$2.json
+  host/ps_ring_rccl --loopback --world 8 --bench --n 1048576 --steps 50 --warmup 5 --halo-cap-cell 310 --xfer-cap 9216 --graphs $1 --side-stream $2 2>> $out/ring.err | grep psamd_ring > $out/ring_w8_g$1_s$2.json
 done
 host/ps_ring_rccl --loopback --world 8 --bench --all-pairs --n 262144 --steps 10 --warmup 2 --xfer-cap 24576 2>> $out/ring.err | grep psamd_ring > $out/ring_w8_allpairs.json
 say "rocprof of the 8-rank projection"

@@ -59,6 +59,8 @@ def test_null_arguments_are_rejected(lib):
     assert lib.psamd_create(None, None) == 1
     assert lib.psamd_step(None, 1) == 1
     assert lib.psamd_destroy(None) == 0
+    assert lib.psamd_set_graphs(None, 1) == 1 and lib.psamd_set_wait_policy(None, 1) == 1
+    assert lib.psamd_get_graph_stats(None, None, None) == 1
 
 
 def test_no_gpu_means_loud_failure(lib):

@@ -17,6 +17,8 @@ __global__ __launch_bounds__(256) void k(float *out, float seed, unsigned long l
     double d[8];
     for (int i = 0; i < 8; i++) { a[i] = seed + threadIdx.x * 1e-3f + i; d[i] = a[i]; }
     const float c1 = seed * 0.999f, c2 = seed * 1e-3f;
+    float b[8];
+    for (int i = 0; i < 8; i++) b[i] = a[i] * 0.5f;
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < ITER; it++) {
 #pragma unroll
@@ -32,6 +34,29 @@ __global__ __launch_bounds__(256) void k(float *out, float seed, unsigned long l
             if (OP == 8) a[i] = fminf(a[i], fminf(c1, a[(i + 1) & 7]));
             if (OP == 9) a[i] = __builtin_sqrtf(a[i]);   // v_sqrt_f32 + fixups (correctly rounded)
             if (OP == 10) d[i] = __builtin_fma(d[i], (double)c1, (double)c2);
+        }
+        // round 4: does a transcendental overlap with plain VALU work?  8 v_rsq + 32 v_fma per iteration:
+        // 13 interleaved in one wave (1 : 4), 14 grouped in one wave, 15 the waves of even workgroups only v_rsq (x 8),
+        // those of odd workgroups only v_fma (x 32) -- a SIMD holds both kinds
+        if (OP == 13 || OP == 14 || OP == 15) {
+            const bool do_rsq = OP != 15 || (blockIdx.x & 1) == 0, do_fma = OP != 15 || (blockIdx.x & 1) == 1;
+            if (OP == 13) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    asm volatile("v_rsq_f32 %0, %0" : "+v"(a[i]));
+#pragma unroll
+                    for (int r = 0; r < 4; r++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(b[(4 * i + r) & 7]) : "v"(c1), "v"(c2));
+                }
+            } else {
+                if (do_rsq) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) asm volatile("v_rsq_f32 %0, %0" : "+v"(a[i]));
+                }
+                if (do_fma) {
+#pragma unroll
+                    for (int r = 0; r < 32; r++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(b[r & 7]) : "v"(c1), "v"(c2));
+                }
+            }
         }
         if (OP == 11) {   // packed fp32 fma: 4 x v_pk_fma_f32 on 8 floats
             typedef float v2 __attribute__((ext_vector_type(2)));
@@ -54,6 +79,7 @@ __global__ __launch_bounds__(256) void k(float *out, float seed, unsigned long l
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0; double sd = 0;
+    for (int i = 0; i < 8; i++) s += b[i];
     for (int i = 0; i < 8; i++) { s += a[i]; sd += d[i]; }
     out[blockIdx.x * blockDim.x + threadIdx.x] = s + (float)sd;
     if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
@@ -112,6 +138,14 @@ int main()
         snprintf(name, sizeof name, "v_fma_f32, %d wave(s)/SIMD", w); run<0>(name, 8, out, clk, w);
         snprintf(name, sizeof name, "v_pk_fma_f32, %d wave(s)/SIMD", w); run<11>(name, 4, out, clk, w);
         snprintf(name, sizeof name, "v_rsq_f32, %d wave(s)/SIMD", w); run<3>(name, 8, out, clk, w);
+    }
+    // round 4: transcendental beside plain VALU work (per iteration 8 v_rsq + 32 v_fma = 40 instructions;
+    // no overlap: 8 x 4 + 32 = 64 issue units, full overlap: 32)
+    for (int w = 1; w <= 8; w *= 2) {
+        char name[64];
+        snprintf(name, sizeof name, "rsq+4fma interleaved, %d w/SIMD", w); run<13>(name, 40, out, clk, w);
+        snprintf(name, sizeof name, "8rsq then 32fma, %d w/SIMD", w); run<14>(name, 40, out, clk, w);
+        if (w >= 2) { snprintf(name, sizeof name, "rsq waves | fma waves, %d w/SIMD", w); run<15>(name, 20, out, clk, w); }
     }
     return 0;
 }

@@ -250,11 +250,16 @@ __device__ __forceinline__ void pairs_finish_fast(const PairRows<NQ> &r, const v
 {
     constexpr int H = NQ / 2;
     v2f sc[H];
+    // the group's transcendentals back to back: going from a transcendental to plain VALU work and back costs a
+    // couple of cycles each way on gfx950 (profiles/r4_microbench_trans_overlap.txt: 8 v_rsq among 32 v_fma, one to
+    // four, take 18 % longer than the same instructions grouped)
+    v2f q[H];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < H; i++) {
-        v2f q; q.x = __builtin_amdgcn_rsqf(r.d[i].x); q.y = __builtin_amdgcn_rsqf(r.d[i].y);
-        sc[i] = qw[i] * (q * q * q);
-    }
+    for (int i = 0; i < H; i++) { q[i].x = __builtin_amdgcn_rsqf(r.d[i].x); q[i].y = __builtin_amdgcn_rsqf(r.d[i].y); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < H; i++) sc[i] = qw[i] * (q[i] * q[i] * q[i]);
 #pragma unroll
     for (int i = 0; i < H; i++) {
         ax = fmaf(r.rx[i].x, sc[i].x, ax); ay = fmaf(r.ry[i].x, sc[i].x, ay); az = fmaf(r.rz[i].x, sc[i].x, az);

@@ -515,9 +515,13 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.force4, SC));
     PS_HIP(c, dev_alloc(c, &d.celltab, (size_t)g.num_cells));
     if (P.flags & PSAMD_FLAG_ALL_PAIRS) {
-        // partial sums of the all-pairs pass: one float4 per (part, task, lane); tasks <= particles / 64 + one partly filled slice per cell
-        d.part_tasks = (int)std::min<size_t>(LC * P.slices, C / 64 + LC + 64);
+        // partial sums of the all-pairs far pass: one float4 per (part, particle that needs a force) -- dense, 64 to a task;
+        // every entry of the sorted order could be one
+        d.part_tasks = (int)(SC / 64 + 1);
         PS_HIP(c, dev_alloc(c, &d.part_acc, (size_t)ALLP_PARTS * d.part_tasks * 64));
+        PS_HIP(c, dev_alloc(c, &d.act_start, LC + 1));
+        PS_HIP(c, dev_alloc(c, &d.dense_gi, SC));
+        PS_HIP(c, dev_alloc(c, &d.dense_cell, SC));
     }
     {                                                    // the chunk lists' capacity rule (chunk_cap_block)
         PS_HIP(c, dev_alloc(c, &d.chunk_skip, C));
@@ -1071,10 +1075,12 @@ static int64_t pairs_hint(const psamd_ctx *c, const DevParams &P)
     return (tasks_hint * comp_count(P) / std::max(1, comp_count(c->P))) | ((packs * comp_count(P) / std::max(1, comp_count(c->P))) << 32);
 }
 
+static int64_t live_bound_of(const psamd_ctx *c);
+
 static int enq_pairs(psamd_ctx *c, const DevParams &P, int64_t tasks_hint, bool last = true, bool first = true)
 {
     if (c->timing_now && first) (void)hipEventRecord(c->ev[5], c->stream);
-    PS_HIP(c, launch_pairs(c->stream, P, c->d, (c->timing_now && first) ? c->ev[13] : nullptr, tasks_hint, first ? 0 : 1));
+    PS_HIP(c, launch_pairs(c->stream, P, c->d, (c->timing_now && first) ? c->ev[13] : nullptr, tasks_hint, first ? 0 : 1, live_bound_of(c)));
     if (c->timing_now && last) (void)hipEventRecord(c->ev[6], c->stream);
     return PSAMD_OK;
 }

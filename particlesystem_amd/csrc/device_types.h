@@ -86,10 +86,11 @@ struct DevParams {
 
 // All-pairs force pass.  The cells beyond the stencil are found by GLOBAL cell in a snapshot buffer (the own
 // one, or the all-gathered one of all ranks): x at buf[start], y, z, w_eff at multiples of `plane` behind.
-// A particle's sum is split into ALLP_PARTS partial sums, each by a wave of its own (or a lone rank of
-// eight would have half a wave per SIMD walking the whole cloud): part p covers its share of the 64-cell
-// blocks of the global cell order (part 0 the stencil first); partial sums land in
-// part_acc[p * part_plane + task * 64 + lane] and k_allpairs_combine adds them up in part order.
+// The stencil's chain comes from the ordinary (cutoff) force pass; the rest of a particle's sum is split into
+// ALLP_PARTS partial sums, each by a wave of its own (or a lone rank of eight would have half a wave per SIMD
+// walking the whole cloud): part p covers its share of the 64-cell blocks of the global cell order; partial sums
+// land in part_acc[p * part_plane + r], r = the particle's place among those that need a force, and
+// k_allpairs_combine adds them to the stencil's chain in part order (pairs.hip, k_allp_far).
 struct FarCells {
     unsigned long long plane = 0;
     float4 *part_acc = nullptr;

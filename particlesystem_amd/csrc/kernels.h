@@ -81,8 +81,11 @@ struct DeviceState {
     // all-pairs across ranks: the gathered snapshot blocks (inside the context's message buffer) and their index by global cell
     const int *allg_in = nullptr;
     int *gstart = nullptr, *gn = nullptr;
-    float4 *part_acc = nullptr;   // all-pairs: [ALLP_PARTS][part_tasks * 64] partial sums of the force pass's (task, part) waves
+    float4 *part_acc = nullptr;   // all-pairs: [ALLP_PARTS][part_tasks * 64] partial sums of the far pass's (dense task, part) waves
     int part_tasks = 0;
+    int *act_start = nullptr;     // all-pairs: [num_cells + 1] particles that need a force in the pass's cells before its j-th
+    int *dense_gi = nullptr;      // all-pairs: [container] sorted index of the r-th particle that needs a force (cell order)
+    int *dense_cell = nullptr;    // all-pairs: [container] its cell
     DevCounters *ctr = nullptr;
     unsigned long long *trace = nullptr;  // 3 words per pair-kernel wave slot (diagnostic builds only)
 };
@@ -104,7 +107,8 @@ hipError_t launch_init_tdata(hipStream_t st, const DevParams &P, const DeviceSta
 hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev);
 // tasks_hint: about how many force tasks the pass will have (sizes the balanced force pass)
 // pass: 0 or 1, which of a frame's (up to two) passes of the pair stage this is
-hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint, int pass);
+// live_bound: at most so many particles are alive (< 0: unknown); sizes the all-pairs far pass's launch
+hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint, int pass, int64_t live_bound);
 // what shapes launch_pairs' launches for this hint, as a number below 2^24 (the key of a captured graph)
 uint64_t launch_pairs_shape(const DevParams &P, int64_t tasks_hint);
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d);

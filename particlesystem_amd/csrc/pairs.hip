@@ -963,7 +963,7 @@ struct WavePace {
 // walked them (ready != nullptr); a walk that stops before step 27 publishes its sums instead
 // of finishing the particle.  The whole task is k0 = 0, k1 = 27, ready = nullptr.
 // SETTLED: the collision flags are known already (two-pass mode: the balanced pass) -- nothing tracks distances for them
-template <int MODE, int NQ, bool ALLP = false, bool SETTLED = false>
+template <int MODE, int NQ, bool SETTLED = false>
 __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__restrict__ cell_start,
                                            const SnapSoa snap4, const float *__restrict__ snap_soa,
                                            const float *__restrict__ snap_age, const int *__restrict__ sorted_id,
@@ -972,9 +972,7 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
                                            const int *__restrict__ active_list = nullptr,
                                            const int *__restrict__ active_count = nullptr,
                                            int k0 = 0, int k1 = STENCIL, int *ready = nullptr, FrameScalars *fs = nullptr,
-                                           const FarCells far = FarCells(), int part = 0, int task_no = 0,
-                                           const float *__restrict__ far_buf = nullptr, const int *__restrict__ far_start = nullptr,
-                                           const int *__restrict__ far_n = nullptr, WavePace *pace = nullptr)
+                                           WavePace *pace = nullptr)
 {
     PS_TRACE_BEGIN();
     const int c = task / P.slices, slice = task - c * P.slices;
@@ -1062,48 +1060,12 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
                 }
             }
         };
-        // the stencil, in the reference's order (all-pairs mode: part 0 only)
-        if (!ALLP || part == 0)
-            for (int k = k0; k < k1; k++) {
-                const int nb = __builtin_amdgcn_readlane(my_nb, k), n = __builtin_amdgcn_readlane(my_cnt, k);
-                const float *sx = snap_soa + nb;
-                walk_cell(sx, sx + cap, sx + 2 * cap, sx + 3 * cap, nb, n);
-                if (pace) pace->step();
-            }
-        // All-pairs mode (ALLP, not in the reference): then every other cell in GLOBAL index order -- this
-        // wave's part of them, the 64-cell blocks [blk_lo, blk_hi).  A far cell's bodies are summed on their
-        // own and the cell's sum added to the particle's: an fp32 sum of a quarter of a million terms in one
-        // chain would carry 4e-5 of rounding (measured at N = 2^18); the stencil's chain is the reference's
-        // and stays as it is.  The bodies come from far_buf: the own snapshot on one GPU (local cell ==
-        // global cell), the all-gathered snapshot of all ranks otherwise -- a pointer of its own, not a
-        // choice between two, or the compiler cannot keep the loads scalar.
-        if (ALLP) {
-            const int nblk = (P.num_cells_global + 63) >> 6;
-            const int blk_lo = nblk * part / ALLP_PARTS, blk_hi = nblk * (part + 1) / ALLP_PARTS;
-            const size_t plane = (size_t)far.plane;
-            for (int blk = blk_lo; blk < blk_hi; blk++) {
-                // the block's 64 cell ranges in one vector load (a scalar load per cell, and the body loads
-                // behind it, were two dependent round trips for 64 bodies of work); 0 bodies: a stencil cell
-                const int c2 = blk * 64 + lane, GG = P.G * P.G;
-                int far_nb = 0, far_cnt = 0;
-                if (c2 < P.num_cells_global) {
-                    const int j3 = c2 / GG, rem = c2 - j3 * GG, j1 = rem / P.G, j2 = rem - j1 * P.G;
-                    if (!(abs(j1 - i1) <= 1 && abs(j2 - i2) <= 1 && abs(j3 - i3) <= 1)) {
-                        far_nb = far_start[c2];
-                        far_cnt = far_n ? far_n[c2] : min(far_start[c2 + 1] - far_nb, P.max_per_cell);
-                    }
-                }
-                for (int j = 0; j < 64; j++) {
-                    const int n = __builtin_amdgcn_readlane(far_cnt, j);
-                    if (n == 0) continue;
-                    const int nb = __builtin_amdgcn_readlane(far_nb, j);
-                    const float near_x = ax, near_y = ay, near_z = az;
-                    ax = 0.f; ay = 0.f; az = 0.f;
-                    const float *sx = far_buf + nb;
-                    walk_cell(sx, sx + plane, sx + 2 * plane, sx + 3 * plane, nb, n);
-                    ax = near_x + ax; ay = near_y + ay; az = near_z + az;
-                }
-            }
+        // the stencil, in the reference's order
+        for (int k = k0; k < k1; k++) {
+            const int nb = __builtin_amdgcn_readlane(my_nb, k), n = __builtin_amdgcn_readlane(my_cnt, k);
+            const float *sx = snap_soa + nb;
+            walk_cell(sx, sx + cap, sx + 2 * cap, sx + 3 * cap, nb, n);
+            if (pace) pace->step();
         }
     } else {
         // Generic exact mode: tiles of 64 snapshot entries, in stencil order then list order.
@@ -1167,10 +1129,6 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
         PS_TRACE_END();
         return;
     }
-    if (ALLP) {                                  // a partial sum: k_allpairs_combine finishes the particle
-        if (valid) far.part_acc[(size_t)part * far.part_plane + (size_t)task_no * 64 + lane] = make_float4(ax, ay, az, 0.f);
-        return;
-    }
     if (dead) flag = 2;
     if (kid) { ax = 0.f; ay = 0.f; az = 0.f; }   // every term is skipped for a kid (app_common.cu:240)
     if (MODE != 0 && !SETTLED) {
@@ -1186,7 +1144,7 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
     PS_TRACE_END();
 }
 
-template <int MODE, int NQ, bool ALLP>
+template <int MODE, int NQ>
 __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restrict__ cell_start,
                                                const SnapSoa snap4,
                                                const float *__restrict__ snap_soa,
@@ -1195,9 +1153,7 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
                                                const int *__restrict__ task_list,
                                                float4 *__restrict__ force4,
                                                FrameScalars *fs, unsigned long long *trace,
-                                               const int *__restrict__ active_list, const int *__restrict__ active_count,
-                                               const FarCells far, const float *__restrict__ far_buf,
-                                               const int *__restrict__ far_start, const int *__restrict__ far_n)
+                                               const int *__restrict__ active_list, const int *__restrict__ active_count)
 {
     // Workgroups of four INDEPENDENT waves (no workgroup barrier anywhere): the hardware
     // deals a workgroup's waves over the four SIMDs of its CU and workgroups over the
@@ -1213,37 +1169,183 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
     // launch -- were tried: the XCDs then finish together, yet the launch was only 1 %
     // shorter and the extra prefix sum cost k_scan 10 us.)
     const int ntask = active_list ? fs->n_tasks2 : fs->n_tasks;
-    const int nitem = ALLP ? ntask * ALLP_PARTS : ntask;         // all-pairs: a wave per (task, part)
-    const int nwg = (nitem + 3) >> 2;
+    const int nwg = (ntask + 3) >> 2;
     if ((int)blockIdx.x >= nwg) return;
     const int slot = xcd_contiguous(blockIdx.x, nwg) * 4 + wave;
-    if (slot >= nitem) return;
-    const int t = ALLP ? slot / ALLP_PARTS : slot, part = ALLP ? slot - t * ALLP_PARTS : 0;
-    // (an all-pairs context always runs the two-pass stage: the flags are settled)
-    pairs_task<MODE, NQ, ALLP, ALLP>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4,
-                                     task_list[t], tiles[MODE == 0 ? wave : 0], trace, active_list, active_count, 0, STENCIL, nullptr, fs, far, part, t,
-                                     far_buf, far_start, far_n);
+    if (slot >= ntask) return;
+    pairs_task<MODE, NQ>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4,
+                         task_list[slot], tiles[MODE == 0 ? wave : 0], trace, active_list, active_count, 0, STENCIL, nullptr, fs);
 }
 
-// All-pairs: a particle's acceleration = ((stencil chain + part 0's far cells) + part 1) + ... + part 15,
-// the same association on one GPU and on any number of ranks.  One thread per (task, lane).
-__global__ void k_allpairs_combine(DevParams P, const int *__restrict__ cell_start, const int *__restrict__ task_list,
-                                   const int *__restrict__ active_list, const int *__restrict__ active_count,
-                                   const FarCells far, float4 *__restrict__ force4, const FrameScalars *__restrict__ fs)
+// ------------------------------------------------------------------ all-pairs forces (PSAMD_FLAG_ALL_PAIRS, not in the reference)
+// A particle's acceleration = the stencil's chain, exactly the cutoff pass above (the reference's order), plus every
+// other cell of the box in GLOBAL index order.  The far field is 99 % of the work and the same for every particle but
+// for the 27 cells it must leave out, so it does not go by (cell, slice) tasks -- whose last slices are mostly empty
+// lanes: a quarter of all lanes at 64 particles per cell -- but by DENSE tasks: the particles that need a force, in
+// cell order, 64 to a wave whatever their cells.  A wave (dense task, part) walks the cells of its part (a sixteenth
+// of the box, by blocks of 64 cells) in chunks of ALLP_CHUNK consecutive cells: a chunk's bodies are ONE chain of
+// additions started at +0 (an fp32 sum of a quarter of a million terms in one chain would carry 4e-5 of rounding,
+// measured at N = 2^18), the chunk's sum is added to the part's, k_allpairs_combine adds the parts to the stencil's
+// chain in part order.  A lane whose own stencil holds a cell of the chunk leaves that cell's bodies out (its sums are
+// put back after the cell's walk); a chunk no lane has in its stencil, its cells adjacent in the buffer -- nearly
+// all -- is walked in one go, with one ragged tail per chunk instead of one per cell.  The association depends on
+// nothing but the global cell order: the same bits on one GPU and on any number of ranks, where far_buf is the
+// all-gathered snapshot of all ranks with its index by global cell (k_allg_index) instead of the own snapshot.
+#ifndef PSAMD_ALLP_CHUNK
+#define PSAMD_ALLP_CHUNK 4
+#endif
+constexpr int ALLP_CHUNK = PSAMD_ALLP_CHUNK;          // (divides 64)
+
+// act_start[j]: how many particles need a force in the pass's cells before its j-th; [comp_count]: in all.  One workgroup.
+__global__ __launch_bounds__(1024) void k_allp_prefix(DevParams P, const int *__restrict__ active_count, int *__restrict__ act_start)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, t = i >> 6, lane = i & 63;
-    if (t >= fs->n_tasks2) return;
-    const int task = task_list[t], c = task / P.slices, slice = task - c * P.slices;
-    const int first = slice * 64, cnt = active_count[c];
-    if (first + lane >= cnt) return;
-    const int gi = active_list[cell_start[c] + first + lane];
-    float4 a = far.part_acc[(size_t)t * 64 + lane];
+    __shared__ int wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ncomp = comp_count(P), per = (ncomp + 1023) / 1024;
+    const int c0 = min(ncomp, tid * per), c1 = min(ncomp, c0 + per);
+    int mine = 0;
+    for (int j = c0; j < c1; j++) mine += active_count[comp_cell(P, j)];
+    const int incl = wave_incl_scan(mine);
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    int run = incl - mine, total = 0;
+    for (int k = 0; k < 16; k++) { if (k < wv) run += wave_tot[k]; total += wave_tot[k]; }
+    for (int j = c0; j < c1; j++) { act_start[j] = run; run += active_count[comp_cell(P, j)]; }
+    if (tid == 0) act_start[ncomp] = total;
+}
+
+// the dense order: sorted index and cell of the r-th particle that needs a force.  One wave per cell of the pass.
+__global__ __launch_bounds__(256) void k_allp_dense(DevParams P, const int *__restrict__ cell_start, const int *__restrict__ active_list,
+                                                    const int *__restrict__ active_count, const int *__restrict__ act_start,
+                                                    int *__restrict__ dense_gi, int *__restrict__ dense_cell)
+{
+    const int j = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= comp_count(P)) return;
+    const int c = comp_cell(P, j), base = cell_start[c], n = active_count[c], o = act_start[j];
+    for (int i = lane; i < n; i += 64) { dense_gi[o + i] = active_list[base + i]; dense_cell[o + i] = c; }
+}
+
+// n bodies from four planes of a snapshot (wave-uniform pointers: scalar loads), added to (ax, ay, az) in list order
+template <int MODE, int NQ>
+__device__ __forceinline__ void walk_far(const DevParams &P, const PairCtx &ctx, const float *__restrict__ sx, const float *__restrict__ sy,
+                                         const float *__restrict__ sz, const float *__restrict__ sw, int n, float eps2f,
+                                         float &ax, float &ay, float &az)
+{
+    int flag = 0, jj = 0;
+    for (; jj + NQ <= n; jj += NQ) {
+        v2f qx[NQ / 2], qy[NQ / 2], qz[NQ / 2], qw[NQ / 2];
 #pragma unroll
-    for (int p = 1; p < ALLP_PARTS; p++) {
-        const float4 b = far.part_acc[(size_t)p * far.part_plane + (size_t)t * 64 + lane];
-        a.x += b.x; a.y += b.y; a.z += b.z;
+        for (int i = 0; i < NQ / 2; i++) {
+            qx[i] = v2f{sx[jj + 2 * i], sx[jj + 2 * i + 1]};
+            qy[i] = v2f{sy[jj + 2 * i], sy[jj + 2 * i + 1]};
+            qz[i] = v2f{sz[jj + 2 * i], sz[jj + 2 * i + 1]};
+            qw[i] = v2f{sw[jj + 2 * i], sw[jj + 2 * i + 1]};
+        }
+        if (MODE == 1) pairsN_exact_lean<NQ>(P, ctx, qx, qy, qz, qw, 0, nullptr, nullptr, ax, ay, az, flag);
+        else (void)pairsN_fast<NQ>(ctx, qx, qy, qz, qw, eps2f, ax, ay, az);
     }
-    force4[gi] = make_float4(a.x, a.y, a.z, __int_as_float(0));     // (on the active list: flag 0, not a kid)
+    for (; jj < n; jj++) {
+        const float4 q = make_float4(sx[jj], sy[jj], sz[jj], sw[jj]);
+        if (MODE == 1) pair1_exact_lean(P, ctx, q, 0, nullptr, nullptr, ax, ay, az, flag);
+        else (void)pair_fast(ctx.xi, ctx.yi, ctx.zi, q, eps2f, ax, ay, az);
+    }
+}
+
+template <int MODE, int NQ>
+__global__ __launch_bounds__(256, PSAMD_BALANCED_WAVES) void k_allp_far(DevParams P, const SnapSoa snap4, const int *__restrict__ act_start,
+                                                                        const int *__restrict__ dense_gi, const int *__restrict__ dense_cell,
+                                                                        const FarCells far, const float *__restrict__ far_buf,
+                                                                        const int *__restrict__ far_start, const int *__restrict__ far_n)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n_act = act_start[comp_count(P)];
+    const int ntask = min((n_act + 63) >> 6, (int)(far.part_plane >> 6));      // (the partial sums' room: never short, see capi.hip)
+    const int nitem = ntask * ALLP_PARTS, nwg = (nitem + 3) >> 2;
+    // (the launch is sized from the host's bound of the live count, the items from the device's own count: a launch
+    // that is too small for them -- it should not be -- takes several rounds instead of leaving particles out)
+    for (int b = blockIdx.x; b < nwg; b += gridDim.x) {
+    // part-major: an XCD's contiguous eighth of the items is two parts -- an eighth of the far bodies, which then sit in its L2
+    const int slot = xcd_contiguous(b, nwg) * 4 + wave;
+    if (slot >= nitem) continue;
+    const int part = slot / ntask, T = slot - part * ntask;
+    const int r = T * 64 + lane;
+    const bool valid = r < n_act;
+    const int rr = valid ? r : T * 64;                      // (a lane past the end rides along on the task's first particle; nothing of it is stored)
+    const int gi = dense_gi[rr], c = dense_cell[rr];
+    const float4 me = snap4[gi];
+    int i1, i2, i3;
+    cell_coords(P, c, i1, i2, i3);
+    const PairCtx ctx = {me.x, me.y, me.z, 0.f, 0, gi, false};
+    const float eps2f = (float)P.eps2;
+    const size_t plane = (size_t)far.plane;
+    const int nblk = (P.num_cells_global + 63) >> 6, GG = P.G * P.G;
+    const int blk_lo = nblk * part / ALLP_PARTS, blk_hi = nblk * (part + 1) / ALLP_PARTS;
+    float px = 0.f, py = 0.f, pz = 0.f;                     // the part's sum
+    for (int blk = blk_lo; blk < blk_hi; blk++) {
+        // the block's 64 cell ranges in one vector load, lane = cell (a scalar load per cell, and the body loads
+        // behind it, were two dependent round trips for 64 bodies of work); with each cell's grid coordinates
+        const int c2 = blk * 64 + lane;
+        int f_nb = 0, f_cnt = 0, f_j = 0;
+        if (c2 < P.num_cells_global) {
+            const int j3 = c2 / GG, rem = c2 - j3 * GG, j1 = rem / P.G, j2 = rem - j1 * P.G;
+            f_nb = far_start[c2];
+            f_cnt = far_n ? far_n[c2] : min(far_start[c2 + 1] - f_nb, P.max_per_cell);
+            f_j = (j3 << 20) | (j1 << 10) | j2;
+        }
+        for (int q0 = 0; q0 < 64; q0 += ALLP_CHUNK) {
+            int n[ALLP_CHUNK], nb[ALLP_CHUNK];
+            int total = 0, first = 0;
+            bool adjacent = true, hit[ALLP_CHUNK], any_hit = false;
+#pragma unroll
+            for (int q = 0; q < ALLP_CHUNK; q++) {
+                n[q] = __builtin_amdgcn_readlane(f_cnt, q0 + q);
+                nb[q] = __builtin_amdgcn_readlane(f_nb, q0 + q);
+                const int j = __builtin_amdgcn_readlane(f_j, q0 + q);
+                if (n[q] > 0) {
+                    if (total == 0) first = nb[q]; else adjacent = adjacent && nb[q] == first + total;
+                    total += n[q];
+                }
+                hit[q] = n[q] > 0 && abs((j >> 20) - i3) <= 1 && abs(((j >> 10) & 1023) - i1) <= 1 && abs((j & 1023) - i2) <= 1;
+                any_hit |= hit[q];
+            }
+            if (total == 0) continue;
+            float ax = 0.f, ay = 0.f, az = 0.f;
+            if (adjacent && !__any(any_hit)) {
+                const float *sx = far_buf + first;
+                walk_far<MODE, NQ>(P, ctx, sx, sx + plane, sx + 2 * plane, sx + 3 * plane, total, eps2f, ax, ay, az);
+            } else {
+#pragma unroll
+                for (int q = 0; q < ALLP_CHUNK; q++) {
+                    if (n[q] == 0) continue;
+                    const float kx = ax, ky = ay, kz = az;
+                    const float *sx = far_buf + nb[q];
+                    walk_far<MODE, NQ>(P, ctx, sx, sx + plane, sx + 2 * plane, sx + 3 * plane, n[q], eps2f, ax, ay, az);
+                    if (hit[q]) { ax = kx; ay = ky; az = kz; }      // a cell of this lane's own stencil: the cutoff pass has it
+                }
+            }
+            px += ax; py += ay; pz += az;
+        }
+    }
+    if (valid) far.part_acc[(size_t)part * far.part_plane + (size_t)r] = make_float4(px, py, pz, 0.f);
+    }
+}
+
+// All-pairs: a particle's acceleration = (((stencil chain + part 0) + part 1) + ...) + part 15, the same
+// association on one GPU and on any number of ranks.  One thread per particle that needs a force, in the dense order.
+__global__ void k_allpairs_combine(DevParams P, const int *__restrict__ act_start, const int *__restrict__ dense_gi,
+                                   const FarCells far, float4 *__restrict__ force4)
+{
+    const int n = min(act_start[comp_count(P)], (int)far.part_plane);
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const int gi = dense_gi[r];
+        float4 a = force4[gi];                              // (flag 0, not a kid: it is on the active list)
+#pragma unroll
+        for (int p = 0; p < ALLP_PARTS; p++) {
+            const float4 b = far.part_acc[(size_t)p * far.part_plane + (size_t)r];
+            a.x += b.x; a.y += b.y; a.z += b.z;
+        }
+        force4[gi] = a;
+    }
 }
 
 constexpr int MERGE_TILE = 4 * 64 + 4;          // floats per lane group: x[64] y[64] z[64] w[64] + skew
@@ -1527,9 +1629,9 @@ __global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : WALK == 1 ?
             if (t < nord) pairs_task_tile<MODE, NQ, 1, WALK != 1>(P, cell_start, snap4, force4, G, tiles[wave], active_list, k0, k1, task_ready + t, fs);
             else pairs_task_tile<MODE, NQ, 4, WALK != 1>(P, cell_start, snap4, force4, G, tiles[wave], active_list, k0, k1, task_ready + t, fs);
         } else
-            pairs_task<MODE, NQ, false, true>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, task_list[t], nullptr, trace,
-                                              active_list, active_count, k0, k1, task_ready + t, fs, FarCells(), 0, 0, nullptr, nullptr, nullptr,
-                                              WALK == 0 ? &pace : nullptr);          // (per_tick == 0: no pacing)
+            pairs_task<MODE, NQ, true>(P, cell_start, snap4, snap_soa, snap_age, sorted_id, force4, task_list[t], nullptr, trace,
+                                       active_list, active_count, k0, k1, task_ready + t, fs,
+                                       WALK == 0 ? &pace : nullptr);          // (per_tick == 0: no pacing)
     }
 }
 
@@ -1740,8 +1842,8 @@ static PairShape pair_shape(const DevParams &P, bool lean, int64_t hint)
     static const bool merge_off = std::getenv("PSAMD_NO_MERGE") != nullptr;
     static const bool balance_off = std::getenv("PSAMD_NO_BALANCE") != nullptr;
     static const int waves_env = std::getenv("PSAMD_WAVES") ? std::atoi(std::getenv("PSAMD_WAVES")) : 0;
-    s.merge = s.two && !merge_off && (P.world == 1 || tasks_hint >= 3000) && !(P.flags & PSAMD_FLAG_ALL_PAIRS);   // (the merged kernel walks the stencil only)
-    s.balanced = s.two && !balance_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS);
+    s.merge = s.two && !merge_off && (P.world == 1 || tasks_hint >= 3000);
+    s.balanced = s.two && !balance_off;
     // Balanced pass: a fixed number of waves, all resident, each walking the same number of
     // bodies.  At least four per SIMD when there are that many tasks (fewer cannot cover their
     // scalar-load latency: 1024 / 2048 / 4096 / 6144 waves took 3.73 / 2.54 / 2.27 / 2.29 ms on
@@ -1768,7 +1870,7 @@ static PairShape pair_shape(const DevParams &P, bool lean, int64_t hint)
     // that use the scalar walk, beside the pass on one GPU, none with the tile walk.
     // (Round 4: with persistent pack workgroups sized by the packs' share of the work and the waves paced, a slab of two
     // is served better by the one-GPU form too -- pair stage 1.32 -> 1.12 ms -- so the packs are in the list only on request.)
-    s.packs_in_list = s.balanced && !merge_off && !(P.flags & PSAMD_FLAG_ALL_PAIRS) && (s.tile ? tile_packs : (s.merge && unified_packs));
+    s.packs_in_list = s.balanced && !merge_off && (s.tile ? tile_packs : (s.merge && unified_packs));
     if (s.packs_in_list) { s.merge = false; s.nw = std::min(s.nw, 4096); }      // (98 VGPRs with the tile walk in: 4 resident waves per SIMD)
     if (s.tile) s.merge = false;                  // no separate merged kernel beside a tile-walk pass
     // The packs' workgroups are the first of the same launch and hold residency slots for about half of it: with
@@ -1804,7 +1906,7 @@ uint64_t launch_pairs_shape(const DevParams &P, int64_t tasks_hint)
 }
 
 template <int MODE, int NQ>
-static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint, int pass)
+static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint, int pass, int64_t live_bound)
 {
     const int ncomp = comp_count(P);
     if (ncomp <= 0) return hipSuccess;
@@ -1841,39 +1943,44 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
 #undef PS_BALANCED
     }
     else {
-        FarCells far;
-        // where the all-pairs walk finds the cells beyond the stencil: the own snapshot (one GPU: local cell == global cell,
-        // lengths from consecutive starts) or the all-gathered snapshot of all ranks with its index by global cell
-        const bool gathered = (P.flags & PSAMD_FLAG_ALL_PAIRS) && P.world > 1;
-        const float *far_buf = gathered ? reinterpret_cast<const float *>(d.allg_in) : d.snap_soa;
-        const int *far_start = gathered ? d.gstart : d.cell_start, *far_n = gathered ? d.gn : nullptr;
-        far.plane = gathered ? (unsigned long long)P.allg_cap : (unsigned long long)P.sorted_cap;
-        far.part_acc = d.part_acc; far.part_plane = (unsigned long long)d.part_tasks * 64;
-        if (MODE != 0 && (P.flags & PSAMD_FLAG_ALL_PAIRS)) {
-            // (two == true here: all-pairs contexts are created only with the two-pass pair stage)
-            const int items = std::min(tasks, d.part_tasks) * ALLP_PARTS;
-            k_pairs<MODE, NQ, MODE != 0><<<(items + 3) / 4, 256, 0, st>>>(P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
-                                                                        d.fs, d.trace, active_list, active_count, far, far_buf, far_start, far_n);
-            k_allpairs_combine<<<(std::min(tasks, d.part_tasks) * 64 + 255) / 256, 256, 0, st>>>(P, d.cell_start, task_list, active_list, active_count, far, d.force4, d.fs);
-        } else
-            k_pairs<MODE, NQ, false><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
-                                                                      d.fs, d.trace, active_list, active_count, far, nullptr, nullptr, nullptr);
+        k_pairs<MODE, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
+                                                         d.fs, d.trace, active_list, active_count);
         // (unbalanced pass, A/B runs only: the packs as a kernel of their own behind it)
         if (merge) k_pairs_merged<MODE == 0 ? 1 : MODE, NQ><<<(ncomp + 3) / 4, 256, 0, st>>>(
                 P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
     }
+    if (MODE != 0 && (P.flags & PSAMD_FLAG_ALL_PAIRS)) {
+        // All-pairs forces: what ran above is the stencil's chain; now every other cell (k_allp_far) and the sum.
+        // (two == true here: all-pairs contexts are created only with the two-pass pair stage.)  Where the far cells are
+        // found: the own snapshot (one GPU: local cell == global cell, lengths from consecutive starts) or the
+        // all-gathered snapshot of all ranks with its index by global cell.
+        FarCells far;
+        const bool gathered = P.world > 1;
+        const float *far_buf = gathered ? reinterpret_cast<const float *>(d.allg_in) : d.snap_soa;
+        const int *far_start = gathered ? d.gstart : d.cell_start, *far_n = gathered ? d.gn : nullptr;
+        far.plane = gathered ? (unsigned long long)P.allg_cap : (unsigned long long)P.sorted_cap;
+        far.part_acc = d.part_acc; far.part_plane = (unsigned long long)d.part_tasks * 64;
+        // dense tasks: at most the particles alive (the host's bound; a slab also computes its neighbour's lent layers:
+        // every entry of the sorted order).  The kernels go by the device's own count.
+        const int64_t dense_bound = std::min<int64_t>(d.part_tasks, ((live_bound >= 0 && P.world == 1) ? live_bound : (int64_t)P.sorted_cap) / 64 + 2);
+        k_allp_prefix<<<1, 1024, 0, st>>>(P, d.active_count, d.act_start);
+        k_allp_dense<<<(ncomp + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.active_list, d.active_count, d.act_start, d.dense_gi, d.dense_cell);
+        k_allp_far<MODE == 0 ? 1 : MODE, NQ><<<(unsigned)((dense_bound * ALLP_PARTS + 3) / 4), 256, 0, st>>>(P, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.act_start, d.dense_gi, d.dense_cell,
+                                                                                                  far, far_buf, far_start, far_n);
+        k_allpairs_combine<<<(unsigned)((dense_bound * 64 + 255) / 256), 256, 0, st>>>(P, d.act_start, d.dense_gi, far, d.force4);
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint, int pass)
+hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t ev_force, int64_t tasks_hint, int pass, int64_t live_bound)
 {
     // fast math shares the lean modes' validity range (finite 1/sqrt(eps2^3))
     static const int fast_nq = std::getenv("PSAMD_FAST_NQ") ? std::atoi(std::getenv("PSAMD_FAST_NQ")) : 8;      // (A/B runs)
     if ((P.flags & PSAMD_FLAG_FAST_MATH) && P.lean_math)
-        return fast_nq == 4 ? launch_pairs_mode<2, 4>(st, P, d, ev_force, tasks_hint, pass) : launch_pairs_mode<2, 8>(st, P, d, ev_force, tasks_hint, pass);
+        return fast_nq == 4 ? launch_pairs_mode<2, 4>(st, P, d, ev_force, tasks_hint, pass, live_bound) : launch_pairs_mode<2, 8>(st, P, d, ev_force, tasks_hint, pass, live_bound);
     // 8 pairs per slow-branch test: measured 3 % (full GPU) to 5 % (a 1/8 share) faster than 4
-    if (P.lean_math) return launch_pairs_mode<1, 8>(st, P, d, ev_force, tasks_hint, pass);
-    return launch_pairs_mode<0, 4>(st, P, d, ev_force, tasks_hint, pass);
+    if (P.lean_math) return launch_pairs_mode<1, 8>(st, P, d, ev_force, tasks_hint, pass, live_bound);
+    return launch_pairs_mode<0, 4>(st, P, d, ev_force, tasks_hint, pass, live_bound);
 }
 
 }  // namespace psamd

@@ -388,7 +388,7 @@ def sim_world(args, ps, cfg_over, flags):
            "message_bytes_rank1": msg[min(1, W - 1)], "halo_cap_cell": int(args.halo_cap_cell),
            "modelled_step_ms": step_hi, "modelled_step_ms_optimistic": step_lo,
            "modelled_updates_per_s": updates / (step_hi * 1e-3), "updates_per_step": updates, "timed_steps": args.steps,
-           "all_pairs": bool(args.all_pairs),
+           "all_pairs": bool(args.all_pairs), "max_ops_one_queue_per_rank": [int(g.counters["max_ops_one_queue"]) for g in ranks],
            "note": "one GPU runs the ranks one after the other; compute times are measured (HIP events); a transfer is modelled "
                    "as 10 us + bytes / %.0f GB/s (halo up, force, the two xfer messages in parallel; the all-pairs snapshot "
                    "all-gather as a ring of W - 1 such hops); the halo overlaps the interior pass, the rest is not overlapped.  "

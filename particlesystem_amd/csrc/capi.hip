@@ -64,6 +64,7 @@ struct psamd_ctx {
     FrameScalars *h_fs = nullptr;     // pinned host copy of the per-frame scalars
     int64_t processed_total = 0;      // sum over steps of the live particles at build_grid
     int64_t max_bucket_seen = 0;
+    int bucket_cap0 = 2048;           // the longest operation list the step's first replay instance takes (2048, or 4096 on the last step's hint)
     char *snapshot = nullptr;         // device image for snapshot_save / _restore
     int snapshot_step = 0;
     void *staging = nullptr;          // device staging for AoS transfers
@@ -1112,13 +1113,22 @@ static int64_t lifecycle_bound(const psamd_ctx *c, int64_t bound)
 // free-slot queues and relocation, the part enqueued without waiting for the host (in slab mode: after the
 // arrivals were merged in): census, bucketing -- the last bucketing workgroup hands the step's scalars to the
 // host's pinned record -- and the replay of the usual lists
+// Which instance replays the usual lists this step: the last step's longest list is the hint (lists longer than the
+// choice still get the long-list instance once the host has this step's scalars, so a wrong hint only costs time).
+static uint64_t pick_bucket_cap(psamd_ctx *c)
+{
+    const int last = c->steps_total > 0 ? c->h_fs->max_bucket : 0;
+    c->bucket_cap0 = (last > 2048 && last <= 4096) ? 4096 : 2048;
+    return c->bucket_cap0 > 2048 ? 1ull << 62 : 0ull;       // (part of a captured graph's key)
+}
+
 static int enq_lifecycle(psamd_ctx *c, int64_t bound)
 {
     const int par = (int)(c->steps_total & 1);   // not c->step: a snapshot restore rewinds that
     if (c->timing_now) { collect_lifecycle_time(c, par); (void)hipEventRecord(c->ev[par ? 11 : 8], c->stream); }
     if (c->P.world > 1) PS_HIP(c, launch_inbox_merge(c->stream, c->P, c->d, c->xfer_in));
     PS_HIP(c, launch_ops_bucket(c->stream, c->P, c->d, c->geo.queue_infos, lifecycle_bound(c, bound)));
-    PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->geo.queue_infos, lifecycle_bound(c, bound), 0, false));
+    PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->geo.queue_infos, lifecycle_bound(c, bound), 0, false, c->bucket_cap0));
     return PSAMD_OK;
 }
 
@@ -1240,7 +1250,7 @@ static int finish_step(psamd_ctx *c, int64_t bound)
         PS_HIP(c, launch_lifecycle_sorted(c->stream, c->P, c->d, c->geo.queue_infos, c->h_fs->n_ops, c->h_fs->n_moves));
     else                                       // the long lists' instance if there is one (launched only then: the host's copy of
                                                // max_bucket is the device's), and the commit (the replay above is still running)
-        PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->geo.queue_infos, lifecycle_bound(c, bound), 1, c->h_fs->max_bucket > 2048));
+        PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->geo.queue_infos, lifecycle_bound(c, bound), 1, c->h_fs->max_bucket > c->bucket_cap0, c->bucket_cap0));
     if (c->timing_now) {
         // No wait for the end of the step: everything up to `apply` was complete when the
         // scalars landed; the life-cycle interval is read one step later (or by get_timing).
@@ -1301,6 +1311,7 @@ int psamd_calc_forces_apply(psamd_ctx *c)
     if (c->P.world > 1) return slab_only(c, "calc_forces");
     if (!c->grid_built || !c->pairs_done) return fail(c, PSAMD_ERR_STATE, "apply needs build_grid and the pair pass first");
     const int64_t bound = live_bound_of(c);
+    (void)pick_bucket_cap(c);
     int rc = enq_apply(c, bound);
     if (rc == PSAMD_OK) rc = enq_lifecycle(c, bound);
     if (rc != PSAMD_OK) return rc;
@@ -1323,7 +1334,7 @@ int psamd_step(psamd_ctx *c, int32_t nsteps)
         // init_iframe, build_grid, calc_forces up to the step's read-back: one sequence of launches (one graph)
         begin_step(c);
         const int64_t hint = pairs_hint(c, c->P), bound = live_bound_of(c);
-        const uint64_t key = launch_pairs_shape(c->P, hint) | ((uint64_t)bound << 24);
+        const uint64_t key = launch_pairs_shape(c->P, hint) | ((uint64_t)bound << 24) | pick_bucket_cap(c);
         int rc = run_segment(c, SEG_STEP, key, [&]() {
             int r = enq_init_iframe(c);
             if (r == PSAMD_OK) r = enq_build_grid(c);
@@ -1425,7 +1436,7 @@ int psamd_slab_finish(psamd_ctx *c)
     if (c->slab_stage != 3) return fail(c, PSAMD_ERR_STATE, "slab_finish needs slab_apply (and the transfer exchange) first");
     c->slab_stage = 0;
     const int64_t bound = c->slab_bound;
-    const int rc = run_segment(c, SEG_FINISH, (uint64_t)bound, [&]() { return enq_lifecycle(c, bound); });
+    const int rc = run_segment(c, SEG_FINISH, (uint64_t)bound | pick_bucket_cap(c), [&]() { return enq_lifecycle(c, bound); });
     if (rc != PSAMD_OK) return rc;
     return finish_step(c, bound);
 }

@@ -116,7 +116,7 @@ hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame
 // the bucketed life cycle, sized from a bound of the live count: bucket the operations (afterwards the
 // frame scalars are complete), then replay + relocation
 hipError_t launch_ops_bucket(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_bound);
-hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_bound, int part, bool long_lists);
+hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_bound, int part, bool long_lists, int cap0);
 hipError_t launch_lifecycle_sorted(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec,
                                    int n_ops, int n_moves);
 // slab exchange (messages are int arrays with a 16-word header, see kernels.hip)

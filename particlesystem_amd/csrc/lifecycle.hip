@@ -367,11 +367,14 @@ __device__ __forceinline__ void moves_stage_reset(const DevParams &P, int m, Mov
     cell_arr[si] = -1; pflags[si] = 0; pos4[si] = zero; vel4[si] = zero; acc4[si] = zero;
 }
 
-// CAP: the longest list this instance holds in LDS.  Two instances: CAP = 2048 (27 KB of LDS: five
-// workgroups per CU, every queue of the usual step at once) serves the queues with up to 2048 operations and is
-// launched every step; CAP = BUCKET_MAX (104 KB, one workgroup per CU) the longer lists -- launched by the HOST
-// only in a step whose scalars show such a list (launch_lifecycle part 1: h_fs->max_bucket > 2048; the host's copy
-// of the scalars is the device's, so its test agrees with the kernel's own `fs->max_bucket <= 2048` backstop).
+// CAP: the longest list this instance holds in LDS; it serves the queues with more than `lo` and at most CAP
+// operations.  The instance launched every step, one workgroup per queue, has CAP = 2048 (27 KB of LDS: five
+// workgroups per CU, every queue of the usual step at once) -- or CAP = 4096 (54 KB, two per CU) when the LAST step's
+// longest list lay between the two (the host's hint: a cloud whose surface implodes keeps a queue or two of the end
+// ranks at 2 400-2 700 operations, N = 2^22 on eight ranks, and the long-list instance behind the usual one cost those
+// ranks 55 us a step).  CAP = BUCKET_MAX (104 KB, one workgroup per CU) takes what is longer than that -- launched by
+// the HOST only in a step whose scalars show such a list (launch_lifecycle part 1: h_fs->max_bucket > the step's
+// first cap; the host's copy of the scalars is the device's, so its test agrees with the kernel's own backstop).
 // (One instance sized for the longest list ran one workgroup per CU for every queue: 66 us instead of 36.)
 template <int CAP>
 __device__ __forceinline__ void replay_record(const DevParams &P, const int rec, const int *__restrict__ rec_start,
@@ -381,7 +384,7 @@ __device__ __forceinline__ void replay_record(const DevParams &P, const int rec,
                                                         DevCounters *ctr, const FrameScalars *__restrict__ fs,
                                                         unsigned long long *trace,
                                                         float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr, uint8_t *pflags,
-                                                        float4 *stage)
+                                                        float4 *stage, const int lo)
 {
 #ifdef PSAMD_REPLAY_TRACE
     unsigned long long tk[6]; int ti = 0;
@@ -392,8 +395,7 @@ __device__ __forceinline__ void replay_record(const DevParams &P, const int rec,
     RT();
     // keys + args while sorting; afterwards the same bytes hold ins_arg (closed form) or the
     // copy of the segment the serial walk works on
-    constexpr int RANK_MAX = 2048;
-    static_assert(CAP == RANK_MAX || CAP == BUCKET_MAX, "two instances: short lists, long lists");
+    static_assert(CAP == 2048 || CAP == 4096 || CAP == BUCKET_MAX, "three instances: the usual lists (two sizes), long lists");
     constexpr int KEY_BYTES = (CAP + 64) * 8, SORT_BYTES = KEY_BYTES + CAP * 4;
     constexpr int RAW_BYTES = SORT_BYTES;
     constexpr int WINDOW_SLOTS = KEY_BYTES / 4;         // largest segment the serial walk copies into the key area (4224 / 16512 slots)
@@ -412,7 +414,7 @@ __device__ __forceinline__ void replay_record(const DevParams &P, const int rec,
     if (lifecycle_deferred(fs)) return;
     const int start = rec_start[rec];
     const int n = min(rec_start[rec + 1] - start, BUCKET_MAX);
-    if (n == 0 || (CAP == RANK_MAX ? n > RANK_MAX : n <= RANK_MAX)) return;       // (the other instance's)
+    if (n == 0 || n <= lo || n > CAP) return;           // (another instance's)
     QueueInfo q = qinfo[rec];
     const bool in_lds = q.seg_size <= WINDOW_SLOTS;
     queue += slot_index(P, q.rloc) - q.rloc;           // owned segments only, back to back
@@ -420,7 +422,7 @@ __device__ __forceinline__ void replay_record(const DevParams &P, const int rec,
     // operation's place in the bucket packed in below it -- one 8-byte word per operation, its argument fetched
     // through that place once the order is known.  (With the arguments carried along as a second array every
     // exchange moved 24 bytes instead of 16; the sort is bound by LDS bandwidth, five workgroups to a CU.)
-    constexpr int IDX_BITS = CAP == RANK_MAX ? 11 : 13;
+    constexpr int IDX_BITS = CAP == 2048 ? 11 : CAP == 4096 ? 12 : 13;
     static_assert((1 << IDX_BITS) >= CAP, "an operation's place in the bucket must fit");
     const bool packed_keys = P.key_rec_shift + IDX_BITS <= 64;              // (else, a geometry with > 2^51 (chunk, id) pairs: keys and arguments side by side)
     const uint64_t low_mask = P.key_rec_shift >= 64 ? ~0ull : ((1ull << P.key_rec_shift) - 1ull);
@@ -590,29 +592,29 @@ __device__ __forceinline__ void replay_record(const DevParams &P, const int rec,
 #undef RT
 }
 
-// The instance for the usual lists runs one workgroup per queue record (and the first relocation phase in the
-// workgroups past them); the one for long lists -- launched only in a step that has one, see above -- strides
-// over the records with a few workgroups.
-template <int CAP>
+// The instance for the usual lists (PER_RECORD) runs one workgroup per queue record (and the first relocation phase
+// in the workgroups past them); the one for long lists -- launched only in a step that has one, see above --
+// strides over the records with a few workgroups.
+template <int CAP, bool PER_RECORD>
 __global__ __launch_bounds__(REPLAY_THREADS) void k_replay_bucket(DevParams P, int nrec, const int *__restrict__ rec_start,
                                                         const uint64_t *__restrict__ keys, const int *__restrict__ args,
                                                         QueueInfo *qinfo, int *queue, MoveRec *moves,
                                                         DevCounters *ctr, const FrameScalars *__restrict__ fs,
                                                         unsigned long long *trace,
                                                         float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr, uint8_t *pflags,
-                                                        float4 *stage)
+                                                        float4 *stage, int lo)
 {
-    if (CAP == 2048) {
+    if (PER_RECORD) {
         if ((int)blockIdx.x >= nrec) {
             moves_stage_reset(P, ((int)blockIdx.x - nrec) * REPLAY_THREADS + (int)threadIdx.x, moves, fs, pos4, vel4, acc4, cell_arr, pflags, stage);
             return;
         }
-        replay_record<CAP>(P, (int)blockIdx.x, rec_start, keys, args, qinfo, queue, moves, ctr, fs, trace, pos4, vel4, acc4, cell_arr, pflags, stage);
+        replay_record<CAP>(P, (int)blockIdx.x, rec_start, keys, args, qinfo, queue, moves, ctr, fs, trace, pos4, vel4, acc4, cell_arr, pflags, stage, lo);
         return;
     }
-    if (fs->max_bucket <= 2048) return;
+    if (fs->max_bucket <= lo) return;
     for (int rec = blockIdx.x; rec < nrec; rec += gridDim.x) {
-        replay_record<CAP>(P, rec, rec_start, keys, args, qinfo, queue, moves, ctr, fs, trace, pos4, vel4, acc4, cell_arr, pflags, stage);
+        replay_record<CAP>(P, rec, rec_start, keys, args, qinfo, queue, moves, ctr, fs, trace, pos4, vel4, acc4, cell_arr, pflags, stage, lo);
         __syncthreads();
     }
 }
@@ -741,23 +743,28 @@ hipError_t launch_ops_bucket(hipStream_t st, const DevParams &P, const DeviceSta
     return hipSuccess;
 }
 
-// part 0: the replay of the usual lists (with the first relocation phase), enqueued without waiting for the host;
+// part 0: the replay of the usual lists (with the first relocation phase), enqueued without waiting for the host --
+// lists of up to `cap0` operations, 2048 or 4096 (the host's hint from the last step);
 // part 1, once the host has the step's scalars (they are out before part 0 starts running): the instance for
-// long lists only if some queue got more than 2048 operations (`long_lists`), and the commit.  (The long-list
+// long lists only if some queue got more than cap0 operations (`long_lists`), and the commit.  (The long-list
 // instance used to be launched every step and leave at once: ~4.5 us on the timeline for nothing.)
-hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_bound, int part, bool long_lists)
+hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_bound, int part, bool long_lists, int cap0)
 {
     const int64_t max_moves = std::min<int64_t>(d.moves_cap, 2 * live_bound);
     const int nb = (int)((max_moves + REPLAY_THREADS - 1) / REPLAY_THREADS);
     if (part == 0) {
-        k_replay_bucket<2048><<<nrec + nb, REPLAY_THREADS, 0, st>>>(P, nrec, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
-                                              d.moves, d.ctr, d.fs, d.trace, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
+        if (cap0 > 2048)
+            k_replay_bucket<4096, true><<<nrec + nb, REPLAY_THREADS, 0, st>>>(P, nrec, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
+                                                  d.moves, d.ctr, d.fs, d.trace, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage, 0);
+        else
+            k_replay_bucket<2048, true><<<nrec + nb, REPLAY_THREADS, 0, st>>>(P, nrec, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
+                                                  d.moves, d.ctr, d.fs, d.trace, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage, 0);
         PS_LAUNCH_CHECK();
         return hipSuccess;
     }
     if (long_lists) {
-        k_replay_bucket<BUCKET_MAX><<<std::min(nrec, 256), REPLAY_THREADS, 0, st>>>(P, nrec, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
-                                              d.moves, d.ctr, d.fs, d.trace, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage);
+        k_replay_bucket<BUCKET_MAX, false><<<std::min(nrec, 256), REPLAY_THREADS, 0, st>>>(P, nrec, d.rec_start, d.op_keys_sorted, d.op_args_sorted, d.qinfo, d.queue,
+                                              d.moves, d.ctr, d.fs, d.trace, d.pos4, d.vel4, d.acc4, d.cell, d.pflags, d.stage, cap0 > 2048 ? 4096 : 2048);
         PS_LAUNCH_CHECK();
     }
     if (nb > 0) {

@@ -152,11 +152,17 @@ __global__ __launch_bounds__(1024) void k_halo_prefix_in(DevParams P, HaloIn2 H,
     }
 }
 
+// One workgroup per cell of the messages.  Two-pass pair stage (`lists`): the cell then lists its bodies in the
+// halos of the cells around it, like k_sort_cells does for the own cells -- the workgroup has just written them
+// (this was a launch of its own, k_remote_halo_lists: 15-20 us of a rank-step for a few microseconds of work).
 __global__ __launch_bounds__(256) void k_halo_bodies_in(DevParams P, HaloIn2 H,
                                                          const int *__restrict__ cell_start,
-                                                         float *__restrict__ snap_soa, float *__restrict__ snap_age,
-                                                         int *__restrict__ sorted_id, int *__restrict__ snap_cid)
+                                                         float *snap_soa, float *__restrict__ snap_age,
+                                                         int *__restrict__ sorted_id, int *snap_cid, int lists,
+                                                         int *__restrict__ halo_count, float *__restrict__ halo_f,
+                                                         int *__restrict__ halo_id)
 {
+    __shared__ int s_halo[27], s_halo_base[27];
     int j = blockIdx.x, k = 0;
     if (j >= H.h[0].ncell) { j -= H.h[0].ncell; k = 1; }
     const HaloIn h = H.h[k];
@@ -175,26 +181,9 @@ __global__ __launch_bounds__(256) void k_halo_bodies_in(DevParams P, HaloIn2 H,
         sorted_id[dst + e] = id;
         snap_cid[dst + e] = (!(age < P.kid_thr) && !(age > P.life_thr)) ? id : -1;
     }
-}
-
-// Remote cells list their bodies in the halos of the cells around them, like k_sort_cells
-// does for the own cells.  One workgroup per remote cell: the local cells [lo[i], hi[i]) of up to three regions.
-struct CellRanges3 { int lo[3], hi[3]; };
-__global__ __launch_bounds__(256) void k_remote_halo_lists(DevParams P, CellRanges3 R, const int *__restrict__ cell_start,
-                                                           const SnapSoa snap4, const int *__restrict__ snap_cid,
-                                                           int *__restrict__ halo_count, float *__restrict__ halo_f,
-                                                           int *__restrict__ halo_id)
-{
-    __shared__ int s_halo[27], s_halo_base[27];
-    int b = blockIdx.x, c = -1;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const int n = R.hi[i] - R.lo[i];
-        if (c < 0 && n > 0) { if (b < n) c = R.lo[i] + b; else b -= n; }
-    }
-    if (c < 0) return;
-    const int start = cell_start[c], n = min(cell_start[c + 1] - start, P.max_per_cell);
-    list_in_neighbour_halos(P, c, start, max(n, 0), snap4, snap_cid, halo_count, halo_f, halo_id, s_halo, s_halo_base, false);
+    if (!lists) return;
+    __syncthreads();                    // the cell's bodies, as written above, for every thread of the workgroup
+    list_in_neighbour_halos(P, lc, dst, max(n, 0), SnapSoa{snap_soa, sc}, snap_cid, halo_count, halo_f, halo_id, s_halo, s_halo_base, false);
 }
 
 // The force records of the lent layers go back as header + float4[bodies], in the order their
@@ -436,29 +425,21 @@ hipError_t launch_unpack_halos(hipStream_t st, const DevParams &P, const DeviceS
 {
     const int GG = P.G * P.G;
     HaloIn2 H{};
-    CellRanges3 R{};
-    int nr = 0;
     if (ncell_below > 0) {
         const int split = P.reg_layers[1] * GG;
         H.h[H.n++] = HaloIn{P.reg_base[1], P.reg_base[2], ncell_below, split, P.reg_sorted[1], P.reg_sorted[2], P.reg_layers[2] > 0 ? 1 : 0, msg_below, off_below};
-        if (split > 0) { R.lo[nr] = P.reg_base[1]; R.hi[nr] = P.reg_base[1] + split; nr++; }
-        if (ncell_below > split) { R.lo[nr] = P.reg_base[2]; R.hi[nr] = P.reg_base[2] + ncell_below - split; nr++; }
     }
     if (ncell_above > 0) {
         H.h[H.n++] = HaloIn{P.reg_base[3], 0, ncell_above, ncell_above, P.reg_sorted[3], 0, 0, msg_above, off_above};
-        R.lo[nr] = P.reg_base[3]; R.hi[nr] = P.reg_base[3] + ncell_above; nr++;
     }
     if (H.n == 0) return hipSuccess;
     if (H.n == 1) H.h[1] = HaloIn{0, 0, 0, 0, 0, 0, 0, nullptr, nullptr};
     k_halo_prefix_in<<<H.n, 1024, 0, st>>>(P, H, d.cell_start, d.task_list, d.fs);
     PS_LAUNCH_CHECK();
     const int cells = H.h[0].ncell + H.h[1].ncell;
-    k_halo_bodies_in<<<cells, 256, 0, st>>>(P, H, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.snap_cid);
+    k_halo_bodies_in<<<cells, 256, 0, st>>>(P, H, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.snap_cid, P.two_pass ? 1 : 0,
+                                            d.halo_count, d.halo_f, d.halo_id);
     PS_LAUNCH_CHECK();
-    if (P.two_pass) {
-        k_remote_halo_lists<<<cells, 256, 0, st>>>(P, R, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_cid, d.halo_count, d.halo_f, d.halo_id);
-        PS_LAUNCH_CHECK();
-    }
     return hipSuccess;
 }
 

@@ -22,6 +22,8 @@ say "PMC SQ (tolerance mode)"
 bash scripts/pmc_bench.sh r4art_fast_sq "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE" --fast-math --steps 3 --warmup 2 --settle-seconds 0 --no-side-runs > $out/pmc_fast_sq.log 2>&1
 say "all-pairs (configs[1])"
 python bench.py --all-pairs --steps 10 --warmup 3 > $out/allpairs_line.json 2> $out/allpairs_line.err
+say "kernel stats (all-pairs)"
+bash scripts/profile_bench.sh r4art_allpairs --all-pairs --steps 5 --warmup 2 --settle-seconds 0 --no-side-runs > $out/prof_allpairs.log 2>&1
 say "projections, N = 2^20"
 python bench.py --no-cpu --no-side-runs --steps 30 --warmup 5 > $out/one_n20_s30.json 2> /dev/null
 for w in 2 4 8; do python bench.py --sim-world $w --steps 30 --warmup 5 > $out/sim${w}_n20.json 2> $out/sim${w}_n20.err; done

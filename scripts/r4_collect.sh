@@ -20,6 +20,7 @@ last $g/prof_r4art_exact/bench_stdout.json > $p/r4_bench_under_rocprof.json
 cp $g/prof_r4art_fast/bench_kernel_stats.csv $p/r4_fast_kernel_stats.csv
 last $g/prof_r4art_fast/bench_stdout.json > $p/r4_fast_under_rocprof.json
 cp $g/prof_r4art_sim8/sim_kernel_stats.csv $p/r4_sim_world8_kernel_stats.csv
+cp $g/prof_r4art_allpairs/bench_kernel_stats.csv $p/r4_allpairs_kernel_stats.csv
 cp $g/pmc_r4art_fetch/pmc_counter_collection.csv $p/r4_pmc_fetch_size.csv
 cp $g/pmc_r4art_write/pmc_counter_collection.csv $p/r4_pmc_write_size.csv
 python scripts/make_traffic_json.py $p/r4_pmc_fetch_size.csv $p/r4_pmc_write_size.csv $p/r4_traffic.json

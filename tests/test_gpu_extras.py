@@ -186,6 +186,54 @@ def test_all_pairs_at_config1_size():
     g.close()
 
 
+@pytest.mark.parametrize("chunk_factor,chunk_dim,world", [(3, 4, 3), (3, 5, 3), (5, 3, 2)])
+def test_all_pairs_on_grids_that_are_no_multiple_of_four(chunk_factor, chunk_dim, world):
+    """The far walk takes four consecutive global cells as one chain of additions and 64-cell blocks as the unit of
+    its 16 parts: grids of 12^3 and 15^3 cells (chains straddle rows of the grid, the last block is ragged, a part
+    may hold no block at all) against an fp64 direct sum, and across slabs against one GPU, byte for byte."""
+    from particlesystem_amd.slab import merge_owned, step_local
+    over = dict(chunk_factor=chunk_factor, chunk_dim=chunk_dim)
+    G = chunk_factor * chunk_dim
+    n = 5000
+    rng = np.random.default_rng(300 + G)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    age[::19] = 0.5
+    fert = (1e6 + np.arange(n)).astype(np.float32)
+    g = ps.ParticleSystem(ps.default_config(flags=ps.FLAG_ALL_PAIRS, collision_radius=1e-6, **over))
+    xyz = g.uniform_cloud(n, 300 + G)                  # (an odd grid's box is not centred on the origin)
+    ids = g.fill_particles(xyz, age=age, fert_age=fert)
+    order, f = force_of(g, n)
+    pos = xyz.astype(np.float64)
+    kid = age < 1.5
+    d = pos[None, :, :] - pos[:, None, :]
+    r2 = (d * d).sum(2) + 0.2
+    sc = np.where(kid[None, :], 0.0, 60.0 / (r2 * np.sqrt(r2)))
+    np.fill_diagonal(sc, 0.0)
+    exact = (d * sc[:, :, None]).sum(1)
+    where = np.empty(g.sizes.container_size, np.int64)
+    where[ids] = np.arange(n)
+    idx = where[order]
+    adults = ~kid[idx]
+    got = f[:, :3].astype(np.float64)[adults]
+    want = exact[idx][adults]
+    rel = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
+    print("all-pairs on %d^3 cells vs fp64 direct sum: max relative deviation %.3g" % (G, rel.max()))
+    assert rel.max() < 1e-5
+    g.close()
+    one = ps.ParticleSystem(ps.default_config(flags=ps.FLAG_ALL_PAIRS, **over))
+    ranks = [ps.ParticleSystem(ps.default_config(flags=ps.FLAG_ALL_PAIRS, rank=r, world=world, **over)) for r in range(world)]
+    for s_ in [one] + ranks:
+        s_.fill_particles(xyz, age=age, fert_age=fert)
+    plans = [q.slab_plan() for q in ranks]
+    for step in range(4):
+        one.step(1)
+        step_local(ranks)
+        union = merge_owned([q.download_particles() for q in ranks], plans)
+        assert_same_particles(union, one.download_particles(), "all-pairs, %d^3 cells, %d slabs, step %d" % (G, world, step + 1))
+    for s_ in [one] + ranks:
+        s_.close()
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_all_pairs_across_slabs_equals_one_gpu(world):
     """SURVEY 8(e) row 1 / BASELINE configs[3]'s exchange: every rank contributes the snapshot of its

@@ -176,12 +176,14 @@ __device__ __forceinline__ void pairs_dist(const PairCtx &c, const v2f (&qx)[NQ 
 // throughput-bound (four or more waves per SIMD: -3.7 % on the N = 2^20 force pass); the two-
 // transcendental form has the shorter dependency chain and wins where a SIMD holds one or two waves
 // (a 1/8 slab's tile walk: 0.57 against 0.64 ms).
+// In two halves, so that a walk with a SIMD (almost) to itself can put the NEXT group's distances between them:
+// pairs_scale_exact -- every pair's w / d^3 (the branches are in here) -- and pairs_add, the ordered additions.
 template <int NQ, bool ONE_T>
-__device__ __forceinline__ void pairs_finish_exact(const DevParams &P, const PairCtx &c, const PairRows<NQ> &r,
-                                                   const v2f (&qw)[NQ / 2], int gj0,
-                                                   const float *__restrict__ snap_age,
-                                                   const int *__restrict__ sorted_id,
-                                                   float &ax, float &ay, float &az, int &flag)
+__device__ __forceinline__ void pairs_scale_exact(const DevParams &P, const PairCtx &c, const PairRows<NQ> &r,
+                                                  const v2f (&qw)[NQ / 2], int gj0,
+                                                  const float *__restrict__ snap_age,
+                                                  const int *__restrict__ sorted_id,
+                                                  v2f (&sc)[NQ / 2], int &flag)
 {
     constexpr int H = NQ / 2;
     v2f e[H];
@@ -215,7 +217,6 @@ __device__ __forceinline__ void pairs_finish_exact(const DevParams &P, const Pai
 #pragma unroll
         for (int i = 0; i < H; i++) e[i] = r.d[i] + eps;
     }
-    v2f sc[H];
     if (!ONE_T) {
 #pragma unroll
         for (int i = 0; i < H; i++) sc[i] = qw[i] * inv_sqrt_selected2(e[i] * e[i] * e[i]);
@@ -235,12 +236,29 @@ __device__ __forceinline__ void pairs_finish_exact(const DevParams &P, const Pai
 #pragma unroll
         for (int i = 0; i < H; i++) sc[i] = qw[i] * sc[i];
     }
+}
+
+template <int NQ>
+__device__ __forceinline__ void pairs_add(const PairRows<NQ> &r, const v2f (&sc)[NQ / 2], float &ax, float &ay, float &az)
+{
 #pragma unroll
-    for (int i = 0; i < H; i++) {                       // sums in list order
+    for (int i = 0; i < NQ / 2; i++) {                  // sums in list order
         const v2f px = r.rx[i] * sc[i], py = r.ry[i] * sc[i], pz = r.rz[i] * sc[i];
         ax += px.x; ay += py.x; az += pz.x;
         ax += px.y; ay += py.y; az += pz.y;
     }
+}
+
+template <int NQ, bool ONE_T>
+__device__ __forceinline__ void pairs_finish_exact(const DevParams &P, const PairCtx &c, const PairRows<NQ> &r,
+                                                   const v2f (&qw)[NQ / 2], int gj0,
+                                                   const float *__restrict__ snap_age,
+                                                   const int *__restrict__ sorted_id,
+                                                   float &ax, float &ay, float &az, int &flag)
+{
+    v2f sc[NQ / 2];
+    pairs_scale_exact<NQ, ONE_T>(P, c, r, qw, gj0, snap_age, sorted_id, sc, flag);
+    pairs_add<NQ>(r, sc, ax, ay, az);
 }
 
 // Fast-math finish (FMA + v_rsq) on softened distances.
@@ -1937,10 +1955,19 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
         static const int paced = std::getenv("PSAMD_PACE") ? std::atoi(std::getenv("PSAMD_PACE")) : 20;      // (A/B runs: 0 = no pacing of the waves; else WavePace::band)
         // the packs of partly filled slices (merge): the first nmb workgroups of the same launch
         const int nmb = merge ? std::max(8, shape.nmb) : 0;
-#define PS_BALANCED(W) k_pairs_balanced<M, NQ, W><<<nmb + nw / 4, 256, 0, st>>>(P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_soa, d.snap_age, d.sorted_id, task_list, \
+#define PS_BALANCED_Q(W, Q) k_pairs_balanced<M, Q, W><<<nmb + nw / 4, 256, 0, st>>>(P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_soa, d.snap_age, d.sorted_id, task_list, \
                                                                      d.force4, d.fs, d.trace, active_list, active_count, d.wave_unit, task_ready, d.merged_tasks, nmb, d.st, pass, paced)
-        if (tile) PS_BALANCED(1); else if (packs_in_list) PS_BALANCED(2); else PS_BALANCED(0);
+#define PS_BALANCED(W) PS_BALANCED_Q(W, NQ)
+        // The tile walk -- a wave with its SIMD (almost) to itself -- takes 16 bodies per group: every group costs such a
+        // wave two branches on a vector compare and the tail of three chains of dependent additions, all of it exposed;
+        // half as many groups: -5 % on the pair stage of an eighth of the N = 2^20 cloud, -6 % in the tolerance mode (profiles/r4_ab_tile_nq.txt).
+        // (The next group's distances between a group's scale factors and its additions, in one basic block: 9 % SLOWER.)
+        static const int tile_nq = std::getenv("PSAMD_TILE_NQ") ? std::atoi(std::getenv("PSAMD_TILE_NQ")) : 16;      // (A/B runs)
+        // (The same in the scalar walk where a SIMD holds four waves -- N = 2^22 on eight ranks -- gave 1 %: not kept.)
+        if (tile && NQ == 8 && tile_nq == 16) PS_BALANCED_Q(1, 16);
+        else if (tile) PS_BALANCED(1); else if (packs_in_list) PS_BALANCED(2); else PS_BALANCED(0);
 #undef PS_BALANCED
+#undef PS_BALANCED_Q
     }
     else {
         k_pairs<MODE, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,

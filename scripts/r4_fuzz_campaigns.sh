@@ -2,8 +2,8 @@
 # builder-run randomised parity campaigns on the round's final kernels (beyond the fixed-seed slice in tests/test_gpu_fuzz.py)
 O=gpurun_out/r4_fuzz.log
 : > $O
-python scripts/fuzz_parity.py --cases 60 --seed 4201 --graphs --log $O
-python scripts/fuzz_parity.py --cases 50 --seed 4202 --worlds 5,6,7,8 --sizes 3000,12000,40000 --graphs --log $O
-python scripts/fuzz_parity.py --cases 50 --seed 4203 --worlds 1,2,4,8 --max-steps 10 --log $O
-python scripts/fuzz_parity.py --cases 16 --seed 4204 --worlds 1,2,8 --sizes 90000,262144 --max-steps 5 --log $O
+python scripts/fuzz_parity.py --cases 60 --seed 4301 --graphs --log $O
+python scripts/fuzz_parity.py --cases 50 --seed 4302 --worlds 5,6,7,8 --sizes 3000,12000,40000 --graphs --log $O
+python scripts/fuzz_parity.py --cases 50 --seed 4303 --worlds 1,2,4,8 --max-steps 10 --log $O
+python scripts/fuzz_parity.py --cases 16 --seed 4304 --worlds 1,2,8 --sizes 90000,262144 --max-steps 5 --log $O
 grep -c "^case" $O; grep "fuzz done" $O; grep -c MISMATCH $O

@@ -91,8 +91,7 @@ def parse_args():
     ap.add_argument("--ring-side-stream", type=int, default=1, help="C++ ranks: RCCL on a second HIP stream (0: on the compute stream)")
     ap.add_argument("--ring-timeout", type=float, default=0.0, help="seconds a C++ rank may take before it is ended and the ranks fall back (0: from --steps)")
     ap.add_argument("--sustained-steps", type=int, default=200, help="one GPU: when --steps is shorter than this, a second timed region of this "
-                    "many steps is reported beside the line's figure (the chip is power-bound: a region of seconds runs at a lower clock "
-                    "than one of tens of milliseconds); 0: none")
+                    "many steps is reported beside the line's figure (which clock a figure was taken at is part of the figure); 0: none")
     return ap.parse_args()
 
 
@@ -252,7 +251,7 @@ def force_terms(n, f, G, all_pairs):
     return pair_count(n, f, G)
 
 
-def side_run(ps, cfg_over, device, xyz, age, fert, flags, steps, restore, warm=10, all_pairs=False, timing_period=1, **cfg_extra):
+def side_run(ps, cfg_over, device, xyz, age, fert, flags, steps, restore, warm=30, all_pairs=False, timing_period=1, **cfg_extra):
     """A second, short measurement on a fresh context: the same timed loop with other flags (fast
     math), other constants (life cycle off) or free-running (restore=False).  Never the headline.
     Returns updates, seconds, live counts per step, and -- from HIP events on the context's stream
@@ -263,11 +262,15 @@ def side_run(ps, cfg_over, device, xyz, age, fert, flags, steps, restore, warm=1
     g.fill_particles(xyz, age=age, fert_age=fert)
     g.snapshot_save()
     live = []
+    G = g.sizes.grid_dim
+    # (the census before the warmup, so that the warmup runs straight into the timed region: a GPU left idle for the
+    # downloads costs the first timed steps their clock)
+    n0, f0 = pass_counts(g, restore) if restore else (None, None)
+    g.set_timing(True, period=timing_period)
+    g.set_timing(False)
     if restore:
         for _ in range(warm):
             g.snapshot_restore(); g.step(1)
-    G = g.sizes.grid_dim
-    n0, f0 = pass_counts(g, restore) if restore else (None, None)
     g.set_timing(True, period=timing_period)
     g.synchronize()
     p0 = g.counters["particles_processed"]
@@ -766,18 +769,10 @@ def main():
         dist.all_reduce(t)
         return t.cpu().numpy()
 
-    # untimed: let the clocks settle (the first launches of a process run at a lower clock).
-    # All ranks must take the same number of steps: they decide together, ten steps at a time.
-    settle = 0
-    t_end = time.perf_counter() + args.settle_seconds
-    while not args.evolve and int(allsum(np.array([1 if time.perf_counter() < t_end else 0]))[0]) == world:
-        for _ in range(10):
-            one_step()
-        settle += 10
-    for _ in range(args.warmup):
-        one_step()
-    sync()
-
+    # The frame's census (downloads, host work) comes BEFORE the settling steps and the warmup, so that the warmup runs
+    # straight into the timed region: with the census between them the GPU sat idle for tens of milliseconds and the
+    # first timed steps ran at a lower clock -- a fixed 2.4 ms that a 20-step region showed as 5 % (2.33 against 2.21 ms
+    # per step) and a 200-step region hid.  The events of the kernel timers are created here too.
     def frame_counts():
         """particles per cell and particles the force pass visits per cell, whole system"""
         if not args.evolve:
@@ -809,13 +804,31 @@ def main():
         counts0 = fcounts0 = mine0 = None
     else:
         counts0, fcounts0, mine0 = frame_counts()
+    g.set_timing(True)
+    g.set_timing(False)
+    # (the clock watchers are made here as well: finding the card in sysfs imports torch and asks it for the device's PCI
+    # address -- hundreds of milliseconds with the GPU idle if it happened between the warmup and the timed region)
+    clock = ClockWatch(local_rank if args.backend == "nccl" or world == 1 else 0)
+    clock2 = ClockWatch(local_rank)
+    # untimed: let the clocks settle (the first launches of a process run at a lower clock).
+    # All ranks must take the same number of steps: they decide together, ten steps at a time.
+    settle = 0
+    t_end = time.perf_counter() + args.settle_seconds
+    while not args.evolve and int(allsum(np.array([1 if time.perf_counter() < t_end else 0]))[0]) == world:
+        for _ in range(10):
+            one_step()
+        settle += 10
+    for _ in range(args.warmup):
+        one_step()
+    sync()
+
     # the events that time the kernels go in on every timing_period-th step (each costs ~6 us of idle GPU
     # between two kernels); kernel_us_per_step and the rooflines are means over those steps
     period = 1 if args.kernel_times else max(1, min(args.timing_period, args.steps))
     g.set_timing(True, every_stage=args.kernel_times, period=period)
     sync()
     processed0 = g.counters["particles_processed"]
-    with ClockWatch(local_rank if args.backend == "nccl" or world == 1 else 0) as clock:
+    with clock:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             one_step()
@@ -827,10 +840,12 @@ def main():
     own_updates = float(ctr["particles_processed"] - processed0)
     sustained = None
     if world == 1 and not args.evolve and 0 < args.steps < args.sustained_steps:
-        # The chip is power-bound under this load: a timed region of tens of milliseconds (the driver's --steps 20) runs at
-        # a higher clock than one of seconds.  The same loop again, long enough to show the sustained figure beside it.
+        # A timed region of tens of milliseconds (the driver's --steps 20) says little about the clock a long run holds:
+        # the same loop again, long enough to show the sustained figure beside it.  (Until the census and the clock
+        # watchers' setup moved ahead of the warmup, the short region was the SLOWER of the two: it started on a GPU
+        # that had sat idle, and its first dozen steps ran at a lower clock.)
         sync()
-        with ClockWatch(local_rank) as clock2:
+        with clock2:
             t1 = time.perf_counter()
             for _ in range(args.sustained_steps):
                 one_step()

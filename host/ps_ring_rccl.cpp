@@ -439,18 +439,8 @@ int main(int argc, char **argv)
             if (!evolve) for (Slab &s : R.local) PS_OK(s.ctx, psamd_snapshot_restore(s.ctx));
             return ring_step(R, no_hook);
         };
-        // untimed: let the clocks settle; all ranks must take the same number of steps: they decide together, ten at a time
-        int settle = 0;
-        const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(settle_seconds);
-        for (;;) {
-            int64_t go = (!evolve && std::chrono::steady_clock::now() < t_end) ? 1 : 0;
-            if (reduce_i64(&go, 1, ncclMin)) return bail();
-            if (!go) break;
-            for (int k = 0; k < 10; k++) if (one_step()) return bail();
-            settle += 10;
-        }
-        for (int k = 0; k < warmup; k++) if (one_step()) return bail();
-        if (barrier()) return bail();
+        // (The census -- downloads, host work -- comes BEFORE the settling steps and the warmup, so that the warmup runs
+        // straight into the timed region: an idle GPU in between cost the first timed steps their clock.)
         // the frame's census: particles per cell (whole system) and particles the force pass visits per cell (own, and whole system)
         std::vector<int32_t> cellgrid((size_t)sz.n_cellgrid), fc((size_t)sz.num_cells);
         std::vector<int64_t> n_cell((size_t)sz.num_cells), f_all((size_t)sz.num_cells);
@@ -485,6 +475,19 @@ int main(int argc, char **argv)
         double terms0 = 0, terms1 = 0;
         int64_t wf0 = 0, wf1 = 0, live0 = 0, live1 = 0;
         if (!evolve && census(&terms0, &wf0, &live0)) return bail();
+        { psamd_ctx *c = R.local[0].ctx; PS_OK(c, psamd_set_timing(c, 1)); PS_OK(c, psamd_set_timing(c, 0)); }      // (the timers' events exist before the timed region)
+        // untimed: let the clocks settle; all ranks must take the same number of steps: they decide together, ten at a time
+        int settle = 0;
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(settle_seconds);
+        for (;;) {
+            int64_t go = (!evolve && std::chrono::steady_clock::now() < t_end) ? 1 : 0;
+            if (reduce_i64(&go, 1, ncclMin)) return bail();
+            if (!go) break;
+            for (int k = 0; k < 10; k++) if (one_step()) return bail();
+            settle += 10;
+        }
+        for (int k = 0; k < warmup; k++) if (one_step()) return bail();
+        if (barrier()) return bail();
         psamd_ctx *c0 = R.local[0].ctx;
         const int period = std::max(1, std::min(timing_period, steps));
         PS_OK(c0, psamd_set_timing_period(c0, period));

@@ -251,7 +251,7 @@ def force_terms(n, f, G, all_pairs):
     return pair_count(n, f, G)
 
 
-def side_run(ps, cfg_over, device, xyz, age, fert, flags, steps, restore, warm=30, all_pairs=False, timing_period=1, **cfg_extra):
+def side_run(ps, cfg_over, device, xyz, age, fert, flags, steps, restore, warm=30, all_pairs=False, timing_period=1, warm_ctx=None, **cfg_extra):
     """A second, short measurement on a fresh context: the same timed loop with other flags (fast
     math), other constants (life cycle off) or free-running (restore=False).  Never the headline.
     Returns updates, seconds, live counts per step, and -- from HIP events on the context's stream
@@ -271,6 +271,12 @@ def side_run(ps, cfg_over, device, xyz, age, fert, flags, steps, restore, warm=3
     if restore:
         for _ in range(warm):
             g.snapshot_restore(); g.step(1)
+    elif warm_ctx is not None:
+        # a free-running stretch has no warmup of its own (its steps change its state): another context keeps the GPU
+        # busy until the moment it starts, so that its few steps do not run on a chip that has just sat idle
+        for _ in range(warm):
+            warm_ctx.snapshot_restore(); warm_ctx.step(1)
+        warm_ctx.synchronize()
     g.set_timing(True, period=timing_period)
     g.synchronize()
     p0 = g.counters["particles_processed"]
@@ -944,7 +950,7 @@ def main():
                                   "tests/test_gpu_fast.py measures and bounds (also at this density); not the headline",
                     "value": d / t, "unit": "particle-updates/s", "ms_per_step": 1e3 * t / 50, "steps": 50,
                     "roofline": roof, "kernel_us_per_step": kt}
-                d, t, lv, _, _ = side_run(ps, cfg_over, local_rank, xyz, age, fert, flags, args.evolve_steps, False)
+                d, t, lv, _, _ = side_run(ps, cfg_over, local_rank, xyz, age, fert, flags, args.evolve_steps, False, warm_ctx=g)
                 out["evolve"] = {"what": "%d free-running steps from the same cloud (the population collapses: surface implosion, "
                                          "collisions), exact arithmetic" % args.evolve_steps,
                                  "value": d / t, "unit": "particle-updates/s", "ms_per_step": 1e3 * t / args.evolve_steps,

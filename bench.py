@@ -286,10 +286,13 @@ def side_run(ps, cfg_over, device, xyz, age, fert, flags, steps, restore, warm=3
             g.snapshot_restore()
         g.step(1)
         if not restore:
-            live.append(int(g.device_view().live))      # particles that step processed (host copy, no sync)
+            live.append(int(g.device_view().live))      # host copy, no sync: the library reads a step's scalars a step late
     g.synchronize()
     dt = time.perf_counter() - t0
+    if not restore:
+        live = live[1:] + [int(g.device_view().live)]   # ... so entry k was step k - 1's: shift, the last step's is in now
     tim, launches = g.timing()
+    med, mx, _ = g.timing_stats()
     g.set_timing(False)
     done = g.counters["particles_processed"] - p0
     roof = None
@@ -302,7 +305,8 @@ def side_run(ps, cfg_over, device, xyz, age, fert, flags, steps, restore, warm=3
                 "pairs_per_launch": float(pairs), "flop_per_pair": FLOP_PER_PAIR, "us_per_launch": us,
                 "particles_with_a_force_term": int(f0.sum())}
     g.close()
-    return done, dt, live, roof, {k: v / max(launches, 1) for k, v in tim.items() if v > 0}
+    return done, dt, live, roof, {"median": {k: v for k, v in med.items() if v > 0}, "max": {k: v for k, v in mx.items() if v > 0},
+                                  "mean": {k: v / max(launches, 1) for k, v in tim.items() if v > 0}, "timed_steps": launches}
 
 
 def sim_world(args, ps, cfg_over, flags):
@@ -413,12 +417,29 @@ def sim_world(args, ps, cfg_over, flags):
     return out
 
 class ClockWatch:
-    """Samples the GPU's shader clock (sysfs pp_dpm_sclk, the level marked current) in a thread while a timed region runs:
-    the chip is power-bound under this load, and which clock a figure was taken at is part of the figure."""
+    """Samples the GPU's shader clock (sysfs pp_dpm_sclk, the level marked current) while a timed region runs: the chip is
+    power-bound under this load, and which clock a figure was taken at is part of the figure.  The sampler is a CHILD
+    PROCESS (a few lines of Python that never touch the GPU): a thread of this process would share the interpreter lock
+    with the timed loop -- round 4's driver run lost 0.6 ms on three timed steps to exactly that."""
+
+    SAMPLER = (
+        "import sys,time\n"
+        "path,period=sys.argv[1],float(sys.argv[2])\n"
+        "sys.stdout.write('ready\\n'); sys.stdout.flush()\n"
+        "sys.stdin.readline()\n"                           # 'go'
+        "import select\n"
+        "while True:\n"
+        "    try:\n"
+        "        for line in open(path):\n"
+        "            if line.strip().endswith('*'):\n"
+        "                sys.stdout.write(''.join(ch for ch in line.split(':')[1] if ch.isdigit())+'\\n')\n"
+        "    except Exception: pass\n"
+        "    if select.select([sys.stdin],[],[],period)[0]: break\n"
+        "sys.stdout.flush()\n")
 
     def __init__(self, index=0, period=0.02):
         import glob
-        self.path = None
+        self.path, self.proc, self.samples, self.period = None, None, [], period
         try:
             # the card whose PCI address is the HIP device's (a box may show the host's other GPUs in sysfs)
             import torch
@@ -429,35 +450,32 @@ class ClockWatch:
                     self.path = f
         except Exception:
             pass
-        self.period, self.samples, self._stop, self._thread = period, [], False, None
-
-    def _read(self):
-        try:
-            for line in open(self.path):
-                if line.strip().endswith("*"):
-                    return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
-        except Exception:
-            return None
-        return None
+        if self.path:
+            # started here, ahead of the warmup (an interpreter takes tens of milliseconds to come up); it samples
+            # between 'go' and the next line on its stdin
+            try:
+                self.proc = subprocess.Popen([sys.executable, "-c", self.SAMPLER, self.path, str(period)], stdin=subprocess.PIPE,
+                                             stdout=subprocess.PIPE, text=True)
+                self.proc.stdout.readline()
+            except Exception:
+                self.proc = None
 
     def __enter__(self):
-        if self.path:
-            import threading
-
-            def loop():
-                while not self._stop:
-                    v = self._read()
-                    if v:
-                        self.samples.append(v)
-                    time.sleep(self.period)
-            self._thread = threading.Thread(target=loop, daemon=True)
-            self._thread.start()
+        if self.proc:
+            try:
+                self.proc.stdin.write("go\n"); self.proc.stdin.flush()
+            except Exception:
+                self.proc = None
         return self
 
     def __exit__(self, *a):
-        self._stop = True
-        if self._thread:
-            self._thread.join(timeout=1.0)
+        if self.proc:
+            try:
+                out, _ = self.proc.communicate("stop\n", timeout=5.0)
+                self.samples = [int(x) for x in out.split() if x.isdigit()]
+            except Exception:
+                self.proc.kill()
+            self.proc = None
 
     def summary(self):
         if not self.samples:
@@ -845,6 +863,7 @@ def main():
         sync()
         elapsed = time.perf_counter() - t0
     tim, launches = g.timing()
+    tmed, tmax, _ = g.timing_stats()
     g.set_timing(False)
     ctr = g.counters
     own_updates = float(ctr["particles_processed"] - processed0)
@@ -920,8 +939,11 @@ def main():
                                    "bytes_per_update": APPLY_BYTES_PER_UPDATE, "us_per_launch": us_apply},
             "shader_clock_mhz": clock.summary(),
             "sustained": sustained,
-            "kernel_us_per_step": {k: v / max(launches, 1) for k, v in tim.items() if v > 0},
-            "kernel_times_from": "HIP events on the context's stream on %d of the %d timed steps (every %d%s)" % (launches, args.steps, period, "th" if period > 1 else "st"),
+            "kernel_us_per_step": {k: v for k, v in tmed.items() if v > 0},
+            "kernel_us_per_step_max": {k: v for k, v in tmax.items() if v > 0},
+            "kernel_us_per_step_mean": {k: v / max(launches, 1) for k, v in tim.items() if v > 0},
+            "kernel_times_from": "HIP events on the context's stream on %d of the %d timed steps (every %d%s): kernel_us_per_step is the MEDIAN over "
+                                 "those steps, _max the slowest, _mean what the rooflines use" % (launches, args.steps, period, "th" if period > 1 else "st"),
         }
         if world > 1:
             out["config"]["host"] = "Python ranks over torch.distributed (particlesystem_amd/slab.py)" + \

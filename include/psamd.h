@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PSAMD_ABI_VERSION 5
+#define PSAMD_ABI_VERSION 6
 
 #define PSAMD_MAX_RANKS 64
 
@@ -201,10 +201,20 @@ int psamd_calc_forces(psamd_ctx *ctx);  /* task 6, ps.cpp:1120-1383 / psCUDA.cu:
  * psamd_calc_forces == _pairs then _apply. */
 int psamd_calc_forces_pairs(psamd_ctx *ctx);
 int psamd_calc_forces_apply(psamd_ctx *ctx);
-/* nsteps x {init_iframe, build_grid, calc_forces}; asynchronous on the context's
- * stream unless lifecycle bookkeeping forces a sync. */
+/* nsteps x {init_iframe, build_grid, calc_forces}, enqueued on the context's stream.  NOTHING in a step waits
+ * for the host: the step's one read-back (live count, sticky error bits, list sizes -- what the reference's driver
+ * fetches as hostGridMax, ps.cpp:1878-1900) lands in a pinned host record that the library reads ONE STEP LATE.
+ * A stage call therefore returns the verdict of the steps BEFORE the one it has just enqueued (run-ahead 1, the
+ * default: the host stays a step ahead of the GPU and is never on the step's critical path); psamd_synchronize
+ * waits for everything enqueued and returns whatever verdict is outstanding.  psamd_set_run_ahead(ctx, 0): every
+ * call that ends a step (psamd_step, psamd_calc_forces[_apply], psamd_slab_finish) waits for that step's own
+ * record before it returns, as the reference's driver waits for its task (ps.cpp:1716).  Calls that hand buffers or
+ * counters to the caller synchronise by themselves.  If a step's record does not arrive within 10 s (environment
+ * PSAMD_WAIT_LIMIT_S) while its stream stays busy, the call returns PSAMD_ERR_STATE and the context refuses all
+ * further work: a wedged GPU is reported, not waited for. */
 int psamd_step(psamd_ctx *ctx, int32_t nsteps);
 int psamd_synchronize(psamd_ctx *ctx);
+int psamd_set_run_ahead(psamd_ctx *ctx, int steps);   /* 0 or 1 */
 
 /* float4 (ax, ay, az, flag-as-int-bits) entries [first, first+count) of the sorted-order
  * force array (diagnostics). */
@@ -290,10 +300,10 @@ int psamd_slab_buffers_get(psamd_ctx *ctx, psamd_slab_buffers *out);
  * record 0 wherever they were (ps.cpp:1523-1526), and the rank's part of every chunk's particle count
  * per segment type, from which all ranks reproduce the chunk lists' capacity rule (ps.cpp:1502-1508)
  * and hostGridMax[0].  A slab fails COLLECTIVELY: slab_finish returns an error only for error bits
- * that were in this step's status records, which all ranks see alike; an error raised after a rank's
+ * that were in a step's status records, which all ranks see alike -- with run-ahead 1 (the default) from the
+ * slab_finish of the step AFTER, on every rank alike; an error raised after a rank's
  * record was closed goes out with the next step's record and stops every rank there (or is reported by
- * psamd_synchronize).  All asynchronous on the
- * context's stream except finish, which ends with the per-step read-back.  With world == 1
+ * psamd_synchronize).  All asynchronous on the context's stream.  With world == 1
  * the four calls are psamd_step(1) cut in four and no message exists. */
 int psamd_slab_build(psamd_ctx *ctx);   /* init_iframe + build_grid of the own layers; packs halo_out   */
 int psamd_slab_pairs_interior(psamd_ctx *ctx);  /* optional, while the halo travels: the pair stage of the cells whose
@@ -321,9 +331,11 @@ int psamd_set_stream(psamd_ctx *ctx, void *hip_stream);
  * PSAMD_ERR_UNSUPPORTED (and says why) if the runtime refused a capture and the context fell back to plain launches. */
 int psamd_set_graphs(psamd_ctx *ctx, int enabled);
 int psamd_get_graph_stats(psamd_ctx *ctx, int64_t *launches, int64_t *captures);
-/* How the calling thread waits for a step's scalars (the one read-back of a step, ps.cpp:1878-1900): 0 spins on the
+/* How the calling thread waits for a step's scalars when it has to (the one read-back of a step, ps.cpp:1878-1900;
+ * with run-ahead the record is there long before it is asked for): 0 spins on the
  * pinned record (default of a single context: lowest latency), 1 spins for a few microseconds and then sleeps in
- * 5-us naps (default of a slab: a node's eight ranks do not pin eight cores). */
+ * 5-us naps (default of a slab: a node's eight ranks do not pin eight cores).  While it naps the library lowers the
+ * calling thread's timer slack (prctl PR_SET_TIMERSLACK) to 1 us and restores the old value before the call returns. */
 int psamd_set_wait_policy(psamd_ctx *ctx, int policy);
 
 /* ---- introspection -------------------------------------------------------- */
@@ -345,7 +357,8 @@ int psamd_selftest_math(psamd_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, uint
  * sort, pairs (the force pass), apply, lifecycle, frame reset, collide (collision flags and the
  * lists of the particles that need a force: the two-pass prologue of the pair stage).  level 0: off; 1: collide, pairs, apply and lifecycle
  * only (four events per step); 2: every stage (an event between two kernels costs a few
- * microseconds of idle GPU, so this is for diagnosis).  Never makes a step wait.
+ * microseconds of idle GPU, so this is for diagnosis).  Never makes a step wait: a step's events are read two timed
+ * steps later, or by psamd_get_timing.
  * psamd_set_timing_period(ctx, n): record the events on every n-th step only (n >= 1; default 1) --
  * the accumulated times and `launches` then count those steps; what a long timed run uses so that
  * the events' idle gaps (four to six per step at level 1) do not weigh on the steps in between. */
@@ -353,6 +366,8 @@ int psamd_selftest_math(psamd_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, uint
 int psamd_set_timing(psamd_ctx *ctx, int level);
 int psamd_set_timing_period(psamd_ctx *ctx, int every);
 int psamd_get_timing(psamd_ctx *ctx, double us_out[PSAMD_NUM_TIMERS], int64_t *launches);
+/* the same intervals as a distribution over the timed steps: median and maximum per timer (a mean hides a stall) */
+int psamd_get_timing_stats(psamd_ctx *ctx, double median_us[PSAMD_NUM_TIMERS], double max_us[PSAMD_NUM_TIMERS], int64_t *samples);
 
 #ifdef __cplusplus
 }

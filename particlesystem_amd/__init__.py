@@ -20,7 +20,7 @@ from . import build as _build
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PSAMD_LIB") or os.path.join(HERE, "libpsamd.so")   # PSAMD_LIB: another build, for A/B measurements
 
-ABI_VERSION = 5         # the struct layouts below are include/psamd.h's at this PSAMD_ABI_VERSION
+ABI_VERSION = 6         # the struct layouts below are include/psamd.h's at this PSAMD_ABI_VERSION
 MAX_RANKS = 64
 FLAG_EXPLOSIONS = 0x1
 FLAG_FAST_MATH = 0x2
@@ -171,6 +171,8 @@ ABI = [
     ("psamd_set_timing", C.c_int, [_vp, C.c_int]),
     ("psamd_set_timing_period", C.c_int, [_vp, C.c_int]),
     ("psamd_get_timing", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    ("psamd_get_timing_stats", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
+    ("psamd_set_run_ahead", C.c_int, [_vp, C.c_int]),
 ]
 
 _lib = None
@@ -487,6 +489,10 @@ class ParticleSystem:
     def set_wait_policy(self, policy):
         self._ck(self.lib.psamd_set_wait_policy(self.h, int(policy)))
 
+    def set_run_ahead(self, steps):
+        """1 (default): a call that ends a step returns once the step BEFORE has reported; 0: waits for its own step"""
+        self._ck(self.lib.psamd_set_run_ahead(self.h, int(steps)))
+
     def set_timing(self, on=True, every_stage=False, period=1):
         """HIP-event timing of the step's kernels: pair pass, apply and life cycle, or every
         stage (an event between two kernels costs ~6 us of idle GPU each); period n: on every
@@ -499,3 +505,10 @@ class ParticleSystem:
         n = C.c_int64()
         self._ck(self.lib.psamd_get_timing(self.h, us, C.byref(n)))
         return dict(zip(TIMER_NAMES, list(us))), n.value
+
+    def timing_stats(self):
+        """({timer: median us}, {timer: max us}, samples) over the timed steps"""
+        med, mx = (C.c_double * NUM_TIMERS)(), (C.c_double * NUM_TIMERS)()
+        n = C.c_int64()
+        self._ck(self.lib.psamd_get_timing_stats(self.h, med, mx, C.byref(n)))
+        return dict(zip(TIMER_NAMES, list(med))), dict(zip(TIMER_NAMES, list(mx))), n.value

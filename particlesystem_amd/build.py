@@ -6,8 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpsamd.so")
-# the step's kernels by stage (kernels_common.hpp holds the map), the host context + C ABI, the radix sort behind long op lists
-SOURCES = ["grid.hip", "pairs.hip", "apply.hip", "lifecycle.hip", "slab.hip", "capi.hip", "lifecycle_sort.hip"]
+# the step's kernels by stage (kernels_common.hpp holds the map), the host context + C ABI
+SOURCES = ["grid.hip", "pairs.hip", "apply.hip", "lifecycle.hip", "slab.hip", "capi.hip"]
 DEPS = SOURCES + ["kernels_common.hpp", "kernels.h", "device_types.h", "geometry.hpp", "partition.hpp", os.path.join("..", "..", "include", "psamd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 

@@ -16,6 +16,7 @@
 #include <ctime>
 #include <new>
 #include <random>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -61,20 +62,23 @@ struct psamd_ctx {
     std::vector<QueueInfo> h_qinfo;   // valid while !queues_on_device_newer
     std::vector<int32_t> h_queue;
     bool host_queues_valid = true;    // host mirror == device copy
-    FrameScalars *h_fs = nullptr;     // pinned host copy of the per-frame scalars
+    FrameScalars *h_fs = nullptr;     // pinned host copies of the per-frame scalars: TWO records, a step's number picks one
+    FrameScalars last{};              // the record of the last step the host has read (consume_scalars)
     int64_t processed_total = 0;      // sum over steps of the live particles at build_grid
     int64_t max_bucket_seen = 0;
-    int bucket_cap0 = 2048;           // the longest operation list the step's first replay instance takes (2048, or 4096 on the last step's hint)
+    int bucket_cap0 = 2048;           // the longest operation list the step's replay instance sorts in LDS (2048 / 4096 / 8192, from the last lists seen)
     char *snapshot = nullptr;         // device image for snapshot_save / _restore
     int snapshot_step = 0;
     void *staging = nullptr;          // device staging for AoS transfers
     size_t staging_bytes = 0;
     // stage state machine
     bool frame_reset = false, grid_built = false, pairs_done = false;
+    bool frame_clean = true;          // the per-frame counts are zero: a finished step leaves them so (its last kernel is the next init_iframe)
     int step = 0;
     int64_t steps_total = 0;
     int live_at_build = -1;           // host copy of fs->live (valid after a sync)
     bool interior_ran = false;        // this step's pair stage ran in two passes (the scalars hold the second pass's task count)
+    std::set<int> interior_steps;     // ... the numbers of such steps whose records have not been read yet
     int64_t tasks_last = 0;           // force tasks of the last step (all passes), sizes the next step's balanced pass
     int64_t packs_last = 0;           // ... of which packs of partly filled slices
     // upper bound of the live count at the next build_grid, kept on the host so that the
@@ -85,11 +89,25 @@ struct psamd_ctx {
     int timing_period = 1;             // events are recorded on every timing_period-th step since set_timing
     int64_t timing_steps = 0;          // steps since set_timing
     int timing_now = 0;                // the level in force for the step being run (0 on the steps in between)
-    int scalars_seq = 0;               // number of the last step whose scalars were asked for (h_fs->seq follows it)
-    hipEvent_t ev[14]{};               // 10 frame reset | 0 hist 1 scan 2 scatter 3 sort 4 | 5 collide 13 force pass 6 | 7 apply 8,11 | life cycle 9,12
-    bool lifecycle_pending[2] = {false, false};   // ev[8|11] -> ev[9|12] recorded, not yet read
+    // The step's scalars: the device numbers the records it hands out (StepState.seq), the host counts the steps it has
+    // enqueued (scalars_seq) and the records it has read (scalars_seen).  run_ahead = 1: step k + 1 is enqueued once the
+    // record of step k - 1 has been read -- the host is never on a step's critical path; 0: every step's own record is
+    // waited for before the call returns.
+    int scalars_seq = 0, scalars_seen = 0;
+    int run_ahead = 1;
+    int pending_status = PSAMD_OK;     // the verdict of a step whose record was read by a call that does not report verdicts (kept for the next that does)
+    std::string pending_err;
+    bool wedged = false;               // a step's scalars did not arrive within the wall-clock bound: the context refuses further work
+    // Timing events: two sets, a timed step takes the one that was read longest ago; a set is read when it is taken again
+    // or by psamd_get_timing -- never by the step that recorded it (the host runs ahead of the GPU).
+    enum { E_RESET = 0, E_HIST, E_SCAN, E_SCATTER, E_SORT, E_SORT_END, E_COLLIDE, E_FORCE, E_PAIRS_END, E_APPLY, E_LIFE, E_END, E_COUNT };
+    hipEvent_t ev[2][E_COUNT]{};
+    int ev_level[2] = {0, 0};          // level a set was recorded at, 0: nothing outstanding in it
+    int tset = 0;                      // the set of the step being run
+    int64_t timed_steps = 0;
     bool ev_made = false;
     double t_us[PSAMD_NUM_TIMERS]{};
+    std::vector<float> t_samples[PSAMD_NUM_TIMERS];
     int64_t t_launches = 0;
     // stage sequences as hipGraphs (psamd_set_graphs): per kind of sequence, the shapes captured so far
     struct GraphSlot { uint64_t key; hipGraphExec_t exec; uint64_t stamp; };
@@ -100,6 +118,7 @@ struct psamd_ctx {
     std::string graph_refused;         // why the runtime would not capture (the context then runs without graphs)
     int64_t slab_bound = 0;            // the bound slab_apply sized its launches from; slab_finish uses the same
     int wait_policy = 0;               // how the host waits for the step's scalars: 0 spin, 1 spin briefly, then nap
+    double wait_limit_s = 10.0;        // ... and for how long at most (PSAMD_WAIT_LIMIT_S)
 };
 
 namespace {
@@ -221,7 +240,7 @@ int check_device_errors(psamd_ctx *c)   // after a sync: sticky error bits raise
 {
     FrameScalars fs{};
     PS_HIP(c, hipMemcpy(&fs, c->d.fs, sizeof fs, hipMemcpyDeviceToHost));
-    c->live_at_build = fs.live;
+    if (!c->grid_built) for (int k = 0; k < 5; k++) fs.n_out[k] = c->last.n_out[k];      // (between steps the device's record is the next frame's, zeroed)
     if (fs.error & (ERR_BAD_ID | ERR_BAD_POS)) {
         // an upload error is reported once and then cleared: the rejected records stay in the
         // container, the caller is expected to upload valid ones over them
@@ -252,25 +271,39 @@ int check_device_errors(psamd_ctx *c)   // after a sync: sticky error bits raise
     return PSAMD_OK;
 }
 
-// life-cycle interval of the step of parity `par`, if one is outstanding
-void collect_lifecycle_time(psamd_ctx *c, int par)
-{
-    if (!c->lifecycle_pending[par]) return;
-    // called one step later (the interval ended long ago, this returns at once) or by
-    // get_timing (waits for the last step's life cycle)
-    (void)hipEventSynchronize(c->ev[par ? 12 : 9]);
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->ev[par ? 11 : 8], c->ev[par ? 12 : 9]) == hipSuccess) {
-        c->t_us[6] += 1000.0 * ms;
-        c->lifecycle_pending[par] = false;
-    }
-}
-
 void make_events(psamd_ctx *c)
 {
     if (c->ev_made) return;
-    for (auto &e : c->ev) (void)hipEventCreate(&e);
+    for (auto &set : c->ev) for (auto &e : set) (void)hipEventCreate(&e);
     c->ev_made = true;
+}
+
+// read a set of timing events (waits for its step's last kernel: a set is read when it is taken again, two timed
+// steps later, or by psamd_get_timing)
+void collect_timing(psamd_ctx *c, int set)
+{
+    const int level = c->ev_level[set];
+    if (!level) return;
+    c->ev_level[set] = 0;
+    if (hipEventSynchronize(c->ev[set][psamd_ctx::E_END]) != hipSuccess) return;
+    // timers: hist scan scatter sort | force pass, apply, life cycle | frame reset | flags + active lists (two-pass prologue)
+    using X = psamd_ctx;
+    const int a[PSAMD_NUM_TIMERS] = {X::E_HIST, X::E_SCAN, X::E_SCATTER, X::E_SORT, X::E_FORCE, X::E_APPLY, X::E_LIFE, X::E_RESET, X::E_COLLIDE};
+    const int b[PSAMD_NUM_TIMERS] = {X::E_SCAN, X::E_SCATTER, X::E_SORT, X::E_SORT_END, X::E_PAIRS_END, X::E_LIFE, X::E_END, X::E_HIST, X::E_FORCE};
+    for (int k = 0; k < PSAMD_NUM_TIMERS; k++) {
+        if (level < 2 && (k < 4 || k == 7)) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev[set][a[k]], c->ev[set][b[k]]) == hipSuccess) {
+            c->t_us[k] += 1000.0 * ms;
+            c->t_samples[k].push_back(1000.0f * ms);
+        }
+    }
+    c->t_launches++;
+}
+
+void tick(psamd_ctx *c, int e)        // a timing event on the context's stream, if this step carries them
+{
+    if (c->timing_now) (void)hipEventRecord(c->ev[c->tset][e], c->stream);
 }
 
 }  // namespace
@@ -544,13 +577,12 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.op_keys_sorted, (size_t)d.ops_cap));
     PS_HIP(c, dev_alloc(c, &d.op_args, (size_t)d.ops_cap));
     PS_HIP(c, dev_alloc(c, &d.op_args_sorted, (size_t)d.ops_cap));
-    PS_HIP(c, sort_ops_tmp_bytes((size_t)d.ops_cap, P.key_bits, &d.sort_tmp_bytes));
-    { char *tmp = nullptr; PS_HIP(c, dev_alloc(c, &tmp, d.sort_tmp_bytes)); d.sort_tmp = tmp; }
-    // the host polls this record (wait_scalars): coherent mapping whatever HIP_HOST_COHERENT says, and zeroed --
+    // the host polls these records (wait_scalars): coherent mapping whatever HIP_HOST_COHERENT says, and zeroed --
     // hipHostMalloc does not promise zeroed pages, and a recycled page whose seq word happened to hold the number
     // the first step waits for would be taken for that step's scalars
-    PS_HIP(c, hipHostMalloc((void **)&c->h_fs, sizeof(FrameScalars), hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(c->h_fs, 0, sizeof(FrameScalars));
+    PS_HIP(c, hipHostMalloc((void **)&c->h_fs, 2 * sizeof(FrameScalars), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->h_fs, 0, 2 * sizeof(FrameScalars));
+    if (const char *lim = std::getenv("PSAMD_WAIT_LIMIT_S")) c->wait_limit_s = std::max(0.05, std::atof(lim));
     PS_HIP(c, hipHostGetDevicePointer((void **)&c->d.fs_host, c->h_fs, 0));
     PS_HIP(c, dev_alloc(c, &d.moves, (size_t)d.moves_cap));
     PS_HIP(c, dev_alloc(c, &d.stage, 3 * (size_t)d.moves_cap));
@@ -707,7 +739,7 @@ int psamd_destroy(psamd_ctx *c)
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->staging) (void)hipFree(c->staging);
     if (c->h_fs) (void)hipHostFree(c->h_fs);
-    if (c->ev_made) for (auto &e : c->ev) (void)hipEventDestroy(e);
+    if (c->ev_made) for (auto &set : c->ev) for (auto &e : set) (void)hipEventDestroy(e);
     if (c->d.ev_fork) (void)hipEventDestroy(c->d.ev_fork);
     if (c->d.ev_join) (void)hipEventDestroy(c->d.ev_join);
     if (c->d.side_stream) (void)hipStreamDestroy(c->d.side_stream);
@@ -1013,14 +1045,22 @@ int psamd_get_cell_table(const psamd_ctx *c, int32_t *out)
     return PSAMD_OK;
 }
 
+static int drain_scalars(psamd_ctx *c, bool quiet = false);
+
 int psamd_get_gridmax(psamd_ctx *c, int32_t out2[2])
 {
     if (!c || !out2) return PSAMD_ERR_INVALID_ARG;
-    PS_HIP(c, hipStreamSynchronize(c->stream));
-    FrameScalars fs{};
-    PS_HIP(c, hipMemcpy(&fs, c->d.fs, sizeof fs, hipMemcpyDeviceToHost));
-    out2[0] = fs.gridmax[0]; out2[1] = fs.gridmax[1];
-    c->live_at_build = fs.live;
+    // inside a frame (after build_grid) the device's record is the frame's; once calc_forces has run the device's record
+    // belongs to the next frame already and the step's scalars are in the host's copy (ps.cpp:1900 reads hostGridMax
+    // between the stages; the reference's array keeps the build's values until the next init_iframe)
+    const int rc = drain_scalars(c);
+    if (rc != PSAMD_OK && !c->grid_built) return rc;
+    if (c->grid_built) {
+        FrameScalars fs{};
+        PS_HIP(c, hipMemcpy(&fs, c->d.fs, sizeof fs, hipMemcpyDeviceToHost));
+        out2[0] = fs.gridmax[0]; out2[1] = fs.gridmax[1];
+        c->live_at_build = fs.live;
+    } else { out2[0] = c->last.gridmax[0]; out2[1] = c->last.gridmax[1]; }
     return PSAMD_OK;
 }
 
@@ -1031,9 +1071,13 @@ int psamd_get_gridmax(psamd_ctx *c, int32_t out2[2])
 // enq_* functions only enqueue; the host-side state machine is advanced by their callers -- so that a
 // sequence can be captured once into a hipGraph and replayed (psamd_set_graphs): one submission per stage
 // instead of one per kernel.  A graph is keyed by what shapes its launches: the size of the balanced force
-// pass (from the last step's task count) and the bound of the live count the life-cycle grids are sized
+// pass (from the last task count the host has seen) and the hint of the live count the life-cycle grids are sized
 // from, rounded up to 64 Ki so that a free-running population does not mean a capture per step.  Steps
 // that carry timing events run eagerly (the events sit between the kernels).
+//
+// NOTHING in a step waits for the host: the step's tail decides everything on the device (lifecycle.hip), and the
+// one read-back of a step -- live count, sticky errors, list sizes: what the reference's driver fetches as
+// hostGridMax, ps.cpp:1878-1900 -- lands in a pinned record that the host reads a step late (consume_scalars).
 
 static int slab_only(psamd_ctx *c, const char *what)
 {
@@ -1041,55 +1085,73 @@ static int slab_only(psamd_ctx *c, const char *what)
                                                          "_pairs / _apply / _finish and exchange the messages in between");
 }
 
+static int refuse_wedged(psamd_ctx *c)
+{
+    return fail(c, PSAMD_ERR_STATE, "the GPU stopped answering (a step's scalars did not arrive within " + std::to_string((int)c->wait_limit_s) +
+                                    " s while its stream stayed busy): this context takes no further work; destroy it");
+}
+
 // which steps carry timing events is settled when the step begins (before anything is enqueued or replayed)
 static void begin_step(psamd_ctx *c)
 {
     // (an event between two kernels costs ~6 us of idle GPU: a long timed run records them on every n-th step)
     c->timing_now = (c->timing && c->timing_steps++ % c->timing_period == 0) ? c->timing : 0;
-    if (c->timing_now) make_events(c);
+    if (c->timing_now) {
+        make_events(c);
+        c->tset = (int)(c->timed_steps & 1);
+        collect_timing(c, c->tset);          // (the set's last use is two timed steps old: this returns at once)
+    }
 }
 
 static int enq_init_iframe(psamd_ctx *c)
 {
-    if (c->timing_now >= 2) (void)hipEventRecord(c->ev[10], c->stream);
-    // cell / chunk / queue-record counts and the per-frame scalars (the sticky error word stays)
-    PS_HIP(c, launch_frame_reset(c->stream, c->d, c->frame_ints, c->P.world > 1 ? 4 * c->geo.num_chunks : 0));
+    tick(c, psamd_ctx::E_RESET);
+    // cell / chunk / queue-record counts and the per-frame scalars (the sticky error word stays): the last kernel of
+    // the step before did it, unless there was none
+    if (!c->frame_clean) PS_HIP(c, launch_frame_reset(c->stream, c->d, c->frame_ints, c->P.world > 1 ? 4 * c->geo.num_chunks : 0));
     return PSAMD_OK;
 }
 
 static int enq_build_grid(psamd_ctx *c)
 {
-    PS_HIP(c, launch_build_grid(c->stream, c->P, c->d, c->timing_now >= 2 ? c->ev : nullptr));
+    PS_HIP(c, launch_build_grid(c->stream, c->P, c->d, c->timing_now >= 2 ? &c->ev[c->tset][psamd_ctx::E_HIST] : nullptr));
     return PSAMD_OK;
 }
 
-// size of the balanced force pass: the tasks of the last step this context ran (the read-back of its
-// scalars is on the host already), else the bound of the live count (a pass over part of the cells gets
-// its share of the hint)
+// size of the balanced force pass: the tasks of the last step whose scalars the host has read, else the bound of the
+// live count (a pass over part of the cells gets its share of the hint)
+static int64_t live_bound_of(const psamd_ctx *c);
 static int64_t pairs_hint(const psamd_ctx *c, const DevParams &P)
 {
-    int64_t tasks_hint = (c->steps_total > 0 && c->tasks_last > 0) ? c->tasks_last
+    int64_t tasks_hint = (c->scalars_seen > 0 && c->tasks_last > 0) ? c->tasks_last
                          : (c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total) / 64 + comp_count(c->P);
     // (high word: about how many packs of partly filled slices the pass will have -- their workgroups hold residency
     // slots of the same launch; in steps of 64 so that the launch shape does not change with every step)
-    const int64_t packs = ((c->steps_total > 0 ? c->packs_last : 0) + 63) & ~(int64_t)63;
+    const int64_t packs = ((c->scalars_seen > 0 ? c->packs_last : 0) + 63) & ~(int64_t)63;
     return (tasks_hint * comp_count(P) / std::max(1, comp_count(c->P))) | ((packs * comp_count(P) / std::max(1, comp_count(c->P))) << 32);
 }
 
-static int64_t live_bound_of(const psamd_ctx *c);
-
 static int enq_pairs(psamd_ctx *c, const DevParams &P, int64_t tasks_hint, bool last = true, bool first = true)
 {
-    if (c->timing_now && first) (void)hipEventRecord(c->ev[5], c->stream);
-    PS_HIP(c, launch_pairs(c->stream, P, c->d, (c->timing_now && first) ? c->ev[13] : nullptr, tasks_hint, first ? 0 : 1, live_bound_of(c)));
-    if (c->timing_now && last) (void)hipEventRecord(c->ev[6], c->stream);
+    if (first) tick(c, psamd_ctx::E_COLLIDE);
+    PS_HIP(c, launch_pairs(c->stream, P, c->d, (c->timing_now && first) ? c->ev[c->tset][psamd_ctx::E_FORCE] : nullptr, tasks_hint, first ? 0 : 1, live_bound_of(c)));
+    if (last) tick(c, psamd_ctx::E_PAIRS_END);
     return PSAMD_OK;
 }
 
-// the live count the life-cycle grids are sized from (live_bound < 0: unknown -- state was uploaded -- every owned slot)
+// An upper bound of the particles alive at the NEXT build_grid, as far as the host can know it (< 0 inside: unknown --
+// state was uploaded -- every owned slot).  The host's figure comes from the scalars of the last step it has READ,
+// which with run-ahead is not the last step enqueued: every step in between may have added a child per particle
+// (explosions on) and a slab its arrivals.  Only the all-pairs far pass sizes a launch from this that must cover
+// every particle; everything else takes it as a hint.
 static int64_t live_bound_of(const psamd_ctx *c)
 {
-    const int64_t b = c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total;
+    int64_t b = c->live_bound >= 0 ? c->live_bound : (int64_t)c->P.slots_total;
+    for (int k = c->scalars_seen; k < c->scalars_seq && b < c->P.slots_total; k++) {
+        if (c->P.flags & PSAMD_FLAG_EXPLOSIONS) b *= 2;
+        b += 2 * (int64_t)c->P.xfer_cap + 2 * (int64_t)c->P.xfer2_cap + (int64_t)c->P.far_cap * c->P.world;
+    }
+    b = std::min<int64_t>(b, c->P.slots_total);
     return c->graphs ? std::min<int64_t>((b + 65535) & ~(int64_t)65535, std::max<int64_t>(c->P.slots_total, 65536)) : b;
 }
 
@@ -1097,38 +1159,38 @@ static int64_t live_bound_of(const psamd_ctx *c)
 // that leave for a neighbour's segment are in the outboxes when this has run
 static int enq_apply(psamd_ctx *c, int64_t bound)
 {
-    if (c->timing_now) (void)hipEventRecord(c->ev[7], c->stream);
+    tick(c, psamd_ctx::E_APPLY);
     PS_HIP(c, launch_apply(c->stream, c->P, c->S, c->d));
     if (c->P.world > 1) PS_HIP(c, launch_outbox_close(c->stream, c->P, c->d, bound, c->xfer_out));
     return PSAMD_OK;
 }
 
-// arrivals on top of the own particles: what the op lists and move records of a step can hold at most
+// arrivals on top of the own particles: about what the op lists and move records of a step hold at most
 static int64_t lifecycle_bound(const psamd_ctx *c, int64_t bound)
 {
     return bound + 2 * (int64_t)c->P.xfer_cap + 2 * (int64_t)c->P.xfer2_cap + (int64_t)c->P.far_cap * c->P.world
            + (c->P.world > 1 ? (int64_t)c->P.world * STATUS_KILL_CAP : 0);
 }
 
-// free-slot queues and relocation, the part enqueued without waiting for the host (in slab mode: after the
-// arrivals were merged in): census, bucketing -- the last bucketing workgroup hands the step's scalars to the
-// host's pinned record -- and the replay of the usual lists
-// Which instance replays the usual lists this step: the last step's longest list is the hint (lists longer than the
-// choice still get the long-list instance once the host has this step's scalars, so a wrong hint only costs time).
+// Which instance replays the lists this step: the longest list of the last step the host has read is the hint (lists
+// longer than the instance sorts in LDS are sorted in global memory by the same workgroup: a wrong hint only costs time).
 static uint64_t pick_bucket_cap(psamd_ctx *c)
 {
-    const int last = c->steps_total > 0 ? c->h_fs->max_bucket : 0;
-    c->bucket_cap0 = (last > 2048 && last <= 4096) ? 4096 : 2048;
-    return c->bucket_cap0 > 2048 ? 1ull << 62 : 0ull;       // (part of a captured graph's key)
+    const int last = c->scalars_seen > 0 ? c->last.max_bucket : 0;
+    c->bucket_cap0 = last > 4096 ? BUCKET_MAX : last > 2048 ? 4096 : 2048;
+    return c->bucket_cap0 > 4096 ? 2ull << 61 : c->bucket_cap0 > 2048 ? 1ull << 61 : 0ull;       // (part of a captured graph's key)
 }
 
+// free-slot queues and relocation (in slab mode: after the arrivals were merged in): census, bucketing -- the last
+// bucketing workgroup hands the step's scalars to the host's pinned record --, replay + commit; the last launch
+// is also the next frame's init_iframe
 static int enq_lifecycle(psamd_ctx *c, int64_t bound)
 {
-    const int par = (int)(c->steps_total & 1);   // not c->step: a snapshot restore rewinds that
-    if (c->timing_now) { collect_lifecycle_time(c, par); (void)hipEventRecord(c->ev[par ? 11 : 8], c->stream); }
+    tick(c, psamd_ctx::E_LIFE);
     if (c->P.world > 1) PS_HIP(c, launch_inbox_merge(c->stream, c->P, c->d, c->xfer_in));
-    PS_HIP(c, launch_ops_bucket(c->stream, c->P, c->d, c->geo.queue_infos, lifecycle_bound(c, bound)));
-    PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->geo.queue_infos, lifecycle_bound(c, bound), 0, false, c->bucket_cap0));
+    PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->geo.queue_infos, lifecycle_bound(c, bound), c->bucket_cap0,
+                               c->frame_ints, c->P.world > 1 ? 4 * c->geo.num_chunks : 0));
+    tick(c, psamd_ctx::E_END);
     return PSAMD_OK;
 }
 
@@ -1188,19 +1250,35 @@ static int run_segment(psamd_ctx *c, int seg, uint64_t key, F enqueue)
 }
 }  // extern "C++"
 
-// Wait until the step's scalars are in the host's record: the publishing workgroup stores the record's
-// number last.  The stream is looked at now and then so that a failed launch cannot leave the host waiting.
-// Policy 0 spins on the word (lowest latency: one GPU, the step's critical path); policy 1, the default of
-// a slab, spins for a few microseconds and then sleeps in short naps -- eight ranks of a node do not pin
-// eight cores for the whole run (the word arrives while the GPU still has the queue replay to do).
+// The host's and the device's count of the scalar records part ways if a launch fails between the kernel that
+// publishes a record and the host's bookkeeping of the step: after an error both are set to what the device holds.
+static void resync_scalars(psamd_ctx *c)
+{
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return;
+    StepState st{};
+    if (hipMemcpy(&st, c->d.st, sizeof st, hipMemcpyDeviceToHost) != hipSuccess) return;
+    c->scalars_seq = c->scalars_seen = st.seq;
+}
+
+// Wait until the scalars of step `seq` are in the host's record: the publishing workgroup stores the record's
+// number last.  The stream is looked at now and then so that a failed launch cannot leave the host waiting, and
+// the wall clock too: a stream that stays busy without ever publishing is a wedged GPU, reported as such
+// (PSAMD_ERR_STATE, sticky) instead of a host thread that never comes back.
+// Policy 0 spins on the word (lowest latency); policy 1, the default of a slab, spins for a few microseconds and
+// then sleeps in short naps -- eight ranks of a node do not pin eight cores for the whole run.  The naps need a
+// timer slack of ~1 us (the default 50 us would BE the nap): set for the wait, restored before it returns.
 static int wait_scalars(psamd_ctx *c, int seq)
 {
-    volatile int32_t *word = &c->h_fs->seq;
+    volatile int32_t *word = &c->h_fs[seq & 1].seq;
+    if (*word == seq) { std::atomic_thread_fence(std::memory_order_acquire); return PSAMD_OK; }
     const bool naps = c->wait_policy == 1;
+    long old_slack = -1;
+    int rc = PSAMD_OK;
+    struct timespec t0;
+    (void)clock_gettime(CLOCK_MONOTONIC, &t0);
     for (uint64_t spins = 1; *word != seq; spins++) {
         if (naps && spins > 2000) {
-            static thread_local bool slack_set = false;
-            if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); slack_set = true; }   // 1 us: the default 50 us would be the nap
+            if (old_slack < 0) { old_slack = prctl(PR_GET_TIMERSLACK, 0UL, 0UL, 0UL, 0UL); (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); }
             struct timespec ts = {0, 5000};
             (void)nanosleep(&ts, nullptr);
         } else
@@ -1209,75 +1287,99 @@ static int wait_scalars(psamd_ctx *c, int seq)
             const hipError_t e = hipStreamQuery(c->stream);
             if (e == hipSuccess) {
                 if (*word == seq) break;
-                return fail(c, PSAMD_ERR_STATE, "the step's scalars never arrived on the host");
+                rc = fail(c, PSAMD_ERR_STATE, "the step's scalars never arrived on the host");
+                break;
             }
-            if (e != hipErrorNotReady) return hip_fail(c, e, "waiting for the step's scalars");
+            if (e != hipErrorNotReady) { rc = hip_fail(c, e, "waiting for the step's scalars"); break; }
+            struct timespec t1;
+            (void)clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > c->wait_limit_s) { c->wedged = true; rc = refuse_wedged(c); break; }
         }
     }
+    if (old_slack >= 0) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)old_slack, 0UL, 0UL, 0UL);
     std::atomic_thread_fence(std::memory_order_acquire);
+    return rc;
+}
+
+// Read the records of the steps up to number `upto` (waiting for them) and whatever has arrived beyond: the host's
+// bookkeeping of a step -- hints for the launches to come, the counters, and the step's verdict.
+// A slab fails COLLECTIVELY: only on error bits that were in a step's all-gathered status records,
+// which every rank sees alike (status_error) -- all ranks return the error from the same call.  An error this
+// rank raised after its status record was closed (a message that did not fit, an arrival for a queue it does not
+// hold) stays sticky, goes out with the next step's record and stops every rank there; returning it at once would
+// leave the ranks that have not heard of it waiting in the next exchange.  (psamd_synchronize reports whatever is pending.)
+static int consume_scalars(psamd_ctx *c, int upto)
+{
+    int verdict = PSAMD_OK;
+    while (c->scalars_seen < c->scalars_seq) {
+        const int s = c->scalars_seen + 1;
+        if (s <= upto) { const int st = wait_scalars(c, s); if (st != PSAMD_OK) { if (!c->wedged) resync_scalars(c); return st; } }
+        else if (*(volatile int32_t *)&c->h_fs[s & 1].seq != s) break;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        const FrameScalars r = c->h_fs[s & 1];
+        c->scalars_seen = s;
+        c->last = r;
+        c->live_at_build = r.live;
+        const int64_t tasks_now = (int64_t)r.n_tasks2 + r.n_merged;       // ordinary tasks + packs of partial slices
+        // (a pair stage in two passes -- interior_ran is noted per step below -- reports the second pass's task count)
+        const bool two = c->interior_steps.count(s) != 0;
+        c->interior_steps.erase(s);
+        c->tasks_last = two ? tasks_now * comp_count(c->P) / std::max(1, comp_count(c->P_rest)) : tasks_now;
+        c->packs_last = two ? (int64_t)r.n_merged * comp_count(c->P) / std::max(1, comp_count(c->P_rest)) : r.n_merged;
+        c->live_bound = std::min<int64_t>(c->P.slots_total, (int64_t)r.live + r.n_moves);   // births and arrivals <= moves
+        c->processed_total += r.live;
+        c->max_bucket_seen = std::max<int64_t>(c->max_bucket_seen, r.max_bucket);
+        if (verdict == PSAMD_OK && (c->P.world > 1 ? r.status_error != 0 : r.error != 0)) verdict = check_device_errors(c);
+    }
+    if (verdict != PSAMD_OK && c->pending_status == PSAMD_OK) { c->pending_status = verdict; c->pending_err = c->err; }
     return PSAMD_OK;
 }
 
-// the rest of the step, once enq_lifecycle is enqueued (or replayed): the step's one read-back, the host's
-// bookkeeping, the commit of the relocations
-static int finish_step(psamd_ctx *c, int64_t bound)
+static int take_verdict(psamd_ctx *c)
 {
-    const int par = (int)(c->steps_total & 1);
+    if (c->pending_status == PSAMD_OK) return PSAMD_OK;
+    const int st = c->pending_status;
+    c->err = c->pending_err;
+    c->pending_status = PSAMD_OK;
+    return st;
+}
+
+// the rest of the step, once enq_lifecycle is enqueued (or replayed): the host's bookkeeping
+static int finish_step(psamd_ctx *c)
+{
     c->host_queues_valid = false;
-    // one small read-back per step, as the reference's driver does for hostGridMax
-    // (ps.cpp:1878-1900): live count, sticky errors and the sizes of the op lists -- written into the
-    // pinned host record by the census kernels themselves (publish_scalars) with the record's number behind
-    // them, which the host polls: no copy command, no event.  The replay is enqueued behind it already
-    // (the kernels size themselves from the same scalars on the device), so the GPU is busy while the host catches up.
     const int seq = ++c->scalars_seq;
-    { const int st = wait_scalars(c, seq); if (st != PSAMD_OK) return st; }
-    c->live_at_build = c->h_fs->live;
-    const int64_t tasks_now = (int64_t)c->h_fs->n_tasks2 + c->h_fs->n_merged;       // ordinary tasks + packs of partial slices
-    c->tasks_last = c->interior_ran ? tasks_now * comp_count(c->P) / std::max(1, comp_count(c->P_rest)) : tasks_now;
-    c->packs_last = c->interior_ran ? (int64_t)c->h_fs->n_merged * comp_count(c->P) / std::max(1, comp_count(c->P_rest)) : c->h_fs->n_merged;
+    if (c->interior_ran) c->interior_steps.insert(seq);
     c->interior_ran = false;
-    c->live_bound = std::min<int64_t>(c->P.slots_total, (int64_t)c->h_fs->live + c->h_fs->n_moves);   // births and arrivals <= moves
-    c->processed_total += c->h_fs->live;
-    c->max_bucket_seen = std::max<int64_t>(c->max_bucket_seen, c->h_fs->max_bucket);
-    // A slab fails COLLECTIVELY: only on error bits that were in this step's all-gathered status records,
-    // which every rank sees alike (status_error) -- all ranks return the error from the same
-    // slab_finish.  An error this rank raised after its status record was closed (a message that did
-    // not fit, an arrival for a queue it does not hold) stays sticky, goes out with the next step's
-    // record and stops every rank there; returning it now would leave the ranks that have not heard
-    // of it waiting in the next exchange.  (psamd_synchronize reports whatever is pending.)
-    if (c->P.world > 1 ? c->h_fs->status_error != 0 : c->h_fs->error != 0) return check_device_errors(c);
-    if (c->h_fs->max_bucket > BUCKET_MAX)      // rare: the replay above stood down
-        PS_HIP(c, launch_lifecycle_sorted(c->stream, c->P, c->d, c->geo.queue_infos, c->h_fs->n_ops, c->h_fs->n_moves));
-    else                                       // the long lists' instance if there is one (launched only then: the host's copy of
-                                               // max_bucket is the device's), and the commit (the replay above is still running)
-        PS_HIP(c, launch_lifecycle(c->stream, c->P, c->d, c->geo.queue_infos, lifecycle_bound(c, bound), 1, c->h_fs->max_bucket > c->bucket_cap0, c->bucket_cap0));
-    if (c->timing_now) {
-        // No wait for the end of the step: everything up to `apply` was complete when the
-        // scalars landed; the life-cycle interval is read one step later (or by get_timing).
-        (void)hipEventRecord(c->ev[par ? 12 : 9], c->stream);
-        c->lifecycle_pending[par] = true;
-        collect_lifecycle_time(c, par ^ 1);
-        // slots: hist scan scatter sort | force pass, apply | frame reset | flags + active lists (two-pass prologue)
-        const int a[] = {0, 1, 2, 3, 13, 7, 10, 5}, b[] = {1, 2, 3, 4, 6, par ? 11 : 8, 0, 13}, slot[] = {0, 1, 2, 3, 4, 5, 7, 8};
-        for (int k = (c->timing_now >= 2 ? 0 : 4); k < 8; k++) {
-            if (c->timing_now < 2 && k == 6) continue;
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, c->ev[a[k]], c->ev[b[k]]) == hipSuccess) c->t_us[slot[k]] += 1000.0 * ms;
-        }
-        c->t_launches++;
-    }
+    if (c->timing_now) { c->ev_level[c->tset] = c->timing_now; c->timed_steps++; }
     c->grid_built = false; c->pairs_done = false;
+    c->frame_clean = true;                       // (the step's last kernel zeroed the counts for the frame that follows)
     c->step++; c->steps_total++;
-    return PSAMD_OK;
+    // run-ahead: this step's record is read when the NEXT step has been enqueued (the record of the step before must be
+    // out of the way by then: the two pinned records alternate); else now
+    const int rc = consume_scalars(c, c->run_ahead ? seq - 1 : seq);
+    return rc != PSAMD_OK ? rc : take_verdict(c);
+}
+
+// everything enqueued so far has run: read every record outstanding (psamd_synchronize and the calls that hand
+// state or counters to the caller)
+static int drain_scalars(psamd_ctx *c, bool quiet)
+{
+    PS_HIP(c, hipStreamSynchronize(c->stream));
+    const int rc = consume_scalars(c, c->scalars_seq);
+    return rc != PSAMD_OK ? rc : quiet ? (int)PSAMD_OK : take_verdict(c);
 }
 
 int psamd_init_iframe(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (c->wedged) return refuse_wedged(c);
     if (c->P.world > 1) return slab_only(c, "init_iframe");
     begin_step(c);
+    if (c->grid_built) c->frame_clean = false;      // (a frame abandoned after its build: its counts are in the way)
     const int rc = enq_init_iframe(c);
     if (rc != PSAMD_OK) return rc;
+    c->frame_clean = true;
     c->frame_reset = true; c->grid_built = false; c->pairs_done = false;
     return PSAMD_OK;
 }
@@ -1285,18 +1387,19 @@ int psamd_init_iframe(psamd_ctx *c)
 int psamd_build_grid(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (c->wedged) return refuse_wedged(c);
     if (c->P.world > 1) return slab_only(c, "build_grid");
     if (!c->frame_reset) return fail(c, PSAMD_ERR_STATE, "build_grid needs init_iframe first");
     const int rc = enq_build_grid(c);
     if (rc != PSAMD_OK) return rc;
-    c->frame_reset = false; c->grid_built = true; c->pairs_done = false;
-    c->live_at_build = -1;
+    c->frame_reset = false; c->grid_built = true; c->pairs_done = false; c->frame_clean = false;
     return PSAMD_OK;
 }
 
 int psamd_calc_forces_pairs(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (c->wedged) return refuse_wedged(c);
     if (c->P.world > 1) return slab_only(c, "calc_forces");
     if (!c->grid_built) return fail(c, PSAMD_ERR_STATE, "calc_forces needs build_grid first");
     const int rc = enq_pairs(c, c->P, pairs_hint(c, c->P));
@@ -1308,14 +1411,15 @@ int psamd_calc_forces_pairs(psamd_ctx *c)
 int psamd_calc_forces_apply(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (c->wedged) return refuse_wedged(c);
     if (c->P.world > 1) return slab_only(c, "calc_forces");
     if (!c->grid_built || !c->pairs_done) return fail(c, PSAMD_ERR_STATE, "apply needs build_grid and the pair pass first");
     const int64_t bound = live_bound_of(c);
     (void)pick_bucket_cap(c);
     int rc = enq_apply(c, bound);
     if (rc == PSAMD_OK) rc = enq_lifecycle(c, bound);
-    if (rc != PSAMD_OK) return rc;
-    return finish_step(c, bound);
+    if (rc != PSAMD_OK) { resync_scalars(c); return rc; }
+    return finish_step(c);
 }
 
 int psamd_calc_forces(psamd_ctx *c)
@@ -1329,12 +1433,14 @@ int psamd_calc_forces(psamd_ctx *c)
 int psamd_step(psamd_ctx *c, int32_t nsteps)
 {
     if (!c || nsteps < 0) return PSAMD_ERR_INVALID_ARG;
+    if (c->wedged) return refuse_wedged(c);
     if (c->P.world > 1 && nsteps > 0) return slab_only(c, "step");
     for (int k = 0; k < nsteps; k++) {
-        // init_iframe, build_grid, calc_forces up to the step's read-back: one sequence of launches (one graph)
+        // init_iframe, build_grid, calc_forces: one sequence of launches (one graph)
         begin_step(c);
+        if (c->grid_built) c->frame_clean = false;
         const int64_t hint = pairs_hint(c, c->P), bound = live_bound_of(c);
-        const uint64_t key = launch_pairs_shape(c->P, hint) | ((uint64_t)bound << 24) | pick_bucket_cap(c);
+        const uint64_t key = launch_pairs_shape(c->P, hint) | ((uint64_t)bound << 24) | pick_bucket_cap(c) | (c->frame_clean ? 0ull : 1ull << 60);
         int rc = run_segment(c, SEG_STEP, key, [&]() {
             int r = enq_init_iframe(c);
             if (r == PSAMD_OK) r = enq_build_grid(c);
@@ -1343,9 +1449,10 @@ int psamd_step(psamd_ctx *c, int32_t nsteps)
             if (r == PSAMD_OK) r = enq_lifecycle(c, bound);
             return r;
         });
-        if (rc != PSAMD_OK) return rc;
-        c->frame_reset = false; c->grid_built = true; c->pairs_done = true; c->live_at_build = -1;
-        rc = finish_step(c, bound);
+        c->frame_clean = false;
+        if (rc != PSAMD_OK) { resync_scalars(c); return rc; }
+        c->frame_reset = false; c->grid_built = true; c->pairs_done = true;
+        rc = finish_step(c);
         if (rc != PSAMD_OK) return rc;
     }
     return PSAMD_OK;
@@ -1356,8 +1463,10 @@ int psamd_step(psamd_ctx *c, int32_t nsteps)
 int psamd_slab_build(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
+    if (c->wedged) return refuse_wedged(c);
     begin_step(c);
-    const int rc = run_segment(c, SEG_BUILD, 0, [&]() {
+    if (c->grid_built) c->frame_clean = false;
+    const int rc = run_segment(c, SEG_BUILD, c->frame_clean ? 0 : 1, [&]() {
         int r = enq_init_iframe(c);
         if (r == PSAMD_OK) r = enq_build_grid(c);
         if (r != PSAMD_OK) return r;
@@ -1366,7 +1475,7 @@ int psamd_slab_build(psamd_ctx *c)
         return (int)PSAMD_OK;
     });
     if (rc != PSAMD_OK) return rc;
-    c->frame_reset = false; c->grid_built = true; c->pairs_done = false; c->live_at_build = -1;
+    c->frame_reset = false; c->grid_built = true; c->pairs_done = false; c->frame_clean = false;
     c->slab_stage = 1;
     return PSAMD_OK;
 }
@@ -1393,6 +1502,8 @@ int psamd_slab_pairs(psamd_ctx *c)
     const DevParams &Pp = c->interior_done ? c->P_rest : c->P;
     const bool second = c->interior_done;
     const int64_t hint = pairs_hint(c, Pp);
+    // (the all-pairs far pass sizes its launch from the live bound on one GPU only -- a slab takes every entry of the
+    // sorted order, see launch_pairs -- so the bound is no part of this key)
     const int rc = run_segment(c, SEG_PAIRS, launch_pairs_shape(Pp, hint) | (second ? 2ull << 40 : 0ull), [&]() {
         const int GG = P.G * P.G;
         // from the rank below: halo layer (region 1), then lent layers (region 2); from the rank above: halo layer (region 3)
@@ -1437,8 +1548,8 @@ int psamd_slab_finish(psamd_ctx *c)
     c->slab_stage = 0;
     const int64_t bound = c->slab_bound;
     const int rc = run_segment(c, SEG_FINISH, (uint64_t)bound | pick_bucket_cap(c), [&]() { return enq_lifecycle(c, bound); });
-    if (rc != PSAMD_OK) return rc;
-    return finish_step(c, bound);
+    if (rc != PSAMD_OK) { resync_scalars(c); return rc; }
+    return finish_step(c);
 }
 
 int psamd_slab_plan_describe(const psamd_config *cfg, psamd_slab_plan *o)
@@ -1530,14 +1641,15 @@ int psamd_slab_msg_upload(psamd_ctx *c, int which, const void *host, int64_t byt
 int psamd_synchronize(psamd_ctx *c)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
-    PS_HIP(c, hipStreamSynchronize(c->stream));
+    const int rc = drain_scalars(c);             // (the verdict of every step whose record had not been read yet)
+    if (rc != PSAMD_OK) return rc;
     return check_device_errors(c);
 }
 
 int psamd_get_counters(psamd_ctx *c, psamd_counters *o)
 {
     if (!c || !o) return PSAMD_ERR_INVALID_ARG;
-    PS_HIP(c, hipStreamSynchronize(c->stream));
+    (void)drain_scalars(c, true);                // (steps / particles_processed count every step enqueued; a step's verdict is psamd_synchronize's to report)
     DevCounters copies[COUNTER_COPIES];
     PS_HIP(c, hipMemcpy(copies, c->d.ctr, sizeof copies, hipMemcpyDeviceToHost));
     DevCounters d{};
@@ -1698,15 +1810,23 @@ int psamd_set_wait_policy(psamd_ctx *c, int policy)
     return PSAMD_OK;
 }
 
+int psamd_set_run_ahead(psamd_ctx *c, int steps)
+{
+    if (!c || steps < 0 || steps > 1) return PSAMD_ERR_INVALID_ARG;
+    c->run_ahead = steps;
+    return PSAMD_OK;
+}
+
 int psamd_set_timing(psamd_ctx *c, int enabled)
 {
     if (!c) return PSAMD_ERR_INVALID_ARG;
+    collect_timing(c, 0); collect_timing(c, 1);          // (whatever is outstanding belongs to the setting that ends here)
     c->timing = enabled < 0 ? 0 : enabled > 2 ? 2 : enabled;
     c->timing_steps = 0; c->timing_now = 0;
     if (c->timing) make_events(c);
     for (double &v : c->t_us) v = 0.0;
+    for (auto &v : c->t_samples) v.clear();
     c->t_launches = 0;
-    c->lifecycle_pending[0] = c->lifecycle_pending[1] = false;
     return PSAMD_OK;
 }
 
@@ -1721,10 +1841,24 @@ int psamd_set_timing_period(psamd_ctx *c, int every)
 int psamd_get_timing(psamd_ctx *c, double us_out[PSAMD_NUM_TIMERS], int64_t *launches)
 {
     if (!c || !us_out) return PSAMD_ERR_INVALID_ARG;
-    collect_lifecycle_time(c, 0);
-    collect_lifecycle_time(c, 1);
+    collect_timing(c, 0); collect_timing(c, 1);
     for (int k = 0; k < PSAMD_NUM_TIMERS; k++) us_out[k] = c->t_us[k];
     if (launches) *launches = c->t_launches;
+    return PSAMD_OK;
+}
+
+int psamd_get_timing_stats(psamd_ctx *c, double median_us[PSAMD_NUM_TIMERS], double max_us[PSAMD_NUM_TIMERS], int64_t *samples)
+{
+    if (!c || !median_us || !max_us) return PSAMD_ERR_INVALID_ARG;
+    collect_timing(c, 0); collect_timing(c, 1);
+    for (int k = 0; k < PSAMD_NUM_TIMERS; k++) {
+        std::vector<float> v = c->t_samples[k];
+        median_us[k] = max_us[k] = 0.0;
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end());
+        median_us[k] = v[v.size() / 2]; max_us[k] = v.back();
+    }
+    if (samples) *samples = c->t_launches;
     return PSAMD_OK;
 }
 

@@ -164,11 +164,13 @@ __device__ __forceinline__ int hist_window(const DevParams &P, const int (&mine)
 }
 
 __global__ __launch_bounds__(1024) void k_hist_lds(DevParams P, const int *__restrict__ cell, int *__restrict__ cell_count,
-                                                    FrameScalars *fs)
+                                                    FrameScalars *fs, StepState *st)
 {
     __shared__ int h[LDS_CELLS];
     __shared__ int s_min;
     const int tid = threadIdx.x, base = blockIdx.x * SLOTS_PER_WG, ncell = P.n_own_cells;
+    // the build's first kernel: the step whose scalars went out last is over (nothing reads the step's number before k_apply)
+    if (blockIdx.x == 0 && tid == 0 && st->pending) { st->step += 1; st->pending = 0; }
     int mine[SLOTS_PER_WG / 1024];
 #pragma unroll
     for (int i = 0; i < SLOTS_PER_WG / 1024; i++) {
@@ -716,7 +718,9 @@ hipError_t launch_place(hipStream_t st, const DevParams &P, int n, const int *id
 }
 
 // init_iframe: zero the per-frame counts (cells, chunks, queue records: one array) and the
-// per-frame scalars; the sticky error word survives
+// per-frame scalars; the sticky error word survives.  A step's last kernel does this for the step that follows
+// (lifecycle.hip, k_replay_commit); this launch is for a frame that has no finished step before it (a frame
+// abandoned half way, state uploaded in between).
 __global__ void k_frame_reset(int *frame, size_t n, FrameScalars *fs, StepState *st, int *status_out, int status_table)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -759,7 +763,7 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
 {
     const int nwg = std::max(1, (P.slots_total + SLOTS_PER_WG - 1) / SLOTS_PER_WG);
     if (ev) (void)hipEventRecord(ev[0], st);
-    k_hist_lds<<<nwg, 1024, 0, st>>>(P, d.cell, d.cell_count, d.fs);
+    k_hist_lds<<<nwg, 1024, 0, st>>>(P, d.cell, d.cell_count, d.fs, d.st);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[1], st);
     k_scan<<<1, 1024, 0, st>>>(P, d.cell_count, d.cell_start, d.cursor, d.task_start, d.task_list, d.chunk_count, d.celltab, d.status_out, d.fs);

@@ -33,7 +33,7 @@ struct DeviceState {
     uint8_t *chunk_skip = nullptr;   // [slots] 1: not in its chunk's (capped) list this frame; valid for the slots of over-cap chunks only
     int2 *chunk_segs = nullptr;      // [num_chunks * 27] (first slot, slots) of the segments a chunk's particles live in, in slot order
     FrameScalars *fs = nullptr;
-    FrameScalars *fs_host = nullptr;  // the host's pinned copy as the device sees it (written by the queue-census kernels)
+    FrameScalars *fs_host = nullptr;  // the host's TWO pinned records as the device sees them (the step's number picks one; written by the queue-census kernels)
     StepState *st = nullptr;          // the step's number and the scalar records' sequence number, device-resident
     int *cell_start = nullptr;    // [num_cells+1]
     int *cursor = nullptr;        // [num_cells]
@@ -71,8 +71,6 @@ struct DeviceState {
     int *rec_count = nullptr;     // [queue_infos] zeroed with the frame
     int *rec_start = nullptr;     // [queue_infos + 1]
     int *rec_cursor = nullptr;    // [queue_infos]
-    void *sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
     MoveRec *moves = nullptr;
     int moves_cap = 0;
     float4 *stage = nullptr;      // 3 float4 per move
@@ -113,12 +111,12 @@ hipError_t launch_pairs(hipStream_t st, const DevParams &P, const DeviceState &d
 uint64_t launch_pairs_shape(const DevParams &P, int64_t tasks_hint);
 hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, const DeviceState &d);
 hipError_t launch_frame_reset(hipStream_t st, const DeviceState &d, size_t frame_ints, int status_table);   // also clears the status record's header and census table
-// the bucketed life cycle, sized from a bound of the live count: bucket the operations (afterwards the
-// frame scalars are complete), then replay + relocation
-hipError_t launch_ops_bucket(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_bound);
-hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_bound, int part, bool long_lists, int cap0);
-hipError_t launch_lifecycle_sorted(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec,
-                                   int n_ops, int n_moves);
+// The step's tail behind k_apply: census of the queue operations (+ relocation phase 1), bucketing (the step's scalars go
+// out to the host's pinned record), replay + commit + the next frame's init_iframe.  live_hint sizes grid-stride
+// launches and nothing else; cap0 (2048 / 4096 / 8192) picks the replay instance -- lists longer than it are sorted in
+// global memory by the same workgroup.  frame_ints / status_table: what the next frame's reset zeroes.
+hipError_t launch_lifecycle(hipStream_t st, const DevParams &P, const DeviceState &d, int nrec, int64_t live_hint, int cap0,
+                            size_t frame_ints, int status_table);
 // slab exchange (messages are int arrays with a 16-word header, see kernels.hip)
 // the snapshots for the rank below (k = 0) / above (k = 1), both in one pair of launches; also closes the status record
 hipError_t launch_pack_halos(hipStream_t st, const DevParams &P, const DeviceState &d, const int c0[2], const int ncell[2],
@@ -126,15 +124,12 @@ hipError_t launch_pack_halos(hipStream_t st, const DevParams &P, const DeviceSta
 hipError_t launch_unpack_halos(hipStream_t st, const DevParams &P, const DeviceState &d, int ncell_below, const int *msg_below,
                                int *off_below, int ncell_above, const int *msg_above, int *off_above);
 hipError_t launch_pack_force(hipStream_t st, const DevParams &P, const DeviceState &d, int *msg, int cap_bodies);
-hipError_t launch_outbox_close(hipStream_t st, const DevParams &P, const DeviceState &d, int64_t live_bound, int *const msgs[5]);
+hipError_t launch_outbox_close(hipStream_t st, const DevParams &P, const DeviceState &d, int64_t live_hint, int *const msgs[5]);
 hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *const msgs[5]);
 hipError_t launch_allg_pack(hipStream_t st, const DevParams &P, const DeviceState &d, int *msg);
 hipError_t launch_allg_index(hipStream_t st, const DevParams &P, const DeviceState &d);
 // status records of all ranks (error bits, cell-overflow kills, chunk counts) + the force records of the lent-out layers (force_msg, may be null)
 hipError_t launch_status_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *status_all,
                                int force_j0, const int *force_msg, const int *pack_off);
-// lifecycle_sort.hip (rocPRIM radix sort of the op keys; library code, not a hot path)
-hipError_t sort_ops_tmp_bytes(size_t n, int key_bits, size_t *bytes);
-hipError_t sort_ops(hipStream_t st, const DeviceState &d, int n, int key_bits);
 
 }  // namespace psamd

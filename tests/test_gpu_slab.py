@@ -294,7 +294,8 @@ def test_slab_failure_is_collective():
     known to the rank that raised it and, through the message header, to its ring neighbours -- not
     to the ranks further away, which would wait in the next exchange for a peer that has stopped.
     So a slab fails only on what the all-gathered status records show: the sticky bit goes out with
-    the next step's record and EVERY rank returns the error from that step's slab_finish."""
+    the next step's record and EVERY rank gets the error as that step's verdict (from the slab_finish after it, or
+    from psamd_synchronize)."""
     world = 4
     n = 60000
     xyz = cloud(n, 302)
@@ -328,7 +329,8 @@ def test_slab_failure_is_collective():
                 ranks[peer].msg_upload(in_slot, g.msg_download(out_slot))
     for g in ranks:
         with pytest.raises(ps.PsamdError):
-            g.slab_finish()
+            g.slab_finish()                 # (a call reports the steps before the one it enqueues: run-ahead) ...
+            g.synchronize()                 # ... and this, whatever is outstanding: the step's own verdict
         failed += 1
     assert failed == world
     for g in ranks:

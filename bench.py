@@ -84,11 +84,16 @@ def parse_args():
     ap.add_argument("--backend", default="ring", help="--gpus > 1: ring = one C++ rank per GPU (host/ps_ring_rccl: RCCL on a second HIP stream, "
                     "stage sequences as hipGraphs; the default); nccl = the same step from Python over torch.distributed (RCCL); gloo: "
                     "messages staged through host memory, for rehearsals on one GPU")
+    ap.add_argument("--host", default="ring", choices=("ring", "python"), help="who drives the timed loop: ring = the C++ host (host/ps_ring_rccl on include/psamd.h), "
+                    "for EVERY --gpus N including 1 -- one host for the whole scaling curve (the default); python = this process through ctypes "
+                    "(one GPU; what the side runs beside the headline use)")
     ap.add_argument("--graphs", action="store_true", help="one GPU / --sim-world / torch ranks: stage sequences as hipGraphs (psamd_set_graphs)")
     ap.add_argument("--wait-policy", type=int, default=-1, help="how the host waits for a step's scalars: 0 spin, 1 short spin then naps (default: the library's)")
     ap.add_argument("--ring-graphs", type=int, default=0, help="C++ ranks: stage sequences as hipGraphs (default 0, plain launches: a graph launch costs "
                     "~10 us on the GPU's timeline, four of them a step -- profiles/r4_ab_graphs.txt)")
-    ap.add_argument("--ring-side-stream", type=int, default=1, help="C++ ranks: RCCL on a second HIP stream (0: on the compute stream)")
+    ap.add_argument("--ring-side-stream", type=int, default=0, help="C++ ranks: 0 = every RCCL call on the compute stream (default: a dependency that crosses "
+                    "streams costs ~15 us each way on the GPU's timeline, measured); 1 = the status gather, and with --overlap-interior the halo, on a second HIP stream; "
+                    "2 = every transfer on the second stream (round 4's form)")
     ap.add_argument("--ring-timeout", type=float, default=0.0, help="seconds a C++ rank may take before it is ended and the ranks fall back (0: from --steps)")
     ap.add_argument("--sustained-steps", type=int, default=200, help="one GPU: when --steps is shorter than this, a second timed region of this "
                     "many steps is reported beside the line's figure (which clock a figure was taken at is part of the figure); 0: none")
@@ -259,6 +264,7 @@ def side_run(ps, cfg_over, device, xyz, age, fert, flags, steps, restore, warm=3
     cfg = dict(cfg_over)
     cfg.update(cfg_extra)
     g = ps.ParticleSystem(ps.default_config(device=device, flags=flags, **cfg))
+    g.set_tdata_mirror(False)           # (as the headline's context: nobody fetches T_DATA here)
     g.fill_particles(xyz, age=age, fert_age=fert)
     g.snapshot_save()
     live = []
@@ -309,6 +315,31 @@ def side_run(ps, cfg_over, device, xyz, age, fert, flags, steps, restore, warm=3
                                   "mean": {k: v / max(launches, 1) for k, v in tim.items() if v > 0}, "timed_steps": launches}
 
 
+def side_runs(out, args, ps, cfg_over, device, xyz, age, fert, flags, period, warm_ctx):
+    """The figures beside the headline, each from a short run of its own on a fresh context (the Python host): SURVEY 8(d)'s
+    lifecycle-off mode, the tolerance mode, a free-running stretch."""
+    # lifecycle off: collision radius 0 (and no births, no deaths of age in these steps), so every one of the N particles
+    # goes through the force loop and is integrated
+    d, t, _, roof, kt = side_run(ps, cfg_over, device, xyz, age, fert, flags, 50, True, timing_period=min(5, period), collision_radius=0.0)
+    out["lifecycle_off"] = {
+        "what": "the same cloud and step with COLLISION_RADIUS = 0: nothing collides, all %d particles get a force and are "
+                "integrated (the headline's step, at the reference's radius 0.4, integrates the particles the "
+                "reference integrates: config.particles_with_a_force_term)" % args.n,
+        "value": d / t, "unit": "particle-updates/s", "ms_per_step": 1e3 * t / 50, "steps": 50,
+        "roofline": roof, "kernel_us_per_step": kt}
+    d, t, _, roof, kt = side_run(ps, cfg_over, device, xyz, age, fert, ps.FLAG_FAST_MATH, 50, True, timing_period=min(5, period))
+    out["within_tolerance_mode"] = {
+        "arithmetic": "PSAMD_FLAG_FAST_MATH (FMA + v_rsq): accelerations deviate from the oracle's by the amounts "
+                      "tests/test_gpu_fast.py measures and bounds (also at this density); not the headline",
+        "value": d / t, "unit": "particle-updates/s", "ms_per_step": 1e3 * t / 50, "steps": 50,
+        "roofline": roof, "kernel_us_per_step": kt}
+    d, t, lv, _, _ = side_run(ps, cfg_over, device, xyz, age, fert, flags, args.evolve_steps, False, warm_ctx=warm_ctx)
+    out["evolve"] = {"what": "%d free-running steps from the same cloud (the population collapses: surface implosion, "
+                             "collisions), exact arithmetic" % args.evolve_steps,
+                     "value": d / t, "unit": "particle-updates/s", "ms_per_step": 1e3 * t / args.evolve_steps,
+                     "live_per_step": lv}
+
+
 def sim_world(args, ps, cfg_over, flags):
     """All ranks of a world-`W` slab run in this process, on this one GPU, one after the other
     on one stream: every rank's stage then takes what it would take with a GPU to itself.
@@ -321,6 +352,7 @@ def sim_world(args, ps, cfg_over, flags):
              for r in range(W)]
     xyz, age, fert = make_inputs(ranks[0], args.n, args.seed)
     for g in ranks:
+        g.set_tdata_mirror(False)
         g.fill_particles(xyz, age=age, fert_age=fert)
         g.snapshot_save()
         if args.graphs:
@@ -505,7 +537,8 @@ def ring_args(args, world, rank, local_rank, cfg_over):
             "--chunk-factor", str(args.chunk_factor), "--chunk-dim", str(args.chunk_dim),
             "--halo-cap-cell", str(args.halo_cap_cell), "--xfer-cap", str(cfg_over.get("xfer_cap", 0)),
             "--max-particles", str(cfg_over["max_particles_num"]),
-            "--graphs", str(args.ring_graphs), "--side-stream", str(args.ring_side_stream)]
+            "--graphs", str(args.ring_graphs), "--side-stream", str(args.ring_side_stream),
+            "--sustained-steps", str(args.sustained_steps if (world == 1 and not args.evolve) else 0)]
     for flag, on in (("--all-pairs", args.all_pairs), ("--fast-math", args.fast_math), ("--evolve", args.evolve),
                      ("--overlap-interior", args.overlap_interior)):
         if on:
@@ -515,24 +548,55 @@ def ring_args(args, world, rank, local_rank, cfg_over):
 
 def run_ring_rank(args, world, rank, local_rank, cfg_over):
     """Start this rank's C++ program as a child process (nothing in this process has touched a GPU), wait for it --
-    not for ever: a rank that hangs is ended by its exact PID --, tell the other ranks how it went through a file beside
-    the id file, and hear from them.  Returns (every rank succeeded, rank 0's record or None, what went wrong)."""
+    not for ever: a rank that hangs is ended by its exact PID, and so is this rank's program the moment ANOTHER rank
+    reports a failure (its peers would otherwise sit in RCCL until the limit) --, tell the other ranks how it went
+    through a file beside the id file, and hear from them.
+    Returns (every rank succeeded, rank 0's record or None, what went wrong, whether a program was ended by a signal or the limit)."""
     id_file, _ = ring_paths()
     mine = "%s.rc%d" % (id_file, rank)
     if os.path.exists(mine):
         os.remove(mine)
-    limit = args.ring_timeout or (240.0 + 0.05 * (args.steps + args.warmup) * max(1, args.n >> 20) * (40 if args.all_pairs else 1))
+    limit = args.ring_timeout or (240.0 + 0.05 * (args.steps + args.warmup + (args.sustained_steps if world == 1 else 0)) * max(1, args.n >> 20) * (40 if args.all_pairs else 1))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    rec, err = None, ""
+    rec, err, violent = None, "", False
+
+    def peer_codes():
+        codes = {}
+        for r in range(world):
+            try:
+                with open("%s.rc%d" % (id_file, r)) as f:
+                    codes[r] = int(f.read().strip() or "1")
+            except (OSError, ValueError):
+                pass
+        return codes
+
     try:
         p = subprocess.Popen(ring_args(args, world, rank, local_rank, cfg_over), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-        try:
-            out, errtxt = p.communicate(timeout=limit)
-            rc = p.returncode
-        except subprocess.TimeoutExpired:
-            p.kill()
-            out, errtxt = p.communicate()
-            rc, errtxt = -9, (errtxt or "") + "\n(ended after %.0f s)" % limit
+        import threading
+        got = {}
+        t = threading.Thread(target=lambda: got.update(zip(("out", "err"), p.communicate())), daemon=True)
+        t.start()
+        t_end = time.time() + limit
+        why = ""
+        while t.is_alive():
+            t.join(timeout=0.25)
+            if not t.is_alive():
+                break
+            if time.time() > t_end:
+                why = "ended after %.0f s" % limit
+            elif any(v != 0 for r, v in peer_codes().items() if r != rank):
+                why = "ended because another rank failed"
+            if why:
+                p.kill()                                # this child, by its PID
+                t.join(timeout=30)
+                break
+        out, errtxt = got.get("out", "") or "", got.get("err", "") or ""
+        rc = p.returncode if p.returncode is not None else -9
+        if why:
+            rc, errtxt = (rc or -9), errtxt + "\n(" + why + ")"
+            violent = violent or why.startswith("ended after")
+        if rc < 0 and not why:
+            violent = True                              # died of a signal: a fault, an abort
         lines = [l for l in out.splitlines() if l.startswith("{") and '"psamd_ring"' in l]     # (librccl prints its banner on stdout too)
         if rc == 0 and (lines or rank != 0):
             rec = json.loads(lines[-1]) if lines else None
@@ -548,16 +612,12 @@ def run_ring_rank(args, world, rank, local_rank, cfg_over):
     codes = {}
     t_end = time.time() + limit + 30.0
     while len(codes) < world and time.time() < t_end:
-        for r in range(world):
-            if r not in codes:
-                try:
-                    with open("%s.rc%d" % (id_file, r)) as f:
-                        codes[r] = int(f.read().strip() or "1")
-                except (OSError, ValueError):
-                    pass
+        codes = peer_codes()
         if len(codes) < world:
             time.sleep(0.05)
     ok = len(codes) == world and all(v == 0 for v in codes.values())
+    if any(v < 0 for v in codes.values()):
+        violent = True
     if not ok and not err:
         err = "ranks %s failed or never reported" % sorted(set(range(world)) - {r for r, v in codes.items() if v == 0})
     if rank == 0:
@@ -567,7 +627,7 @@ def run_ring_rank(args, world, rank, local_rank, cfg_over):
                 os.remove("%s.rc%d" % (id_file, r))
             except OSError:
                 pass
-    return ok, rec, err
+    return ok, rec, err, violent
 
 
 def line_from_ring_record(args, r):
@@ -579,7 +639,8 @@ def line_from_ring_record(args, r):
     ach_tflops = r["pairs_rank0"] * FLOP_PER_PAIR / (us_pairs * 1e-6) / 1e12 if us_pairs > 0 else 0.0
     ach_gbs = r["own_updates"] / steps * APPLY_BYTES_PER_UPDATE / (us_apply * 1e-6) / 1e9 if us_apply > 0 else 0.0
     host = ("C++ ranks (host/ps_ring_rccl on include/psamd.h): RCCL send/recv/all-gather %s, %s" %
-            ("on a second HIP stream, ordered against the stage kernels by events" if r["side_stream"] else "on the compute stream",
+            ({0: "on the compute stream, between the stage kernels", 1: "on the compute stream, the status gather (and an overlapped halo) on a second HIP stream",
+              2: "on a second HIP stream, ordered against the stage kernels by events"}[int(r.get("side_stream_mode", 2 if r["side_stream"] else 0))],
              "every stage's kernels as one hipGraph (%d replays, %d captures on rank 0)" % (r["graph_replays"], r["graph_captures"])
              if r["graphs"] else "plain kernel launches"))
     out = {
@@ -609,12 +670,46 @@ def line_from_ring_record(args, r):
         "roofline_streaming": {"kernel": "k_apply of rank 0", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                                "bytes_per_update": APPLY_BYTES_PER_UPDATE, "us_per_launch": us_apply},
-        "kernel_us_per_step": kt,
-        "kernel_times_from": "HIP events on rank 0's compute stream on %d of the %d timed steps (every %d%s; those steps run as plain launches)" %
+        "shader_clock_mhz": r.get("shader_clock_mhz"),
+        "sustained": ({"steps": r["sustained_steps"], "ms_per_step": r["sustained_ms_per_step"], "shader_clock_mhz": r.get("sustained_shader_clock_mhz"),
+                       "what": "the same timed loop over %d steps, run right after the line's %d (no timing events): the clock a long run holds" % (r["sustained_steps"], steps)}
+                      if r.get("sustained_steps") else None),
+        "kernel_us_per_step": r.get("kernel_us_median", kt),
+        "kernel_us_per_step_max": r.get("kernel_us_max"),
+        "kernel_us_per_step_mean": kt,
+        "kernel_times_from": "HIP events on rank 0's compute stream on %d of the %d timed steps (every %d%s; those steps run as plain launches): kernel_us_per_step "
+                             "is the MEDIAN over those steps, _max the slowest, _mean what the rooflines use" %
                              (r["timed_launches"], steps, r["timing_period"], "th" if r["timing_period"] > 1 else "st"),
+        # what an N-GPU run needs to explain itself: how many ranks RCCL really joined, every rank's own stage times (median
+        # over the timed steps, HIP events on its compute stream), how long the compute stream WAITED for each phase's messages
+        # (end of a stage to the start of the next: the host enqueues at once, only the transfer stream's event holds it back;
+        # minimum and maximum over the ranks), and the bytes rank 0 sends per phase
+        "rccl_ranks": r.get("rccl_ranks"),
+        "stage_ms_per_rank": r.get("stage_ms_per_rank"),
+        "wait_for_messages_ms": r.get("wait_ms"),
+        "bytes_per_phase_rank0": r.get("bytes_per_phase_rank0"),
         "cpu_baseline": None,
     }
     return out
+
+
+def cpu_cache_path(args):
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "psamd_cpu_baseline_n%d_s%d_g%dx%d.json" % (args.n, args.seed, args.chunk_factor, args.chunk_dim))
+
+
+def cpu_baseline_cached(args, cfg_over, world):
+    """The CPU oracle's figure for the multi-rank line: copied from a one-rank run on this box if there was one (bench.py
+    --gpus 1 leaves it in TMPDIR), else measured now on a shorter sample -- after the ranks have finished."""
+    path = cpu_cache_path(args)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        d["one"]["from"] = d["many"]["from"] = "copied from this box's one-rank run (%s)" % path
+        return d["one"], d["many"]
+    except Exception:
+        pass
+    return None, None
+
 
 
 def main():
@@ -643,7 +738,7 @@ def main():
                 if not ps._build.needs_build() and os.path.exists(ps._build.RING) and os.path.getmtime(ps._build.RING) >= os.path.getmtime(ps._build.LIB):
                     break
                 time.sleep(0.5)
-        ok, rec, err = run_ring_rank(args, world, rank, local_rank, {})
+        ok, rec, err, _ = run_ring_rank(args, world, rank, local_rank, {})
         if not ok:
             sys.stderr.write("launch check of the C++ ranks failed: %s\n" % err)
             sys.exit(1)
@@ -696,10 +791,13 @@ def main():
         G = args.chunk_factor * args.chunk_dim
         cfg_over["xfer_cap"] = int(1.25 * args.n / G) + 4096
     flags = (ps.FLAG_FAST_MATH if args.fast_math else 0) | (ps.FLAG_ALL_PAIRS if args.all_pairs else 0)
-    if world > 1 and args.backend == "ring":
-        # The ranks that do the work are C++ programs: this rank's is started as a child process (nothing here has
-        # touched a GPU), rank 0 relays its record.  If any rank's program fails, all ranks hear of it (files beside the
-        # id file) and run the step from Python over torch.distributed instead -- the line then says so.
+    use_ring = (args.backend == "ring" if world > 1 else args.host == "ring") and not args.sim_world
+    if use_ring:
+        # The ranks that do the work are C++ programs -- for ONE GPU too: the whole scaling curve is driven by the same host
+        # (host/ps_ring_rccl).  This rank's is started as a child process (nothing here has touched a GPU), rank 0 relays its
+        # record.  If any rank's program fails, all ranks hear of it (files beside the id file) and run the step from Python
+        # instead (world > 1: over torch.distributed) -- the line then says so, and a program that was ended by a signal or
+        # by the time limit (a fault, a hang: not a clean refusal) makes this command exit non-zero behind its line.
         if rank == 0:
             ps._build.build_ring()
         else:
@@ -707,14 +805,42 @@ def main():
                 if os.path.exists(ps._build.RING) and os.path.getmtime(ps._build.RING) >= os.path.getmtime(ps._build.LIB):
                     break
                 time.sleep(0.5)
-        ok, rec, err = run_ring_rank(args, world, rank, local_rank, cfg_over)
+        ok, rec, err, violent = run_ring_rank(args, world, rank, local_rank, cfg_over)
         if ok:
             if rank == 0:
-                print(json.dumps(line_from_ring_record(args, rec)))
+                out = line_from_ring_record(args, rec)
+                if world == 1:
+                    out["config"]["parallelism"] = "single GPU"
+                    for key, prefix in (("roofline", "k_pairs_balanced"), ("roofline_streaming", "k_apply")):
+                        out[key]["traffic"] = measured_traffic(prefix, args, world)
+                        out[key]["traffic_source"] = TRAFFIC_FILE if out[key]["traffic"] is not None else None
+                    out["roofline"]["kernel"] = "k_pairs_balanced (the packs of partly filled slices are workgroups of the same launch)"
+                    out["roofline_streaming"]["kernel"] = "k_apply"
+                    if not args.all_pairs and not args.no_cpu:
+                        # the side runs and the CPU oracle, from this process (the C++ program has ended: the GPU is free)
+                        g = ps.ParticleSystem(ps.default_config(device=local_rank, flags=flags, **cfg_over))
+                        g.set_tdata_mirror(False)
+                        xyz, age, fert = make_inputs(g, args.n, args.seed)
+                        if not args.no_side_runs and not args.fast_math and not args.evolve:
+                            g.fill_particles(xyz, age=age, fert_age=fert)
+                            g.snapshot_save()
+                            side_runs(out, args, ps, cfg_over, local_rank, xyz, age, fert, flags, max(1, min(args.timing_period, args.steps)), g)
+                        g.close()
+                        out["cpu_baseline"], out["cpu_baseline_many_threads"] = cpu_baseline(args, xyz, age, fert, cfg_over)
+                        try:
+                            with open(cpu_cache_path(args), "w") as f:
+                                json.dump({"one": out["cpu_baseline"], "many": out["cpu_baseline_many_threads"]}, f)
+                        except OSError:
+                            pass
+                elif not args.all_pairs:
+                    out["cpu_baseline"], out["cpu_baseline_many_threads"] = cpu_baseline_cached(args, cfg_over, world)
+                print(json.dumps(out))
             return
-        sys.stderr.write("bench.py rank %d: the C++ ranks failed (%s); falling back to the torch.distributed ranks\n" % (rank, err))
+        sys.stderr.write("bench.py rank %d: the C++ host failed (%s); falling back to the Python host%s\n" %
+                         (rank, err, " over torch.distributed" if world > 1 else ""))
         args.backend = os.environ.get("PSAMD_BENCH_FALLBACK_BACKEND", "nccl")      # (gloo: rehearsals on one GPU)
         args.ring_failed = err
+        args.ring_violent = violent
     import torch
     dist = None
     if world > 1:
@@ -747,6 +873,10 @@ def main():
     device = local_rank if (world == 1 or args.backend == "nccl") else 0
     cfg = ps.default_config(device=device, rank=rank, world=world, flags=flags, halo_cap_cell=args.halo_cap_cell, **cfg_over)
     g = ps.ParticleSystem(cfg)
+    # The reference's T_DATA rows are a mirror the library keeps for callers that fetch that buffer (psamd_download_tdata);
+    # nothing in the step reads them and this host never fetches them: off (the parity tests run with it on AND compare
+    # the rows; the snapshot the pair stage reads is built by the same kernel either way).
+    g.set_tdata_mirror(False)
     xyz, age, fert = make_inputs(g, args.n, args.seed)
     g.fill_particles(xyz, age=age, fert_age=fert)       # a slab rank keeps the particles of its own segments
     G = g.sizes.grid_dim
@@ -925,6 +1055,7 @@ def main():
                                        "transfer messages between ring neighbours over %s" % (world, "RCCL send/recv" if args.backend == "nccl" else args.backend))
                                       if world > 1 else "single GPU",
                        "graphs": ("stage sequences as hipGraphs: %d replays, %d captures" % g.graph_stats()) if args.graphs else None,
+                       "tdata_mirror": False, "run_ahead_steps": 1,
                        "updates_in_timed_region": updates, "live_after": live, "settle_steps_before_warmup": settle,
                        "particles_with_a_force_term": int(fcounts1.sum()),
                        "relocations": ctr["relocations"], "relocations_lost": ctr["relocations_lost"],
@@ -945,9 +1076,11 @@ def main():
             "kernel_times_from": "HIP events on the context's stream on %d of the %d timed steps (every %d%s): kernel_us_per_step is the MEDIAN over "
                                  "those steps, _max the slowest, _mean what the rooflines use" % (launches, args.steps, period, "th" if period > 1 else "st"),
         }
+        out["config"]["host"] = ("Python ranks over torch.distributed (particlesystem_amd/slab.py)" if world > 1 else "this Python process through ctypes (psamd_step)") + \
+            (": FALLBACK, the C++ host failed (%s)" % args.ring_failed if getattr(args, "ring_failed", None) else "")
+        if getattr(args, "ring_failed", None):
+            out["ring_failed"] = args.ring_failed
         if world > 1:
-            out["config"]["host"] = "Python ranks over torch.distributed (particlesystem_amd/slab.py)" + \
-                (": FALLBACK, the C++ ranks failed (%s)" % args.ring_failed if getattr(args, "ring_failed", None) else "")
             out["config"]["halo_cap_cell"] = int(args.halo_cap_cell)
             out["config"]["message_bytes_rank0"] = {name: int(g.msg_bytes(k)) for name, k in
                                                     (("halo_up", 1), ("halo_down", 0), ("force_in", 5), ("xfer_each", 6))}
@@ -957,26 +1090,7 @@ def main():
             out["cpu_baseline"] = None       # the reference has no all-pairs force; the oracle restates the reference only
         if world == 1 and not args.no_cpu and not args.all_pairs:
             if not args.fast_math and not args.evolve and not args.no_side_runs and not args.all_pairs:
-                # SURVEY 8(d)'s lifecycle-off mode: collision radius 0 (and no births, no deaths of age in these
-                # steps), so every one of the N particles goes through the force loop and is integrated
-                d, t, _, roof, kt = side_run(ps, cfg_over, local_rank, xyz, age, fert, flags, 50, True, timing_period=min(5, period), collision_radius=0.0)
-                out["lifecycle_off"] = {
-                    "what": "the same cloud and step with COLLISION_RADIUS = 0: nothing collides, all %d particles get a force and are "
-                            "integrated (the headline's step, at the reference's radius 0.4, integrates the particles the "
-                            "reference integrates: config.particles_with_a_force_term)" % args.n,
-                    "value": d / t, "unit": "particle-updates/s", "ms_per_step": 1e3 * t / 50, "steps": 50,
-                    "roofline": roof, "kernel_us_per_step": kt}
-                d, t, _, roof, kt = side_run(ps, cfg_over, local_rank, xyz, age, fert, ps.FLAG_FAST_MATH, 50, True, timing_period=min(5, period))
-                out["within_tolerance_mode"] = {
-                    "arithmetic": "PSAMD_FLAG_FAST_MATH (FMA + v_rsq): accelerations deviate from the oracle's by the amounts "
-                                  "tests/test_gpu_fast.py measures and bounds (also at this density); not the headline",
-                    "value": d / t, "unit": "particle-updates/s", "ms_per_step": 1e3 * t / 50, "steps": 50,
-                    "roofline": roof, "kernel_us_per_step": kt}
-                d, t, lv, _, _ = side_run(ps, cfg_over, local_rank, xyz, age, fert, flags, args.evolve_steps, False, warm_ctx=g)
-                out["evolve"] = {"what": "%d free-running steps from the same cloud (the population collapses: surface implosion, "
-                                         "collisions), exact arithmetic" % args.evolve_steps,
-                                 "value": d / t, "unit": "particle-updates/s", "ms_per_step": 1e3 * t / args.evolve_steps,
-                                 "live_per_step": lv}
+                side_runs(out, args, ps, cfg_over, local_rank, xyz, age, fert, flags, period, g)
             out["cpu_baseline"], out["cpu_baseline_many_threads"] = cpu_baseline(args, xyz, age, fert, cfg_over)
         elif not args.all_pairs:
             out["cpu_baseline"] = None
@@ -985,6 +1099,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if getattr(args, "ring_violent", False):
+        sys.exit(4)         # the line above is valid (the Python host's), but a C++ rank was ended by a signal or the limit: look into it
 
 
 if __name__ == "__main__":

@@ -35,7 +35,9 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <cctype>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -105,16 +107,78 @@ bool by_peer_then_dir(const Msg &a, const Msg &b) { return a.peer != b.peer ? a.
 
 struct Ring {
     int world = 1;
-    bool loopback = false, side_stream = true, overlap_interior = false;
+    bool loopback = false, overlap_interior = false;
+    int side = 0;                       // 0: every RCCL call on the compute stream (default); 1: what has compute to travel beside goes on the transfer stream; 2: everything does (round 4)
     ncclComm_t comm = nullptr;
     hipStream_t compute = nullptr, transfer = nullptr;      // (transfer == compute without --no-side-stream's opposite)
     hipEvent_t ev_built = nullptr, ev_halo = nullptr, ev_paired = nullptr, ev_force = nullptr, ev_applied = nullptr, ev_xfer = nullptr;
     std::vector<Slab> local;            // the slabs this process holds (one per process in a real run; all of them in loopback mode, where every peer is comm rank 0)
     int64_t moved = 0;
+    // Stage timing on the compute stream (benchmark runs, every n-th step): per local slab eight events -- before / after
+    // each of the four stage calls.  after(stage k) -> before(stage k + 1) is what the compute stream spent WAITING for
+    // the phase's messages (the host enqueues the next stage at once; only the event of the transfer stream holds it).
+    std::vector<std::vector<hipEvent_t>> stage_ev;      // [timed step][slab * 8 + e]
+    int stage_slot = -1;                                // the timed step being recorded, -1: this step carries no events
 };
 
-// One phase's messages as ONE RCCL group on the transfer stream.
-int exchange(Ring &R, Phase ph)
+int mark(Ring &R, size_t slab, int e)
+{
+    if (R.stage_slot < 0) return 0;
+    HIP_OK(hipEventRecord(R.stage_ev[(size_t)R.stage_slot][slab * 8 + (size_t)e], R.compute));
+    return 0;
+}
+
+// Both ends of every message must agree on its size BEFORE the first step: RCCL matches a send and a receive by order
+// alone, and two neighbours that disagree (different halo_cap_cell / xfer_cap / plans) would sit in the transfer until the
+// watchdog ends them.  Every rank's sizes are all-gathered once and checked against the routes.
+struct SizeTable { int64_t halo_out[2], halo_in[2], force_out, force_in, xfer, xfer2, far, status, allg, pad[5]; };
+static_assert(sizeof(SizeTable) == 16 * sizeof(int64_t), "sixteen words");
+SizeTable sizes_of(const Slab &s)
+{
+    SizeTable t{};
+    for (int k = 0; k < 2; k++) { t.halo_out[k] = s.b.halo_out_bytes[k]; t.halo_in[k] = s.b.halo_in_bytes[k]; }
+    t.force_out = s.b.force_out_bytes; t.force_in = s.b.force_in_bytes;
+    t.xfer = s.b.xfer_bytes; t.xfer2 = s.b.xfer2_bytes; t.far = s.b.far_bytes; t.status = s.b.status_bytes; t.allg = s.b.allg_bytes;
+    return t;
+}
+int sizes_agree(const std::vector<SizeTable> &all)
+{
+    const int W = (int)all.size();
+    auto bad = [&](const char *what, int a, int b, long long x, long long y) {
+        std::fprintf(stderr, "message sizes disagree: %s of rank %d is %lld bytes, rank %d expects %lld (same halo_cap_cell / xfer_cap / cuts on every rank?)\n", what, a, x, b, y);
+        return 1;
+    };
+    for (int r = 0; r < W; r++) {
+        if (r + 1 < W) {
+            if (all[r].halo_out[1] != all[r + 1].halo_in[0]) return bad("halo_out[above]", r, r + 1, all[r].halo_out[1], all[r + 1].halo_in[0]);
+            if (all[r + 1].halo_out[0] != all[r].halo_in[1]) return bad("halo_out[below]", r + 1, r, all[r + 1].halo_out[0], all[r].halo_in[1]);
+            if (all[r + 1].force_out != all[r].force_in) return bad("force_out", r + 1, r, all[r + 1].force_out, all[r].force_in);
+        }
+        if (all[r].xfer != all[0].xfer) return bad("xfer", r, 0, all[r].xfer, all[0].xfer);
+        if (all[r].xfer2 != all[0].xfer2) return bad("xfer2", r, 0, all[r].xfer2, all[0].xfer2);
+        if (all[r].far != all[0].far) return bad("far", r, 0, all[r].far, all[0].far);
+        if (all[r].status != all[0].status) return bad("status", r, 0, all[r].status, all[0].status);
+        if (all[r].allg != all[0].allg) return bad("allg", r, 0, all[r].allg, all[0].allg);
+    }
+    return 0;
+}
+int check_sizes(Ring &R)
+{
+    std::vector<SizeTable> all((size_t)R.world);
+    if (R.loopback) { for (const Slab &s : R.local) all[(size_t)s.rank] = sizes_of(s); return sizes_agree(all); }
+    if (R.world == 1) return 0;
+    SizeTable mine = sizes_of(R.local[0]), *d = nullptr;
+    HIP_OK(hipMalloc((void **)&d, sizeof(SizeTable) * ((size_t)R.world + 1)));
+    HIP_OK(hipMemcpyAsync(d + R.world, &mine, sizeof mine, hipMemcpyHostToDevice, R.transfer));
+    NCCL_OK(ncclAllGather(d + R.world, d, sizeof(SizeTable), ncclInt8, R.comm, R.transfer));
+    HIP_OK(hipMemcpyAsync(all.data(), d, sizeof(SizeTable) * (size_t)R.world, hipMemcpyDeviceToHost, R.transfer));
+    HIP_OK(hipStreamSynchronize(R.transfer));
+    (void)hipFree(d);
+    return sizes_agree(all);
+}
+
+// One phase's messages as ONE RCCL group on stream `st`.
+int exchange(Ring &R, Phase ph, hipStream_t st)
 {
     std::vector<Msg> sends, recvs;
     if (R.loopback) {
@@ -149,15 +213,15 @@ int exchange(Ring &R, Phase ph)
     }
     if (sends.empty() && recvs.empty()) return 0;
     NCCL_OK(ncclGroupStart());
-    for (const Msg &m : sends) { NCCL_OK(ncclSend(m.buf, (size_t)m.bytes, ncclInt8, m.peer, R.comm, R.transfer)); R.moved += m.bytes; }
-    for (const Msg &m : recvs) NCCL_OK(ncclRecv(m.buf, (size_t)m.bytes, ncclInt8, m.peer, R.comm, R.transfer));
+    for (const Msg &m : sends) { NCCL_OK(ncclSend(m.buf, (size_t)m.bytes, ncclInt8, m.peer, R.comm, st)); R.moved += m.bytes; }
+    for (const Msg &m : recvs) NCCL_OK(ncclRecv(m.buf, (size_t)m.bytes, ncclInt8, m.peer, R.comm, st));
     NCCL_OK(ncclGroupEnd());
     return 0;
 }
 
 // an all-gathered buffer pair: the status records, the snapshot blocks of an all-pairs run (between slab_build and
 // slab_pairs: SURVEY 8(e)'s "all-gather of positions once per step"), or the far outboxes of the transfer phase
-int gather(Ring &R, Gather what)
+int gather(Ring &R, Gather what, hipStream_t st)
 {
     auto out_of = [&](const Slab &s) { return what == G_FAR ? s.b.far_out : what == G_SNAPSHOT ? s.b.allg_out : s.b.status_out; };
     auto in_of = [&](const Slab &s) { return what == G_FAR ? s.b.far_in : what == G_SNAPSHOT ? s.b.allg_in : s.b.status_in; };
@@ -165,14 +229,14 @@ int gather(Ring &R, Gather what)
     const size_t nb = (size_t)(what == G_FAR ? s0.b.far_bytes : what == G_SNAPSHOT ? s0.b.allg_bytes : s0.b.status_bytes);
     if (R.world == 1 || !nb) return 0;
     if (!R.loopback) {
-        NCCL_OK(ncclAllGather(out_of(s0), in_of(s0), nb, ncclInt8, R.comm, R.transfer));
+        NCCL_OK(ncclAllGather(out_of(s0), in_of(s0), nb, ncclInt8, R.comm, st));
         R.moved += (int64_t)nb;
         return 0;
     }
     // a communicator of one rank: its all-gather is a copy; every slab's record into every slab's block
     for (const Slab &src : R.local)
         for (const Slab &dst : R.local)
-            NCCL_OK(ncclAllGather(out_of(src), (char *)in_of(dst) + (size_t)src.rank * nb, nb, ncclInt8, R.comm, R.transfer));
+            NCCL_OK(ncclAllGather(out_of(src), (char *)in_of(dst) + (size_t)src.rank * nb, nb, ncclInt8, R.comm, st));
     R.moved += (int64_t)nb * (int64_t)R.local.size();
     return 0;
 }
@@ -191,30 +255,99 @@ int order(Ring &R, hipStream_t earlier, hipEvent_t ev, hipStream_t later)
 template <typename Hook>
 int ring_step(Ring &R, Hook between)
 {
-    for (Slab &s : R.local) PS_OK(s.ctx, psamd_slab_build(s.ctx));
+    // Which stream a message travels on.  A dependency that crosses streams costs the GPU's timeline ~15 us each way here
+    // (measured, round 5: with every phase on the transfer stream a rank with NO messages at all spent 29 us per phase
+    // between two stage kernels -- 88 us of a 720-us rank-step at eight ranks), and pays only where there is compute to
+    // travel beside: the all-gather of the status records runs beside the whole pair pass and is joined long after it has
+    // landed (an event that has fired costs next to nothing), the halo runs beside the interior pass when that is asked
+    // for.  Force and transfer messages have nothing to travel beside -- the next stage needs them -- and go on the compute
+    // stream: an RCCL kernel between two stage kernels, no event.  The default (--side-stream 0) puts EVERYTHING there:
+    // the status gather is a 16-KB all-gather, ~15 us in front of the pair pass, less than one cross-stream join; 1 is for
+    // runs that overlap the halo with the interior pass (--overlap-interior), 2 is round 4's form, kept for comparison.
+    const bool one = R.world == 1;
+    hipStream_t s_halo = (R.side == 2 || (R.side == 1 && R.overlap_interior)) ? R.transfer : R.compute;
+    hipStream_t s_status = R.side >= 1 ? R.transfer : R.compute;
+    hipStream_t s_late = R.side == 2 ? R.transfer : R.compute;      // force, transfer, far outboxes
+    for (size_t i = 0; i < R.local.size(); i++) { Slab &s = R.local[i]; if (mark(R, i, 0)) return 1; PS_OK(s.ctx, psamd_slab_build(s.ctx)); if (mark(R, i, 1)) return 1; }
     if (between(0)) return 1;
-    if (order(R, R.compute, R.ev_built, R.transfer)) return 1;
-    if (exchange(R, HALO)) return 1;
-    if (gather(R, G_SNAPSHOT)) return 1;                       // all-pairs forces only
-    if (R.transfer != R.compute) HIP_OK(hipEventRecord(R.ev_halo, R.transfer));
-    if (gather(R, G_STATUS)) return 1;                         // travels beside the pair pass; slab_apply needs it
+    if (!one) {
+        if (s_halo != R.compute || s_status != R.compute) if (order(R, R.compute, R.ev_built, R.transfer)) return 1;
+        if (exchange(R, HALO, s_halo)) return 1;
+        if (gather(R, G_SNAPSHOT, s_halo)) return 1;                   // all-pairs forces only
+        if (s_halo != R.compute) HIP_OK(hipEventRecord(R.ev_halo, R.transfer));
+        if (gather(R, G_STATUS, s_status)) return 1;                   // travels beside the pair pass; slab_apply needs it
+        if (s_status != R.compute) HIP_OK(hipEventRecord(R.ev_force, R.transfer));
+    }
     if (R.overlap_interior)
         for (Slab &s : R.local) PS_OK(s.ctx, psamd_slab_pairs_interior(s.ctx));      // cells whose stencil lies in the own layers: no halo needed
-    if (R.transfer != R.compute) HIP_OK(hipStreamWaitEvent(R.compute, R.ev_halo, 0));
-    for (Slab &s : R.local) PS_OK(s.ctx, psamd_slab_pairs(s.ctx));
+    if (!one && s_halo != R.compute) HIP_OK(hipStreamWaitEvent(R.compute, R.ev_halo, 0));
+    for (size_t i = 0; i < R.local.size(); i++) { Slab &s = R.local[i]; if (mark(R, i, 2)) return 1; PS_OK(s.ctx, psamd_slab_pairs(s.ctx)); if (mark(R, i, 3)) return 1; }
     if (between(1)) return 1;
-    if (order(R, R.compute, R.ev_paired, R.transfer)) return 1;
-    if (exchange(R, FORCE)) return 1;
-    if (order(R, R.transfer, R.ev_force, R.compute)) return 1;      // (behind the status gather on the transfer stream: that has landed too)
-    for (Slab &s : R.local) PS_OK(s.ctx, psamd_slab_apply(s.ctx));
-    if (order(R, R.compute, R.ev_applied, R.transfer)) return 1;
-    if (exchange(R, XFER)) return 1;
-    if (gather(R, G_FAR)) return 1;                            // (births on, four or more ranks)
-    if (order(R, R.transfer, R.ev_xfer, R.compute)) return 1;
-    for (Slab &s : R.local) PS_OK(s.ctx, psamd_slab_finish(s.ctx));
+    if (!one) {
+        if (s_late != R.compute) { if (order(R, R.compute, R.ev_paired, R.transfer)) return 1; }
+        if (exchange(R, FORCE, s_late)) return 1;
+        if (s_late != R.compute) { if (order(R, R.transfer, R.ev_force, R.compute)) return 1; }      // (behind the status gather on the transfer stream: that has landed too)
+        else if (s_status != R.compute) HIP_OK(hipStreamWaitEvent(R.compute, R.ev_force, 0));       // the status gather: recorded before the pair pass began
+    }
+    for (size_t i = 0; i < R.local.size(); i++) { Slab &s = R.local[i]; if (mark(R, i, 4)) return 1; PS_OK(s.ctx, psamd_slab_apply(s.ctx)); if (mark(R, i, 5)) return 1; }
+    if (!one) {
+        if (s_late != R.compute) { if (order(R, R.compute, R.ev_applied, R.transfer)) return 1; }
+        if (exchange(R, XFER, s_late)) return 1;
+        if (gather(R, G_FAR, s_late)) return 1;                        // (births on, four or more ranks)
+        if (s_late != R.compute) { if (order(R, R.transfer, R.ev_xfer, R.compute)) return 1; }
+    }
+    for (size_t i = 0; i < R.local.size(); i++) { Slab &s = R.local[i]; if (mark(R, i, 6)) return 1; PS_OK(s.ctx, psamd_slab_finish(s.ctx)); if (mark(R, i, 7)) return 1; }
     return 0;
 }
 int no_hook(int) { return 0; }
+
+// the shader clock while a timed region runs (sysfs pp_dpm_sclk of the HIP device's PCI function, the level marked current):
+// the chip is power-bound under this load, and which clock a figure was taken at is part of the figure
+struct ClockWatch {
+    std::string path;
+    std::vector<int> samples;
+    std::atomic<bool> stop{false};
+    std::thread th;
+    explicit ClockWatch(int device)
+    {
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) == hipSuccess) {
+            for (char *c = bus; *c; c++) *c = (char)std::tolower((unsigned char)*c);
+            path = std::string("/sys/bus/pci/devices/") + bus + "/pp_dpm_sclk";
+            std::ifstream f(path);
+            if (!f) path.clear();
+        }
+    }
+    void start()
+    {
+        if (path.empty()) return;
+        stop = false;
+        th = std::thread([this]() {
+            while (!stop) {
+                std::ifstream f(path);
+                std::string line;
+                while (std::getline(f, line)) {
+                    if (line.find('*') == std::string::npos) continue;
+                    const size_t c = line.find(':');
+                    int v = 0;
+                    for (size_t i = c == std::string::npos ? 0 : c + 1; i < line.size(); i++) if (std::isdigit((unsigned char)line[i])) v = v * 10 + (line[i] - '0');
+                    if (v) samples.push_back(v);
+                }
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            }
+        });
+    }
+    void end() { if (th.joinable()) { stop = true; th.join(); } }
+    std::string json()
+    {
+        if (samples.empty()) return "null";
+        std::vector<int> v = samples;
+        std::sort(v.begin(), v.end());
+        char b[256];
+        std::snprintf(b, sizeof b, "{\"min\": %d, \"median\": %d, \"max\": %d, \"samples\": %zu, \"source\": \"%s\"}", v.front(), v[v.size() / 2], v.back(), v.size(), path.c_str());
+        return b;
+    }
+};
 
 struct Particle72 { unsigned char bytes[72]; };
 
@@ -250,8 +383,9 @@ int main(int argc, char **argv)
     int64_t n = 60000;
     uint32_t seed = 2026;
     bool loopback = false, id_only = false, all_pairs = false, births = false, graphs = false, bench = false, evolve = false;
-    bool side_stream = true, overlap_interior = false, fast_math = false, launch_check = false;
-    int steps = 200, warmup = 5, chunk_factor = 4, chunk_dim = 4, halo_cap_cell = 0, xfer_cap = 0, timing_period = 8, wait_policy = -1;
+    bool overlap_interior = false, fast_math = false, launch_check = false, break_sizes = false;
+    int side_stream = 0;
+    int steps = 200, warmup = 5, chunk_factor = 4, chunk_dim = 4, halo_cap_cell = 0, xfer_cap = 0, timing_period = 8, wait_policy = -1, sustained_steps = 0;
     double settle_seconds = 0.5;
     int64_t max_particles = 0;
     uint64_t job = 0;
@@ -270,11 +404,12 @@ int main(int argc, char **argv)
         else if (a == "--job") job = (uint64_t)std::strtoull(next(), nullptr, 10);
         else if (a == "--id-only") id_only = true;
         else if (a == "--launch-check") launch_check = true;
+        else if (a == "--test-size-mismatch") break_sizes = true;      // (test hook: rank 1 is created with other message sizes than its neighbours expect)
         else if (a == "--all-pairs") all_pairs = true;
         else if (a == "--births") births = true;
         else if (a == "--fast-math") fast_math = true;
         else if (a == "--graphs") graphs = std::atoi(next()) != 0;
-        else if (a == "--side-stream") side_stream = std::atoi(next()) != 0;
+        else if (a == "--side-stream") side_stream = std::max(0, std::min(2, std::atoi(next())));
         else if (a == "--overlap-interior") overlap_interior = true;
         else if (a == "--wait") wait_policy = std::atoi(next());
         else if (a == "--bench") bench = true;
@@ -283,6 +418,7 @@ int main(int argc, char **argv)
         else if (a == "--warmup") warmup = std::atoi(next());
         else if (a == "--settle-seconds") settle_seconds = std::atof(next());
         else if (a == "--timing-period") timing_period = std::max(1, std::atoi(next()));
+        else if (a == "--sustained-steps") sustained_steps = std::max(0, std::atoi(next()));
         else if (a == "--chunk-factor") chunk_factor = std::atoi(next());
         else if (a == "--chunk-dim") chunk_dim = std::atoi(next());
         else if (a == "--halo-cap-cell") halo_cap_cell = std::atoi(next());
@@ -292,7 +428,7 @@ int main(int argc, char **argv)
     }
     if (world < 1 || rank < 0 || rank >= world || (!loopback && world > 1 && id_file.empty())) {
         std::fprintf(stderr, "usage: ps_ring_rccl --world W (--loopback | --rank r --id-file F --job J [--device d]) [--n N] [--iters K] [--seed S] "
-                             "[--all-pairs] [--births] [--graphs 0|1] [--side-stream 0|1] [--overlap-interior] [--bench --steps K --warmup W ...]\n");
+                             "[--all-pairs] [--births] [--graphs 0|1] [--side-stream 0|1|2] [--overlap-interior] [--bench --steps K --warmup W ...]\n");
         return 2;
     }
     if (psamd_abi_version() != PSAMD_ABI_VERSION) {
@@ -302,7 +438,7 @@ int main(int argc, char **argv)
     if (device < 0) device = loopback ? 0 : rank;
     const bool no_gpu = id_only || launch_check;
     Ring R;
-    R.world = world; R.loopback = loopback; R.side_stream = side_stream; R.overlap_interior = overlap_interior;
+    R.world = world; R.loopback = loopback; R.side = side_stream; R.overlap_interior = overlap_interior;
     if (!no_gpu) {
         HIP_OK(hipSetDevice(device));
         HIP_OK(hipStreamCreateWithFlags(&R.compute, hipStreamNonBlocking));
@@ -384,6 +520,7 @@ int main(int argc, char **argv)
         Slab s; s.rank = r;
         psamd_config cfg = cfg0;
         cfg.device = device; cfg.rank = r; cfg.world = world;
+        if (break_sizes && r == 1) cfg.halo_cap_cell = (cfg.halo_cap_cell > 0 ? cfg.halo_cap_cell : 64) + 8;
         psamd_ctx *ctx = nullptr;
         PS_OK(ctx, psamd_create(&cfg, &ctx));
         s.ctx = ctx;
@@ -400,6 +537,7 @@ int main(int argc, char **argv)
         PS_OK(ctx, psamd_fill_particles(ctx, n, xyz.data(), nullptr, nullptr, age.data(), fert.data(), nullptr, nullptr));
         PS_OK(ctx, psamd_set_stream(ctx, (void *)R.compute));
         PS_OK(ctx, psamd_set_graphs(ctx, graphs ? 1 : 0));
+        if (bench) PS_OK(ctx, psamd_set_tdata_mirror(ctx, 0));      // (this host never fetches the reference's T_DATA buffer)
         if (wait_policy >= 0) PS_OK(ctx, psamd_set_wait_policy(ctx, wait_policy));
         PS_OK(ctx, psamd_slab_buffers_get(ctx, &s.b));
         PS_OK(ctx, psamd_get_slab_plan(ctx, &s.plan));
@@ -407,6 +545,7 @@ int main(int argc, char **argv)
     }
     psamd_sizes sz;
     PS_OK(R.local[0].ctx, psamd_get_sizes(R.local[0].ctx, &sz));
+    if (check_sizes(R)) return bail();          // every message has the size its receiver expects, or nobody starts
 
     // ---------------------------------------------------------------- benchmark protocol (bench.py --gpus N relays the record)
     if (bench) {
@@ -492,22 +631,63 @@ int main(int argc, char **argv)
         const int period = std::max(1, std::min(timing_period, steps));
         PS_OK(c0, psamd_set_timing_period(c0, period));
         PS_OK(c0, psamd_set_timing(c0, 1));
+        // this host's own events around the four stage calls of every local slab, on the same steps
+        const size_t n_local = R.local.size();
+        R.stage_ev.assign((size_t)((steps + period - 1) / period), std::vector<hipEvent_t>(n_local * 8));
+        for (auto &v : R.stage_ev) for (auto &e : v) HIP_OK(hipEventCreate(&e));
         psamd_counters cn0{}, cn1{};
         int64_t processed0 = 0;
         for (Slab &s : R.local) { PS_OK(s.ctx, psamd_get_counters(s.ctx, &cn0)); processed0 += cn0.particles_processed; }
+        ClockWatch clock(device), clock2(device);
         if (barrier()) return bail();
+        clock.start();
         const auto t0 = std::chrono::steady_clock::now();
-        for (int k = 0; k < steps; k++) if (one_step()) return bail();
+        for (int k = 0; k < steps; k++) {
+            R.stage_slot = k % period == 0 ? k / period : -1;
+            if (one_step()) return bail();
+        }
+        R.stage_slot = -1;
         if (barrier()) return bail();
         double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        double us[PSAMD_NUM_TIMERS];
+        clock.end();
+        double us[PSAMD_NUM_TIMERS], us_med[PSAMD_NUM_TIMERS], us_max[PSAMD_NUM_TIMERS];
         int64_t launches = 0;
         PS_OK(c0, psamd_get_timing(c0, us, &launches));
+        PS_OK(c0, psamd_get_timing_stats(c0, us_med, us_max, nullptr));
         PS_OK(c0, psamd_set_timing(c0, 0));
         int64_t processed1 = 0;
         for (Slab &s : R.local) { PS_OK(s.ctx, psamd_get_counters(s.ctx, &cn1)); processed1 += cn1.particles_processed; }
         PS_OK(c0, psamd_get_counters(c0, &cn1));
         const int64_t own_updates = processed1 - processed0;
+        // a short timed region says little about the clock a long run holds: the same loop again, long enough (no events)
+        double sustained_ms = 0.0;
+        if (sustained_steps > steps && !evolve) {
+            if (barrier()) return bail();
+            clock2.start();
+            const auto s0 = std::chrono::steady_clock::now();
+            for (int k = 0; k < sustained_steps; k++) if (one_step()) return bail();
+            if (barrier()) return bail();
+            sustained_ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count() / sustained_steps;
+            clock2.end();
+            int64_t ns = (int64_t)(sustained_ms * 1e6);
+            if (reduce_i64(&ns, 1, ncclMax)) return bail();
+            sustained_ms = (double)ns * 1e-6;
+        }
+        // stage and wait times: the median over the timed steps per local slab, then every rank's figures on every rank
+        // ([world][7]: build pairs apply finish | wait for halo, force, xfer), in nanoseconds through the int64 all-reduce
+        // (each rank fills its own rows, the others' are zero: a sum is an all-gather)
+        std::vector<int64_t> tab((size_t)world * 7, 0);
+        for (size_t i = 0; i < n_local; i++) {
+            const int a[7] = {0, 2, 4, 6, 1, 3, 5}, b[7] = {1, 3, 5, 7, 2, 4, 6};
+            for (int k = 0; k < 7; k++) {
+                std::vector<float> v;
+                for (auto &evs : R.stage_ev) { float ms = 0.f; if (hipEventElapsedTime(&ms, evs[i * 8 + (size_t)a[k]], evs[i * 8 + (size_t)b[k]]) == hipSuccess) v.push_back(ms); }
+                std::sort(v.begin(), v.end());
+                tab[(size_t)R.local[i].rank * 7 + (size_t)k] = v.empty() ? 0 : (int64_t)(1e6 * (double)v[v.size() / 2]);
+            }
+        }
+        if (reduce_i64(tab.data(), tab.size(), ncclSum)) return bail();
+        for (auto &v : R.stage_ev) for (auto &e : v) (void)hipEventDestroy(e);
         if (census(&terms1, &wf1, &live1)) return bail();
         if (evolve) { terms0 = terms1; wf0 = wf1; }
         int64_t red[2] = {own_updates, (int64_t)(elapsed * 1e9)};
@@ -517,26 +697,55 @@ int main(int argc, char **argv)
         elapsed = (double)red[1] * 1e-9;
         int64_t gl = 0, gc = 0;
         const int grc = psamd_get_graph_stats(c0, &gl, &gc);
+        int rccl_ranks = 0;
+        NCCL_OK(ncclCommCount(R.comm, &rccl_ranks));
         if (rank == 0 || loopback) {
             static const char *names[PSAMD_NUM_TIMERS] = {"hist", "scan", "scatter", "sort_cells", "pairs", "apply", "lifecycle", "init_iframe", "collide"};
-            std::string kt;
-            for (int k = 0; k < PSAMD_NUM_TIMERS; k++)
-                if (us[k] > 0) { char b[96]; std::snprintf(b, sizeof b, "%s\"%s\": %.3f", kt.empty() ? "" : ", ", names[k], us[k] / (double)std::max<int64_t>(launches, 1)); kt += b; }
+            auto timers = [&](const double *v, double div) {
+                std::string kt;
+                for (int k = 0; k < PSAMD_NUM_TIMERS; k++)
+                    if (us[k] > 0) { char b[96]; std::snprintf(b, sizeof b, "%s\"%s\": %.3f", kt.empty() ? "" : ", ", names[k], v[k] / div); kt += b; }
+                return kt;
+            };
+            const std::string kt = timers(us, (double)std::max<int64_t>(launches, 1)), kt_med = timers(us_med, 1.0), kt_max = timers(us_max, 1.0);
+            // per-rank stage times, and the waits as minimum / maximum over the ranks
+            static const char *stage_names[4] = {"build", "pairs", "apply", "finish"}, *wait_names[3] = {"halo", "force", "xfer"};
+            std::string stages, waits;
+            for (int k = 0; k < 4; k++) {
+                stages += std::string(k ? ", " : "") + "\"" + stage_names[k] + "\": [";
+                for (int r = 0; r < world; r++) { char b[32]; std::snprintf(b, sizeof b, "%s%.4f", r ? ", " : "", (double)tab[(size_t)r * 7 + (size_t)k] * 1e-6); stages += b; }
+                stages += "]";
+            }
+            for (int k = 0; k < 3; k++) {
+                int64_t lo = INT64_MAX, hi = 0;
+                for (int r = 0; r < world; r++) { lo = std::min(lo, tab[(size_t)r * 7 + 4 + (size_t)k]); hi = std::max(hi, tab[(size_t)r * 7 + 4 + (size_t)k]); }
+                char b[96];
+                std::snprintf(b, sizeof b, "%s\"%s\": {\"min\": %.4f, \"max\": %.4f}", k ? ", " : "", wait_names[k], (double)lo * 1e-6, (double)hi * 1e-6);
+                waits += b;
+            }
             const psamd_slab_buffers &b = R.local[0].b;
-            std::printf("{\"psamd_ring\": 1, \"world\": %d, \"loopback\": %s, \"n\": %lld, \"grid_dim\": %d, \"steps\": %d, \"warmup\": %d, \"settle_steps\": %d, "
+            std::printf("{\"psamd_ring\": 1, \"world\": %d, \"loopback\": %s, \"rccl_ranks\": %d, \"n\": %lld, \"grid_dim\": %d, \"steps\": %d, \"warmup\": %d, \"settle_steps\": %d, "
                         "\"elapsed_s\": %.9f, \"updates\": %lld, \"own_updates\": %lld, \"live_after\": %lld, \"particles_with_a_force_term\": %lld, "
-                        "\"pairs_rank0\": %.6e, \"kernel_us\": {%s}, \"timed_launches\": %lld, \"timing_period\": %d, "
+                        "\"pairs_rank0\": %.6e, \"kernel_us\": {%s}, \"kernel_us_median\": {%s}, \"kernel_us_max\": {%s}, \"timed_launches\": %lld, \"timing_period\": %d, "
+                        "\"stage_ms_per_rank\": {%s}, \"wait_ms\": {%s}, "
                         "\"relocations\": %lld, \"relocations_lost\": %lld, \"cell_overflow_kills\": %lld, "
                         "\"message_bytes_rank0\": {\"halo_up\": %lld, \"halo_down\": %lld, \"force_in\": %lld, \"xfer_each\": %lld, \"status\": %lld, \"snapshot_block\": %lld}, "
+                        "\"bytes_per_phase_rank0\": {\"halo\": %lld, \"force\": %lld, \"xfer\": %lld, \"gathers\": %lld}, "
                         "\"rccl_mb_rank0\": %.3f, \"graphs\": %s, \"graph_replays\": %lld, \"graph_captures\": %lld, \"side_stream\": %s, \"overlap_interior\": %s, "
-                        "\"all_pairs\": %s, \"fast_math\": %s, \"evolve\": %s, \"halo_cap_cell\": %d, \"xfer_cap\": %d}\n",
-                        world, loopback ? "true" : "false", (long long)n, sz.grid_dim, steps, warmup, settle, elapsed, (long long)upd, (long long)own_updates,
-                        (long long)live1, (long long)wf1, 0.5 * (terms0 + terms1), kt.c_str(), (long long)launches, period,
+                        "\"all_pairs\": %s, \"fast_math\": %s, \"evolve\": %s, \"halo_cap_cell\": %d, \"xfer_cap\": %d, \"side_stream_mode\": %d, "
+                        "\"shader_clock_mhz\": %s, \"sustained_steps\": %d, \"sustained_ms_per_step\": %.6f, \"sustained_shader_clock_mhz\": %s}\n",
+                        world, loopback ? "true" : "false", rccl_ranks, (long long)n, sz.grid_dim, steps, warmup, settle, elapsed, (long long)upd, (long long)own_updates,
+                        (long long)live1, (long long)wf1, 0.5 * (terms0 + terms1), kt.c_str(), kt_med.c_str(), kt_max.c_str(), (long long)launches, period,
+                        stages.c_str(), waits.c_str(),
                         (long long)cn1.relocations, (long long)cn1.relocations_lost, (long long)cn1.cell_overflow_kills,
                         (long long)b.halo_out_bytes[1], (long long)b.halo_out_bytes[0], (long long)b.force_in_bytes, (long long)b.xfer_bytes, (long long)b.status_bytes,
-                        (long long)b.allg_bytes, R.moved / 1e6, (graphs && grc == PSAMD_OK) ? "true" : "false", (long long)gl, (long long)gc,
+                        (long long)b.allg_bytes,
+                        (long long)(b.halo_out_bytes[0] + b.halo_out_bytes[1]), (long long)b.force_out_bytes,
+                        (long long)(world > 1 ? 2 * b.xfer_bytes + 2 * b.xfer2_bytes : 0), (long long)(world > 1 ? b.status_bytes + b.allg_bytes + b.far_bytes : 0),
+                        R.moved / 1e6, (graphs && grc == PSAMD_OK) ? "true" : "false", (long long)gl, (long long)gc,
                         side_stream ? "true" : "false", overlap_interior ? "true" : "false", all_pairs ? "true" : "false", fast_math ? "true" : "false",
-                        evolve ? "true" : "false", halo_cap_cell, xfer_cap);
+                        evolve ? "true" : "false", halo_cap_cell, xfer_cap, side_stream,
+                        clock.json().c_str(), sustained_steps > steps ? sustained_steps : 0, sustained_ms, clock2.json().c_str());
             std::fflush(stdout);
         }
         if (barrier()) return bail();
@@ -571,7 +780,8 @@ int main(int argc, char **argv)
     }
     std::printf("rank %d of %d%s: %d steps, %.1f MB through RCCL, %.3f ms per step, %lld live here, %lld graph replays (%lld captures)%s%s\n", rank, world,
                 loopback ? " (all slabs in this process)" : "", iters, R.moved / 1e6, 1e3 * secs / std::max(1, iters), (long long)live,
-                (long long)replays, (long long)captures, side_stream ? ", transfers on a second stream" : "", overlap_interior ? ", interior pass beside the halo" : "");
+                (long long)replays, (long long)captures, side_stream == 2 ? ", every transfer on a second stream" : side_stream ? ", the status gather (and an overlapped halo) on a second stream" : "",
+                overlap_interior ? ", interior pass beside the halo" : "");
 
     int rc = 0;
     if (loopback) {

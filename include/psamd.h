@@ -124,7 +124,8 @@ typedef struct psamd_device_view {
     void    *pflags;      /* uint8[container]   bit0 = is_parent                */
     void    *sorted_id;   /* int[container]     slot ids, cell-major, id-ascending in a cell */
     void    *snap_soa;    /* float[4][sorted_cap] snapshot in sorted order: x, y, z, w_eff planes */
-    void    *force4;      /* float4[container]  ax,ay,az,collision flag in sorted order */
+    void    *force4;      /* float4[sorted_cap] sorted order: force records of the lent region, hand-off scratch (the own cells'
+                             records live by slot since ABI 6: read them with psamd_download_force4) */
     void    *cell_start;  /* int[num_cells+1]   exclusive prefix of cell counts */
     int64_t  container_size;
     int32_t  num_cells;
@@ -172,8 +173,14 @@ int psamd_uniform_cloud(const psamd_ctx *ctx, int64_t n, uint32_t seed, float *x
 /* P_DATA_TYPE[count] (72-byte records, common.h:94-120) for slots first..first+count-1 */
 int psamd_upload_particles(psamd_ctx *ctx, const void *p72, int64_t first, int64_t count);
 int psamd_download_particles(psamd_ctx *ctx, void *p72, int64_t first, int64_t count);
-/* T_DATA_TYPE[count] (24-byte records, common.h:122-132): the build_grid snapshot */
+/* T_DATA_TYPE[count] (24-byte records, common.h:122-132): the build_grid snapshot.  Inside the library the rows are a
+ * MIRROR kept for this call: nothing in the step reads them (the pair stage reads its own sorted snapshot, gathered
+ * from the particle arrays).  A host that never fetches T_DATA switches the mirror off -- psamd_set_tdata_mirror(ctx, 0):
+ * build_grid then leaves the rows alone (56 bytes of traffic per particle and step less) and this call returns
+ * PSAMD_ERR_STATE; switching it on again makes the rows exact from the next build_grid on for the slots alive then
+ * (rows of slots that were alive only while it was off keep their older contents).  Default: on. */
 int psamd_download_tdata(psamd_ctx *ctx, void *t24, int64_t first, int64_t count);
+int psamd_set_tdata_mirror(psamd_ctx *ctx, int enabled);
 /* QUEUE_INFO[queue_info_size] + int[container_size] (common.h:134-139, ps.cpp:72-73) */
 int psamd_upload_queues(psamd_ctx *ctx, const void *queue_info24, const int32_t *queue);
 int psamd_download_queues(psamd_ctx *ctx, void *queue_info24, int32_t *queue);

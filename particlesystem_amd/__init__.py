@@ -173,6 +173,7 @@ ABI = [
     ("psamd_get_timing", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
     ("psamd_get_timing_stats", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
     ("psamd_set_run_ahead", C.c_int, [_vp, C.c_int]),
+    ("psamd_set_tdata_mirror", C.c_int, [_vp, C.c_int]),
 ]
 
 _lib = None
@@ -488,6 +489,10 @@ class ParticleSystem:
 
     def set_wait_policy(self, policy):
         self._ck(self.lib.psamd_set_wait_policy(self.h, int(policy)))
+
+    def set_tdata_mirror(self, on):
+        """build_grid also writes the reference's T_DATA rows (needed by download_tdata only); default on"""
+        self._ck(self.lib.psamd_set_tdata_mirror(self.h, 1 if on else 0))
 
     def set_run_ahead(self, steps):
         """1 (default): a call that ends a step returns once the step BEFORE has reported; 0: waits for its own step"""

@@ -20,16 +20,31 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
-def needs_build():
+STAMP = os.path.join(HERE, "build", "flags.stamp")
+
+
+def _flags_stamp(extra=()):
+    return " ".join(FLAGS + list(extra) + os.environ.get("PSAMD_EXTRA_FLAGS", "").split())
+
+
+def needs_build(extra=()):
+    """the library is older than a source, or was built with other flags (PSAMD_EXTRA_FLAGS: diagnostic builds)"""
     if not os.path.exists(LIB):
+        return True
+    try:
+        with open(STAMP) as f:
+            if f.read() != _flags_stamp(extra):
+                return True
+    except OSError:
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
 def build(force=False, verbose=False, extra=()):
+    stamp = _flags_stamp(extra)
     extra = list(extra) + os.environ.get("PSAMD_EXTRA_FLAGS", "").split()
-    if not force and not needs_build():
+    if not force and not needs_build(extra[:len(extra) - len(os.environ.get("PSAMD_EXTRA_FLAGS", "").split())]):
         return LIB
     tmp = LIB + ".tmp"
     # a failed build must not leave a stale library behind to be tested by mistake
@@ -50,6 +65,8 @@ def build(force=False, verbose=False, extra=()):
         raise subprocess.CalledProcessError(1, failed[0])
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj for _, obj, _ in jobs] + ["-o", tmp])
     os.replace(tmp, LIB)
+    with open(STAMP, "w") as f:
+        f.write(stamp)
     return LIB
 
 
@@ -64,8 +81,10 @@ def build_driver(force=False):
     if not force and os.path.exists(DRIVER) and os.path.getmtime(DRIVER) > max(
             os.path.getmtime(DRIVER_SRC), os.path.getmtime(os.path.join(inc, "psamd.h")), os.path.getmtime(LIB)):
         return DRIVER
+    tmp = DRIVER + ".tmp.%d" % os.getpid()
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I" + inc, DRIVER_SRC, "-L" + HERE, "-lpsamd",
-                           "-Wl,-rpath,$ORIGIN/../particlesystem_amd", "-Wl,-rpath-link,/opt/rocm/lib", "-o", DRIVER])
+                           "-Wl,-rpath,$ORIGIN/../particlesystem_amd", "-Wl,-rpath-link,/opt/rocm/lib", "-o", tmp])
+    os.replace(tmp, DRIVER)
     return DRIVER
 
 
@@ -80,8 +99,11 @@ def build_ring(force=False):
     if not force and os.path.exists(RING) and os.path.getmtime(RING) > max(
             os.path.getmtime(RING_SRC), os.path.getmtime(os.path.join(inc, "psamd.h")), os.path.getmtime(LIB)):
         return RING
+    # linked beside its final name and renamed: another rank that sees the file sees a whole program
+    tmp = RING + ".tmp.%d" % os.getpid()
     subprocess.check_call([HIPCC, "-std=c++17", "-O2", "-Wall", "-I" + inc, RING_SRC, "-L" + HERE, "-lpsamd", "-lrccl",
-                           "-Wl,-rpath,$ORIGIN/../particlesystem_amd", "-o", RING])
+                           "-Wl,-rpath,$ORIGIN/../particlesystem_amd", "-o", tmp])
+    os.replace(tmp, RING)
     return RING
 
 

@@ -6,8 +6,8 @@ namespace psamd {
 // ------------------------------------------------------------------ apply
 // Death, survival, integration, wrap and re-hash for every particle of the frame
 // (ps.cpp:1182-1242, 1261-1302), one thread per owned SLOT so that the particle arrays stream
-// through coalesced (live slots are dense at the head of every segment); only the
-// force record is gathered through the slot's rank in the sorted order.  Lifecycle side
+// through coalesced (live slots are dense at the head of every segment) -- the force record too: the pair stage
+// leaves it by slot (ForceBuf).  Lifecycle side
 // effects that depend on the reference's serial order (free-slot queues) are emitted
 // as (key, arg) queue operations and MoveRec records and replayed afterwards.  A particle
 // (or a child) whose new segment belongs to a neighbour rank leaves through the outbox:
@@ -24,8 +24,7 @@ struct ApplyEmit {
 // the workgroup count is what bounds it; one slot per thread in 1024-thread workgroups stays.
 template <int ITEMS>
 __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, const StepState *__restrict__ stp,
-                                                const int *__restrict__ rank_of_slot,
-                                                const float4 *__restrict__ force4,
+                                                const float4 *__restrict__ force_slot,
                                                 float4 *pos4, float4 *vel4, float4 *acc4,
                                                 int *cell_arr, uint8_t *pflags,
                                                 const CellInfo *__restrict__ celltab,
@@ -66,15 +65,14 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, const 
         const int old_cell = old_cells[it];
         const bool active = old_cell >= 0;
         const int id = active ? slot_of_index(P, si) : 0;             // slot == particle id
-        const int gi = active ? rank_of_slot[si] : 0;
 
     int flag = 0, new_cell = 0;
     float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-    // the particle's own state is asked for together with its force record (its address needs
-    // nothing but the slot), not after the flag in that record has come back
+    // the particle's own state and its force record, one batch of loads (all by slot)
     float4 p = f, v = f;
     float fert = 0.f;
-    if (active) { p = pos4[si]; v = vel4[si]; fert = acc4[si].w; f = force4[gi]; flag = __float_as_int(f.w); }
+    uint8_t pf0 = 0;
+    if (active) { p = pos4[si]; v = vel4[si]; fert = acc4[si].w; f = force_slot[si]; pf0 = pflags[si]; flag = __float_as_int(f.w); }
     const CellInfo old_ci = active ? celltab[old_cell] : CellInfo{0, 1, 0, 0};
 
     const bool killed = active && flag == 2, survived = active && flag == 1, moved = active && flag == 0;
@@ -125,7 +123,7 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, const 
         float vx = v.x + axv * t, vy = v.y + ayv * t, vz = v.z + azv * t;   // ps.cpp:1289-1296
         vx = clamp_mag(vx, P.vmax); vy = clamp_mag(vy, P.vmax); vz = clamp_mag(vz, P.vmax);
         const float age = v.w + t;                                         // ps.cpp:1302
-        uint8_t pf = pflags[si];
+        uint8_t pf = pf0;
         const CellInfo new_ci = celltab[new_cell];
         new_rec = segment_record(S, new_ci.seg_type, new_ci.seg_tid);
 
@@ -293,7 +291,7 @@ hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, 
 {
     if (P.slots_total <= 0) return hipSuccess;
     // slots per thread: one (PSAMD_APPLY_ITEMS: the measurement quoted at the kernel)
-#define PS_APPLY(I) k_apply<I><<<(P.slots_total + I * 1024 - 1) / (I * 1024), 1024, 0, st>>>(P, S, d.st, d.rank_of_slot, d.force4, d.pos4, \
+#define PS_APPLY(I) k_apply<I><<<(P.slots_total + I * 1024 - 1) / (I * 1024), 1024, 0, st>>>(P, S, d.st, d.force_slot, d.pos4, \
         d.vel4, d.acc4, d.cell, d.pflags, d.celltab, d.op_keys, d.op_args, d.ops_cap, \
         d.moves, d.moves_cap, Outboxes{{d.xfer_out[0], d.xfer_out[1], d.xfer_out[2], d.xfer_out[3], d.xfer_out[4]}}, d.chunk_count, d.chunk_skip, d.fs, d.ctr)
     static const int items_env = std::getenv("PSAMD_APPLY_ITEMS") ? std::atoi(std::getenv("PSAMD_APPLY_ITEMS")) : 0;

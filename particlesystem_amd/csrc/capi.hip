@@ -73,6 +73,7 @@ struct psamd_ctx {
     size_t staging_bytes = 0;
     // stage state machine
     bool frame_reset = false, grid_built = false, pairs_done = false;
+    bool tdata_mirror = true;         // build_grid also writes the reference's T_DATA rows (psamd_set_tdata_mirror)
     bool frame_clean = true;          // the per-frame counts are zero: a finished step leaves them so (its last kernel is the next init_iframe)
     int step = 0;
     int64_t steps_total = 0;
@@ -532,7 +533,6 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.ctask_start, 2 * LC + 2));     // (+ one virtual cell per merged pack)
     PS_HIP(c, dev_alloc(c, &d.cost_start, 2 * LC + 2));
     PS_HIP(c, dev_alloc(c, &d.wave_pos, (size_t)MAX_PAIR_WAVES + 1));
-    PS_HIP(c, dev_alloc(c, &d.wave_unit, (size_t)MAX_PAIR_WAVES + 1));
     PS_HIP(c, dev_alloc(c, &d.rec_start, (size_t)g.queue_infos + 1));
     PS_HIP(c, dev_alloc(c, &d.fs, 1));
     PS_HIP(c, dev_alloc(c, &d.st, 1));
@@ -543,7 +543,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.task_start, LC + 1));
     PS_HIP(c, dev_alloc(c, &d.task_list, LC * P.slices));
     PS_HIP(c, dev_alloc(c, &d.sorted_id, SC));
-    PS_HIP(c, dev_alloc(c, &d.rank_of_slot, C));
+    PS_HIP(c, dev_alloc(c, &d.force_slot, C));
     PS_HIP(c, dev_alloc(c, &d.snap_soa, 4 * (size_t)P.sorted_cap + 64));
     PS_HIP(c, dev_alloc(c, &d.snap_age, SC));
     PS_HIP(c, dev_alloc(c, &d.force4, SC));
@@ -715,6 +715,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, hipMemsetAsync(d.acc4, 0, std::max<size_t>(C, 1) * sizeof(float4), c->stream));
     PS_HIP(c, hipMemsetAsync(d.pflags, 0, std::max<size_t>(C, 1), c->stream));
     PS_HIP(c, hipMemsetAsync(d.force4, 0, SC * sizeof(float4), c->stream));
+    PS_HIP(c, hipMemsetAsync(d.force_slot, 0, std::max<size_t>(C, 1) * sizeof(float4), c->stream));
     PS_HIP(c, hipMemsetAsync(d.fs, 0, sizeof(FrameScalars), c->stream));
     PS_HIP(c, hipMemsetAsync(d.ctr, 0, sizeof(DevCounters) * COUNTER_COPIES, c->stream));
     PS_HIP(c, hipMemsetAsync(frame, 0, frame_ints * sizeof(int), c->stream));
@@ -913,6 +914,7 @@ int psamd_download_tdata(psamd_ctx *c, void *t24, int64_t first, int64_t count)
 {
     if (!c || !t24 || first < 0 || count < 0 || first + count > c->geo.container) return PSAMD_ERR_INVALID_ARG;
     if (count == 0) return PSAMD_OK;
+    if (!c->tdata_mirror) return fail(c, PSAMD_ERR_STATE, "the T_DATA mirror is off (psamd_set_tdata_mirror): build_grid has not been writing the rows");
     PS_HIP(c, hipStreamSynchronize(c->stream));
     // rows of slots another rank owns: as init_particles left them (id, zeros; ps.cpp:743-748)
     uint32_t *out = (uint32_t *)t24;
@@ -1112,9 +1114,14 @@ static int enq_init_iframe(psamd_ctx *c)
     return PSAMD_OK;
 }
 
+// is a cell with more than 1024 ids to be expected?  (the last frames the host has read; a wrong guess only costs time:
+// without the crowded cells' instance the ordinary one ranks such a cell through global memory)
+static bool big_cells_hint(const psamd_ctx *c) { return c->scalars_seen > 0 && c->last.max_cell_raw > 960; }
+static uint64_t build_key(const psamd_ctx *c) { return (c->frame_clean ? 0ull : 1ull) | (c->tdata_mirror ? 2ull : 0ull) | (big_cells_hint(c) ? 4ull : 0ull); }
+
 static int enq_build_grid(psamd_ctx *c)
 {
-    PS_HIP(c, launch_build_grid(c->stream, c->P, c->d, c->timing_now >= 2 ? &c->ev[c->tset][psamd_ctx::E_HIST] : nullptr));
+    PS_HIP(c, launch_build_grid(c->stream, c->P, c->d, c->timing_now >= 2 ? &c->ev[c->tset][psamd_ctx::E_HIST] : nullptr, c->tdata_mirror, big_cells_hint(c)));
     return PSAMD_OK;
 }
 
@@ -1440,7 +1447,7 @@ int psamd_step(psamd_ctx *c, int32_t nsteps)
         begin_step(c);
         if (c->grid_built) c->frame_clean = false;
         const int64_t hint = pairs_hint(c, c->P), bound = live_bound_of(c);
-        const uint64_t key = launch_pairs_shape(c->P, hint) | ((uint64_t)bound << 24) | pick_bucket_cap(c) | (c->frame_clean ? 0ull : 1ull << 60);
+        const uint64_t key = launch_pairs_shape(c->P, hint) | ((uint64_t)bound << 24) | pick_bucket_cap(c) | (build_key(c) << 58);
         int rc = run_segment(c, SEG_STEP, key, [&]() {
             int r = enq_init_iframe(c);
             if (r == PSAMD_OK) r = enq_build_grid(c);
@@ -1466,7 +1473,7 @@ int psamd_slab_build(psamd_ctx *c)
     if (c->wedged) return refuse_wedged(c);
     begin_step(c);
     if (c->grid_built) c->frame_clean = false;
-    const int rc = run_segment(c, SEG_BUILD, c->frame_clean ? 0 : 1, [&]() {
+    const int rc = run_segment(c, SEG_BUILD, build_key(c), [&]() {
         int r = enq_init_iframe(c);
         if (r == PSAMD_OK) r = enq_build_grid(c);
         if (r != PSAMD_OK) return r;
@@ -1696,7 +1703,10 @@ int psamd_download_force4(psamd_ctx *c, void *out, int64_t first, int64_t count)
 {
     if (!c || !out || first < 0 || count < 0 || first + count > c->P.sorted_cap) return PSAMD_ERR_INVALID_ARG;
     if (count == 0) return PSAMD_OK;
-    PS_HIP(c, hipMemcpyAsync(out, c->d.force4 + first, (size_t)count * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    int rc = ensure_staging(c, (size_t)count * sizeof(float4));
+    if (rc != PSAMD_OK) return rc;
+    PS_HIP(c, launch_force_gather(c->stream, c->P, c->d, c->staging, (int)first, (int)count));
+    PS_HIP(c, hipMemcpyAsync(out, c->staging, (size_t)count * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     PS_HIP(c, hipStreamSynchronize(c->stream));
     return PSAMD_OK;
 }
@@ -1807,6 +1817,13 @@ int psamd_set_wait_policy(psamd_ctx *c, int policy)
 {
     if (!c || policy < 0 || policy > 1) return PSAMD_ERR_INVALID_ARG;
     c->wait_policy = policy;
+    return PSAMD_OK;
+}
+
+int psamd_set_tdata_mirror(psamd_ctx *c, int enabled)
+{
+    if (!c) return PSAMD_ERR_INVALID_ARG;
+    c->tdata_mirror = enabled != 0;
     return PSAMD_OK;
 }
 

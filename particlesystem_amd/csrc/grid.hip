@@ -163,6 +163,8 @@ __device__ __forceinline__ int hist_window(const DevParams &P, const int (&mine)
     return *s_min;
 }
 
+constexpr int SCAN_LDS_CHUNKS = 4096;
+
 __global__ __launch_bounds__(1024) void k_hist_lds(DevParams P, const int *__restrict__ cell, int *__restrict__ cell_count,
                                                     FrameScalars *fs, StepState *st)
 {
@@ -196,10 +198,12 @@ __global__ __launch_bounds__(1024) void k_hist_lds(DevParams P, const int *__res
 }
 // Workgroups [0, nwg): the scatter.  Workgroups [nwg, nwg + num_chunks), one GPU only: the chunk
 // lists' capacity rule for chunk blockIdx.x - nwg (chunk_cap_block; idle unless the chunk is over).
-// The scatter also writes the T_DATA snapshot rows (id, x, y, z, w, age; ps.cpp:1495-1500): here a
-// workgroup's live slots are consecutive, so are their 24-byte rows, and k_sort_cells gathers a
-// particle's snapshot from its row -- one scattered read instead of two (pos4, vel4) and no scattered
-// 24-byte row writes (which cost that kernel half again what it stored).
+// ROWS: the scatter also writes the reference's T_DATA rows (id, x, y, z, w, age; ps.cpp:1495-1500) -- here a
+// workgroup's live slots are consecutive, so are their 24-byte rows.  The rows are a MIRROR for callers that fetch the
+// reference's buffer (psamd_download_tdata; psamd_set_tdata_mirror): nothing in the step reads them -- the snapshot the
+// pair stage reads is gathered from the particle arrays by k_sort_cells, with or without the mirror -- and a host that
+// never fetches T_DATA switches them off (24 B written and 32 B read per particle and step for nothing).
+template <bool ROWS>
 __global__ __launch_bounds__(1024) void k_scatter_lds(DevParams P, int nwg, const int *__restrict__ cell, int *__restrict__ cursor,
                                                        int *__restrict__ sorted_id, const int *__restrict__ chunk_count,
                                                        const CellInfo *__restrict__ celltab, const int2 *__restrict__ chunk_segs,
@@ -244,30 +248,37 @@ __global__ __launch_bounds__(1024) void k_scatter_lds(DevParams P, int nwg, cons
             const int pos = c - w0 < LDS_CELLS ? atomicAdd(&h[c - w0], 1) : atomicAdd(&cursor[c], 1);
             const int si = base + i * 1024 + tid, id = slot_of_index(P, si);
             sorted_id[pos] = id;
-            const float4 p = pos4[si];
-            const float age = vel4[si].w;
-            uint2 *t = reinterpret_cast<uint2 *>(tdata + (size_t)6 * si);
-            t[0] = make_uint2((uint32_t)id, __float_as_uint(p.x));
-            t[1] = make_uint2(__float_as_uint(p.y), __float_as_uint(p.z));
-            t[2] = make_uint2(__float_as_uint(p.w), __float_as_uint(age));
+            if (ROWS) {
+                const float4 p = pos4[si];
+                const float age = vel4[si].w;
+                uint2 *t = reinterpret_cast<uint2 *>(tdata + (size_t)6 * si);
+                t[0] = make_uint2((uint32_t)id, __float_as_uint(p.x));
+                t[1] = make_uint2(__float_as_uint(p.y), __float_as_uint(p.z));
+                t[2] = make_uint2(__float_as_uint(p.w), __float_as_uint(age));
+            }
         }
 }
 
 // One workgroup: exclusive prefix of the own cells' counts, the scatter cursors, the chunk
 // totals and hostGridMax (ps.cpp:1504-1516: maxima are of stored entries, so capped).
+// (Round 5 tried this as the histogram launch's last-arriving workgroup -- a ticket, no launch of its own: 28.5 us for the
+// pair instead of 7.4 + 12.1.  The counts are written by other workgroups' device-scope atomics in the same launch, so
+// the scan had to read them with agent-scope loads -- every one a trip past the XCD's L2 -- and a device-scope FENCE on
+// this chip writes back and invalidates an L2: 733 workgroups fencing made the histogram 250 us.  A kernel boundary, on
+// the other hand, costs this timeline nothing: rocprofv3 shows back-to-back kernels of one stream with no gap.)
 __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restrict__ cell_count,
                                                 int *__restrict__ cell_start, int *__restrict__ cursor,
                                                 int *__restrict__ task_start, int *__restrict__ task_list,
                                                 int *__restrict__ chunk_count,
                                                 const CellInfo *__restrict__ celltab, int *__restrict__ status_out, FrameScalars *fs)
 {
+    __shared__ long long wave_tot[16];
+    __shared__ int maxcell_s, maxraw_s;
+    __shared__ int chunk_s[SCAN_LDS_CHUNKS];
     // Two prefix sums at once, packed in 64 bits: particles per cell (low word) and
     // 64-particle pair-kernel tasks per cell (high word; only the cells this rank computes).
     // Each thread owns a contiguous run of cells, so the whole scan needs one pass and two barriers.
-    constexpr int LDS_CHUNKS = 4096;
-    __shared__ long long wave_tot[16];
-    __shared__ int maxcell_s, maxraw_s;
-    __shared__ int chunk_s[LDS_CHUNKS];
+    constexpr int LDS_CHUNKS = SCAN_LDS_CHUNKS;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool chunks_in_lds = P.num_chunks <= LDS_CHUNKS;
     const int ncell = P.n_own_cells, cell_off = P.reg_first[0] * P.G * P.G;
@@ -380,18 +391,20 @@ __global__ __launch_bounds__(1024) void k_scan(DevParams P, const int *__restric
 // adding r*0 = +-0 leaves an fp32 sum that started at +0 bit-identical).
 // Ids ranked at or past the list capacity are the ones the reference kills
 // (ps.cpp:1517-1526): their sorted_id entry becomes -1 and the slot is reset.
-// CAP: the ids an instance ranks in LDS.  Two instances are launched back to back: CAP = 1024 (8 KB of
-// LDS: the workgroups of sixteen cells per CU in flight -- the kernel is a chain of global round trips
-// per cell, not a stream) serves the cells with up to 1024 ids, CAP = SORT_MAX (33 KB: four cells per
-// CU) the fuller ones; a workgroup leaves at once where the cell is the other instance's.
+// CAP: the ids an instance ranks in LDS.  CAP = 1024 (8 KB of LDS: the kernel is a chain of global round trips
+// per cell, not a stream) is launched every step, one workgroup per cell; CAP = SORT_MAX (33 KB: four cells per CU)
+// serves cells with more than 1024 ids and is launched only when the last frames the host has seen had such a cell
+// (`take_big` false in the small instance).  When it is not launched the small instance takes a crowded cell itself,
+// ranking through global memory (slow, rare: a cell that jumps past 1024 ids between two frames) -- so the host's
+// hint, which is a step or two old, only ever costs time.  The same path serves cells beyond SORT_MAX ids in either
+// instance (a dense clump in one cell of an 8-cell segment reaches 8 x 514 = 4112), whatever the list capacity.
 template <int CAP>
-__device__ __forceinline__ void sort_cell(const DevParams &P, const int c, const int *__restrict__ cell_start,
-                                                     int *__restrict__ sorted_id,
+__device__ __forceinline__ void sort_cell(const DevParams &P, const int c, const bool take_big, const int *__restrict__ cell_start,
+                                                     int *__restrict__ sorted_id, int *__restrict__ scratch_ids,
                                                      float4 *pos4, float4 *vel4, float4 *acc4,
                                                      int *cell_arr, uint8_t *pflags,
                                                      float *__restrict__ snap_soa,
                                                      float *__restrict__ snap_age,
-                                                     const uint32_t *__restrict__ tdata, int *__restrict__ rank_of_slot,
                                                      uint64_t *op_keys, int *op_args, int ops_cap,
                                                      int *__restrict__ halo_count, float *__restrict__ halo_f,
                                                      int *__restrict__ halo_id, int *__restrict__ snap_cid,
@@ -402,99 +415,42 @@ __device__ __forceinline__ void sort_cell(const DevParams &P, const int c, const
     __shared__ __attribute__((aligned(16))) int ids[CAP + 4];
     __shared__ int ordered[CAP];
     __shared__ int s_halo[27], s_halo_base[27];    // bodies this cell lists in each neighbour's halo
-    constexpr int BITMAP_WORDS = 512;              // the ids' span the bitmap ranking covers: 16384 slots
+    constexpr int BITMAP_WORDS = 512;              // the ids' span one bitmap pass covers: 16384 slots
     __shared__ unsigned bitmap[BITMAP_WORDS];
-    __shared__ int s_lo, s_hi, s_wt[4];
+    __shared__ int s_lo, s_hi, s_wt[4], s_total;
     const int tid = threadIdx.x;
     if (tid < 27) s_halo[tid] = 0;
-    if (tid == 0) { s_lo = 0x7fffffff; s_hi = -1; }
+    if (tid == 0) { s_lo = 0x7fffffff; s_hi = -1; s_total = 0; }
     const int start = cell_start[c];
-    int n = cell_start[c + 1] - start;
-    if (n == 0 || (CAP == SMALL ? n > SMALL : n <= SMALL)) return;       // (empty, or the other instance's)
+    const int n = cell_start[c + 1] - start;
+    if (n == 0) return;
+    if (CAP == SMALL ? (n > SMALL && !take_big) : n <= SMALL) return;       // (the other instance's)
+    const bool in_lds = n <= CAP;                   // else: ids read from, and the ordered list written to, global memory
     int ci1, ci2, ci3;
     cell_coords(P, c, ci1, ci2, ci3);
-    // A cell may hold more ids than fit the LDS ranking (its segment's capacity is the bound: a
-    // dense clump in one cell of an 8-cell segment reaches 8 x 514 = 4112).  All but the
-    // MAX_PARTICLES_PER_CELL lowest are killed anyway, so such a cell first finds that many lowest
-    // ids -- bisection on the id value, counting in global memory -- ranks those in LDS as usual
-    // and treats the rest as the overflow it is (rare: slow is fine, wrong is not).
-    if (n > SORT_MAX && P.max_per_cell > SORT_MAX) {
-        // (a list capacity above what the LDS ranking holds -- N = 2^24 in 16^3 cells -- AND a cell that
-        // full: the kept ids alone do not fit; refused as before)
-        if (tid == 0) atomicOr(&fs->error, ERR_CELL_TOO_BIG);
-        n = SORT_MAX;
-    }
-    const int n_all = n;
-    int big_limit = 0x7fffffff;                      // ids >= big_limit are past the list capacity (big cells only)
-    if (n > SORT_MAX) {
-        __shared__ int s_count;
-        int lo = 0, hi = 0x7fffffff;                 // smallest t with #(id < t) >= max_per_cell
-        while (lo < hi) {
-            const int mid = lo + (hi - lo) / 2;
-            if (tid == 0) s_count = 0;
-            __syncthreads();
-            int mine = 0;
-            for (int e = tid; e < n_all; e += 256) mine += sorted_id[start + e] < mid ? 1 : 0;
-            atomicAdd(&s_count, mine);
-            __syncthreads();
-            const int cnt = s_count;
-            __syncthreads();
-            if (cnt >= P.max_per_cell) hi = mid; else lo = mid + 1;
-        }
-        big_limit = lo;
-        // gather the kept ids (exactly max_per_cell of them: ids are distinct) to the front of the LDS list
-        if (tid == 0) s_count = 0;
-        __syncthreads();
-        for (int e = tid; e < n_all; e += 256) {
-            const int id = sorted_id[start + e];
-            if (id < big_limit) ids[atomicAdd(&s_count, 1)] = id;
-        }
-        __syncthreads();
-        n = s_count;                                 // == max_per_cell
-        __syncthreads();
-        // the overflow: same treatment as the ranked tail below, in any order (the frees are keyed by id)
-        for (int e = tid; e < n_all; e += 256) {
-            const int id = sorted_id[start + e];
-            if (id < big_limit) continue;
-            const int si = slot_index(P, id);                      // (its snapshot row was written by the scatter pass)
-            cell_arr[si] = P.world > 1 ? -2 - cell_arr[si] : -1; pflags[si] = 0;       // (slab: the chunk-capacity walk still needs the cell, see chunk_cap_block)
-            pos4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
-            vel4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
-            acc4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
-            atomicAdd(&(ctr + (blockIdx.x % COUNTER_COPIES))->cell_overflow_kills, 1ull);
-            if (owns_record(P, 0)) {
-                const int k = atomicAdd(&fs->n_ops, 1);
-                if (k < ops_cap) { op_keys[k] = ((uint64_t)(uint32_t)id << 2) | 2ull; op_args[k] = id; }
-                else atomicOr(&fs->error, ERR_OPS_OVERFLOW);
-            } else {
-                const int k = atomicAdd(&status_out[0], 1);
-                if (k < STATUS_KILL_CAP) status_out[MSG_HEADER_WORDS + k] = id;
-                else atomicOr(&fs->error, ERR_REMOTE_RECORD0);
-            }
-        }
-        __syncthreads();                             // (all reads of the arrival-order list are done)
-        for (int e = n + tid; e < n_all; e += 256) sorted_id[start + e] = -1;
-    } else {
-        for (int e = tid; e < n; e += 256) ids[e] = sorted_id[start + e];
-    }
+    if (in_lds) for (int e = tid; e < n; e += 256) ids[e] = sorted_id[start + e];
     __syncthreads();
+    auto id_at = [&](int e) { return in_lds ? ids[e] : sorted_id[start + e]; };
     // The ids in ascending order.  A cell's particles live in the slots of one segment, so the ids span a few
     // thousand values: a bitmap of the span in LDS (one atomicOr per id), a prefix of the words' population
     // counts, and every thread writes out the ids of its two words.  (Before: every id counted the smaller ones
     // among all of them, n/4 16-byte broadcast reads per thread -- at 256 ids per cell the LDS pipe's
-    // 14 us of the kernel.)  Ids spread wider than the bitmap holds are ranked by counting as before.
+    // 14 us of the kernel.)  A span wider than the bitmap (a large chunk_dim: the interior segment of an 8^3-cell
+    // chunk spans 111 000 slots) takes one pass per 16384 slots of it.
     int lo = 0x7fffffff, hi = -1;
-    for (int e = tid; e < n; e += 256) { const int v = ids[e]; lo = min(lo, v); hi = max(hi, v); }
+    for (int e = tid; e < n; e += 256) { const int v = id_at(e); lo = min(lo, v); hi = max(hi, v); }
 #pragma unroll
     for (int sft = 32; sft > 0; sft >>= 1) { lo = min(lo, __shfl_xor(lo, sft)); hi = max(hi, __shfl_xor(hi, sft)); }
     if ((tid & 63) == 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
     __syncthreads();
-    const int id_base = s_lo, span = s_hi - id_base + 1;
-    if (span <= BITMAP_WORDS * 32) {
-        const int words = (span + 31) >> 5;
+    const int id_lo = s_lo, id_hi = s_hi;
+    int *ordered_out = in_lds ? ordered : scratch_ids + start;
+    for (int w0 = id_lo; w0 <= id_hi; w0 += BITMAP_WORDS * 32) {
+        const int span = min(id_hi - w0 + 1, BITMAP_WORDS * 32), words = (span + 31) >> 5;
+        const bool whole = w0 == id_lo && span == id_hi - id_lo + 1;        // one pass: every id is in the window
         for (int w = tid; w < words; w += 256) bitmap[w] = 0;
         __syncthreads();
-        for (int e = tid; e < n; e += 256) { const int b = ids[e] - id_base; atomicOr(&bitmap[b >> 5], 1u << (b & 31)); }
+        for (int e = tid; e < n; e += 256) { const int b = id_at(e) - w0; if (whole || (b >= 0 && b < span)) atomicOr(&bitmap[b >> 5], 1u << (b & 31)); }
         __syncthreads();
         constexpr int WPT = BITMAP_WORDS / 256;                 // words per thread
         unsigned w[WPT];
@@ -504,28 +460,15 @@ __device__ __forceinline__ void sort_cell(const DevParams &P, const int c, const
         const int incl = wave_incl_scan(cnt);
         if ((tid & 63) == 63) s_wt[tid >> 6] = incl;
         __syncthreads();
-        int pos = incl - cnt;
+        int pos = s_total + incl - cnt;
         for (int k = 0; k < (tid >> 6); k++) pos += s_wt[k];
 #pragma unroll
         for (int i = 0; i < WPT; i++)
-            for (unsigned m = w[i]; m; m &= m - 1) ordered[pos++] = id_base + (WPT * tid + i) * 32 + (__ffs(m) - 1);
-    } else {
-        // pad to a multiple of 4 with INT_MAX so the ranking reads whole 16-byte LDS words
-        for (int e = n + tid; e < ((n + 3) & ~3); e += 256) ids[e] = 0x7fffffff;
+            for (unsigned m = w[i]; m; m &= m - 1) ordered_out[pos++] = w0 + (WPT * tid + i) * 32 + (__ffs(m) - 1);
         __syncthreads();
-        for (int e = tid; e < n; e += 256) {
-            const int mine = ids[e];
-            int rank = 0;
-            const int4 *v = reinterpret_cast<const int4 *>(ids);
-#pragma unroll 4
-            for (int j = 0; j < (n + 3) / 4; j++) {
-                const int4 q = v[j];
-                rank += (q.x < mine) + (q.y < mine) + (q.z < mine) + (q.w < mine);
-            }
-            ordered[rank] = mine;
-        }
+        if (tid == 0) s_total += s_wt[0] + s_wt[1] + s_wt[2] + s_wt[3];
+        __syncthreads();
     }
-    __syncthreads();
     // (the small instance keeps what the halo lists need -- position, collision id, face bits -- in registers
     // instead of reading the rows back and redoing the three divisions)
     constexpr int KR = CAP == SMALL ? SMALL / 256 : 1;
@@ -534,25 +477,22 @@ __device__ __forceinline__ void sort_cell(const DevParams &P, const int c, const
 #pragma unroll
     for (int k = 0; k < KR; k++) hm3[k] = 0;
     bool wild_any = false;
+    const bool regs = CAP == SMALL && in_lds;      // the register form of the halo pass
     auto row = [&](int e, int k) {
-        const int id = ordered[e], si = slot_index(P, id);
-        // the particle's T_DATA row (written by the scatter pass for every live slot, before the overflow
-        // check as in ps.cpp:1495-1500): x, y, z, w, age in one 24-byte read
-        const uint2 *t = reinterpret_cast<const uint2 *>(tdata + (size_t)6 * si);
-        const uint2 t0 = t[0], t1 = t[1], t2 = t[2];
-        float4 p = make_float4(__uint_as_float(t0.y), __uint_as_float(t1.x), __uint_as_float(t1.y), __uint_as_float(t2.x));
-        const float age = __uint_as_float(t2.y);
+        const int id = ordered_out[e], si = slot_index(P, id);
+        // the particle's snapshot (what the reference copies into its T_DATA row, ps.cpp:1495-1500): x, y, z, w and the age
+        float4 p = pos4[si];
+        const float age = vel4[si].w;
         // A kid is skipped by the reference's force loop and never collides (app_common.cu:240-243, 284-287);
         // here it stays in the lists with mass 0, so that r * 0 = +-0 leaves every sum as it was -- which needs r
         // to be a number.  A child born with the direction (0, 0, 0) has a velocity and, a step later, a position
-        // that is not one (0/0, ps.cpp:1306-1333): in the snapshot a kid's position is the origin (its T_DATA row
-        // and its own state keep what the reference has).
+        // that is not one (0/0, ps.cpp:1306-1333): in the snapshot a kid's position is the origin (its own state,
+        // and its T_DATA row, keep what the reference has).
         if (age < P.kid_thr) p.x = p.y = p.z = 0.0f;
         if (e < P.max_per_cell) {
             sorted_id[start + e] = id;
-            rank_of_slot[si] = start + e;
             const float w_eff = (age < P.kid_thr) ? 0.0f : (P.force_sign < 0.f ? -p.w : p.w);
-            {   // the same four values as separate arrays: what the pair kernel streams
+            {   // four separate arrays: what the pair kernel streams
                 const size_t cap = (size_t)P.sorted_cap;
                 snap_soa[start + e] = p.x; snap_soa[cap + start + e] = p.y;
                 snap_soa[2 * cap + start + e] = p.z; snap_soa[3 * cap + start + e] = w_eff;
@@ -561,14 +501,14 @@ __device__ __forceinline__ void sort_cell(const DevParams &P, const int c, const
             // collision id: the slot id, or -1 for a body that can never collide (kid, over age)
             const bool collides = !(age < P.kid_thr) && !(age > P.life_thr);
             snap_cid[start + e] = collides ? id : -1;
-            // (small instance: a candidate whose position is no number -- HALO_ALL -- is left to a pass of its own
+            // (register form: a candidate whose position is no number -- HALO_ALL -- is left to a pass of its own
             // below, so that the loop every body takes knows nothing of it: with the 26-neighbour case in here
             // the kernel took 10 us more, measured)
-            const int m3 = !(halo_count && collides) ? 0 : CAP == SMALL ? halo_dirs_of_numbers(P, ci1, ci2, ci3, p.x, p.y, p.z)
-                                                                        : halo_dirs(P, ci1, ci2, ci3, p.x, p.y, p.z);
-            if (CAP == SMALL && halo_count && collides && !finite3(p.x, p.y, p.z)) wild_any = true;
+            const int m3 = !(halo_count && collides) ? 0 : regs ? halo_dirs_of_numbers(P, ci1, ci2, ci3, p.x, p.y, p.z)
+                                                                : halo_dirs(P, ci1, ci2, ci3, p.x, p.y, p.z);
+            if (regs && halo_count && collides && !finite3(p.x, p.y, p.z)) wild_any = true;
             if (m3) {
-                if (CAP == SMALL) {
+                if (regs) {
 #pragma unroll
                     for (int m = 1; m < 8; m++) { const int dir = halo_dir_of_subset(m3, m); if (dir >= 0) atomicAdd(&s_halo[dir], 1); }
                     hx[k] = p.x; hy[k] = p.y; hz[k] = p.z; hid[k] = id; hm3[k] = m3;
@@ -576,6 +516,8 @@ __device__ __forceinline__ void sort_cell(const DevParams &P, const int c, const
                     for_each_halo_dir(m3, [&](int dir) { atomicAdd(&s_halo[dir], 1); });
             }
         } else {
+            // ranked at or past the list capacity: the reference kills it (ps.cpp:1517-1526) -- its entry of the sorted
+            // order becomes -1, the slot is reset
             sorted_id[start + e] = -1;
             cell_arr[si] = P.world > 1 ? -2 - cell_arr[si] : -1; pflags[si] = 0;       // (slab: the chunk-capacity walk still needs the cell, see chunk_cap_block)
             pos4[si] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -585,17 +527,17 @@ __device__ __forceinline__ void sort_cell(const DevParams &P, const int c, const
             // freed with the already-reset segment (-1,-1): queue record 0 (ps.cpp:1523-1526).  On a
             // slab that does not hold that queue the slot id travels to its owner in the status message.
             if (owns_record(P, 0)) {
-                const int k = atomicAdd(&fs->n_ops, 1);
-                if (k < ops_cap) { op_keys[k] = ((uint64_t)(uint32_t)id << 2) | 2ull; op_args[k] = id; }
+                const int k2 = atomicAdd(&fs->n_ops, 1);
+                if (k2 < ops_cap) { op_keys[k2] = ((uint64_t)(uint32_t)id << 2) | 2ull; op_args[k2] = id; }
                 else atomicOr(&fs->error, ERR_OPS_OVERFLOW);
             } else {
-                const int k = atomicAdd(&status_out[0], 1);
-                if (k < STATUS_KILL_CAP) status_out[MSG_HEADER_WORDS + k] = id;
+                const int k2 = atomicAdd(&status_out[0], 1);
+                if (k2 < STATUS_KILL_CAP) status_out[MSG_HEADER_WORDS + k2] = id;
                 else atomicOr(&fs->error, ERR_REMOTE_RECORD0);
             }
         }
     };
-    if (CAP == SMALL) {
+    if (regs) {
 #pragma unroll
         for (int k = 0; k < KR; k++) { const int e = tid + 256 * k; if (e < n) row(e, k); }
     } else {
@@ -603,7 +545,7 @@ __device__ __forceinline__ void sort_cell(const DevParams &P, const int c, const
     }
     if (!halo_count) return;
     const bool wild_cell = __syncthreads_or(wild_any);   // the snapshot rows of this cell are in memory, the directions counted
-    if (CAP != SMALL) {
+    if (!regs) {
         list_in_neighbour_halos(P, c, start, min(n, P.max_per_cell), SnapSoa{snap_soa, (size_t)P.sorted_cap}, snap_cid, halo_count, halo_f, halo_id, s_halo, s_halo_base, true);
         return;
     }
@@ -663,26 +605,26 @@ __device__ __forceinline__ void sort_cell(const DevParams &P, const int c, const
 }
 
 // The instance for ordinary cells runs one workgroup per cell; the one for crowded cells (more than 1024 ids: a
-// collapsing cloud) is launched every step too, with a few workgroups that leave at once unless the frame has
-// such a cell (max_cell_raw, from k_scan) and otherwise stride over the cells.
+// collapsing cloud, 1024 particles per cell) strides over the cells with a few workgroups and is launched only when the
+// host's last look at the frame scalars (max_cell_raw) showed a cell nearly that full.
 template <int CAP>
-__global__ __launch_bounds__(256) void k_sort_cells(DevParams P, const int *__restrict__ cell_start, int *__restrict__ sorted_id,
+__global__ __launch_bounds__(256) void k_sort_cells(DevParams P, int take_big, const int *__restrict__ cell_start, int *__restrict__ sorted_id,
+                                                     int *__restrict__ scratch_ids,
                                                      float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr, uint8_t *pflags,
                                                      float *__restrict__ snap_soa, float *__restrict__ snap_age,
-                                                     const uint32_t *__restrict__ tdata, int *__restrict__ rank_of_slot,
                                                      uint64_t *op_keys, int *op_args, int ops_cap,
                                                      int *__restrict__ halo_count, float *__restrict__ halo_f,
                                                      int *__restrict__ halo_id, int *__restrict__ snap_cid,
                                                      int *__restrict__ status_out, FrameScalars *fs, DevCounters *ctr)
 {
     if (CAP == 1024) {
-        sort_cell<CAP>(P, (int)blockIdx.x, cell_start, sorted_id, pos4, vel4, acc4, cell_arr, pflags, snap_soa, snap_age, tdata, rank_of_slot,
+        sort_cell<CAP>(P, (int)blockIdx.x, take_big != 0, cell_start, sorted_id, scratch_ids, pos4, vel4, acc4, cell_arr, pflags, snap_soa, snap_age,
                        op_keys, op_args, ops_cap, halo_count, halo_f, halo_id, snap_cid, status_out, fs, ctr);
         return;
     }
     if (fs->max_cell_raw <= 1024) return;
     for (int c = blockIdx.x; c < P.n_own_cells; c += gridDim.x) {
-        sort_cell<CAP>(P, c, cell_start, sorted_id, pos4, vel4, acc4, cell_arr, pflags, snap_soa, snap_age, tdata, rank_of_slot,
+        sort_cell<CAP>(P, c, true, cell_start, sorted_id, scratch_ids, pos4, vel4, acc4, cell_arr, pflags, snap_soa, snap_age,
                        op_keys, op_args, ops_cap, halo_count, halo_f, halo_id, snap_cid, status_out, fs, ctr);
         __syncthreads();
     }
@@ -759,7 +701,29 @@ hipError_t launch_init_tdata(hipStream_t st, const DevParams &P, const DeviceSta
     return hipSuccess;
 }
 
-hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev)
+// diagnostics (psamd_download_force4): the force records in sorted order, from where they live (ForceBuf)
+__global__ void k_force_gather(DevParams P, const int *__restrict__ cell_start, const int *__restrict__ sorted_id,
+                               const float4 *__restrict__ force4, const float4 *__restrict__ force_slot, float4 *__restrict__ out, int first, int count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int gi = first + i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gi < cell_start[P.n_own_cells]) {                      // an own cell's entry (the own block starts at 0)
+        const int id = sorted_id[gi], si = id >= 0 ? slot_index(P, id) : -1;
+        if (si >= 0) v = force_slot[si];
+    } else if (gi >= P.reg_sorted[1] && P.world > 1) v = force4[gi];
+    out[i] = v;
+}
+
+hipError_t launch_force_gather(hipStream_t st, const DevParams &P, const DeviceState &d, void *out, int first, int count)
+{
+    if (count <= 0) return hipSuccess;
+    k_force_gather<<<(count + 255) / 256, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.force4, d.force_slot, (float4 *)out, first, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev, bool tdata_rows, bool big_cells)
 {
     const int nwg = std::max(1, (P.slots_total + SLOTS_PER_WG - 1) / SLOTS_PER_WG);
     if (ev) (void)hipEventRecord(ev[0], st);
@@ -769,18 +733,22 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     k_scan<<<1, 1024, 0, st>>>(P, d.cell_count, d.cell_start, d.cursor, d.task_start, d.task_list, d.chunk_count, d.celltab, d.status_out, d.fs);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[2], st);
-    k_scatter_lds<<<nwg + (P.world == 1 ? P.num_chunks : 0), 1024, 0, st>>>(P, nwg, d.cell, d.cursor, d.sorted_id, d.chunk_count, d.celltab,
-                                                                             d.chunk_segs, d.chunk_skip, d.pos4, d.vel4, d.tdata);
+    const int grid = nwg + (P.world == 1 ? P.num_chunks : 0);
+    if (tdata_rows) k_scatter_lds<true><<<grid, 1024, 0, st>>>(P, nwg, d.cell, d.cursor, d.sorted_id, d.chunk_count, d.celltab, d.chunk_segs, d.chunk_skip, d.pos4, d.vel4, d.tdata);
+    else k_scatter_lds<false><<<grid, 1024, 0, st>>>(P, nwg, d.cell, d.cursor, d.sorted_id, d.chunk_count, d.celltab, d.chunk_segs, d.chunk_skip, d.pos4, d.vel4, d.tdata);
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[3], st);
-    k_sort_cells<1024><<<P.n_own_cells, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
-                                               d.pflags, d.snap_soa, d.snap_age, d.tdata, d.rank_of_slot, d.op_keys, d.op_args, d.ops_cap,
+    // (the ordered ids of a cell that is ranked through global memory go through active_list: written by k_collide_cell later in the frame)
+    k_sort_cells<1024><<<P.n_own_cells, 256, 0, st>>>(P, big_cells ? 0 : 1, d.cell_start, d.sorted_id, d.active_list, d.pos4, d.vel4, d.acc4, d.cell,
+                                               d.pflags, d.snap_soa, d.snap_age, d.op_keys, d.op_args, d.ops_cap,
                                                P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.snap_cid, d.status_out, d.fs, d.ctr);
     PS_LAUNCH_CHECK();
-    k_sort_cells<SORT_MAX><<<std::min(P.n_own_cells, 512), 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.pos4, d.vel4, d.acc4, d.cell,
-                                               d.pflags, d.snap_soa, d.snap_age, d.tdata, d.rank_of_slot, d.op_keys, d.op_args, d.ops_cap,
+    if (big_cells) {
+        k_sort_cells<SORT_MAX><<<std::min(P.n_own_cells, 512), 256, 0, st>>>(P, 1, d.cell_start, d.sorted_id, d.active_list, d.pos4, d.vel4, d.acc4, d.cell,
+                                               d.pflags, d.snap_soa, d.snap_age, d.op_keys, d.op_args, d.ops_cap,
                                                P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.snap_cid, d.status_out, d.fs, d.ctr);
-    PS_LAUNCH_CHECK();
+        PS_LAUNCH_CHECK();
+    }
     if (ev) (void)hipEventRecord(ev[4], st);
     return hipSuccess;
 }

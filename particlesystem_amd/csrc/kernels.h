@@ -52,17 +52,16 @@ struct DeviceState {
     int *ctask_start = nullptr;   // [computed cells + 1] first entry of task_list2 of the j-th computed cell
     long long *cost_start = nullptr;  // [computed cells + 1] cost of all tasks before the j-th computed cell
     long long *wave_pos = nullptr; // [waves + 1] where every wave slot of the balanced pass starts: task index << 32 | cost already walked inside the task
-    int *wave_unit = nullptr;      // [waves + 1] the same as (task, stencil step) units: task index * 27 + step
     int *task_ready = nullptr;    // [num_cells * slices] hand-off flags, zeroed with the frame
     int4 *merged_tasks = nullptr; // [num_cells] cells whose leftover slices share one wave (-1: unused)
     // the merged tasks run beside k_pairs on a stream of their own (fork / join by events)
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int *sorted_id = nullptr;     // [container] cell-major, id ascending inside a cell
-    int *rank_of_slot = nullptr;  // [container] inverse of sorted_id for the slots of this frame
     float *snap_soa = nullptr;    // [4][sorted_cap] sorted order: x, y, z, w_eff as four arrays (what the pair walk streams)
     float *snap_age = nullptr;    // [container] sorted order
-    float4 *force4 = nullptr;     // [container] sorted order: ax,ay,az,flag
+    float4 *force4 = nullptr;     // [sorted_cap] sorted order: (ax, ay, az, flag) of the lent region's particles; the hand-off mailbox of the force pass
+    float4 *force_slot = nullptr; // [slots] by slot: (ax, ay, az, flag) of the own cells' particles (ForceBuf, kernels_common.hpp)
     CellInfo *celltab = nullptr;  // [num_cells]
     // lifecycle
     uint64_t *op_keys = nullptr, *op_keys_sorted = nullptr;
@@ -101,8 +100,12 @@ hipError_t launch_validate_eps(hipStream_t st, uint32_t lo_bits, uint32_t hi_bit
                                unsigned long long *out);
 hipError_t launch_selftest_math(hipStream_t st, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out24);
 hipError_t launch_init_tdata(hipStream_t st, const DevParams &P, const DeviceState &d);
-// ev (optional) = 5 events recorded before hist, scan, scatter, sort and after sort
-hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev);
+// ev (optional) = 5 events recorded before hist, scan, scatter, sort and after sort.  tdata_rows: also write the reference's T_DATA rows (a mirror for
+// psamd_download_tdata; nothing in the step reads them).  big_cells: launch the instance for cells of more than 1024 ids
+// (a hint: without it such a cell is ranked through global memory by the ordinary instance).
+hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceState &d, hipEvent_t *ev, bool tdata_rows, bool big_cells);
+// psamd_download_force4: entries [first, first + count) of the sorted order, gathered from where the records live
+hipError_t launch_force_gather(hipStream_t st, const DevParams &P, const DeviceState &d, void *out, int first, int count);
 // tasks_hint: about how many force tasks the pass will have (sizes the balanced force pass)
 // pass: 0 or 1, which of a frame's (up to two) passes of the pair stage this is
 // live_bound: at most so many particles are alive (< 0: unknown); sizes the all-pairs far pass's launch

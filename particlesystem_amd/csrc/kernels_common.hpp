@@ -281,6 +281,33 @@ __device__ __forceinline__ void list_in_neighbour_halos(const DevParams &P, int 
     }
 }
 
+// Where a particle's force record (ax, ay, az, collision flag) lives.  The records of the OWN cells are kept BY SLOT:
+// k_apply walks the slots and streams a particle's record with its state, no detour through its place in the sorted
+// order (until round 5 every record was in sorted order and k_apply gathered it through rank_of_slot: one more
+// dependent round trip in a kernel that is nothing but a chain of them, plus a scattered 4-byte write per particle
+// in k_sort_cells).  The records of cells computed for the rank below (the lent region) stay in sorted order, where
+// k_pack_force takes them from; and the sorted-order array is also the mailbox through which a task that is cut hands
+// its partial sums from wave to wave (`buf + gi`).
+struct ForceBuf {
+    float4 *sorted;
+    float4 *by_slot;
+    const int *sorted_id;
+    __device__ __forceinline__ float4 *operator+(int gi) const { return sorted + gi; }
+    // lc: the (local) cell the particle at sorted index gi belongs to
+    __device__ __forceinline__ void put(const DevParams &P, int lc, int gi, const float4 v) const
+    {
+        if (lc < P.n_own_cells) by_slot[slot_index(P, sorted_id[gi])] = v; else sorted[gi] = v;
+    }
+    __device__ __forceinline__ void put_id(const DevParams &P, int lc, int gi, int id, const float4 v) const     // (the caller has the slot id at hand)
+    {
+        if (lc < P.n_own_cells) by_slot[slot_index(P, id)] = v; else sorted[gi] = v;
+    }
+    __device__ __forceinline__ float4 get(const DevParams &P, int lc, int gi) const
+    {
+        return lc < P.n_own_cells ? by_slot[slot_index(P, sorted_id[gi])] : sorted[gi];
+    }
+};
+
 // the four outboxes of a slab: records for the rank below [0] / above [1] (xfer_cap each), two ranks below [2] / above [3] (xfer2_cap)
 constexpr int FAR_MAGIC = 0x21524146;       // "FAR!": header word 3 of a far outbox that was closed this step
 struct Outboxes { XferRec *o[5]; };         // below, above, two below, two above, far (all-gathered)

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256, CAP <= 1024 ? 6 : 3) void k_collide_cell(DevPa
                                                       const int *__restrict__ halo_count, const float *__restrict__ halo_f,
                                                       const int *__restrict__ halo_id, int *__restrict__ active_list,
                                                       int *__restrict__ active_count, int *__restrict__ task_cost,
-                                                      float4 *__restrict__ force4)
+                                                      const ForceBuf force4)
 {
     constexpr int KB = CAP / 256;                                 // bodies a thread bins (held in registers between the passes)
     __shared__ float4 s_body[CAP];
@@ -542,13 +542,13 @@ __global__ __launch_bounds__(256, CAP <= 1024 ? 6 : 3) void k_collide_cell(DevPa
         __syncthreads();
     }
     const float dmax = P.coll_d2_max;
-    // the flag, the final force4 record of the particles the force pass does not visit, and the list of the ones it does
+    // the flag, the force record of the particles the force pass does not visit, and the list of the ones it does
     // (flag 0 and not a kid), packed at active_list[cell_start[c] ...] in whatever order the cell's waves arrive
     auto finish = [&](bool valid, int gi, bool dead, bool kid, bool met_higher, bool met_lower, bool alone = false) {
         int flag = met_higher ? 2 : met_lower ? 1 : 0;
         if (dead) flag = 2;                                          // ps.cpp:1183
-        if (valid) force4[gi] = make_float4(0.f, 0.f, 0.f, __int_as_float(flag));   // final unless the force pass overwrites it
         const bool on = valid && flag == 0 && !kid && !alone;       // (alone: stencil_adults)
+        if (valid && !on) force4.put(P, c, gi, make_float4(0.f, 0.f, 0.f, __int_as_float(flag)));   // (the force pass writes the records of the particles it visits)
         const unsigned long long m = __ballot(on);
         if (m) {
             int off = 0;
@@ -670,7 +670,8 @@ __global__ __launch_bounds__(1024) void k_plan_force(DevParams P, int nw, int me
                                                      const int *__restrict__ active_count, const int *__restrict__ task_cost,
                                                      int *__restrict__ task_list2, int *__restrict__ ctask_start_g,
                                                      long long *__restrict__ cost_start_g, int4 *__restrict__ merged_tasks,
-                                                     long long *__restrict__ wave_pos, FrameScalars *fs, unsigned long long *trace)
+                                                     long long *__restrict__ wave_pos, FrameScalars *fs, unsigned long long *trace,
+                                                     StepState *st, int pass)
 {
 #ifdef PSAMD_PLAN_TRACE    // diagnostic build: time stamps (100 MHz) of workgroup x's phases in trace[8 x ...]
 #define PT(i) do { if (threadIdx.x == 0) trace[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -819,29 +820,26 @@ __global__ __launch_bounds__(1024) void k_plan_force(DevParams P, int nw, int me
     for (int j = tid; j < m; j += 1024)                   // equal shares of the run's own cost range
         wave_pos[x * m + j] = j == 0 ? run_lo : max(run_lo, min(run_hi, pos_at(lo + (hi - lo) * j / m, false)));
     if (x == 7 && tid == 0) wave_pos[nw] = run_hi;        // = (ntask, 0)
-    __syncthreads();
-    PT(5);
-#undef PT
-}
-
-// wave_pos -> wave_unit: one WAVE per wave-slot boundary.  The stencil step of a position (task, cost
-// already walked inside the task) is the number of leading stencil cells the residual covers whole:
-// 27 lanes look the cells' populations up, one scan, one ballot.  (One THREAD per boundary walking
-// the 27 counts serially -- some 2000 instructions -- was the bulk of the old split kernel.)
-__global__ __launch_bounds__(256) void k_resolve_steps(DevParams P, int nw, const int *__restrict__ cell_start,
-                                                       const int *__restrict__ task_list, const long long *__restrict__ wave_pos,
-                                                       int *__restrict__ wave_unit, StepState *st, int pass)
-{
-    const int s = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (x == 0 && tid == 0) {
         // the clock of the pass that follows (WavePace): how long the last one took, and when this one was planned
         const unsigned long long a = st->pairs_t0[pass], b = st->pairs_end[pass];
         st->pairs_ticks[pass] = (b > a && b - a < (1ull << 30)) ? (int)(b - a) : 0;
         st->pairs_t0[pass] = __builtin_amdgcn_s_memrealtime();
         st->pairs_end[pass] = 0;
     }
-    if (s > nw) return;
-    const long long pos = wave_pos[s];
+    __syncthreads();
+    PT(5);
+#undef PT
+}
+
+// wave_pos -> (task, stencil step) unit, by the wave that starts (or stops) there.  The stencil step of a position
+// (task, cost already walked inside the task) is the number of leading stencil cells the residual covers whole:
+// 27 lanes look the cells' populations up, one scan, one ballot.  Every wave of the balanced pass resolves its own two
+// boundaries as its first instructions (until round 5 a launch of its own did it, k_resolve_steps: 5.5 us on the step's
+// critical path for what a wave does in the shadow of its first loads).  Returns a wave-uniform number.
+__device__ __forceinline__ int resolve_unit(const DevParams &P, long long pos, const int *__restrict__ cell_start, const int *__restrict__ task_list)
+{
+    const int lane = (int)(threadIdx.x & 63);
     const int t = __builtin_amdgcn_readfirstlane((int)(pos >> 32)), r = __builtin_amdgcn_readfirstlane((int)(pos & 0xffffffffll));
     int k = 0;
     if (r & (1 << 30)) k = r & 63;                           // a merged pack: the residual is the step
@@ -856,7 +854,7 @@ __global__ __launch_bounds__(256) void k_resolve_steps(DevParams P, int nw, cons
         const int cum = wave_incl_scan(cnt);
         k = __popcll(__ballot(lane < STENCIL - 1 && cum <= r));
     }
-    if (lane == 0) wave_unit[s] = t * STENCIL + k;
+    return t * STENCIL + k;
 }
 
 // One wave = 64 consecutive particles of one cell (four independent waves per workgroup).
@@ -985,7 +983,7 @@ template <int MODE, int NQ, bool SETTLED = false>
 __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__restrict__ cell_start,
                                            const SnapSoa snap4, const float *__restrict__ snap_soa,
                                            const float *__restrict__ snap_age, const int *__restrict__ sorted_id,
-                                           float4 *__restrict__ force4, int task,
+                                           const ForceBuf force4, int task,
                                            float4 *tile, unsigned long long *trace,
                                            const int *__restrict__ active_list = nullptr,
                                            const int *__restrict__ active_count = nullptr,
@@ -1158,7 +1156,7 @@ __device__ __forceinline__ void pairs_task(const DevParams &P, const int *__rest
             if (lost && adults <= 1) { ax = 0.f; ay = 0.f; az = 0.f; }
         }
     }
-    if (valid) force4[gi] = make_float4(ax, ay, az, __int_as_float(flag));
+    if (valid) force4.put_id(P, c, gi, id_i, make_float4(ax, ay, az, __int_as_float(flag)));
     PS_TRACE_END();
 }
 
@@ -1169,7 +1167,7 @@ __global__ __launch_bounds__(256) void k_pairs(DevParams P, const int *__restric
                                                const float *__restrict__ snap_age,
                                                const int *__restrict__ sorted_id,
                                                const int *__restrict__ task_list,
-                                               float4 *__restrict__ force4,
+                                               const ForceBuf force4,
                                                FrameScalars *fs, unsigned long long *trace,
                                                const int *__restrict__ active_list, const int *__restrict__ active_count)
 {
@@ -1351,18 +1349,18 @@ __global__ __launch_bounds__(256, PSAMD_BALANCED_WAVES) void k_allp_far(DevParam
 // All-pairs: a particle's acceleration = (((stencil chain + part 0) + part 1) + ...) + part 15, the same
 // association on one GPU and on any number of ranks.  One thread per particle that needs a force, in the dense order.
 __global__ void k_allpairs_combine(DevParams P, const int *__restrict__ act_start, const int *__restrict__ dense_gi,
-                                   const FarCells far, float4 *__restrict__ force4)
+                                   const int *__restrict__ dense_cell, const FarCells far, const ForceBuf force4)
 {
     const int n = min(act_start[comp_count(P)], (int)far.part_plane);
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        const int gi = dense_gi[r];
-        float4 a = force4[gi];                              // (flag 0, not a kid: it is on the active list)
+        const int gi = dense_gi[r], lc = dense_cell[r];
+        float4 a = force4.get(P, lc, gi);                   // (flag 0, not a kid: it is on the active list)
 #pragma unroll
         for (int p = 0; p < ALLP_PARTS; p++) {
             const float4 b = far.part_acc[(size_t)p * far.part_plane + (size_t)r];
             a.x += b.x; a.y += b.y; a.z += b.z;
         }
-        force4[gi] = a;
+        force4.put(P, lc, gi, a);
     }
 }
 
@@ -1392,7 +1390,7 @@ struct TileGroups {
 // NG: how many groups the code is built for (1: an ordinary task, nothing per-group left in it; 4: a pack)
 template <int MODE, int NQ, int NG, bool ONE_T>
 __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *__restrict__ cell_start,
-                                                const SnapSoa snap4, float4 *__restrict__ force4,
+                                                const SnapSoa snap4, const ForceBuf force4,
                                                 const TileGroups &G, float *tile, const int *__restrict__ active_list,
                                                 int k0, int k1, int *ready, FrameScalars *fs)
 {
@@ -1521,7 +1519,7 @@ __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *_
         }
     }
     if (k1 < STENCIL) { handoff_publish(force4 + gi, ax, ay, az, flag, valid, ready, k1); return; }
-    if (valid) force4[gi] = make_float4(ax, ay, az, __int_as_float(flag));
+    if (valid) force4.put(P, gc, gi, make_float4(ax, ay, az, __int_as_float(flag)));
 }
 
 // The force pass, balanced: `nw` waves (all resident), wave slot s walks the (task, stencil step)
@@ -1544,7 +1542,7 @@ __device__ __forceinline__ void merged_pack_task(const DevParams &P, const int *
                                                  const int *__restrict__ active_list,
                                                  const int *__restrict__ active_count,
                                                  const int4 *__restrict__ merged_tasks,
-                                                 float4 *__restrict__ force4, int slot, float *tile, WavePace *pace = nullptr);
+                                                 const ForceBuf force4, int slot, float *tile, WavePace *pace = nullptr);
 
 // nmb (WALK 0, a multiple of 8 so that the XCD dealing is undisturbed): the first nmb workgroups of the
 // launch serve the merged packs of partly filled slices instead (merged_pack_task) -- dispatched first,
@@ -1559,10 +1557,10 @@ __global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : WALK == 1 ?
                                                         const float *__restrict__ snap_age,
                                                         const int *__restrict__ sorted_id,
                                                         const int *__restrict__ task_list,
-                                                        float4 *__restrict__ force4,
+                                                        const ForceBuf force4,
                                                         FrameScalars *fs, unsigned long long *trace,
                                                         const int *__restrict__ active_list, const int *__restrict__ active_count,
-                                                        const int *__restrict__ wave_unit, int *__restrict__ task_ready,
+                                                        const long long *__restrict__ wave_pos, int *__restrict__ task_ready,
                                                         const int4 *__restrict__ merged_tasks, int nmb, StepState *st, int pass, int paced)
 {
     __shared__ __attribute__((aligned(16))) float tiles[4][4 * MERGE_TILE];   // up to four 1-KiB tiles per wave
@@ -1595,7 +1593,9 @@ __global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : WALK == 1 ?
         return;
     }
     const int slot = xcd_contiguous((int)blockIdx.x - nmb, (int)gridDim.x - nmb) * 4 + wave;
-    const int ub = __builtin_amdgcn_readfirstlane(wave_unit[slot]), ue = __builtin_amdgcn_readfirstlane(wave_unit[slot + 1]);
+    const long long pos_b = wave_pos[slot], pos_e = wave_pos[slot + 1];
+    if (pos_e <= pos_b) return;                              // (positions order like units: task-major, cost inside the task)
+    const int ub = resolve_unit(P, pos_b, cell_start, task_list), ue = resolve_unit(P, pos_e, cell_start, task_list);
     if (ue <= ub) return;
     WavePace pace;
     if (WALK == 0 && paced) {
@@ -1669,7 +1669,7 @@ __device__ __forceinline__ void merged_pack_task(const DevParams &P, const int *
                                                  const int *__restrict__ active_list,
                                                  const int *__restrict__ active_count,
                                                  const int4 *__restrict__ merged_tasks,
-                                                 float4 *__restrict__ force4, int slot, float *tile, WavePace *pace)
+                                                 const ForceBuf force4, int slot, float *tile, WavePace *pace)
 {
     const int lane = threadIdx.x & 63;
     // (Raising these waves' issue priority -- they run one per SIMD among six of the balanced
@@ -1758,7 +1758,7 @@ __device__ __forceinline__ void merged_pack_task(const DevParams &P, const int *
         }
         if (pace) pace->step();
     }
-    if (valid) force4[gi] = make_float4(ax, ay, az, 0.f);
+    if (valid) force4.put(P, c, gi, make_float4(ax, ay, az, 0.f));
 }
 
 template <int MODE, int NQ>
@@ -1767,7 +1767,7 @@ __global__ __launch_bounds__(256, 6) void k_pairs_merged(DevParams P, const int 
                                                       const int *__restrict__ active_list,
                                                       const int *__restrict__ active_count,
                                                       const int4 *__restrict__ merged_tasks,
-                                                      float4 *__restrict__ force4, const FrameScalars *__restrict__ fs)
+                                                      const ForceBuf force4, const FrameScalars *__restrict__ fs)
 {
     __shared__ __attribute__((aligned(16))) float tiles[4][4 * MERGE_TILE];
     const int wave = threadIdx.x >> 6;
@@ -1928,6 +1928,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
 {
     const int ncomp = comp_count(P);
     if (ncomp <= 0) return hipSuccess;
+    const ForceBuf fbuf{d.force4, d.force_slot, d.sorted_id};
     const int tasks = ncomp * P.slices;
     const PairShape shape = pair_shape(P, MODE != 0, tasks_hint);
     const bool two = shape.two, merge = shape.merge, balanced = shape.balanced, tile = shape.tile, packs_in_list = shape.packs_in_list;
@@ -1936,13 +1937,12 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
         // collision flags and the per-cell lists of the particles that need a force, then the plan of the force pass
         if (P.max_per_cell + HALO_CAP / 2 <= 1024)
             k_collide_cell<1024><<<ncomp, 256, 0, st>>>(P, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.snap_cid, d.halo_count, d.halo_f,
-                                                        d.halo_id, d.active_list, d.active_count, d.task_cost, d.force4);
+                                                        d.halo_id, d.active_list, d.active_count, d.task_cost, fbuf);
         else
             k_collide_cell<2560><<<ncomp, 256, 0, st>>>(P, d.cell_start, d.snap_soa, d.snap_age, d.sorted_id, d.snap_cid, d.halo_count, d.halo_f,
-                                                        d.halo_id, d.active_list, d.active_count, d.task_cost, d.force4);
+                                                        d.halo_id, d.active_list, d.active_count, d.task_cost, fbuf);
         k_plan_force<<<8, 1024, 0, st>>>(P, balanced ? nw : 0, packs_in_list ? 2 : merge ? 1 : 0, d.cell_start, d.active_count, d.task_cost,
-                                         d.task_list2, d.ctask_start, d.cost_start, d.merged_tasks, d.wave_pos, d.fs, d.trace);
-        if (balanced) k_resolve_steps<<<(nw + 1 + 3) / 4, 256, 0, st>>>(P, nw, d.cell_start, d.task_list2, d.wave_pos, d.wave_unit, d.st, pass);
+                                         d.task_list2, d.ctask_start, d.cost_start, d.merged_tasks, d.wave_pos, d.fs, d.trace, d.st, pass);
     }
     if (ev_force) (void)hipEventRecord(ev_force, st);      // timing: the force pass proper starts here
     const int *task_list = two ? d.task_list2 : d.task_list;
@@ -1956,7 +1956,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
         // the packs of partly filled slices (merge): the first nmb workgroups of the same launch
         const int nmb = merge ? std::max(8, shape.nmb) : 0;
 #define PS_BALANCED_Q(W, Q) k_pairs_balanced<M, Q, W><<<nmb + nw / 4, 256, 0, st>>>(P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_soa, d.snap_age, d.sorted_id, task_list, \
-                                                                     d.force4, d.fs, d.trace, active_list, active_count, d.wave_unit, task_ready, d.merged_tasks, nmb, d.st, pass, paced)
+                                                                     fbuf, d.fs, d.trace, active_list, active_count, d.wave_pos, task_ready, d.merged_tasks, nmb, d.st, pass, paced)
 #define PS_BALANCED(W) PS_BALANCED_Q(W, NQ)
         // The tile walk -- a wave with its SIMD (almost) to itself -- takes 16 bodies per group: every group costs such a
         // wave two branches on a vector compare and the tail of three chains of dependent additions, all of it exposed;
@@ -1970,11 +1970,11 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
 #undef PS_BALANCED_Q
     }
     else {
-        k_pairs<MODE, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_soa, d.snap_age, d.sorted_id, task_list, d.force4,
+        k_pairs<MODE, NQ><<<(tasks + 3) / 4, 256, 0, st>>>(P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_soa, d.snap_age, d.sorted_id, task_list, fbuf,
                                                          d.fs, d.trace, active_list, active_count);
         // (unbalanced pass, A/B runs only: the packs as a kernel of their own behind it)
         if (merge) k_pairs_merged<MODE == 0 ? 1 : MODE, NQ><<<(ncomp + 3) / 4, 256, 0, st>>>(
-                P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.active_list, d.active_count, d.merged_tasks, d.force4, d.fs);
+                P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.active_list, d.active_count, d.merged_tasks, fbuf, d.fs);
     }
     if (MODE != 0 && (P.flags & PSAMD_FLAG_ALL_PAIRS)) {
         // All-pairs forces: what ran above is the stencil's chain; now every other cell (k_allp_far) and the sum.
@@ -1994,7 +1994,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
         k_allp_dense<<<(ncomp + 3) / 4, 256, 0, st>>>(P, d.cell_start, d.active_list, d.active_count, d.act_start, d.dense_gi, d.dense_cell);
         k_allp_far<MODE == 0 ? 1 : MODE, NQ><<<(unsigned)((dense_bound * ALLP_PARTS + 3) / 4), 256, 0, st>>>(P, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.act_start, d.dense_gi, d.dense_cell,
                                                                                                   far, far_buf, far_start, far_n);
-        k_allpairs_combine<<<(unsigned)((dense_bound * 64 + 255) / 256), 256, 0, st>>>(P, d.act_start, d.dense_gi, far, d.force4);
+        k_allpairs_combine<<<(unsigned)((dense_bound * 64 + 255) / 256), 256, 0, st>>>(P, d.act_start, d.dense_gi, d.dense_cell, far, fbuf);
     }
     return hipGetLastError();
 }

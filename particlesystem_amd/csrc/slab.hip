@@ -200,7 +200,7 @@ __global__ void k_pack_force(DevParams P, const float4 *__restrict__ force4, int
 // Receiver (the owner): message cell j0 + b is own local cell lentout_c0 + b; its stored bodies
 // sit at pack_off[j0 + b] - pack_off[j0] in the message.  One workgroup per lent-out cell.
 __device__ __forceinline__ void unpack_force_block(const DevParams &P, int b, int j0, const int *__restrict__ msg, const int *__restrict__ pack_off,
-                                                   const int *__restrict__ cell_start, float4 *__restrict__ force4, FrameScalars *fs)
+                                                   const int *__restrict__ cell_start, const ForceBuf force4, FrameScalars *fs)
 {
     const int c = P.lentout_c0 + b;
     const int ncell = P.lentout_c1 - P.lentout_c0;
@@ -211,7 +211,7 @@ __device__ __forceinline__ void unpack_force_block(const DevParams &P, int b, in
     }
     if (msg[1] != pack_off[j0 + ncell] - pack_off[j0]) return;
     const int rel = pack_off[j0 + b] - pack_off[j0], n = pack_off[j0 + b + 1] - pack_off[j0 + b], dst = cell_start[c];
-    for (int e = threadIdx.x; e < n; e += blockDim.x) force4[dst + e] = src[rel + e];
+    for (int e = threadIdx.x; e < n; e += blockDim.x) force4.put(P, c, dst + e, src[rel + e]);      // (an own cell: by slot)
 }
 
 // Arrivals: every record a neighbour sent becomes a MoveRec whose state is staged already,
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(1024) void k_status_merge(DevParams P, const int *_
                                                         const CellInfo *__restrict__ celltab, const int2 *__restrict__ chunk_segs,
                                                         uint8_t *__restrict__ chunk_skip, FrameScalars *fs,
                                                         int force_j0, const int *__restrict__ force_msg, const int *__restrict__ pack_off,
-                                                        const int *__restrict__ cell_start, float4 *__restrict__ force4)
+                                                        const int *__restrict__ cell_start, const ForceBuf force4)
 {
     __shared__ int s_before[4];
     // workgroups past the status records and the chunks: the force records of the lent-out layers come home
@@ -395,7 +395,7 @@ hipError_t launch_status_merge(hipStream_t st, const DevParams &P, const DeviceS
     if (!status_all || P.world <= 1) return hipSuccess;
     const int ncell = force_msg ? std::max(0, P.lentout_c1 - P.lentout_c0) : 0;
     k_status_merge<<<P.world + P.num_chunks + ncell, 1024, 0, st>>>(P, status_all, d.op_keys, d.op_args, d.ops_cap, d.chunk_count, d.cell, d.celltab,
-                                                                    d.chunk_segs, d.chunk_skip, d.fs, force_j0, force_msg, pack_off, d.cell_start, d.force4);
+                                                                    d.chunk_segs, d.chunk_skip, d.fs, force_j0, force_msg, pack_off, d.cell_start, ForceBuf{d.force4, d.force_slot, d.sorted_id});
     return hipGetLastError();
 }
 

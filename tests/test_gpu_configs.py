@@ -80,6 +80,72 @@ def test_config3_n22_two_slabs_on_one_gpu():
 
 
 @pytest.mark.timeout(1500)
+def test_config3_literally_n22_all_pairs_eight_slabs_snapshot_all_gather():
+    """configs[3] as BASELINE words it: N = 2^22 sharded over EIGHT slabs with an all-gather of the positions once
+    per step (PSAMD_FLAG_ALL_PAIRS: every rank contributes the snapshot of its own cells, walks the gathered buffer).
+    One whole step; the union of the eight slabs must be the one-context step byte for byte (particles, QUEUE_INFO,
+    queues), and -- no CPU re-does 1.8e13 pairs -- three windows of 200 particles of the one-context pair pass are
+    held against an fp64 direct sum over all 2^22 bodies (1e-5 relative, BASELINE's bar)."""
+    n = 1 << 22
+    over = dict(max_particles_num=n, flags=ps.FLAG_ALL_PAIRS)
+    one = ps.ParticleSystem(ps.default_config(**over))
+    xyz = one.uniform_cloud(n, 33)
+    rng = np.random.default_rng(33)
+    age = rng.uniform(15 / 7, 7.5, n).astype(np.float32)
+    fert = np.full(n, 1e6, np.float32)
+    ids = one.fill_particles(xyz, age=age, fert_age=fert)
+    one.init_iframe(); one.build_grid()
+    cg = one.download_cellgrid()
+    assert cg[:, 0].sum() == n and cg[:, 0].max() <= one.sizes.max_per_cell
+    order = np.concatenate([row[1:1 + row[0]] for row in cg])              # slot id at every place of the sorted order
+    one.calc_forces_pairs()
+    where = np.empty(one.sizes.container_size, np.int64)
+    where[ids] = np.arange(n)
+    import torch
+    pos = torch.from_numpy(xyz.astype(np.float64)).cuda()
+    W = 6000
+    worst = 0.0
+    for lo in (0, n // 2 + 777, n - W):
+        f = one.download_force4(lo, W)
+        free = np.nonzero(f[:, 3].view(np.int32) == 0)[0][:200]              # a flagged particle's force is never looked at
+        assert len(free) == 200, "window at %d holds only %d particles the force pass visits" % (lo, len(free))
+        idx = torch.from_numpy(where[order[lo + free]]).cuda()
+        exact = torch.empty((200, 3), dtype=torch.float64, device="cuda")
+        for a in range(0, 200, 20):                                          # 20 particles x 2^22 bodies x 3 doubles at a time
+            d = pos[None, :, :] - pos[idx[a:a + 20], None, :]
+            r2 = (d * d).sum(2) + 0.2
+            sc = 60.0 / (r2 * torch.sqrt(r2))
+            sc[torch.arange(len(idx[a:a + 20]), device="cuda"), idx[a:a + 20]] = 0.0     # not itself (ps.cpp:1258)
+            exact[a:a + 20] = (d * sc[:, :, None]).sum(1)
+            del d, r2, sc
+        ex = exact.cpu().numpy()
+        rel = np.linalg.norm(f[free, :3].astype(np.float64) - ex, axis=1) / np.linalg.norm(ex, axis=1)
+        worst = max(worst, float(rel.max()))
+    del pos
+    torch.cuda.empty_cache()
+    print("configs[3], all-pairs N=2^22 vs fp64 direct sum (3 x 200 particles): max relative deviation %.3g" % worst)
+    assert worst < 1e-5
+    one.calc_forces_apply()
+    whole = digest(one.download_particles(), *one.download_queues())
+    c1 = one.counters
+    one.close()
+    world = 8
+    ranks = [ps.ParticleSystem(ps.default_config(rank=r, world=world, **over)) for r in range(world)]
+    for h in ranks:
+        h.fill_particles(xyz, age=age, fert_age=fert)
+    assert ranks[0].msg_bytes(ps.MSG_ALLG_OUT) > 0 and ranks[0].msg_bytes(ps.MSG_ALLG_IN) == world * ranks[0].msg_bytes(ps.MSG_ALLG_OUT)
+    step_local(ranks)                                                        # (the snapshot all-gather is one of its exchanges)
+    plans = [h.slab_plan() for h in ranks]
+    union_p = merge_owned([h.download_particles() for h in ranks], plans)
+    qs = [h.download_queues() for h in ranks]
+    union = digest(union_p, merge_owned([q[0] for q in qs], plans, "records"), merge_owned([q[1] for q in qs], plans))
+    assert union == whole
+    assert sum(h.counters["integrated"] for h in ranks) == c1["integrated"] > 0
+    for h in ranks:
+        h.close()
+
+
+@pytest.mark.timeout(1500)
 def test_config4_n24_in_40_cubed_cells():
     """configs[4]: N = 2^24, grid scaled to the reference's density (40^3 cells, 262 per cell):
     sorted partition, windows of the pair pass vs the oracle, determinism of a whole step."""

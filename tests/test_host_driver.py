@@ -60,10 +60,10 @@ def test_driver_ends_in_the_oracle_state(fetch_back):
 
 G1 = ["--graphs", "1"]       # every stage's kernels as one hipGraph (off by default: profiles/r4_ab_graphs.txt)
 RING_CASES = [
-    (2, []), (3, ["--overlap-interior"] + G1), (4, ["--births"] + G1), (8, G1),
+    (2, []), (3, ["--overlap-interior", "--side-stream", "1"] + G1), (4, ["--births", "--side-stream", "2"] + G1), (8, G1),
     (2, ["--all-pairs"] + G1), (4, ["--all-pairs"]), (8, ["--all-pairs", "--n", "30000"]),
-    (3, ["--side-stream", "0"]),                               # the round-3 form: plain launches, RCCL on the compute stream
-    (4, ["--births", "--overlap-interior", "--wait", "0"]), (8, ["--births"]),
+    (3, ["--side-stream", "2"]),                               # the round-4 form: every transfer on a second stream, events in between
+    (4, ["--births", "--overlap-interior", "--wait", "0"]), (8, ["--births", "--side-stream", "1"]),
 ]
 
 
@@ -73,8 +73,8 @@ RING_CASES = [
 def test_cpp_ring_moves_every_message_with_rccl(world, extra):
     """host/ps_ring_rccl --loopback: all slabs in one C++ process on this GPU, a communicator of one
     rank, every halo / force / transfer message an ncclSend to self matched by an ncclRecv from self
-    on the TRANSFER stream (events order it against the compute stream, where every stage runs as one
-    captured hipGraph), the status records -- and, with --all-pairs, the snapshot blocks: SURVEY 8(e)'s
+    -- on the compute stream between the stage kernels by default, on a second HIP stream ordered by events with
+    --side-stream 1 / 2 (where every stage may run as one captured hipGraph) --, the status records -- and, with --all-pairs, the snapshot blocks: SURVEY 8(e)'s
     all-gather of positions once per step -- by ncclAllGather.  The program itself requires the
     union of the slabs to equal the single-context run byte for byte (which the parity tests tie to
     the oracle) and exits non-zero otherwise.  Stage loop: ps.cpp:1843-1928; what a rank subscribes
@@ -105,7 +105,7 @@ def test_cpp_ring_bench_record_in_loopback():
     exe = psbuild.build_ring()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([exe, "--loopback", "--world", "4", "--bench", "--n", "131072", "--steps", "6", "--warmup", "2",
-                        "--settle-seconds", "0.05", "--timing-period", "2", "--graphs", "1"], env=env, capture_output=True, text=True, timeout=560)
+                        "--settle-seconds", "0.05", "--timing-period", "2", "--graphs", "1", "--side-stream", "2"], env=env, capture_output=True, text=True, timeout=560)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
     recs = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{") and '"psamd_ring"' in l]
     assert len(recs) == 1, p.stdout

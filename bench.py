@@ -369,7 +369,8 @@ def sim_world(args, ps, cfg_over, flags):
         for r in range(W):
             for ph, out_slot, peer, in_slot in routes(r, W):
                 if ph == phase and out_slot in rings[r].t:
-                    rings[peer].t[in_slot].copy_(rings[r].t[out_slot], non_blocking=True)
+                    n = ranks[r].msg_bytes(out_slot) // 4          # (a transfer message: what travels now, a prefix of its buffer)
+                    rings[peer].t[in_slot][:n].copy_(rings[r].t[out_slot][:n], non_blocking=True)
         if phase == "halo":                  # the all-gathers: status records, and -- all-pairs forces -- the snapshot blocks
             for out_slot, in_slot in ((10, 11), (12, 13)):
                 if out_slot not in rings[0].t:

@@ -291,6 +291,8 @@ int ring_step(Ring &R, Hook between)
     }
     for (size_t i = 0; i < R.local.size(); i++) { Slab &s = R.local[i]; if (mark(R, i, 4)) return 1; PS_OK(s.ctx, psamd_slab_apply(s.ctx)); if (mark(R, i, 5)) return 1; }
     if (!one) {
+        // (the transfer messages may have grown: every rank adopts the capacity all of them agreed on two steps ago in the same step)
+        for (Slab &s : R.local) PS_OK(s.ctx, psamd_slab_buffers_get(s.ctx, &s.b));
         if (s_late != R.compute) { if (order(R, R.compute, R.ev_applied, R.transfer)) return 1; }
         if (exchange(R, XFER, s_late)) return 1;
         if (gather(R, G_FAR, s_late)) return 1;                        // (births on, four or more ranks)

@@ -84,12 +84,22 @@ typedef struct psamd_config {
     int32_t  world;
     int32_t  halo_cap_cell;      /* bodies per cell, ON AVERAGE OVER A CELL LAYER, a halo message has room for (any one cell up to its list
                                     capacity: the room is pooled); 0 = MAX_PARTICLES_PER_CELL (never overflows) */
-    int32_t  xfer_cap;           /* particles per step and direction that may change owner; 0 = a quarter of what a cell layer can hold */
+    int32_t  xfer_cap;           /* records a transfer message carries per step and direction (particles changing owner) TO BEGIN WITH;
+                                    0 = a quarter of what a cell layer can hold.  The ranks raise it together when the traffic asks for
+                                    it (see xfer_cap_max) */
     int32_t  cuts[PSAMD_MAX_RANKS + 1];
     /* Not in the reference (BASELINE.json asks for them; nothing there can pin them): */
     double   drag;               /* linear drag k >= 0: the acceleration that is integrated and stored is a - k*v; 0 = the
                                     reference's arithmetic, untouched                                          */
     double   force_sign;         /* +1 gravity (reference), -1 repulsion: multiplies every mass in the force term; 0 reads as +1 */
+    int32_t  xfer_cap_max;       /* how far the transfer messages may grow: their BUFFERS have this room from the start, the bytes that
+                                    travel are xfer_cap's and grow on demand.  Every rank reports in its status record how many records it
+                                    sent in the step before; all ranks see all records and apply the same rule -- twice (the busiest rank's
+                                    count + four times its rise since the step before), from the step after next, never shrinking -- so both
+                                    ends of every message change size in the same step with no negotiation round (psamd_slab_buffers_get().xfer_bytes is the size to post,
+                                    read it after psamd_slab_apply).  0 = what two cell layers and their children can hold (a step's
+                                    worst case: the reference ships whole segments, ps.cpp:431-487); < xfer_cap: no growth. */
+    int32_t  reserved0;
 } psamd_config;
 
 /* Sizes DoInit derives (ps.cpp:2204-2222), in elements. */
@@ -252,8 +262,9 @@ int psamd_snapshot_restore(psamd_ctx *ctx);
  * id) of its boundary layers; the force records of lent layers; and the particles whose new
  * segment belongs to the neighbour (periodic box: the ring closes), keyed so that the
  * neighbour's queue hands out their slots in the reference's order.  Nothing is replicated
- * but the O(cells) tables.  Messages have fixed sizes; the transport (RCCL send/recv on
- * device memory, or anything else) is the caller's: see particlesystem_amd/slab.py. */
+ * but the O(cells) tables.  Message sizes are known to both ends without a word between them (fixed by the plan;
+ * the transfer messages grow by a rule every rank evaluates on the same all-gathered numbers); the transport (RCCL
+ * send/recv on device memory, or anything else) is the caller's: see particlesystem_amd/slab.py. */
 typedef struct psamd_slab_plan {
     int32_t world, rank, grid_dim;
     int32_t cut_lo, cut_hi;          /* compute layers [lo, hi)                                  */
@@ -280,7 +291,8 @@ typedef struct psamd_slab_buffers {
     void   *force_out, *force_in;          /* force records of lent layers: out to rank-1, in from rank+1 */
     int64_t force_out_bytes, force_in_bytes;
     void   *xfer_out[2], *xfer_in[2];      /* particles changing owner (ring: down_rank / up_rank) */
-    int64_t xfer_bytes;                    /* all four the same size                              */
+    int64_t xfer_bytes;                    /* all four the same size: what to post THIS step -- it may grow from step to step, on
+                                              every rank in the same step (config.xfer_cap_max); read it after psamd_slab_apply */
     void   *status_out, *status_in;        /* ALL-GATHERED once per step: status_in = world records of status_bytes each, by rank */
     int64_t status_bytes;
     void   *allg_out, *allg_in;            /* PSAMD_FLAG_ALL_PAIRS only, ALL-GATHERED once per step between slab_build and slab_pairs:
@@ -296,6 +308,7 @@ typedef struct psamd_slab_buffers {
                                               reference's conversion): only births make such particles, so the buffers exist in worlds
                                               of >= 4 ranks with PSAMD_FLAG_EXPLOSIONS; else 0 bytes */
     int64_t far_bytes;
+    int64_t xfer_bytes_max;                /* the room of the xfer_* buffers: xfer_bytes never grows beyond it (config.xfer_cap_max) */
 } psamd_slab_buffers;
 int psamd_slab_buffers_get(psamd_ctx *ctx, psamd_slab_buffers *out);
 

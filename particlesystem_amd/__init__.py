@@ -52,7 +52,8 @@ class Config(C.Structure):
                 ("rank", C.c_int32), ("world", C.c_int32),
                 ("halo_cap_cell", C.c_int32), ("xfer_cap", C.c_int32),
                 ("cuts", C.c_int32 * (MAX_RANKS + 1)),
-                ("drag", C.c_double), ("force_sign", C.c_double)]
+                ("drag", C.c_double), ("force_sign", C.c_double),
+                ("xfer_cap_max", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class Sizes(C.Structure):
@@ -96,7 +97,7 @@ class SlabBuffers(C.Structure):
                 ("status_out", C.c_void_p), ("status_in", C.c_void_p), ("status_bytes", C.c_int64),
                 ("allg_out", C.c_void_p), ("allg_in", C.c_void_p), ("allg_bytes", C.c_int64),
                 ("xfer2_out", C.c_void_p * 2), ("xfer2_in", C.c_void_p * 2), ("xfer2_bytes", C.c_int64),
-                ("far_out", C.c_void_p), ("far_in", C.c_void_p), ("far_bytes", C.c_int64)]
+                ("far_out", C.c_void_p), ("far_in", C.c_void_p), ("far_bytes", C.c_int64), ("xfer_bytes_max", C.c_int64)]
 
 
 # psamd_slab_msg_download / _upload `which`
@@ -409,7 +410,10 @@ class ParticleSystem:
         self._ck(self.lib.psamd_slab_finish(self.h))
 
     def msg_bytes(self, which):
-        """Size of message buffer `which` (psamd_slab_msg_download numbering); 0: no such message."""
+        """Size of message buffer `which` (psamd_slab_msg_download numbering); 0: no such message.  The transfer messages
+        (6-9) may grow from step to step (config.xfer_cap_max): their size is asked for afresh."""
+        if 6 <= which <= 9:
+            return self.slab_buffers().xfer_bytes
         if getattr(self, "_msg_bytes", None) is None:
             b = self.slab_buffers()
             self._msg_bytes = [b.halo_out_bytes[0], b.halo_out_bytes[1], b.halo_in_bytes[0], b.halo_in_bytes[1],

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <ctime>
 #include <new>
+#include <map>
 #include <random>
 #include <set>
 #include <string>
@@ -47,7 +48,8 @@ struct psamd_ctx {
     int *force_out = nullptr, *force_in = nullptr;
     size_t force_out_bytes = 0, force_in_bytes = 0;
     int *xfer_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, *xfer_in[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [2], [3]: two ranks below / above; [4]: the far outbox and the world's far outboxes, all-gathered
-    size_t xfer_bytes = 0, xfer2_bytes = 0, far_bytes = 0;
+    size_t xfer_bytes = 0, xfer2_bytes = 0, far_bytes = 0;      // xfer_bytes: what travels this step (grows with P.xfer_cap); the buffers have room for P.xfer_cap_max
+    std::map<int, int> cap_decisions; // slab: record number -> the transfer capacity all ranks agreed on in that step (adopted two steps on)
     int *status_out = nullptr, *status_in = nullptr;   // status_in: world records, all-gathered
     size_t status_bytes = 0;
     int *allg_out = nullptr, *allg_in = nullptr;       // all-pairs across ranks: own snapshot block, all ranks' blocks (all-gathered)
@@ -256,9 +258,9 @@ int check_device_errors(psamd_ctx *c)   // after a sync: sticky error bits raise
     if (fs.error & ERR_HALO_OVERFLOW) {
         // say what was asked for, so that the caller can size the messages (the error may also have come in with a
         // neighbour's message header: then the numbers below are this rank's own and may all fit)
-        char buf[320];
+        char buf[512];
         std::snprintf(buf, sizeof buf, "a slab message had no room (raise halo_cap_cell / xfer_cap): this step this rank wanted to send %d / %d "
-                      "transfer records down / up (room: xfer_cap = %d each), %d / %d two ranks away (room %d), %d to a far rank (room %d); "
+                      "transfer records down / up (room: %d each now -- it follows the traffic two steps behind, up to xfer_cap_max), %d / %d two ranks away (room %d), %d to a far rank (room %d); "
                       "a halo message holds halo_cap_cell = %d bodies per cell on average over a cell layer",
                       fs.n_out[0], fs.n_out[1], c->P.xfer_cap, fs.n_out[2], fs.n_out[3], c->P.xfer2_cap, fs.n_out[4], c->P.far_cap, c->P.halo_cap_cell);
         return fail(c, PSAMD_ERR_CELL_OVERFLOW, buf);
@@ -340,6 +342,9 @@ int psamd_default_config(psamd_config *cfg)
     return PSAMD_OK;
 }
 
+// bytes of a transfer message that carries up to `cap` records
+static size_t xfer_msg_bytes(int cap) { return ((size_t)MSG_HEADER_WORDS + ((size_t)cap + 1) * (sizeof(XferRec) / sizeof(int))) * sizeof(int); }
+
 static SlabPlan plan_for(const Geometry &g, const psamd_config &cfg)
 {
     const bool given = cfg.world >= 1 && cfg.world <= PSAMD_MAX_RANKS && cfg.cuts[cfg.world] != 0;
@@ -355,6 +360,10 @@ static void fill_slab_params(const Geometry &g, const SlabPlan &pl, const psamd_
     const int layers[4] = {pl.state_hi - pl.state_lo, pl.lentin_lo - pl.below_lo, pl.lentin_hi - pl.lentin_lo, pl.above_hi - pl.above_lo};
     P.halo_cap_cell = (cfg.halo_cap_cell > 0 && cfg.halo_cap_cell < g.max_per_cell) ? cfg.halo_cap_cell : g.max_per_cell;
     P.xfer_cap = pl.world > 1 ? (cfg.xfer_cap > 0 ? cfg.xfer_cap : std::max(4096, GG * g.max_per_cell / 4)) : 0;
+    // how far the transfer messages may grow (their buffers' room): by default a step's worst case -- everything two cell
+    // layers hold, and a child of each (a particle moves one layer a step, two when the rounded sum lands on the far face)
+    P.xfer_cap_max = pl.world > 1 ? std::max(P.xfer_cap, cfg.xfer_cap_max > 0 ? cfg.xfer_cap_max
+                                                         : (int)std::min<int64_t>(4ll * GG * g.max_per_cell, INT32_MAX / 256)) : 0;
     int64_t slots = 0;
     for (int t = 0; t < 4; t++) { P.slot_lo[t] = pl.slot_lo[t]; P.slot_n[t] = pl.slot_hi[t] - pl.slot_lo[t]; slots += P.slot_n[t];
                                   P.rec_lo[t] = pl.rec_lo[t]; P.rec_hi[t] = pl.rec_hi[t]; }
@@ -502,7 +511,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     const size_t C = (size_t)P.slots_total;          // owned slots
     const size_t SC = (size_t)P.sorted_cap + 64;     // sorted-order arrays (+ slack: scalar loads fetch whole groups)
     const size_t LC = (size_t)P.n_local_cells;
-    const size_t xf = (size_t)P.xfer_cap + (size_t)P.xfer2_cap + (size_t)P.far_cap * (size_t)std::max(1, P.world) / 2 + 1;
+    const size_t xf = (size_t)P.xfer_cap_max + (size_t)P.xfer2_cap + (size_t)P.far_cap * (size_t)std::max(1, P.world) / 2 + 1;
     d.ops_cap = (int)std::min<size_t>(3 * C + 2 * xf + 64 + (P.world > 1 ? (size_t)P.world * STATUS_KILL_CAP : 0), (size_t)INT32_MAX / 2);
     d.moves_cap = (int)std::min<size_t>(2 * C + 2 * xf + 64, (size_t)INT32_MAX / 2);
     int *frame = nullptr;
@@ -625,10 +634,11 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
             PS_HIP(c, dev_alloc(c, &c->force_in, c->force_in_bytes / sizeof(int)));
             PS_HIP(c, hipMemsetAsync(c->force_in, 0, c->force_in_bytes, c->stream));
         }
-        c->xfer_bytes = ((size_t)MSG_HEADER_WORDS + xf * (sizeof(XferRec) / sizeof(int))) * sizeof(int);
+        const size_t xfer_alloc = ((size_t)MSG_HEADER_WORDS + xf * (sizeof(XferRec) / sizeof(int))) * sizeof(int);
+        c->xfer_bytes = xfer_msg_bytes(P.xfer_cap);
         c->xfer2_bytes = P.xfer2_cap > 0 ? ((size_t)MSG_HEADER_WORDS + (size_t)P.xfer2_cap * (sizeof(XferRec) / sizeof(int))) * sizeof(int) : 0;
         for (int k = 0; k < 4; k++) {
-            const size_t bytes = k < 2 ? c->xfer_bytes : c->xfer2_bytes;
+            const size_t bytes = k < 2 ? xfer_alloc : c->xfer2_bytes;
             if (bytes == 0) continue;
             PS_HIP(c, dev_alloc(c, &c->xfer_out[k], bytes / sizeof(int)));
             PS_HIP(c, dev_alloc(c, &c->xfer_in[k], bytes / sizeof(int)));
@@ -1336,6 +1346,7 @@ static int consume_scalars(psamd_ctx *c, int upto)
         c->live_bound = std::min<int64_t>(c->P.slots_total, (int64_t)r.live + r.n_moves);   // births and arrivals <= moves
         c->processed_total += r.live;
         c->max_bucket_seen = std::max<int64_t>(c->max_bucket_seen, r.max_bucket);
+        if (c->P.world > 1 && r.xfer_cap_next > c->P.xfer_cap) c->cap_decisions[s] = r.xfer_cap_next;
         if (verdict == PSAMD_OK && (c->P.world > 1 ? r.status_error != 0 : r.error != 0)) verdict = check_device_errors(c);
     }
     if (verdict != PSAMD_OK && c->pending_status == PSAMD_OK) { c->pending_status = verdict; c->pending_err = c->err; }
@@ -1473,6 +1484,16 @@ int psamd_slab_build(psamd_ctx *c)
     if (c->wedged) return refuse_wedged(c);
     begin_step(c);
     if (c->grid_built) c->frame_clean = false;
+    {   // The transfer messages' capacity the ranks agreed on two steps ago (k_status_merge) takes effect now, on every rank
+        // in this same step: the record of step s - 2 has been read by every host that starts step s, whatever its run-ahead.
+        const int s = c->scalars_seq + 1;
+        int cap = c->P.xfer_cap;
+        for (auto it = c->cap_decisions.begin(); it != c->cap_decisions.end() && it->first <= s - 2; it = c->cap_decisions.erase(it)) cap = std::max(cap, it->second);
+        if (cap > c->P.xfer_cap) {
+            c->P.xfer_cap = c->P_int.xfer_cap = c->P_rest.xfer_cap = std::min(cap, c->P.xfer_cap_max);
+            c->xfer_bytes = xfer_msg_bytes(c->P.xfer_cap);
+        }
+    }
     const int rc = run_segment(c, SEG_BUILD, build_key(c), [&]() {
         int r = enq_init_iframe(c);
         if (r == PSAMD_OK) r = enq_build_grid(c);
@@ -1534,7 +1555,7 @@ int psamd_slab_apply(psamd_ctx *c)
     if (!c) return PSAMD_ERR_INVALID_ARG;
     if (c->slab_stage != 2) return fail(c, PSAMD_ERR_STATE, "slab_apply needs slab_pairs (and the force exchange) first");
     const int64_t bound = live_bound_of(c);
-    const int rc = run_segment(c, SEG_APPLY, (uint64_t)bound, [&]() {
+    const int rc = run_segment(c, SEG_APPLY, (uint64_t)bound | ((uint64_t)c->P.xfer_cap << 32), [&]() {
         // the status records of all ranks (all-gathered since slab_build): error bits, cell-overflow kills for the
         // owner of queue record 0, and the chunks' counts over all ranks -- the chunk lists' capacity rule; in
         // the same launch the force records of the lent-out layers (the tail of the snapshot that went up)
@@ -1554,7 +1575,7 @@ int psamd_slab_finish(psamd_ctx *c)
     if (c->slab_stage != 3) return fail(c, PSAMD_ERR_STATE, "slab_finish needs slab_apply (and the transfer exchange) first");
     c->slab_stage = 0;
     const int64_t bound = c->slab_bound;
-    const int rc = run_segment(c, SEG_FINISH, (uint64_t)bound | pick_bucket_cap(c), [&]() { return enq_lifecycle(c, bound); });
+    const int rc = run_segment(c, SEG_FINISH, (uint64_t)bound | ((uint64_t)(c->P.xfer_cap & 0x1fffffff) << 32) | pick_bucket_cap(c), [&]() { return enq_lifecycle(c, bound); });
     if (rc != PSAMD_OK) { resync_scalars(c); return rc; }
     return finish_step(c);
 }
@@ -1599,6 +1620,7 @@ int psamd_slab_buffers_get(psamd_ctx *c, psamd_slab_buffers *o)
     o->force_out = c->force_out; o->force_in = c->force_in;
     o->force_out_bytes = (int64_t)c->force_out_bytes; o->force_in_bytes = (int64_t)c->force_in_bytes;
     o->xfer_bytes = (int64_t)c->xfer_bytes;
+    o->xfer_bytes_max = c->P.world > 1 ? (int64_t)xfer_msg_bytes(c->P.xfer_cap_max) : 0;
     o->status_out = c->status_out; o->status_in = c->status_in; o->status_bytes = (int64_t)c->status_bytes;
     o->allg_out = c->allg_out; o->allg_in = c->allg_in; o->allg_bytes = (int64_t)c->allg_bytes;
     return PSAMD_OK;

@@ -68,7 +68,8 @@ struct DevParams {
     int32_t rec_lo[4], rec_hi[4];    // owned QUEUE_INFO records per segment type
     int32_t rank, world;
     int32_t halo_cap_cell;   // bodies per cell, on average over a cell layer, a halo message has room for (pooled)
-    int32_t xfer_cap;        // relocation records per direction and step
+    int32_t xfer_cap;        // relocation records per direction and step a transfer message carries NOW (grows on demand, all ranks together)
+    int32_t xfer_cap_max;    // ... and at most: the room of its buffers
     int32_t lentout_c0, lentout_c1;  // own local cells computed by the rank above (their force records come back)
     int32_t num_cells_global;
     float drag;              // linear drag coefficient (0: the reference's arithmetic)
@@ -204,6 +205,8 @@ struct FrameScalars {
     int32_t status_error;   // slab mode: OR of the error bits in this step's all-gathered status records (every rank sees the same word)
     int32_t seq;            // host copy only: the number of the step whose scalars these are, written last (the host polls it)
     int32_t max_cell_raw;   // most ids any own cell received this frame, uncapped (gridmax[1] is capped at the list capacity)
+    int32_t xfer_cap_next;  // slab mode: the transfer messages' capacity every rank adopts two steps on (k_status_merge: the same number on every rank)
+    int32_t pad_fs;
     long long cost_total;   // two-pass mode: sum over the force pass's tasks of the bodies each walks (its stencil's population)
 };
 
@@ -213,7 +216,9 @@ struct FrameScalars {
 // that publishes a step's scalars raises `pending`; the next frame's reset kernel -- nothing reads `step`
 // while it runs -- turns that into step + 1.  snapshot_restore rewinds `step` (k_restore).
 struct StepState {
-    int32_t step, pending, seq, pad;
+    int32_t step, pending, seq;
+    int32_t last_departures;   // slab mode: most records this rank sent in one direction in the step before (goes out with the next status record)
+    int32_t peak_prev, pad_st; // slab mode: the busiest rank's count in the status records of the step before (the same number on every rank)
     // The balanced force pass paces its waves against the clock (pairs.hip, WavePace): per pass of a frame (0 / 1), when
     // the pass's planning ended (100 MHz real-time counter), when its last wave ended, and how long the last such pass
     // took -- what this one expects to take.
@@ -271,7 +276,8 @@ struct XferRec {
     float pos[4], vel[4], acc[4];   // relocation: the particle; birth: the parent's position and velocity
 };
 // Status record of a slab, all-gathered once per step (it must have landed before slab_apply): 16 header
-// words ([0] cell-overflow kills, [1] sticky error bits at the end of the build stage, [2] live), the
+// words ([0] cell-overflow kills, [1] sticky error bits at the end of the build stage, [2] live, [3] the most transfer records it
+// sent in one direction in the step before: what the transfer messages' capacity is adapted to), the
 // killed slot ids, then -- per chunk and segment type -- how many of the chunk's particles live in this
 // rank's segments of that type (the chunk lists' capacity rule ranks a chunk's particles in slot
 // order, and a chunk's 27 segments are spread over up to three ranks).

@@ -701,7 +701,7 @@ template <int CAP>
 __global__ __launch_bounds__(REPLAY_THREADS) void k_replay_commit(DevParams P, int nrec, const int *__restrict__ rec_start,
                                                         uint64_t *keys, int *args, uint64_t *keys2, int *args2,
                                                         QueueInfo *qinfo, int *queue, MoveRec *moves,
-                                                        DevCounters *ctr, const StepState *__restrict__ stp,
+                                                        DevCounters *ctr, StepState *stp,
                                                         ParticleArrays A, const float4 *__restrict__ stage,
                                                         int *frame, unsigned frame_ints, FrameScalars *fs, int *status_out, int status_table)
 {
@@ -717,7 +717,11 @@ __global__ __launch_bounds__(REPLAY_THREADS) void k_replay_commit(DevParams P, i
         const unsigned per = (frame_ints + gridDim.x - 1) / gridDim.x, a = min(frame_ints, blockIdx.x * per), b = min(frame_ints, a + per);
         for (unsigned i = a + tid; i < b; i += REPLAY_THREADS) frame[i] = 0;
         if (rec == 0) {
-            if (tid == 0) { const int err = fs->error; *fs = FrameScalars{}; fs->error = err; }
+            if (tid == 0) {
+                // (a slab reports in its NEXT status record how many transfer records it sent this step: what the messages' capacity follows)
+                stp->last_departures = max(fs->n_out[0], fs->n_out[1]);
+                const int err = fs->error; *fs = FrameScalars{}; fs->error = err;
+            }
             if (status_out) {
                 for (int i = tid; i < MSG_HEADER_WORDS; i += REPLAY_THREADS) status_out[i] = 0;
                 for (int i = tid; i < status_table; i += REPLAY_THREADS) status_out[STATUS_CHUNK_OFF + i] = 0;       // the (chunk, type) census

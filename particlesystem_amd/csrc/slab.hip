@@ -71,9 +71,9 @@ __global__ __launch_bounds__(1024) void k_halo_prefix_out(DevParams P, HaloOut2 
 __global__ __launch_bounds__(256) void k_halo_bodies_out(DevParams P, HaloOut2 H, const int *__restrict__ cell_start,
                                                           const SnapSoa snap4,
                                                           const float *__restrict__ snap_age, const int *__restrict__ sorted_id,
-                                                          int *__restrict__ status_out, const FrameScalars *__restrict__ fs)
+                                                          int *__restrict__ status_out, const FrameScalars *__restrict__ fs, const StepState *__restrict__ st)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && status_out) { status_out[1] = fs->error; status_out[2] = fs->live; }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && status_out) { status_out[1] = fs->error; status_out[2] = fs->live; status_out[3] = st->last_departures; }
     int j = blockIdx.x, k = 0;
     if (j >= H.h[0].ncell) { j -= H.h[0].ncell; k = 1; }
     if (k >= H.n) return;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(1024) void k_status_merge(DevParams P, const int *_
                                                         const CellInfo *__restrict__ celltab, const int2 *__restrict__ chunk_segs,
                                                         uint8_t *__restrict__ chunk_skip, FrameScalars *fs,
                                                         int force_j0, const int *__restrict__ force_msg, const int *__restrict__ pack_off,
-                                                        const int *__restrict__ cell_start, const ForceBuf force4)
+                                                        const int *__restrict__ cell_start, const ForceBuf force4, StepState *stp)
 {
     __shared__ int s_before[4];
     // workgroups past the status records and the chunks: the force records of the lent-out layers come home
@@ -378,6 +378,20 @@ __global__ __launch_bounds__(1024) void k_status_merge(DevParams P, const int *_
     const int r = blockIdx.x;
     const int *st = status_all + (size_t)r * P.status_words;
     if (threadIdx.x == 0 && st[1]) { atomicOr(&fs->status_error, st[1]); if (r != P.rank) atomicOr(&fs->error, st[1]); }
+    if (r == 0 && threadIdx.x == 0) {
+        // The transfer messages' capacity follows the traffic: every rank said how many records it sent in one direction in the
+        // step before; all ranks hold all records and apply the same rule, so the number below is the same everywhere and every
+        // host adopts it in the same step (two steps on: psamd_slab_build) -- both ends of every message change size together,
+        // with no negotiation round.  The rule looks three steps ahead (a decision rests on the traffic of the step before and
+        // takes effect two steps on): the busiest rank's count plus four times its rise since the step before, doubled, and
+        // a little on top; the capacity only ever grows, up to the room of the buffers.
+        int peak = 0;
+        for (int q = 0; q < P.world; q++) peak = max(peak, status_all[(size_t)q * P.status_words + 3]);
+        const long long rise = max(0, peak - stp->peak_prev);
+        stp->peak_prev = peak;
+        const long long need = (2ll * ((long long)peak + 4ll * rise) + 64ll + 63ll) & ~63ll;
+        fs->xfer_cap_next = need > (long long)P.xfer_cap ? (int)min((long long)P.xfer_cap_max, need) : P.xfer_cap;
+    }
     if (r == P.rank || !owns_record(P, 0)) return;
     const int n = min(st[0], STATUS_KILL_CAP);
     for (int e = threadIdx.x; e < n; e += 1024) {
@@ -395,7 +409,7 @@ hipError_t launch_status_merge(hipStream_t st, const DevParams &P, const DeviceS
     if (!status_all || P.world <= 1) return hipSuccess;
     const int ncell = force_msg ? std::max(0, P.lentout_c1 - P.lentout_c0) : 0;
     k_status_merge<<<P.world + P.num_chunks + ncell, 1024, 0, st>>>(P, status_all, d.op_keys, d.op_args, d.ops_cap, d.chunk_count, d.cell, d.celltab,
-                                                                    d.chunk_segs, d.chunk_skip, d.fs, force_j0, force_msg, pack_off, d.cell_start, ForceBuf{d.force4, d.force_slot, d.sorted_id});
+                                                                    d.chunk_segs, d.chunk_skip, d.fs, force_j0, force_msg, pack_off, d.cell_start, ForceBuf{d.force4, d.force_slot, d.sorted_id}, d.st);
     return hipGetLastError();
 }
 
@@ -413,7 +427,7 @@ hipError_t launch_pack_halos(hipStream_t st, const DevParams &P, const DeviceSta
         PS_LAUNCH_CHECK();
     }
     const int blocks = std::max(1, H.h[0].ncell + (H.n > 1 ? H.h[1].ncell : 0));
-    k_halo_bodies_out<<<blocks, 256, 0, st>>>(P, H, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_age, d.sorted_id, d.status_out, d.fs);
+    k_halo_bodies_out<<<blocks, 256, 0, st>>>(P, H, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_age, d.sorted_id, d.status_out, d.fs, d.st);
     PS_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -208,8 +208,8 @@ class DeviceRing(_Ring):
         ptrs = {HALO_OUT + 0: (b.halo_out[0], b.halo_out_bytes[0]), HALO_OUT + 1: (b.halo_out[1], b.halo_out_bytes[1]),
                 HALO_IN + 0: (b.halo_in[0], b.halo_in_bytes[0]), HALO_IN + 1: (b.halo_in[1], b.halo_in_bytes[1]),
                 FORCE_OUT: (b.force_out, b.force_out_bytes), FORCE_IN: (b.force_in, b.force_in_bytes),
-                XFER_OUT + 0: (b.xfer_out[0], b.xfer_bytes), XFER_OUT + 1: (b.xfer_out[1], b.xfer_bytes),
-                XFER_IN + 0: (b.xfer_in[0], b.xfer_bytes), XFER_IN + 1: (b.xfer_in[1], b.xfer_bytes),
+                XFER_OUT + 0: (b.xfer_out[0], b.xfer_bytes_max), XFER_OUT + 1: (b.xfer_out[1], b.xfer_bytes_max),
+                XFER_IN + 0: (b.xfer_in[0], b.xfer_bytes_max), XFER_IN + 1: (b.xfer_in[1], b.xfer_bytes_max),
                 STATUS_OUT: (b.status_out, b.status_bytes), STATUS_IN: (b.status_in, b.status_bytes * world),
                 ALLG_OUT: (b.allg_out, b.allg_bytes), ALLG_IN: (b.allg_in, b.allg_bytes * world),
                 XFER2_OUT + 0: (b.xfer2_out[0], b.xfer2_bytes), XFER2_OUT + 1: (b.xfer2_out[1], b.xfer2_bytes),
@@ -226,9 +226,18 @@ class DeviceRing(_Ring):
         stream is NOT held up -- whatever is enqueued next runs beside the transfer -- until
         finish() makes it wait for the arrivals."""
         import torch
-        if phase not in self._phase_ops:
-            self._phase_ops[phase] = self._ops(phase, lambda slot: self.t[slot])
-        ops = self._phase_ops[phase]
+        if phase == "xfer":
+            # the transfer messages grow on demand (every rank in the same step): post what travels now, a prefix of the buffers
+            n = self.s.msg_bytes(XFER_OUT) // 4
+            key = ("xfer", n)
+            if key not in self._phase_ops:
+                self._phase_ops = {k: v for k, v in self._phase_ops.items() if not isinstance(k, tuple)}
+                self._phase_ops[key] = self._ops(phase, lambda slot: self.t[slot][:n] if XFER_OUT <= slot < XFER_IN + 2 else self.t[slot])
+            ops = self._phase_ops[key]
+        else:
+            if phase not in self._phase_ops:
+                self._phase_ops[phase] = self._ops(phase, lambda slot: self.t[slot])
+            ops = self._phase_ops[phase]
         if not ops:
             return []
         with torch.cuda.stream(self.stream):       # RCCL orders against torch's CURRENT stream: make it the context's

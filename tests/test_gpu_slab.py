@@ -211,6 +211,45 @@ def test_slab_context_refuses_the_plain_stage_calls_and_bad_worlds():
         ps.ParticleSystem(ps.default_config(rank=0, world=16))      # 16 layers: one per rank is not enough
 
 
+def test_transfer_messages_grow_with_the_traffic():
+    """A cloud whose density rises towards its tail drifts across the cut between rank 0 and rank 1: the records that change
+    owner per step go from a handful to many hundreds.  The transfer messages start with room for 64 (xfer_cap) and a
+    step would be refused at ~70; instead every rank reports its traffic in its status record, all ranks apply the same
+    rule to the same numbers, and the messages grow on every rank in the same step, two steps ahead of the need -- the run
+    goes on, byte for byte the one-context run, and nobody negotiated anything."""
+    world, n, steps = 4, 30000, 24
+    rng = np.random.default_rng(511)
+    xyz = np.empty((n, 3), np.float32)
+    xyz[:, 0:2] = rng.uniform(-39.9, 39.9, (n, 2))
+    xyz[:, 2] = 20.02 + 18.9 * rng.uniform(0, 1, n) ** (1.0 / 3.0)          # cell layers i3 = 0..3 (rank 0), thin at the cut (z = 20)
+    v = np.zeros((n, 3), np.float32)
+    v[:, 2] = -10.0                                                         # half a cell width per step towards the cut (i3 grows as z falls)
+    over = dict(max_particles_num=1 << 18, collision_radius=0.0)
+    fert = (1e6 + np.arange(n)).astype(np.float32)
+    kw = dict(age=np.float32(3.0), fert_age=fert, vxyz=v, w=np.float32(1e-3))   # (light particles: gravity leaves the drift alone)
+    one = ps.ParticleSystem(ps.default_config(**over))
+    ranks = [ps.ParticleSystem(ps.default_config(rank=r, world=world, xfer_cap=64, **over)) for r in range(world)]
+    for g in [one] + ranks:
+        g.fill_particles(xyz, **kw)
+    plans = [g.slab_plan() for g in ranks]
+    first = ranks[0].msg_bytes(ps.MSG_XFER_OUT)
+    sizes, sent = [], []
+    for k in range(steps):
+        one.step(1)
+        step_local(ranks)
+        sizes.append([g.msg_bytes(ps.MSG_XFER_OUT) for g in ranks])
+        sent.append(int(ranks[0].msg_download(ps.MSG_XFER_OUT + 1, 64)[0]))
+        assert len(set(sizes[-1])) == 1, "the ranks disagree on the transfer messages' size in step %d: %r" % (k + 1, sizes[-1])
+        union = merge_owned([g.download_particles() for g in ranks], plans)
+        assert_same_particles(union, one.download_particles(), "drifting cloud, step %d" % (k + 1))
+    for g in ranks:
+        g.synchronize()                                                     # (no sticky error anywhere)
+    print("records rank 0 sent up per step:", sent, "message bytes:", [s_[0] for s_ in sizes])
+    assert max(sent) > 3 * 64 and sizes[-1][0] > first and sizes[-1][0] <= ranks[0].slab_buffers().xfer_bytes_max
+    for g in [one] + ranks:
+        g.close()
+
+
 def test_slab_message_overflow_is_loud():
     """halo_cap_cell too small for what a boundary LAYER holds (8 per cell on average, the cloud has 15) => a sticky
     error on the ranks involved, not a silent truncation.  (One crowded cell alone is served: the room is pooled over

@@ -1522,131 +1522,6 @@ __device__ __forceinline__ void pairs_task_tile(const DevParams &P, const int *_
     if (valid) force4.put(P, gc, gi, make_float4(ax, ay, az, __int_as_float(flag)));
 }
 
-// ---- two waves to a task (WALK 3) --------------------------------------------------------------------------------
-// A small share has fewer force tasks than would give every SIMD two waves (an eighth of the N = 2^20 cloud: ~1500 tasks for
-// 1024 SIMDs), a lone wave issues at 75-80 % of what a SIMD sustains, and a task cannot be cut between waves that run at
-// the same time: a particle's sum is ONE chain of ordered fp32 additions.  But only the additions are a chain.  Everything
-// before them -- the differences, r.r, (d + eps2)^3, the reciprocal square root, w / d^3: four fifths of the instructions --
-// has no dependence from body to body.  So two waves of one workgroup share a task: both hold the same 64 particles and
-// stage the same tiles (each its own copy: no cross-wave ordering for the tiles), wave h computes the terms of the groups
-// of NQ bodies with (group number & 1) == h into registers, and the running sums travel between them through LDS as a
-// TOKEN: the owner of group G waits for token G (the sums before that group), adds its NQ terms in list order, hands on
-// token G + 1.  While one adds, the other is already computing the terms of the next group: the additions are the only
-// thing that is serialised, and every addition is made in the reference's order by construction -- same bits.
-// Token: ax, ay, az per lane + the number of the group they stand before.  LDS operations of one wave complete in
-// order, so the number written last is seen last; the waiting wave polls it (s_sleep between polls).  The sums sit in
-// a ring of four buffers indexed by the group number: at the seam between two pieces of work the wave that does not
-// finish the first piece is already a group or two into the next one -- it writes token G + 2 while its partner has yet
-// to read token G -- and can get no further than that before it needs a token from the partner itself.  For the same
-// reason the number only ever grows and a waiter asks for "at least G".
-struct PairToken { float a[4][3][64]; int seq; int pad[3]; };
-
-// One piece (stencil steps [k0, k1)) of task (cell c, particles first .. first + count of its active list) by the wave
-// `half` (0 / 1) of a pair.  gseq: the pair's running group number (the same in both waves; advanced by the groups of
-// this piece).  Returns nothing; the wave that holds the sums at the end finishes the piece (hand-off or force record).
-template <int MODE, int NQ, bool ONE_T>
-__device__ __forceinline__ void pairs_task_tile2(const DevParams &P, const int *__restrict__ cell_start,
-                                                 const SnapSoa snap4, const ForceBuf force4,
-                                                 int c, int first, int count, float *tile, const int *__restrict__ active_list,
-                                                 int k0, int k1, int *ready, FrameScalars *fs,
-                                                 const int half, PairToken *tok, int &gseq)
-{
-    static_assert(MODE == 1, "the paired walk is built for the exact lean arithmetic");
-    const int lane = threadIdx.x & 63;
-    const bool valid = lane < count;
-    const int gi = active_list[cell_start[c] + first + (valid ? lane : 0)];
-    const float4 me = snap4[gi];
-    int tab_nb = 0, tab_cnt = 0;
-    if (lane < STENCIL) {
-        int i1, i2, i3;
-        cell_coords(P, c, i1, i2, i3);
-        const int nc = local_cell(P, i3 + c_stencil[lane][2], i1 + c_stencil[lane][1], i2 + c_stencil[lane][0]);
-        if (nc >= 0) { tab_nb = cell_start[nc]; tab_cnt = min(cell_start[nc + 1] - tab_nb, P.max_per_cell); }
-    }
-    float ax = 0.f, ay = 0.f, az = 0.f;
-    int flag = 0;
-    const PairCtx ctx = {me.x, me.y, me.z, 0.f, 0, gi, false};
-    const int g_start = gseq;
-    // the sums this piece starts from belong to the wave that owns the piece's first group
-    if (k0 > 0 && (g_start & 1) == half && !handoff_consume(force4 + gi, ax, ay, az, flag, valid, ready, k0)) {
-        if (lane == 0) atomicOr(&fs->error, ERR_HANDOFF_TIMEOUT);
-    }
-    const float far = 1.0e6f;                                       // padding body, mass 0
-    const float *tx = tile, *ty = tx + 64, *tz = tx + 128, *tw = tx + 192;
-    int nb = 0, cnt = 0;
-    auto step_range = [&](int k) -> int {
-        nb = __builtin_amdgcn_readlane(tab_nb, k);
-        cnt = __builtin_amdgcn_readlane(tab_cnt, k);
-        return cnt;
-    };
-    float4 pre;
-    auto fetch = [&](int t0) {
-        pre = make_float4(far, far, far, 0.f);
-        if (lane < cnt - t0) pre = snap4[nb + t0 + lane];
-    };
-    volatile int *seqp = &tok->seq;
-    int k = k0, t0 = 0, longest = 0;
-    while (k < k1 && (longest = step_range(k)) == 0) k++;
-    bool have = k < k1;
-    if (have) fetch(0);
-    while (have) {
-        const int n = (min(64, longest - t0) + NQ - 1) & ~(NQ - 1);
-        PS_WAVE_SYNC();                               // previous tile fully consumed
-        { float *t = tile + lane; t[0] = pre.x; t[64] = pre.y; t[128] = pre.z; t[192] = pre.w; }
-        PS_WAVE_SYNC();
-        t0 += 64;
-        if (t0 >= longest) {
-            t0 = 0; longest = 0; k++;
-            while (k < k1 && (longest = step_range(k)) == 0) k++;
-        }
-        have = k < k1;
-        if (have) fetch(t0);
-        for (int jj = 0; jj < n; jj += NQ) {
-            const int G = gseq++;
-            if ((G & 1) != half) continue;                             // the partner's group
-            v2f qx[NQ / 2], qy[NQ / 2], qz[NQ / 2], qw[NQ / 2];
-#pragma unroll
-            for (int i = 0; i < NQ / 2; i += 2) {
-                const float4 vx = *reinterpret_cast<const float4 *>(tx + jj + 2 * i);
-                const float4 vy = *reinterpret_cast<const float4 *>(ty + jj + 2 * i);
-                const float4 vz = *reinterpret_cast<const float4 *>(tz + jj + 2 * i);
-                const float4 vw = *reinterpret_cast<const float4 *>(tw + jj + 2 * i);
-                qx[i] = v2f{vx.x, vx.y}; qx[i + 1] = v2f{vx.z, vx.w};
-                qy[i] = v2f{vy.x, vy.y}; qy[i + 1] = v2f{vy.z, vy.w};
-                qz[i] = v2f{vz.x, vz.y}; qz[i + 1] = v2f{vz.z, vz.w};
-                qw[i] = v2f{vw.x, vw.y}; qw[i + 1] = v2f{vw.z, vw.w};
-            }
-            // the terms: no dependence on the sums
-            PairRows<NQ> r;
-            pairs_dist<NQ, false>(ctx, qx, qy, qz, 0.f, r);
-            v2f sc[NQ / 2];
-            pairs_scale_exact<NQ, ONE_T>(P, ctx, r, qw, 0, nullptr, nullptr, sc, flag);
-            // the token: the sums before group G (the piece's first group starts from what this wave holds)
-            if (G != g_start) {
-                int spins = 0;
-                while (__builtin_amdgcn_readfirstlane(*seqp) - G < 0) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1 << 24)) { if (lane == 0) atomicOr(&fs->error, ERR_HANDOFF_TIMEOUT); break; }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                ax = tok->a[G & 3][0][lane]; ay = tok->a[G & 3][1][lane]; az = tok->a[G & 3][2][lane];
-            }
-            pairs_add<NQ>(r, sc, ax, ay, az);                           // the ordered additions
-            tok->a[(G + 1) & 3][0][lane] = ax; tok->a[(G + 1) & 3][1][lane] = ay; tok->a[(G + 1) & 3][2][lane] = az;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            // (a maximum, not a store: the owner of a piece's LAST group hands on a token nobody waits for, and its partner --
-            // done with the piece earlier -- may already have handed on the first token of the next piece: the number must not go back)
-            if (lane == 0) atomicMax(&tok->seq, G + 1);
-        }
-    }
-    // who holds the piece's final sums: the owner of its last group (it handed them on, and kept them), or -- a piece
-    // without bodies -- the wave that started with them
-    const int holder = gseq > g_start ? ((gseq - 1) & 1) : (g_start & 1);
-    if (holder != half) return;
-    if (k1 < STENCIL) { handoff_publish(force4 + gi, ax, ay, az, flag, valid, ready, k1); return; }
-    if (valid) force4.put(P, c, gi, make_float4(ax, ay, az, __int_as_float(flag)));
-}
-
 // The force pass, balanced: `nw` waves (all resident), wave slot s walks the (task, stencil step)
 // units from wave_pos[s] up to wave_pos[s + 1] -- the same number of bodies for every wave
 // (k_split_tasks).  Most of a wave's share is whole tasks; the task its share ends in is started
@@ -1676,7 +1551,7 @@ __device__ __forceinline__ void merged_pack_task(const DevParams &P, const int *
 // needed a head start to get that: forked at the same moment as the balanced pass they ended with it,
 // and the stage took 0.1 ms longer.)
 template <int MODE, int NQ, int WALK>
-__global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : (WALK == 1 || WALK == 3) ? 2 : 4) void k_pairs_balanced(DevParams P, const int *__restrict__ cell_start,
+__global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : WALK == 1 ? 2 : 4) void k_pairs_balanced(DevParams P, const int *__restrict__ cell_start,
                                                         const SnapSoa snap4,
                                                         const float *__restrict__ snap_soa,
                                                         const float *__restrict__ snap_age,
@@ -1717,15 +1592,7 @@ __global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : (WALK == 1 
         }
         return;
     }
-    // WALK 3: a wave slot is a PAIR of waves (two to a task, pairs_task_tile2): two slots per workgroup
-    __shared__ PairToken tokens[WALK == 3 ? 2 : 1];
-    const int slot = WALK == 3 ? xcd_contiguous((int)blockIdx.x - nmb, (int)gridDim.x - nmb) * 2 + (wave >> 1)
-                               : xcd_contiguous((int)blockIdx.x - nmb, (int)gridDim.x - nmb) * 4 + wave;
-    if (WALK == 3) {                                         // (LDS is not cleared between workgroups: the tokens' numbers start below every group's)
-        if ((threadIdx.x & 127) == 0) tokens[wave >> 1].seq = -1;
-        __syncthreads();                                     // the kernel's one barrier, before any wave can leave
-    }
-    int gseq = 0;                                            // WALK 3: the pair's running group number, the same in both waves
+    const int slot = xcd_contiguous((int)blockIdx.x - nmb, (int)gridDim.x - nmb) * 4 + wave;
     const long long pos_b = wave_pos[slot], pos_e = wave_pos[slot + 1];
     if (pos_e <= pos_b) return;                              // (positions order like units: task-major, cost inside the task)
     const int ub = resolve_unit(P, pos_b, cell_start, task_list), ue = resolve_unit(P, pos_e, cell_start, task_list);
@@ -1757,13 +1624,7 @@ __global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : (WALK == 1 
         else if (i - has_head < nwhole) t = first_whole + (i - has_head);
         else { t = tb; k0 = lb; }                                         // the tail of the first task last: its head was published long ago
         const int nord = fs->n_tasks2;
-        if (WALK == 3) {
-            if (MODE == 1) {
-                const int task = task_list[t], c = task / P.slices, slice = task - c * P.slices;
-                pairs_task_tile2<1, NQ, false>(P, cell_start, snap4, force4, c, slice * 64, min(64, active_count[c] - slice * 64), tiles[wave], active_list,
-                                               k0, k1, task_ready + t, fs, wave & 1, &tokens[wave >> 1], gseq);
-            }
-        } else if (WALK == 1 || (WALK == 2 && t >= nord)) {
+        if (WALK == 1 || (WALK == 2 && t >= nord)) {
             // task t: an ordinary (cell, slice) task, or -- past them -- merged pack t - n_tasks2
             TileGroups G;
             if (t < nord) {
@@ -1982,7 +1843,7 @@ hipError_t launch_selftest_math(hipStream_t st, uint32_t lo_bits, uint32_t hi_bi
 // How one pass of the pair stage is launched, from the hint of its task count: everything that shapes the
 // launches and is not read from device memory by the kernels themselves (what a captured graph is keyed by).
 struct PairShape {
-    bool two, merge, balanced, tile, packs_in_list, paired;
+    bool two, merge, balanced, tile, packs_in_list;
     int nw;                  // wave slots of the balanced force pass
     int nmb;                 // workgroups of the same launch, ahead of them, that serve the packs of partly filled slices (WALK 0)
 };
@@ -2030,9 +1891,6 @@ static PairShape pair_shape(const DevParams &P, bool lean, int64_t hint)
     s.packs_in_list = s.balanced && !merge_off && (s.tile ? tile_packs : (s.merge && unified_packs));
     if (s.packs_in_list) { s.merge = false; s.nw = std::min(s.nw, 4096); }      // (98 VGPRs with the tile walk in: 4 resident waves per SIMD)
     if (s.tile) s.merge = false;                  // no separate merged kernel beside a tile-walk pass
-    // two waves to a task (WALK 3): where the tile walk would leave a SIMD with a lone wave (fewer than two tasks per SIMD)
-    static const int paired_env = std::getenv("PSAMD_PAIRED") ? std::atoi(std::getenv("PSAMD_PAIRED")) : -1;      // (A/B runs: 0 / 1; default: by size)
-    s.paired = s.tile && !s.packs_in_list && lean && !(P.flags & PSAMD_FLAG_FAST_MATH) && (paired_env >= 0 ? paired_env != 0 : false);
     // The packs' workgroups are the first of the same launch and hold residency slots for about half of it: with
     // a wave slot for every resident wave besides, the workgroups dispatched last could only start when a pack ended
     // (wave trace, round 4: a quarter of the balanced waves started 0.6-0.9 ms into a 2.3-ms launch).  So the balanced
@@ -2062,7 +1920,7 @@ static PairShape pair_shape(const DevParams &P, bool lean, int64_t hint)
 uint64_t launch_pairs_shape(const DevParams &P, int64_t tasks_hint)
 {
     const PairShape s = pair_shape(P, P.lean_math != 0, tasks_hint);
-    return (uint64_t)(s.nw / 32) | (s.paired ? 1ull << 23 : 0) | (s.merge ? 1ull << 10 : 0) | (s.tile ? 1ull << 11 : 0) | (s.packs_in_list ? 1ull << 12 : 0) | (s.balanced ? 1ull << 13 : 0) | ((uint64_t)(s.nmb / 8) << 14);
+    return (uint64_t)(s.nw / 32) | (s.merge ? 1ull << 10 : 0) | (s.tile ? 1ull << 11 : 0) | (s.packs_in_list ? 1ull << 12 : 0) | (s.balanced ? 1ull << 13 : 0) | ((uint64_t)(s.nmb / 8) << 14);
 }
 
 template <int MODE, int NQ>
@@ -2106,11 +1964,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
         // (The next group's distances between a group's scale factors and its additions, in one basic block: 9 % SLOWER.)
         static const int tile_nq = std::getenv("PSAMD_TILE_NQ") ? std::atoi(std::getenv("PSAMD_TILE_NQ")) : 16;      // (A/B runs)
         // (The same in the scalar walk where a SIMD holds four waves -- N = 2^22 on eight ranks -- gave 1 %: not kept.)
-        if (shape.paired && MODE == 1) {
-            // a slot is a pair of waves: two slots per workgroup
-            k_pairs_balanced<1, 16, 3><<<nw / 2, 256, 0, st>>>(P, d.cell_start, SnapSoa{d.snap_soa, (size_t)P.sorted_cap}, d.snap_soa, d.snap_age, d.sorted_id, task_list,
-                                                               fbuf, d.fs, d.trace, active_list, active_count, d.wave_pos, task_ready, d.merged_tasks, 0, d.st, pass, paced);
-        } else if (tile && NQ == 8 && tile_nq == 16) PS_BALANCED_Q(1, 16);
+        if (tile && NQ == 8 && tile_nq == 16) PS_BALANCED_Q(1, 16);
         else if (tile) PS_BALANCED(1); else if (packs_in_list) PS_BALANCED(2); else PS_BALANCED(0);
 #undef PS_BALANCED
 #undef PS_BALANCED_Q

@@ -19,7 +19,7 @@
 // launch costs ~10 us on the GPU's timeline, the plain launches of a host that runs ahead cost nothing:
 // profiles/r4_ab_graphs.txt; off by default) --, every RCCL call on the TRANSFER stream; events order the two: the halo (and the all-pairs snapshot all-gather)
 // waits for slab_build and travels while the compute stream runs the interior pair pass (--overlap-interior)
-// or simply goes ahead; the all-gather of the status records travels beside the whole pair pass; force and
+// or simply goes ahead; the all-gather of the status records lands before the first pair-stage call; force and
 // transfer messages fork off after slab_pairs / slab_apply and are joined before the stage that reads them.
 //
 // Message routes (particlesystem_amd/slab.py says the same in Python): after slab_build the
@@ -258,36 +258,36 @@ int ring_step(Ring &R, Hook between)
     // Which stream a message travels on.  A dependency that crosses streams costs the GPU's timeline ~15 us each way here
     // (measured, round 5: with every phase on the transfer stream a rank with NO messages at all spent 29 us per phase
     // between two stage kernels -- 88 us of a 720-us rank-step at eight ranks), and pays only where there is compute to
-    // travel beside: the all-gather of the status records runs beside the whole pair pass and is joined long after it has
-    // landed (an event that has fired costs next to nothing), the halo runs beside the interior pass when that is asked
-    // for.  Force and transfer messages have nothing to travel beside -- the next stage needs them -- and go on the compute
-    // stream: an RCCL kernel between two stage kernels, no event.  The default (--side-stream 0) puts EVERYTHING there:
-    // the status gather is a 16-KB all-gather, ~15 us in front of the pair pass, less than one cross-stream join; 1 is for
-    // runs that overlap the halo with the interior pass (--overlap-interior), 2 is round 4's form, kept for comparison.
+    // travel beside: the halo beside the interior pass, when that is asked for.  The status records must be in before the
+    // FIRST pair-stage call (its chunk census decides which particles the stage leaves alone), force and transfer messages
+    // before the stage behind them: nothing to travel beside, they go on the compute stream -- an RCCL kernel between two
+    // stage kernels, no event.  The default (--side-stream 0) puts EVERYTHING there; 1 is for runs that overlap the halo
+    // with the interior pass (--overlap-interior), 2 is round 4's form (every message on the transfer stream), kept for
+    // comparison.
     const bool one = R.world == 1;
     hipStream_t s_halo = (R.side == 2 || (R.side == 1 && R.overlap_interior)) ? R.transfer : R.compute;
-    hipStream_t s_status = R.side >= 1 ? R.transfer : R.compute;
     hipStream_t s_late = R.side == 2 ? R.transfer : R.compute;      // force, transfer, far outboxes
     for (size_t i = 0; i < R.local.size(); i++) { Slab &s = R.local[i]; if (mark(R, i, 0)) return 1; PS_OK(s.ctx, psamd_slab_build(s.ctx)); if (mark(R, i, 1)) return 1; }
     if (between(0)) return 1;
     if (!one) {
-        if (s_halo != R.compute || s_status != R.compute) if (order(R, R.compute, R.ev_built, R.transfer)) return 1;
+        if (s_halo != R.compute) if (order(R, R.compute, R.ev_built, R.transfer)) return 1;
+        if (gather(R, G_STATUS, s_halo)) return 1;                     // first: a 16-KB all-gather, and the interior pass waits for nothing else
+        if (s_halo != R.compute) HIP_OK(hipEventRecord(R.ev_force, R.transfer));
         if (exchange(R, HALO, s_halo)) return 1;
         if (gather(R, G_SNAPSHOT, s_halo)) return 1;                   // all-pairs forces only
         if (s_halo != R.compute) HIP_OK(hipEventRecord(R.ev_halo, R.transfer));
-        if (gather(R, G_STATUS, s_status)) return 1;                   // travels beside the pair pass; slab_apply needs it
-        if (s_status != R.compute) HIP_OK(hipEventRecord(R.ev_force, R.transfer));
     }
-    if (R.overlap_interior)
+    if (R.overlap_interior) {
+        if (!one && s_halo != R.compute) HIP_OK(hipStreamWaitEvent(R.compute, R.ev_force, 0));
         for (Slab &s : R.local) PS_OK(s.ctx, psamd_slab_pairs_interior(s.ctx));      // cells whose stencil lies in the own layers: no halo needed
+    }
     if (!one && s_halo != R.compute) HIP_OK(hipStreamWaitEvent(R.compute, R.ev_halo, 0));
     for (size_t i = 0; i < R.local.size(); i++) { Slab &s = R.local[i]; if (mark(R, i, 2)) return 1; PS_OK(s.ctx, psamd_slab_pairs(s.ctx)); if (mark(R, i, 3)) return 1; }
     if (between(1)) return 1;
     if (!one) {
         if (s_late != R.compute) { if (order(R, R.compute, R.ev_paired, R.transfer)) return 1; }
         if (exchange(R, FORCE, s_late)) return 1;
-        if (s_late != R.compute) { if (order(R, R.transfer, R.ev_force, R.compute)) return 1; }      // (behind the status gather on the transfer stream: that has landed too)
-        else if (s_status != R.compute) HIP_OK(hipStreamWaitEvent(R.compute, R.ev_force, 0));       // the status gather: recorded before the pair pass began
+        if (s_late != R.compute) { if (order(R, R.transfer, R.ev_force, R.compute)) return 1; }
     }
     for (size_t i = 0; i < R.local.size(); i++) { Slab &s = R.local[i]; if (mark(R, i, 4)) return 1; PS_OK(s.ctx, psamd_slab_apply(s.ctx)); if (mark(R, i, 5)) return 1; }
     if (!one) {
@@ -310,9 +310,11 @@ struct ClockWatch {
     std::vector<int> samples;
     std::atomic<bool> stop{false};
     std::thread th;
-    explicit ClockWatch(int device)
+    int period_ms = 10;
+    explicit ClockWatch(int device, int period = 10) : period_ms(period)
     {
         char bus[64] = {0};
+        if (period_ms <= 0) return;
         if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) == hipSuccess) {
             for (char *c = bus; *c; c++) *c = (char)std::tolower((unsigned char)*c);
             path = std::string("/sys/bus/pci/devices/") + bus + "/pp_dpm_sclk";
@@ -335,7 +337,7 @@ struct ClockWatch {
                     for (size_t i = c == std::string::npos ? 0 : c + 1; i < line.size(); i++) if (std::isdigit((unsigned char)line[i])) v = v * 10 + (line[i] - '0');
                     if (v) samples.push_back(v);
                 }
-                std::this_thread::sleep_for(std::chrono::milliseconds(10));
+                std::this_thread::sleep_for(std::chrono::milliseconds(period_ms));
             }
         });
     }
@@ -387,7 +389,7 @@ int main(int argc, char **argv)
     bool loopback = false, id_only = false, all_pairs = false, births = false, graphs = false, bench = false, evolve = false;
     bool overlap_interior = false, fast_math = false, launch_check = false, break_sizes = false;
     int side_stream = 0;
-    int steps = 200, warmup = 5, chunk_factor = 4, chunk_dim = 4, halo_cap_cell = 0, xfer_cap = 0, timing_period = 8, wait_policy = -1, sustained_steps = 0;
+    int steps = 200, warmup = 5, chunk_factor = 4, chunk_dim = 4, halo_cap_cell = 0, xfer_cap = 0, timing_period = 8, wait_policy = -1, sustained_steps = 0, clock_ms = 10;
     double settle_seconds = 0.5;
     int64_t max_particles = 0;
     uint64_t job = 0;
@@ -420,6 +422,7 @@ int main(int argc, char **argv)
         else if (a == "--warmup") warmup = std::atoi(next());
         else if (a == "--settle-seconds") settle_seconds = std::atof(next());
         else if (a == "--timing-period") timing_period = std::max(1, std::atoi(next()));
+        else if (a == "--clock-period-ms") clock_ms = std::atoi(next());      // how often the shader clock is sampled while a timed region runs (0: not at all)
         else if (a == "--sustained-steps") sustained_steps = std::max(0, std::atoi(next()));
         else if (a == "--chunk-factor") chunk_factor = std::atoi(next());
         else if (a == "--chunk-dim") chunk_dim = std::atoi(next());
@@ -640,7 +643,7 @@ int main(int argc, char **argv)
         psamd_counters cn0{}, cn1{};
         int64_t processed0 = 0;
         for (Slab &s : R.local) { PS_OK(s.ctx, psamd_get_counters(s.ctx, &cn0)); processed0 += cn0.particles_processed; }
-        ClockWatch clock(device), clock2(device);
+        ClockWatch clock(device, clock_ms), clock2(device, clock_ms);
         if (barrier()) return bail();
         clock.start();
         const auto t0 = std::chrono::steady_clock::now();

@@ -212,10 +212,13 @@ int psamd_get_gridmax(psamd_ctx *ctx, int32_t out2[2]);
 int psamd_init_iframe(psamd_ctx *ctx);  /* task 3, ps.cpp:1574-1606 / psCUDA.cu:104-150 */
 int psamd_build_grid(psamd_ctx *ctx);   /* task 8, ps.cpp:1468-1537 / psCUDA.cu:442-499 */
 int psamd_calc_forces(psamd_ctx *ctx);  /* task 6, ps.cpp:1120-1383 / psCUDA.cu:152-423 */
-/* calc_forces in its two halves: _pairs fills the sorted-order force array (collision
- * flag + acceleration of every particle, ps.cpp:1182-1263), _apply does everything after the
- * two neighbour loops (kill / survive / integrate / explosion / relocation, ps.cpp:1210-1374).
- * psamd_calc_forces == _pairs then _apply. */
+/* calc_forces in its two halves: _pairs computes every particle's collision flag and acceleration
+ * (ps.cpp:1182-1263) and leaves the acceleration where the particle keeps it -- T_DATA's ax, ay, az, as
+ * the reference's thread does at ps.cpp:1300-1302 -- and the flag beside it (psamd_download_force4 reads
+ * both back in the cell-sorted order); _apply does everything after the two neighbour loops (kill /
+ * survive / integrate / explosion / relocation, ps.cpp:1210-1374).  psamd_calc_forces == _pairs then
+ * _apply; between the two a download of the particles shows the new accelerations beside the old
+ * positions and velocities. */
 int psamd_calc_forces_pairs(psamd_ctx *ctx);
 int psamd_calc_forces_apply(psamd_ctx *ctx);
 /* nsteps x {init_iframe, build_grid, calc_forces}, enqueued on the context's stream.  NOTHING in a step waits
@@ -312,10 +315,11 @@ typedef struct psamd_slab_buffers {
 } psamd_slab_buffers;
 int psamd_slab_buffers_get(psamd_ctx *ctx, psamd_slab_buffers *out);
 
-/* One step = build, [exchange halo_out -> neighbours' halo_in; start the all-gather of
- * status_out into every rank's status_in; with PSAMD_FLAG_ALL_PAIRS the all-gather of allg_out into
- * allg_in, which must have landed], pairs, [force_out -> rank-1's force_in; the status gather must
- * have landed], apply, [xfer_out -> neighbours' xfer_in; where they exist xfer2_* likewise and the all-gather of far_out into far_in], finish.  The status record carries a rank's
+/* One step = build, [all-gather status_out into every rank's status_in -- it must have landed before the
+ * FIRST pair-stage call, pairs_interior where that is used: the stage writes the particles' new accelerations
+ * into their records and has to know whom the chunk lists' capacity rule takes out of the step;
+ * exchange halo_out -> neighbours' halo_in; with PSAMD_FLAG_ALL_PAIRS the all-gather of allg_out into
+ * allg_in, which must have landed], pairs, [force_out -> rank-1's force_in], apply, [xfer_out -> neighbours' xfer_in; where they exist xfer2_* likewise and the all-gather of far_out into far_in], finish.  The status record carries a rank's
  * sticky error bits, the slots the cell-overflow rule killed, which the reference frees into queue
  * record 0 wherever they were (ps.cpp:1523-1526), and the rank's part of every chunk's particle count
  * per segment type, from which all ranks reproduce the chunk lists' capacity rule (ps.cpp:1502-1508)
@@ -327,7 +331,7 @@ int psamd_slab_buffers_get(psamd_ctx *ctx, psamd_slab_buffers *out);
  * the four calls are psamd_step(1) cut in four and no message exists. */
 int psamd_slab_build(psamd_ctx *ctx);   /* init_iframe + build_grid of the own layers; packs halo_out   */
 int psamd_slab_pairs_interior(psamd_ctx *ctx);  /* optional, while the halo travels: the pair stage of the cells whose
-                                                    stencil lies in the rank's own layers (needs no message)          */
+                                                    stencil lies in the rank's own layers (needs the status records only) */
 int psamd_slab_pairs(psamd_ctx *ctx);   /* unpacks halo_in; collision flags + forces (of the remaining cells); packs force_out */
 int psamd_slab_apply(psamd_ctx *ctx);   /* unpacks force_in; integrate ... (calc_forces' tail); closes xfer_out */
 int psamd_slab_finish(psamd_ctx *ctx);  /* merges xfer_in; queue replay and relocation                  */

@@ -6,8 +6,8 @@ namespace psamd {
 // ------------------------------------------------------------------ apply
 // Death, survival, integration, wrap and re-hash for every particle of the frame
 // (ps.cpp:1182-1242, 1261-1302), one thread per owned SLOT so that the particle arrays stream
-// through coalesced (live slots are dense at the head of every segment) -- the force record too: the pair stage
-// leaves it by slot (ForceBuf).  Lifecycle side
+// through coalesced (live slots are dense at the head of every segment) -- the step's force too: the pair stage
+// left it where the particle keeps its acceleration (acc4.xyz; the collision flag in a byte beside it: ForceBuf).  Lifecycle side
 // effects that depend on the reference's serial order (free-slot queues) are emitted
 // as (key, arg) queue operations and MoveRec records and replayed afterwards.  A particle
 // (or a child) whose new segment belongs to a neighbour rank leaves through the outbox:
@@ -24,7 +24,7 @@ struct ApplyEmit {
 // the workgroup count is what bounds it; one slot per thread in 1024-thread workgroups stays.
 template <int ITEMS>
 __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, const StepState *__restrict__ stp,
-                                                const float4 *__restrict__ force_slot,
+                                                const uint8_t *__restrict__ flag_slot,
                                                 float4 *pos4, float4 *vel4, float4 *acc4,
                                                 int *cell_arr, uint8_t *pflags,
                                                 const CellInfo *__restrict__ celltab,
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, const 
     float4 p = f, v = f;
     float fert = 0.f;
     uint8_t pf0 = 0;
-    if (active) { p = pos4[si]; v = vel4[si]; fert = acc4[si].w; f = force_slot[si]; pf0 = pflags[si]; flag = __float_as_int(f.w); }
+    if (active) { p = pos4[si]; v = vel4[si]; f = acc4[si]; pf0 = pflags[si]; flag = (int)flag_slot[si]; fert = f.w; }
     const CellInfo old_ci = active ? celltab[old_cell] : CellInfo{0, 1, 0, 0};
 
     const bool killed = active && flag == 2, survived = active && flag == 1, moved = active && flag == 0;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(1024) void k_apply(DevParams P, SegLayout S, const 
         }
         pos4[si] = make_float4(rx, ry, rz, p.w);
         vel4[si] = make_float4(vx, vy, vz, age);
-        acc4[si] = make_float4(axv, ayv, azv, fert);
+        if (P.drag > 0.f) acc4[si] = make_float4(axv, ayv, azv, fert);      // (else the record holds it already: the pair stage put it there)
         cell_arr[si] = new_cell;
         pflags[si] = pf;
         // segment change => the particle must move to a slot of the new segment
@@ -291,7 +291,7 @@ hipError_t launch_apply(hipStream_t st, const DevParams &P, const SegLayout &S, 
 {
     if (P.slots_total <= 0) return hipSuccess;
     // slots per thread: one (PSAMD_APPLY_ITEMS: the measurement quoted at the kernel)
-#define PS_APPLY(I) k_apply<I><<<(P.slots_total + I * 1024 - 1) / (I * 1024), 1024, 0, st>>>(P, S, d.st, d.force_slot, d.pos4, \
+#define PS_APPLY(I) k_apply<I><<<(P.slots_total + I * 1024 - 1) / (I * 1024), 1024, 0, st>>>(P, S, d.st, d.flag_slot, d.pos4, \
         d.vel4, d.acc4, d.cell, d.pflags, d.celltab, d.op_keys, d.op_args, d.ops_cap, \
         d.moves, d.moves_cap, Outboxes{{d.xfer_out[0], d.xfer_out[1], d.xfer_out[2], d.xfer_out[3], d.xfer_out[4]}}, d.chunk_count, d.chunk_skip, d.fs, d.ctr)
     static const int items_env = std::getenv("PSAMD_APPLY_ITEMS") ? std::atoi(std::getenv("PSAMD_APPLY_ITEMS")) : 0;

@@ -552,7 +552,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, dev_alloc(c, &d.task_start, LC + 1));
     PS_HIP(c, dev_alloc(c, &d.task_list, LC * P.slices));
     PS_HIP(c, dev_alloc(c, &d.sorted_id, SC));
-    PS_HIP(c, dev_alloc(c, &d.force_slot, C));
+    PS_HIP(c, dev_alloc(c, &d.flag_slot, C));
     PS_HIP(c, dev_alloc(c, &d.snap_soa, 4 * (size_t)P.sorted_cap + 64));
     PS_HIP(c, dev_alloc(c, &d.snap_age, SC));
     PS_HIP(c, dev_alloc(c, &d.force4, SC));
@@ -725,7 +725,7 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     PS_HIP(c, hipMemsetAsync(d.acc4, 0, std::max<size_t>(C, 1) * sizeof(float4), c->stream));
     PS_HIP(c, hipMemsetAsync(d.pflags, 0, std::max<size_t>(C, 1), c->stream));
     PS_HIP(c, hipMemsetAsync(d.force4, 0, SC * sizeof(float4), c->stream));
-    PS_HIP(c, hipMemsetAsync(d.force_slot, 0, std::max<size_t>(C, 1) * sizeof(float4), c->stream));
+    PS_HIP(c, hipMemsetAsync(d.flag_slot, 0, std::max<size_t>(C, 1), c->stream));
     PS_HIP(c, hipMemsetAsync(d.fs, 0, sizeof(FrameScalars), c->stream));
     PS_HIP(c, hipMemsetAsync(d.ctr, 0, sizeof(DevCounters) * COUNTER_COPIES, c->stream));
     PS_HIP(c, hipMemsetAsync(frame, 0, frame_ints * sizeof(int), c->stream));
@@ -1516,7 +1516,11 @@ int psamd_slab_pairs_interior(psamd_ctx *c)
     if (c->slab_stage != 1) return fail(c, PSAMD_ERR_STATE, "slab_pairs_interior belongs between slab_build and slab_pairs");
     if (!c->have_interior || c->interior_done) return PSAMD_OK;
     const int64_t hint = pairs_hint(c, c->P_int);
-    const int rc = run_segment(c, SEG_PAIRS, launch_pairs_shape(c->P_int, hint) | (1ull << 40), [&]() { return enq_pairs(c, c->P_int, hint, false, true); });
+    const int rc = run_segment(c, SEG_PAIRS, launch_pairs_shape(c->P_int, hint) | (1ull << 40), [&]() {
+        // (the status records have landed: the chunk lists' capacity rule over all ranks decides which particles the stage leaves alone)
+        PS_HIP(c, launch_chunk_census(c->stream, c->P, c->d, c->status_in));
+        return enq_pairs(c, c->P_int, hint, false, true);
+    });
     if (rc != PSAMD_OK) return rc;
     c->interior_done = true; c->interior_ran = true;
     return PSAMD_OK;
@@ -1538,6 +1542,8 @@ int psamd_slab_pairs(psamd_ctx *c)
         PS_HIP(c, launch_unpack_halos(c->stream, P, c->d, c->halo_in_cells[0], c->halo_in[0], c->unpack_off[0],
                                       c->halo_in_cells[1], c->halo_in[1], c->unpack_off[1]));
         if (c->allg_in) PS_HIP(c, launch_allg_index(c->stream, P, c->d));      // all-pairs: the gathered snapshot, by global cell
+        // the chunk lists' capacity rule over all ranks (the status records have landed): which particles the step leaves alone
+        if (!second) PS_HIP(c, launch_chunk_census(c->stream, P, c->d, c->status_in));
         const int r = enq_pairs(c, Pp, hint, true, !second);
         if (r != PSAMD_OK) return r;
         if (c->force_out) PS_HIP(c, launch_pack_force(c->stream, P, c->d, c->force_out, P.reg_layers[2] * GG * P.halo_cap_cell));
@@ -1557,7 +1563,7 @@ int psamd_slab_apply(psamd_ctx *c)
     const int64_t bound = live_bound_of(c);
     const int rc = run_segment(c, SEG_APPLY, (uint64_t)bound | ((uint64_t)c->P.xfer_cap << 32), [&]() {
         // the status records of all ranks (all-gathered since slab_build): error bits, cell-overflow kills for the
-        // owner of queue record 0, and the chunks' counts over all ranks -- the chunk lists' capacity rule; in
+        // owner of queue record 0, the transfer messages' next capacity; in
         // the same launch the force records of the lent-out layers (the tail of the snapshot that went up)
         PS_HIP(c, launch_status_merge(c->stream, c->P, c->d, c->status_in, c->halo_out_cells[1] - (c->P.lentout_c1 - c->P.lentout_c0),
                                       c->force_in, c->pack_off[1]));

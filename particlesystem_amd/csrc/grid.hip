@@ -703,7 +703,8 @@ hipError_t launch_init_tdata(hipStream_t st, const DevParams &P, const DeviceSta
 
 // diagnostics (psamd_download_force4): the force records in sorted order, from where they live (ForceBuf)
 __global__ void k_force_gather(DevParams P, const int *__restrict__ cell_start, const int *__restrict__ sorted_id,
-                               const float4 *__restrict__ force4, const float4 *__restrict__ force_slot, float4 *__restrict__ out, int first, int count)
+                               const float4 *__restrict__ force4, const float4 *__restrict__ acc4, const uint8_t *__restrict__ flag_slot,
+                               float4 *__restrict__ out, int first, int count)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -711,7 +712,7 @@ __global__ void k_force_gather(DevParams P, const int *__restrict__ cell_start, 
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (gi < cell_start[P.n_own_cells]) {                      // an own cell's entry (the own block starts at 0)
         const int id = sorted_id[gi], si = id >= 0 ? slot_index(P, id) : -1;
-        if (si >= 0) v = force_slot[si];
+        if (si >= 0) { const float4 a = acc4[si]; v = make_float4(a.x, a.y, a.z, __int_as_float((int)flag_slot[si])); }
     } else if (gi >= P.reg_sorted[1] && P.world > 1) v = force4[gi];
     out[i] = v;
 }
@@ -719,7 +720,7 @@ __global__ void k_force_gather(DevParams P, const int *__restrict__ cell_start, 
 hipError_t launch_force_gather(hipStream_t st, const DevParams &P, const DeviceState &d, void *out, int first, int count)
 {
     if (count <= 0) return hipSuccess;
-    k_force_gather<<<(count + 255) / 256, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.force4, d.force_slot, (float4 *)out, first, count);
+    k_force_gather<<<(count + 255) / 256, 256, 0, st>>>(P, d.cell_start, d.sorted_id, d.force4, d.acc4, d.flag_slot, (float4 *)out, first, count);
     return hipGetLastError();
 }
 

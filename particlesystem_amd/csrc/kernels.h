@@ -61,7 +61,7 @@ struct DeviceState {
     float *snap_soa = nullptr;    // [4][sorted_cap] sorted order: x, y, z, w_eff as four arrays (what the pair walk streams)
     float *snap_age = nullptr;    // [container] sorted order
     float4 *force4 = nullptr;     // [sorted_cap] sorted order: (ax, ay, az, flag) of the lent region's particles; the hand-off mailbox of the force pass
-    float4 *force_slot = nullptr; // [slots] by slot: (ax, ay, az, flag) of the own cells' particles (ForceBuf, kernels_common.hpp)
+    uint8_t *flag_slot = nullptr; // [slots] by slot: the step's collision flag of the own cells' particles (their new acceleration goes into acc4.xyz: ForceBuf, kernels_common.hpp)
     CellInfo *celltab = nullptr;  // [num_cells]
     // lifecycle
     uint64_t *op_keys = nullptr, *op_keys_sorted = nullptr;
@@ -131,7 +131,9 @@ hipError_t launch_outbox_close(hipStream_t st, const DevParams &P, const DeviceS
 hipError_t launch_inbox_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *const msgs[5]);
 hipError_t launch_allg_pack(hipStream_t st, const DevParams &P, const DeviceState &d, int *msg);
 hipError_t launch_allg_index(hipStream_t st, const DevParams &P, const DeviceState &d);
-// status records of all ranks (error bits, cell-overflow kills, chunk counts) + the force records of the lent-out layers (force_msg, may be null)
+// the chunk lists' capacity rule over all ranks' status records (start of the pair stage)
+hipError_t launch_chunk_census(hipStream_t st, const DevParams &P, const DeviceState &d, const int *status_all);
+// status records of all ranks (error bits, cell-overflow kills, the transfer messages' next capacity) + the force records of the lent-out layers (force_msg, may be null)
 hipError_t launch_status_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *status_all,
                                int force_j0, const int *force_msg, const int *pack_off);
 

@@ -281,32 +281,63 @@ __device__ __forceinline__ void list_in_neighbour_halos(const DevParams &P, int 
     }
 }
 
-// Where a particle's force record (ax, ay, az, collision flag) lives.  The records of the OWN cells are kept BY SLOT:
-// k_apply walks the slots and streams a particle's record with its state, no detour through its place in the sorted
-// order (until round 5 every record was in sorted order and k_apply gathered it through rank_of_slot: one more
-// dependent round trip in a kernel that is nothing but a chain of them, plus a scattered 4-byte write per particle
-// in k_sort_cells).  The records of cells computed for the rank below (the lent region) stay in sorted order, where
-// k_pack_force takes them from; and the sorted-order array is also the mailbox through which a task that is cut hands
-// its partial sums from wave to wave (`buf + gi`).
+// Where a particle's force record (ax, ay, az, collision flag) goes.  For the OWN cells the acceleration goes straight
+// into the particle's own record -- acc4[slot].xyz, the fertility age in .w stays -- and the flag into a byte by slot:
+// k_apply streams its particles by slot and finds the new acceleration where the particle keeps it, so the record is
+// neither copied nor read twice (until round 5 the records were an array of their own in sorted order, gathered by
+// k_apply through rank_of_slot and copied into acc4: 32 bytes of traffic per moved particle and a dependent round trip
+// in a kernel that is bound by its bytes).  Nothing reads a particle's old acceleration during a step -- with ONE
+// exception: a particle ranked past its chunk list's capacity is not touched by calc_forces at all (ps.cpp:1502-1508;
+// chunk_cap_block), its record keeps last step's acceleration: such a particle's record is not written (the rule's
+// verdict, chunk_skip, is in before the pair stage: k_scan on one GPU, the chunk census of slab_pairs on a slab).
+// The records of cells computed for the rank below (the lent region) stay in sorted order, where k_pack_force takes them
+// from; and the sorted-order array is also the mailbox through which a task that is cut hands its partial sums from
+// wave to wave (`buf + gi`).
 struct ForceBuf {
     float4 *sorted;
-    float4 *by_slot;
+    float4 *acc4;
+    uint8_t *flag_slot;
     const int *sorted_id;
+    const FrameScalars *fs;              // chunk_over: some chunk list is past its capacity this frame (rare)
+    const uint8_t *chunk_skip;
+    const int *chunk_count;
+    const CellInfo *celltab;
+    const int *cell_arr;
     __device__ __forceinline__ float4 *operator+(int gi) const { return sorted + gi; }
+    __device__ __forceinline__ bool untouched(const DevParams &P, int si) const      // calc_forces does not process this particle this step
+    {
+        if (!fs->chunk_over) return false;
+        int c = cell_arr[si];
+        if (c <= -2) c = -2 - c;
+        return c >= 0 && c < P.num_cells_global && chunk_count[celltab[c].chunk] > P.max_per_chunk && chunk_skip[si];
+    }
+    __device__ __forceinline__ void put_slot(const DevParams &P, int si, const float4 v) const
+    {
+        if (si < 0 || untouched(P, si)) return;
+        *reinterpret_cast<float3 *>(acc4 + si) = make_float3(v.x, v.y, v.z);
+        flag_slot[si] = (uint8_t)__float_as_int(v.w);
+    }
     // lc: the (local) cell the particle at sorted index gi belongs to
     __device__ __forceinline__ void put(const DevParams &P, int lc, int gi, const float4 v) const
     {
-        if (lc < P.n_own_cells) by_slot[slot_index(P, sorted_id[gi])] = v; else sorted[gi] = v;
+        if (lc < P.n_own_cells) put_slot(P, slot_index(P, sorted_id[gi]), v); else sorted[gi] = v;
     }
     __device__ __forceinline__ void put_id(const DevParams &P, int lc, int gi, int id, const float4 v) const     // (the caller has the slot id at hand)
     {
-        if (lc < P.n_own_cells) by_slot[slot_index(P, id)] = v; else sorted[gi] = v;
+        if (lc < P.n_own_cells) put_slot(P, slot_index(P, id), v); else sorted[gi] = v;
     }
     __device__ __forceinline__ float4 get(const DevParams &P, int lc, int gi) const
     {
-        return lc < P.n_own_cells ? by_slot[slot_index(P, sorted_id[gi])] : sorted[gi];
+        if (lc >= P.n_own_cells) return sorted[gi];
+        const int si = slot_index(P, sorted_id[gi]);
+        const float4 a = acc4[si];
+        return make_float4(a.x, a.y, a.z, __int_as_float((int)flag_slot[si]));
     }
 };
+inline ForceBuf force_buf(const DeviceState &d)
+{
+    return ForceBuf{d.force4, d.acc4, d.flag_slot, d.sorted_id, d.fs, d.chunk_skip, d.chunk_count, d.celltab, d.cell};
+}
 
 // the four outboxes of a slab: records for the rank below [0] / above [1] (xfer_cap each), two ranks below [2] / above [3] (xfer2_cap)
 constexpr int FAR_MAGIC = 0x21524146;       // "FAR!": header word 3 of a far outbox that was closed this step

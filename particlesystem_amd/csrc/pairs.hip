@@ -1928,7 +1928,7 @@ static hipError_t launch_pairs_mode(hipStream_t st, const DevParams &P, const De
 {
     const int ncomp = comp_count(P);
     if (ncomp <= 0) return hipSuccess;
-    const ForceBuf fbuf{d.force4, d.force_slot, d.sorted_id};
+    const ForceBuf fbuf = force_buf(d);
     const int tasks = ncomp * P.slices;
     const PairShape shape = pair_shape(P, MODE != 0, tasks_hint);
     const bool two = shape.two, merge = shape.merge, balanced = shape.balanced, tile = shape.tile, packs_in_list = shape.packs_in_list;

@@ -330,49 +330,55 @@ hipError_t launch_allg_index(hipStream_t st, const DevParams &P, const DeviceSta
     return hipGetLastError();
 }
 
-// Run once the status records of all ranks are in, before k_apply.
-// Workgroups [0, world), one per rank's record: adopt its error bits (status_error: the OR over ALL
-// records, this rank's own included -- the same word on every rank, which is what makes a failure
-// collective); the owner of queue record 0 queues the reported cell-overflow kills as the inserts
-// build_grid would have made (ps.cpp:1523-1526): key = chunk field 0 | slot | insert, i.e. before
-// every calc_forces operation and in slot order.
-// Workgroups [world, world + num_chunks), one per chunk: the chunk lists' capacity rule
-// (ps.cpp:1502-1508) across ranks.  The chunk's count is the sum of the ranks' parts (also what
-// hostGridMax[0] is the maximum of); if it passed the capacity, this rank ranks the particles in its
-// own segments of the chunk behind what the census says precedes them in slot order.
+// Run once the status records of all ranks are in.  Two launches:
+//
+// k_chunk_census, at the start of the PAIR stage (the records must have landed by then): one workgroup per chunk -- the
+// chunk lists' capacity rule (ps.cpp:1502-1508) across ranks.  The chunk's count is the sum of the ranks' parts (also what
+// hostGridMax[0] is the maximum of); if it passed the capacity, this rank ranks the particles in its own segments of the
+// chunk behind what the census says precedes them in slot order.  Before the pair stage, because that stage writes a
+// particle's new acceleration into the particle's own record (ForceBuf) and must leave the records of the particles the
+// rule takes out of the step alone.
+//
+// k_status_merge, before k_apply.  Workgroups [0, world), one per rank's record: adopt its error bits (status_error: the
+// OR over ALL records, this rank's own included -- the same word on every rank, which is what makes a failure
+// collective); the owner of queue record 0 queues the reported cell-overflow kills as the inserts build_grid would have
+// made (ps.cpp:1523-1526): key = chunk field 0 | slot | insert, i.e. before every calc_forces operation and in slot
+// order; workgroup 0 also settles the transfer messages' next capacity.  Workgroups past them: the force records of the
+// lent-out layers come home (one workgroup per lent-out cell).
+__global__ __launch_bounds__(1024) void k_chunk_census(DevParams P, const int *__restrict__ status_all, int *__restrict__ chunk_count,
+                                                        const int *__restrict__ cell_arr, const CellInfo *__restrict__ celltab,
+                                                        const int2 *__restrict__ chunk_segs, uint8_t *__restrict__ chunk_skip, FrameScalars *fs)
+{
+    __shared__ int s_before[4];
+    const int ch = (int)blockIdx.x;
+    int tot[4] = {0, 0, 0, 0}, below[4] = {0, 0, 0, 0};
+    for (int r = 0; r < P.world; r++) {
+        const int *t = status_all + (size_t)r * P.status_words + STATUS_CHUNK_OFF + 4 * ch;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int v = max(t[k], 0); tot[k] += v; if (r < P.rank) below[k] += v; }
+    }
+    const int total = tot[0] + tot[1] + tot[2] + tot[3];
+    if (threadIdx.x == 0) {
+        chunk_count[ch] = total;                                   // k_apply tests the chunk's whole count
+        atomicMax(&fs->gridmax[0], min(total, P.max_per_chunk));   // hostGridMax[0], ps.cpp:1507
+        if (total > P.max_per_chunk) fs->chunk_over = 1;
+        s_before[0] = below[0]; s_before[1] = tot[0] + below[1]; s_before[2] = tot[0] + tot[1] + below[2];
+        s_before[3] = tot[0] + tot[1] + tot[2] + below[3];
+    }
+    if (total <= P.max_per_chunk) return;
+    __syncthreads();
+    chunk_cap_block(P, ch, chunk_count, cell_arr, celltab, chunk_segs, chunk_skip, s_before);
+}
+
 __global__ __launch_bounds__(1024) void k_status_merge(DevParams P, const int *__restrict__ status_all, uint64_t *op_keys, int *op_args,
-                                                        int ops_cap, int *__restrict__ chunk_count, const int *__restrict__ cell_arr,
-                                                        const CellInfo *__restrict__ celltab, const int2 *__restrict__ chunk_segs,
-                                                        uint8_t *__restrict__ chunk_skip, FrameScalars *fs,
+                                                        int ops_cap, FrameScalars *fs,
                                                         int force_j0, const int *__restrict__ force_msg, const int *__restrict__ pack_off,
                                                         const int *__restrict__ cell_start, const ForceBuf force4, StepState *stp)
 {
-    __shared__ int s_before[4];
-    // workgroups past the status records and the chunks: the force records of the lent-out layers come home
+    // workgroups past the status records: the force records of the lent-out layers come home
     // (one workgroup per lent-out cell; same stage, so the same launch)
-    if ((int)blockIdx.x >= P.world + P.num_chunks) {
-        unpack_force_block(P, (int)blockIdx.x - P.world - P.num_chunks, force_j0, force_msg, pack_off, cell_start, force4, fs);
-        return;
-    }
     if ((int)blockIdx.x >= P.world) {
-        const int ch = (int)blockIdx.x - P.world;
-        int tot[4] = {0, 0, 0, 0}, below[4] = {0, 0, 0, 0};
-        for (int r = 0; r < P.world; r++) {
-            const int *t = status_all + (size_t)r * P.status_words + STATUS_CHUNK_OFF + 4 * ch;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { const int v = max(t[k], 0); tot[k] += v; if (r < P.rank) below[k] += v; }
-        }
-        const int total = tot[0] + tot[1] + tot[2] + tot[3];
-        if (threadIdx.x == 0) {
-            chunk_count[ch] = total;                                   // k_apply tests the chunk's whole count
-            atomicMax(&fs->gridmax[0], min(total, P.max_per_chunk));   // hostGridMax[0], ps.cpp:1507
-            if (total > P.max_per_chunk) fs->chunk_over = 1;
-            s_before[0] = below[0]; s_before[1] = tot[0] + below[1]; s_before[2] = tot[0] + tot[1] + below[2];
-            s_before[3] = tot[0] + tot[1] + tot[2] + below[3];
-        }
-        if (total <= P.max_per_chunk) return;
-        __syncthreads();
-        chunk_cap_block(P, ch, chunk_count, cell_arr, celltab, chunk_segs, chunk_skip, s_before);
+        unpack_force_block(P, (int)blockIdx.x - P.world, force_j0, force_msg, pack_off, cell_start, force4, fs);
         return;
     }
     const int r = blockIdx.x;
@@ -402,14 +408,22 @@ __global__ __launch_bounds__(1024) void k_status_merge(DevParams P, const int *_
     }
 }
 
+// the chunk lists' capacity rule across ranks: before the pair stage (the status records of all ranks have landed)
+hipError_t launch_chunk_census(hipStream_t st, const DevParams &P, const DeviceState &d, const int *status_all)
+{
+    if (!status_all || P.world <= 1) return hipSuccess;
+    k_chunk_census<<<P.num_chunks, 1024, 0, st>>>(P, status_all, d.chunk_count, d.cell, d.celltab, d.chunk_segs, d.chunk_skip, d.fs);
+    return hipGetLastError();
+}
+
 // force_msg (may be null): the force records of the lent-out layers, unpacked by extra workgroups of the same launch
 hipError_t launch_status_merge(hipStream_t st, const DevParams &P, const DeviceState &d, const int *status_all,
                                int force_j0, const int *force_msg, const int *pack_off)
 {
     if (!status_all || P.world <= 1) return hipSuccess;
     const int ncell = force_msg ? std::max(0, P.lentout_c1 - P.lentout_c0) : 0;
-    k_status_merge<<<P.world + P.num_chunks + ncell, 1024, 0, st>>>(P, status_all, d.op_keys, d.op_args, d.ops_cap, d.chunk_count, d.cell, d.celltab,
-                                                                    d.chunk_segs, d.chunk_skip, d.fs, force_j0, force_msg, pack_off, d.cell_start, ForceBuf{d.force4, d.force_slot, d.sorted_id}, d.st);
+    k_status_merge<<<P.world + ncell, 1024, 0, st>>>(P, status_all, d.op_keys, d.op_args, d.ops_cap, d.fs, force_j0, force_msg, pack_off,
+                                                     d.cell_start, force_buf(d), d.st);
     return hipGetLastError();
 }
 

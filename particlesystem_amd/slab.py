@@ -13,8 +13,8 @@ with fixed-size messages, so the transport never negotiates a length.  This modu
 host-side plumbing only; it computes nothing.  Three transports:
 
   * ``DeviceRing``  torch.distributed P2P (RCCL over xGMI) directly on the contexts' device
-    buffers; the transfers run on RCCL's stream: the status records beside the whole pair pass,
-    the halo beside the interior pass if that is asked for (overlap_interior).
+    buffers; the transfers run on RCCL's stream: the status records land before the first
+    pair-stage call, the halo travels beside the interior pass if that is asked for (overlap_interior).
   * ``HostRing``    torch.distributed P2P (gloo) through host copies of the messages: for tests,
     and for several processes that share one GPU.
   * ``step_local``  all ranks live in one process (tests): messages are copied rank to rank.
@@ -71,19 +71,19 @@ def step_local(ranks, overlap_interior=False):
                 assert ranks[peer].msg_bytes(in_slot) == n, (phase, r, peer, n, ranks[peer].msg_bytes(in_slot))
                 ranks[peer].msg_upload(in_slot, sysr.msg_download(out_slot))
 
-    for s in ranks:
-        s.slab_build()
-    if overlap_interior:
-        for s in ranks:
-            s.slab_pairs_interior()   # (in a real run: while the halo travels)
-    deliver("halo")
     def gather(out_slot, in_slot):                                                # the "all-gathers"
         if world > 1 and _bytes(ranks[0], out_slot):
             every = np.concatenate([s.msg_download(out_slot) for s in ranks])
             for s in ranks:
                 s.msg_upload(in_slot, every)
 
-    gather(STATUS_OUT, STATUS_IN)
+    for s in ranks:
+        s.slab_build()
+    gather(STATUS_OUT, STATUS_IN)             # before the first pair-stage call: its chunk census needs every rank's record
+    if overlap_interior:
+        for s in ranks:
+            s.slab_pairs_interior()   # (in a real run: while the halo travels)
+    deliver("halo")
     gather(ALLG_OUT, ALLG_IN)
     for s in ranks:
         s.slab_pairs()
@@ -253,7 +253,7 @@ class DeviceRing(_Ring):
         self.finish(self.start(phase))
 
     def gather_status(self):
-        """start the all-gather of the status records (needed by slab_apply); returns the work or None"""
+        """start the all-gather of the status records (needed by the first pair-stage call); returns the work or None"""
         import torch
         if self.dist is None or STATUS_OUT not in self.t or self.world == 1:
             return None
@@ -292,16 +292,16 @@ class DeviceRing(_Ring):
         s = self.s
         with torch.cuda.stream(self.stream):
             s.slab_build()
+            status = self.gather_status()      # first: the pair stage's chunk census needs every rank's record
             halo = self.start("halo")
             snap = self.gather_snapshot()      # all-pairs forces only
-            status = self.gather_status()      # travels beside the pair pass
+            self.finish_status(status)
             if self.overlap_interior:
                 s.slab_pairs_interior()      # cells whose stencil lies in the own layers: no halo needed
             self.finish(halo)
             self.finish_snapshot(snap)
             s.slab_pairs()
             self.exchange("force")
-            self.finish_status(status)         # slab_apply merges the status records (chunk counts over all ranks, error bits)
             s.slab_apply()
             xfer = self.start("xfer")
             far = self.gather_far()            # births on, four or more ranks: records for ranks the messages do not reach

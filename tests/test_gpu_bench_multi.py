@@ -105,8 +105,9 @@ def _bench(args, env_extra=None, timeout=560):
 @pytest.mark.timeout(900)
 def test_one_gpu_through_the_cpp_host_agrees_with_the_python_host():
     """The whole scaling curve is driven by ONE host: `bench.py --gpus 1` goes through host/ps_ring_rccl --world 1 by
-    default.  Its figure must be the Python host's (psamd_step through ctypes) within 1 % -- same kernels, and neither
-    host is on the step's critical path -- and its record must be the full one-GPU line."""
+    default.  Its figure must be the Python host's (psamd_step through ctypes) within 2 % -- same kernels, and neither
+    host is on the step's critical path; measured 0.6-0.9 % apart on one box, profiles/r5_ab_host.txt, of which 0.35 %
+    are the C++ host's own stage events on every eighth step -- and its record must be the full one-GPU line."""
     common = ["--gpus", "1", "--steps", "150", "--warmup", "5", "--no-side-runs", "--no-cpu"]
     ring, _ = _bench(common)                                   # (--host ring is the default)
     py, _ = _bench(common + ["--host", "python"])
@@ -115,7 +116,7 @@ def test_one_gpu_through_the_cpp_host_agrees_with_the_python_host():
     assert ring["config"]["updates_in_timed_region"] == py["config"]["updates_in_timed_region"] == 150 * (1 << 20)
     assert ring["config"]["particles_with_a_force_term"] == py["config"]["particles_with_a_force_term"]
     print("one GPU: C++ host %.4f ms per step, Python host %.4f" % (ring["ms_per_step"], py["ms_per_step"]))
-    assert abs(ring["ms_per_step"] / py["ms_per_step"] - 1.0) < 0.01
+    assert abs(ring["ms_per_step"] / py["ms_per_step"] - 1.0) < 0.02
     assert ring["rccl_ranks"] == 1 and ring["roofline"]["traffic"] == py["roofline"]["traffic"]
     for d in (ring, py):
         assert set(d["kernel_us_per_step"]) >= {"pairs", "apply", "lifecycle", "collide"} and d["kernel_us_per_step_max"]["pairs"] >= d["kernel_us_per_step"]["pairs"]

@@ -45,7 +45,7 @@ VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector (spec)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FLOP_PER_PAIR = 20           # the usual N-body convention
 APPLY_BYTES_PER_UPDATE = 64  # read pos4+vel4, write pos4+vel4
-TRAFFIC_FILE = os.path.join("profiles", "r4_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r5_traffic.json")
 XGMI_LINK_GBS = 153.0        # MI355X_MICROARCH.md: one xGMI link, one direction (model only)
 
 

@@ -86,16 +86,17 @@ typedef struct psamd_config {
                                     capacity: the room is pooled); 0 = MAX_PARTICLES_PER_CELL (never overflows) */
     int32_t  xfer_cap;           /* records a transfer message carries per step and direction (particles changing owner) TO BEGIN WITH;
                                     0 = a quarter of what a cell layer can hold.  The ranks raise it together when the traffic asks for
-                                    it (see xfer_cap_max) */
+                                    it and lower it again, never below this number, when the traffic has gone (see xfer_cap_max) */
     int32_t  cuts[PSAMD_MAX_RANKS + 1];
     /* Not in the reference (BASELINE.json asks for them; nothing there can pin them): */
     double   drag;               /* linear drag k >= 0: the acceleration that is integrated and stored is a - k*v; 0 = the
                                     reference's arithmetic, untouched                                          */
     double   force_sign;         /* +1 gravity (reference), -1 repulsion: multiplies every mass in the force term; 0 reads as +1 */
     int32_t  xfer_cap_max;       /* how far the transfer messages may grow: their BUFFERS have this room from the start, the bytes that
-                                    travel are xfer_cap's and grow on demand.  Every rank reports in its status record how many records it
+                                    travel are xfer_cap's and follow the traffic.  Every rank reports in its status record how many records it
                                     sent in the step before; all ranks see all records and apply the same rule -- twice (the busiest rank's
-                                    count + four times its rise since the step before), from the step after next, never shrinking -- so both
+                                    count + four times its rise since the step before), from the step after next; down to that number again
+                                    when it is no more than half of what the messages hold -- so both
                                     ends of every message change size in the same step with no negotiation round (psamd_slab_buffers_get().xfer_bytes is the size to post,
                                     read it after psamd_slab_apply).  0 = what two cell layers and their children can hold (a step's
                                     worst case: the reference ships whole segments, ps.cpp:431-487); < xfer_cap: no growth. */
@@ -294,7 +295,7 @@ typedef struct psamd_slab_buffers {
     void   *force_out, *force_in;          /* force records of lent layers: out to rank-1, in from rank+1 */
     int64_t force_out_bytes, force_in_bytes;
     void   *xfer_out[2], *xfer_in[2];      /* particles changing owner (ring: down_rank / up_rank) */
-    int64_t xfer_bytes;                    /* all four the same size: what to post THIS step -- it may grow from step to step, on
+    int64_t xfer_bytes;                    /* all four the same size: what to post THIS step -- it may change from step to step, on
                                               every rank in the same step (config.xfer_cap_max); read it after psamd_slab_apply */
     void   *status_out, *status_in;        /* ALL-GATHERED once per step: status_in = world records of status_bytes each, by rank */
     int64_t status_bytes;

@@ -362,6 +362,7 @@ static void fill_slab_params(const Geometry &g, const SlabPlan &pl, const psamd_
     P.xfer_cap = pl.world > 1 ? (cfg.xfer_cap > 0 ? cfg.xfer_cap : std::max(4096, GG * g.max_per_cell / 4)) : 0;
     // how far the transfer messages may grow (their buffers' room): by default a step's worst case -- everything two cell
     // layers hold, and a child of each (a particle moves one layer a step, two when the rounded sum lands on the far face)
+    P.xfer_cap0 = P.xfer_cap;
     P.xfer_cap_max = pl.world > 1 ? std::max(P.xfer_cap, cfg.xfer_cap_max > 0 ? cfg.xfer_cap_max
                                                          : (int)std::min<int64_t>(4ll * GG * g.max_per_cell, INT32_MAX / 256)) : 0;
     int64_t slots = 0;
@@ -736,6 +737,22 @@ int psamd_create(const psamd_config *cfg, psamd_ctx **out)
     g.initial_queues(c->h_qinfo, c->h_queue);
     c->celltab = g.cell_table();
     PS_HIP(c, hipMemcpyAsync(d.celltab, c->celltab.data(), c->celltab.size() * sizeof(CellInfo), hipMemcpyHostToDevice, c->stream));
+    {   // k_sort_cells' order of the own cells: the cells of one segment (they share its slots, so their gathers share
+        // cache lines) side by side -- one XCD's L2 then sees a segment's lines once
+        const int cell_off = P.reg_first[0] * g.G * g.G;
+        std::vector<int> order((size_t)std::max(P.n_own_cells, 1), 0);
+        for (int lc = 0; lc < P.n_own_cells; lc++) order[(size_t)lc] = lc;
+        const char *e = getenv("PSAMD_CELL_ORDER");
+        if (!e || atoi(e) != 0)
+            std::stable_sort(order.begin(), order.begin() + P.n_own_cells, [&](int a, int b) {
+                const CellInfo &x = c->celltab[(size_t)(a + cell_off)], &y = c->celltab[(size_t)(b + cell_off)];
+                if (x.chunk != y.chunk) return x.chunk < y.chunk;
+                if (x.seg_type != y.seg_type) return x.seg_type < y.seg_type;
+                return x.seg_tid < y.seg_tid;
+            });
+        PS_HIP(c, dev_alloc(c, &d.cell_order, order.size()));
+        PS_HIP(c, hipMemcpy(d.cell_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     int rc = push_queues(c);
     if (rc != PSAMD_OK) return rc;
     c->host_queues_valid = true;
@@ -1346,7 +1363,7 @@ static int consume_scalars(psamd_ctx *c, int upto)
         c->live_bound = std::min<int64_t>(c->P.slots_total, (int64_t)r.live + r.n_moves);   // births and arrivals <= moves
         c->processed_total += r.live;
         c->max_bucket_seen = std::max<int64_t>(c->max_bucket_seen, r.max_bucket);
-        if (c->P.world > 1 && r.xfer_cap_next > c->P.xfer_cap) c->cap_decisions[s] = r.xfer_cap_next;
+        if (c->P.world > 1 && r.xfer_cap_next > 0) c->cap_decisions[s] = r.xfer_cap_next;      // (every step's: an absolute number, the same on every rank)
         if (verdict == PSAMD_OK && (c->P.world > 1 ? r.status_error != 0 : r.error != 0)) verdict = check_device_errors(c);
     }
     if (verdict != PSAMD_OK && c->pending_status == PSAMD_OK) { c->pending_status = verdict; c->pending_err = c->err; }
@@ -1486,11 +1503,13 @@ int psamd_slab_build(psamd_ctx *c)
     if (c->grid_built) c->frame_clean = false;
     {   // The transfer messages' capacity the ranks agreed on two steps ago (k_status_merge) takes effect now, on every rank
         // in this same step: the record of step s - 2 has been read by every host that starts step s, whatever its run-ahead.
+        // A decision is an absolute number (grown, kept or shrunk: the rule is k_status_merge's), the same on every rank.
         const int s = c->scalars_seq + 1;
         int cap = c->P.xfer_cap;
-        for (auto it = c->cap_decisions.begin(); it != c->cap_decisions.end() && it->first <= s - 2; it = c->cap_decisions.erase(it)) cap = std::max(cap, it->second);
-        if (cap > c->P.xfer_cap) {
-            c->P.xfer_cap = c->P_int.xfer_cap = c->P_rest.xfer_cap = std::min(cap, c->P.xfer_cap_max);
+        for (auto it = c->cap_decisions.begin(); it != c->cap_decisions.end() && it->first <= s - 2; it = c->cap_decisions.erase(it)) cap = it->second;
+        cap = std::max(c->P.xfer_cap0, std::min(cap, c->P.xfer_cap_max));
+        if (cap != c->P.xfer_cap) {
+            c->P.xfer_cap = c->P_int.xfer_cap = c->P_rest.xfer_cap = cap;
             c->xfer_bytes = xfer_msg_bytes(c->P.xfer_cap);
         }
     }

@@ -70,6 +70,7 @@ struct DevParams {
     int32_t halo_cap_cell;   // bodies per cell, on average over a cell layer, a halo message has room for (pooled)
     int32_t xfer_cap;        // relocation records per direction and step a transfer message carries NOW (grows on demand, all ranks together)
     int32_t xfer_cap_max;    // ... and at most: the room of its buffers
+    int32_t xfer_cap0;       // ... and at least: what the context was created with
     int32_t lentout_c0, lentout_c1;  // own local cells computed by the rank above (their force records come back)
     int32_t num_cells_global;
     float drag;              // linear drag coefficient (0: the reference's arithmetic)

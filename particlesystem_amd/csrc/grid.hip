@@ -608,7 +608,7 @@ __device__ __forceinline__ void sort_cell(const DevParams &P, const int c, const
 // collapsing cloud, 1024 particles per cell) strides over the cells with a few workgroups and is launched only when the
 // host's last look at the frame scalars (max_cell_raw) showed a cell nearly that full.
 template <int CAP>
-__global__ __launch_bounds__(256) void k_sort_cells(DevParams P, int take_big, const int *__restrict__ cell_start, int *__restrict__ sorted_id,
+__global__ __launch_bounds__(256) void k_sort_cells(DevParams P, int take_big, const int *__restrict__ cell_order, const int *__restrict__ cell_start, int *__restrict__ sorted_id,
                                                      int *__restrict__ scratch_ids,
                                                      float4 *pos4, float4 *vel4, float4 *acc4, int *cell_arr, uint8_t *pflags,
                                                      float *__restrict__ snap_soa, float *__restrict__ snap_age,
@@ -618,7 +618,8 @@ __global__ __launch_bounds__(256) void k_sort_cells(DevParams P, int take_big, c
                                                      int *__restrict__ status_out, FrameScalars *fs, DevCounters *ctr)
 {
     if (CAP == 1024) {
-        sort_cell<CAP>(P, (int)blockIdx.x, take_big != 0, cell_start, sorted_id, scratch_ids, pos4, vel4, acc4, cell_arr, pflags, snap_soa, snap_age,
+        // (workgroups b and b + 8 share an XCD: each XCD takes one contiguous run of the segment-major order)
+        sort_cell<CAP>(P, cell_order[xcd_contiguous((int)blockIdx.x, (int)gridDim.x)], take_big != 0, cell_start, sorted_id, scratch_ids, pos4, vel4, acc4, cell_arr, pflags, snap_soa, snap_age,
                        op_keys, op_args, ops_cap, halo_count, halo_f, halo_id, snap_cid, status_out, fs, ctr);
         return;
     }
@@ -740,12 +741,12 @@ hipError_t launch_build_grid(hipStream_t st, const DevParams &P, const DeviceSta
     PS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[3], st);
     // (the ordered ids of a cell that is ranked through global memory go through active_list: written by k_collide_cell later in the frame)
-    k_sort_cells<1024><<<P.n_own_cells, 256, 0, st>>>(P, big_cells ? 0 : 1, d.cell_start, d.sorted_id, d.active_list, d.pos4, d.vel4, d.acc4, d.cell,
+    k_sort_cells<1024><<<P.n_own_cells, 256, 0, st>>>(P, big_cells ? 0 : 1, d.cell_order, d.cell_start, d.sorted_id, d.active_list, d.pos4, d.vel4, d.acc4, d.cell,
                                                d.pflags, d.snap_soa, d.snap_age, d.op_keys, d.op_args, d.ops_cap,
                                                P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.snap_cid, d.status_out, d.fs, d.ctr);
     PS_LAUNCH_CHECK();
     if (big_cells) {
-        k_sort_cells<SORT_MAX><<<std::min(P.n_own_cells, 512), 256, 0, st>>>(P, 1, d.cell_start, d.sorted_id, d.active_list, d.pos4, d.vel4, d.acc4, d.cell,
+        k_sort_cells<SORT_MAX><<<std::min(P.n_own_cells, 512), 256, 0, st>>>(P, 1, d.cell_order, d.cell_start, d.sorted_id, d.active_list, d.pos4, d.vel4, d.acc4, d.cell,
                                                d.pflags, d.snap_soa, d.snap_age, d.op_keys, d.op_args, d.ops_cap,
                                                P.two_pass ? d.halo_count : nullptr, d.halo_f, d.halo_id, d.snap_cid, d.status_out, d.fs, d.ctr);
         PS_LAUNCH_CHECK();

@@ -61,6 +61,7 @@ struct DeviceState {
     float *snap_soa = nullptr;    // [4][sorted_cap] sorted order: x, y, z, w_eff as four arrays (what the pair walk streams)
     float *snap_age = nullptr;    // [container] sorted order
     float4 *force4 = nullptr;     // [sorted_cap] sorted order: (ax, ay, az, flag) of the lent region's particles; the hand-off mailbox of the force pass
+    int *cell_order = nullptr;    // [n_own_cells] the own (local) cells by (chunk, segment type, cell in the segment): cells that share a segment's slots side by side
     uint8_t *flag_slot = nullptr; // [slots] by slot: the step's collision flag of the own cells' particles (their new acceleration goes into acc4.xyz: ForceBuf, kernels_common.hpp)
     CellInfo *celltab = nullptr;  // [num_cells]
     // lifecycle

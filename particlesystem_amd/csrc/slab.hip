@@ -390,13 +390,17 @@ __global__ __launch_bounds__(1024) void k_status_merge(DevParams P, const int *_
         // host adopts it in the same step (two steps on: psamd_slab_build) -- both ends of every message change size together,
         // with no negotiation round.  The rule looks three steps ahead (a decision rests on the traffic of the step before and
         // takes effect two steps on): the busiest rank's count plus four times its rise since the step before, doubled, and
-        // a little on top; the capacity only ever grows, up to the room of the buffers.
+        // a little on top.  More than the messages hold now: they grow to it (up to the room of the buffers); less than half:
+        // they shrink to it (a run's first step is a rise from nothing -- the forecast then is ten times the traffic, and a
+        // steady run would carry that room for ever), never below what the context was created with.
         int peak = 0;
         for (int q = 0; q < P.world; q++) peak = max(peak, status_all[(size_t)q * P.status_words + 3]);
         const long long rise = max(0, peak - stp->peak_prev);
         stp->peak_prev = peak;
         const long long need = (2ll * ((long long)peak + 4ll * rise) + 64ll + 63ll) & ~63ll;
-        fs->xfer_cap_next = need > (long long)P.xfer_cap ? (int)min((long long)P.xfer_cap_max, need) : P.xfer_cap;
+        long long next = P.xfer_cap;
+        if (need > next) next = need; else if (2 * need <= next) next = need;
+        fs->xfer_cap_next = (int)max((long long)P.xfer_cap0, min((long long)P.xfer_cap_max, next));
     }
     if (r == P.rank || !owns_record(P, 0)) return;
     const int n = min(st[0], STATUS_KILL_CAP);

@@ -58,6 +58,31 @@ __global__ __launch_bounds__(256) void k(float *out, float seed, unsigned long l
                 }
             }
         }
+        // round 5: what a DPP-modified addition costs (the other lane of a pair hands its term over inside the add)
+        if (OP == 16) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("v_add_f32_dpp %0, %1, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b[i]));
+        }
+        if (OP == 17) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("v_add_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b[i]));
+        }
+        if (OP == 18) {   // the same dependent chain without DPP
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("v_add_f32 %0, %1, %0" : "+v"(a[i]) : "v"(b[i]));
+        }
+        if (OP == 19) {   // one accumulator, eight DPP additions in a row (the ordered sum's shape)
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("v_add_f32_dpp %0, %1, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf" : "+v"(a[0]) : "v"(b[i]));
+        }
+        if (OP == 20) {   // ... and without DPP
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("v_add_f32 %0, %1, %0" : "+v"(a[0]) : "v"(b[i]));
+        }
+        if (OP == 21) {   // v_mov_b32_dpp + plain add
+#pragma unroll
+            for (int i = 0; i < 8; i++) { float t; asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf" : "=v"(t) : "v"(b[i])); asm volatile("v_add_f32 %0, %1, %0" : "+v"(a[i]) : "v"(t)); }
+        }
         if (OP == 11) {   // packed fp32 fma: 4 x v_pk_fma_f32 on 8 floats
             typedef float v2 __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -132,6 +157,15 @@ int main()
     run<0, 16>("v_fma_f32, 16 lanes active", 8, out, clk);
     run<11, 32>("v_pk_fma_f32, 32 lanes active", 4, out, clk);
     run<3, 32>("v_rsq_f32, 32 lanes active", 8, out, clk);
+    for (int w = 1; w <= 4; w *= 2) {
+        char name[96];
+        snprintf(name, sizeof name, "v_add_f32_dpp quad_perm, %d w/SIMD", w); run<16>(name, 8, out, clk, w);
+        snprintf(name, sizeof name, "v_add_f32_dpp row_shr:1, %d w/SIMD", w); run<17>(name, 8, out, clk, w);
+        snprintf(name, sizeof name, "v_add_f32 (same shape), %d w/SIMD", w); run<18>(name, 8, out, clk, w);
+        snprintf(name, sizeof name, "one chain of 8 v_add_f32_dpp, %d w/SIMD", w); run<19>(name, 8, out, clk, w);
+        snprintf(name, sizeof name, "one chain of 8 v_add_f32, %d w/SIMD", w); run<20>(name, 8, out, clk, w);
+        snprintf(name, sizeof name, "v_mov_b32_dpp + v_add_f32, %d w/SIMD", w); run<21>(name, 16, out, clk, w);
+    }
     // how fast can ONE wave issue (8 independent chains each)?  waves per SIMD = 1, 2, 3, 4
     for (int w = 1; w <= 4; w++) {
         char name[64];

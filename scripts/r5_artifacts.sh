@@ -6,6 +6,12 @@ mkdir -p $out
 export TMPDIR=/tmp
 say() { echo "[$(date +%H:%M:%S)] $*" | tee -a $out/progress.log; }
 RING="host/ps_ring_rccl --world 1 --rank 0 --device 0 --bench --n 1048576 --seed 2026 --max-particles 1048576 --settle-seconds 0.5"
+say "PMC fetch / write"
+bash scripts/pmc_bench.sh r5art_fetch FETCH_SIZE --host python --steps 3 --warmup 1 --settle-seconds 0 --no-side-runs > $out/pmc_fetch.log 2>&1
+bash scripts/pmc_bench.sh r5art_write WRITE_SIZE --host python --steps 3 --warmup 1 --settle-seconds 0 --no-side-runs > $out/pmc_write.log 2>&1
+# (the lines below quote the counted traffic: the file they read is made from the two passes above, here on the box;
+#  scripts/r5_collect.sh makes the same file from the same CSVs for the repository)
+python scripts/make_traffic_json.py gpurun_out/pmc_r5art_fetch/pmc_counter_collection.csv gpurun_out/pmc_r5art_write/pmc_counter_collection.csv profiles/r5_traffic.json >> $out/pmc_write.log 2>&1
 say "default bench line (the C++ host), the driver's form of it (--steps 20), and the Python host beside it"
 python bench.py > $out/bench_line.json 2> $out/bench_line.err
 python bench.py --steps 20 --warmup 5 --no-cpu --no-side-runs > $out/bench_steps20.json 2>> $out/bench_line.err
@@ -14,9 +20,6 @@ say "kernel stats: the headline's own host (C++), then the Python host (same ker
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r5art_ring -o bench -- $RING --steps 100 --warmup 5 --timing-period 8 > $out/prof_ring_stdout.json 2> $out/prof_ring.err
 bash scripts/profile_bench.sh r5art_exact --host python --steps 100 --warmup 5 --no-side-runs > $out/prof_exact.log 2>&1
 bash scripts/profile_bench.sh r5art_fast --host python --fast-math --steps 50 --warmup 5 --no-side-runs > $out/prof_fast.log 2>&1
-say "PMC fetch / write"
-bash scripts/pmc_bench.sh r5art_fetch FETCH_SIZE --host python --steps 3 --warmup 1 --settle-seconds 0 --no-side-runs > $out/pmc_fetch.log 2>&1
-bash scripts/pmc_bench.sh r5art_write WRITE_SIZE --host python --steps 3 --warmup 1 --settle-seconds 0 --no-side-runs > $out/pmc_write.log 2>&1
 say "PMC SQ (exact)"
 bash scripts/pmc_bench.sh r5art_sq "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE" --host python --steps 3 --warmup 2 --settle-seconds 0 --no-side-runs > $out/pmc_sq.log 2>&1
 bash scripts/pmc_bench.sh r5art_wc "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA" --host python --steps 3 --warmup 2 --settle-seconds 0 --no-side-runs > $out/pmc_wc.log 2>&1

@@ -216,7 +216,9 @@ def test_transfer_messages_grow_with_the_traffic():
     owner per step go from a handful to many hundreds.  The transfer messages start with room for 64 (xfer_cap) and a
     step would be refused at ~70; instead every rank reports its traffic in its status record, all ranks apply the same
     rule to the same numbers, and the messages grow on every rank in the same step, two steps ahead of the need -- the run
-    goes on, byte for byte the one-context run, and nobody negotiated anything."""
+    goes on, byte for byte the one-context run, and nobody negotiated anything.  When the dense tail has crossed, the thin
+    front is at the next cut: the messages shrink again (the same rule, the same step on every rank), and grow with the next
+    ramp."""
     world, n, steps = 4, 30000, 24
     rng = np.random.default_rng(511)
     xyz = np.empty((n, 3), np.float32)
@@ -245,7 +247,10 @@ def test_transfer_messages_grow_with_the_traffic():
     for g in ranks:
         g.synchronize()                                                     # (no sticky error anywhere)
     print("records rank 0 sent up per step:", sent, "message bytes:", [s_[0] for s_ in sizes])
-    assert max(sent) > 3 * 64 and sizes[-1][0] > first and sizes[-1][0] <= ranks[0].slab_buffers().xfer_bytes_max
+    per_step = [s_[0] for s_ in sizes]
+    assert max(sent) > 3 * 64 and max(per_step) > 4 * first and max(per_step) <= ranks[0].slab_buffers().xfer_bytes_max
+    assert min(per_step) >= first                                           # never below what the contexts were created with
+    assert any(b < a for a, b in zip(per_step, per_step[1:])), "the messages never shrank again: %r" % per_step
     for g in [one] + ranks:
         g.close()
 

@@ -213,8 +213,8 @@ struct FrameScalars {
 
 // What a step needs to know about its own number, kept on the device so that no kernel argument changes from
 // one step to the next (a captured hipGraph replays the arguments it was captured with): `step` keys the
-// explosion RNG (k_apply, k_moves_commit), `seq` counts the scalar records handed to the host.  The workgroup
-// that publishes a step's scalars raises `pending`; the next frame's reset kernel -- nothing reads `step`
+// explosion RNG (k_apply, k_replay_commit's commit_move), `seq` counts the scalar records handed to the host.  The workgroup
+// that publishes a step's scalars raises `pending`; the next frame's first kernel (k_hist_lds) -- nothing reads `step`
 // while it runs -- turns that into step + 1.  snapshot_restore rewinds `step` (k_restore).
 struct StepState {
     int32_t step, pending, seq;

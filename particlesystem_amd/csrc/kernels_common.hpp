@@ -1,18 +1,19 @@
 // kernels_common.hpp -- device helpers shared by the stage files (grid.hip, pairs.hip, apply.hip, lifecycle.hip, slab.hip).
 //
 // The step's kernels, hand-written for gfx950 (MI355X, CDNA4), by stage:
-//   grid.hip       AoS <-> SoA, init_iframe (k_frame_reset), build_grid: k_hist_lds / k_scan / k_scatter_lds counting
-//                  sort of the live slots by cell (streaming, HBM), k_sort_cells: the reference's cell-list order
-//                  (ps.cpp:1510-1516), the T_DATA snapshot in that order, the cell-overflow rule, the collision halo lists
+//   grid.hip       AoS <-> SoA, init_iframe (the per-frame counts are zeroed by the last kernel of the step before;
+//                  k_frame_reset only for a frame that was not left clean), build_grid: k_hist_lds / k_scan /
+//                  k_scatter_lds counting sort of the live slots by cell (streaming, HBM), k_sort_cells: the reference's
+//                  cell-list order (ps.cpp:1510-1516), the snapshot in that order, the cell-overflow rule, the collision
+//                  halo lists
 //   pairs.hip      calc_forces' two neighbour loops (ps.cpp:1182-1263): k_collide_cell (collision flags from LDS bins),
-//                  k_plan_force / k_resolve_steps, k_pairs_balanced / k_pairs: 27-cell softened gravity, one wave per 64
+//                  k_plan_force, k_pairs_balanced / k_pairs: 27-cell softened gravity, one wave per 64
 //                  particles of one cell, neighbour bodies as scalar operands of packed fp32 instructions (or LDS tiles on
 //                  a small share), serial fp32 accumulation in the reference's order (fp32 VALU bound; no MFMA: no
 //                  contraction here, every pair needs its own rsqrt)
 //   apply.hip      k_apply: death / survive / integrate / wrap / re-hash in slot order (ps.cpp:1210-1333; streaming, HBM)
 //   lifecycle.hip  free-slot queues + relocation replayed in the reference's serial order (ps.cpp:1335-1374,
-//                  app_common.cu:305-376): k_ops_hist / k_ops_scatter / k_replay_bucket / k_moves_*; lifecycle_sort.hip:
-//                  the radix sort behind very long lists
+//                  app_common.cu:305-376): k_ops_hist / k_ops_scatter / k_replay_commit (lists of any length), k_moves_stage
 //   slab.hip       the messages of a multi-GPU step: halo snapshots, force records, status records, all-pairs snapshot
 //
 // Reference arithmetic is reproduced operation for operation: every file is built with

@@ -1,5 +1,5 @@
 """Births draw from a counter-based generator (splitmix64 of seed, step, parent id: k_apply /
-k_moves_commit, restated in tests/util.py and fed to the oracle, against which the GPU is
+k_replay_commit, restated in tests/util.py and fed to the oracle, against which the GPU is
 exact).  The reference draws from std::random_device (ps.cpp:29-56), which nobody can
 reproduce; what can be checked is that the draws follow the reference's DISTRIBUTIONS:
 three integers uniform on [-50, 49] (get_random_uvector_h, ps.cpp:38-56) and a fertility age

@@ -35,7 +35,7 @@ def splitmix64(x):
 
 def explosion_rng(seed):
     """The product's counter-based explosion RNG restated for the oracle's callback
-    (kernels.hip k_apply / k_moves_commit): keyed on (seed, step, parent id)."""
+    (apply.hip k_apply / lifecycle.hip commit_move): keyed on (seed, step, parent id)."""
     def fn(pid, step):
         h0 = splitmix64(seed ^ ((step & 0xFFFFFFFF) << 32) ^ (pid & 0xFFFFFFFF))
         h1 = splitmix64(h0)

@@ -1565,6 +1565,12 @@ __global__ __launch_bounds__(256, WALK == 0 ? PSAMD_BALANCED_WAVES : WALK == 1 ?
 {
     __shared__ __attribute__((aligned(16))) float tiles[4][4 * MERGE_TILE];   // up to four 1-KiB tiles per wave
     const int wave = threadIdx.x >> 6;
+#ifdef PSAMD_END_TRACE    // (diagnostic build: when every wave ended, and nothing else -- one store at its end: scripts/r5_end_trace.sh)
+    struct EndNote {
+        unsigned long long *trace;
+        __device__ ~EndNote() { if ((threadIdx.x & 63) == 0) trace[blockIdx.x * 4 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime(); }
+    } end_note{trace};
+#endif
 #ifdef PSAMD_WAVE_TRACE   // (diagnostic build: the wave's whole life, first instruction to last piece -- overwrites what its pieces noted)
     const unsigned long long wave_t0 = __builtin_amdgcn_s_memrealtime();
     struct WholeWave {

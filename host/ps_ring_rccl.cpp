@@ -647,9 +647,11 @@ int main(int argc, char **argv)
         if (barrier()) return bail();
         clock.start();
         const auto t0 = std::chrono::steady_clock::now();
+        size_t stage_steps = 0;                             // timed steps that carried the stage events
         for (int k = 0; k < steps; k++) {
             // (the stage events go in on other steps than the library's kernel timers: side by side each delays what the other brackets)
             R.stage_slot = k % period == (period > 1 ? period / 2 : 0) ? k / period : -1;
+            if (R.stage_slot >= 0) stage_steps = (size_t)R.stage_slot + 1;
             if (one_step()) return bail();
         }
         R.stage_slot = -1;
@@ -687,13 +689,20 @@ int main(int argc, char **argv)
             const int a[7] = {0, 2, 4, 6, 1, 3, 5}, b[7] = {1, 3, 5, 7, 2, 4, 6};
             for (int k = 0; k < 7; k++) {
                 std::vector<float> v;
-                for (auto &evs : R.stage_ev) { float ms = 0.f; if (hipEventElapsedTime(&ms, evs[i * 8 + (size_t)a[k]], evs[i * 8 + (size_t)b[k]]) == hipSuccess) v.push_back(ms); }
+                // (only the steps that recorded them: asking an event that never was recorded for its time fails AND leaves
+                // the error behind for the next launch check to find)
+                for (size_t q = 0; q < stage_steps; q++) {
+                    const auto &evs = R.stage_ev[q];
+                    float ms = 0.f;
+                    if (hipEventElapsedTime(&ms, evs[i * 8 + (size_t)a[k]], evs[i * 8 + (size_t)b[k]]) == hipSuccess) v.push_back(ms);
+                }
                 std::sort(v.begin(), v.end());
                 tab[(size_t)R.local[i].rank * 7 + (size_t)k] = v.empty() ? 0 : (int64_t)(1e6 * (double)v[v.size() / 2]);
             }
         }
         if (reduce_i64(tab.data(), tab.size(), ncclSum)) return bail();
         for (auto &v : R.stage_ev) for (auto &e : v) (void)hipEventDestroy(e);
+        (void)hipGetLastError();
         if (census(&terms1, &wf1, &live1)) return bail();
         if (evolve) { terms0 = terms1; wf0 = wf1; }
         int64_t red[2] = {own_updates, (int64_t)(elapsed * 1e9)};

@@ -125,6 +125,19 @@ def test_one_gpu_through_the_cpp_host_agrees_with_the_python_host():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
+def test_the_drivers_form_of_the_bench_runs_through_the_cpp_host():
+    """`bench.py --steps 20 --warmup 5` -- what the driver runs at round end -- must be served by the C++ host and not by
+    the fallback: a timed region whose length is no multiple of the timing period leaves stage events unrecorded, and
+    asking those for their time once left a HIP error behind that failed the next launch (the ranks fell back, quietly)."""
+    for steps in ("20", "50"):
+        d, _ = _bench(["--gpus", "1", "--steps", steps, "--warmup", "5", "--no-side-runs", "--no-cpu"])
+        assert "C++ ranks" in d["config"]["host"] and "FALLBACK" not in d["config"]["host"] and "ring_failed" not in d, d["config"]["host"]
+        assert d["steps"] == int(steps) and d["rccl_ranks"] == 1
+        assert d["sustained"] and abs(d["sustained"]["ms_per_step"] / d["ms_per_step"] - 1.0) < 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
 def test_cpp_host_record_explains_itself_on_eight_slabs():
     """What a multi-GPU run must say about itself (here eight slabs in one process, --loopback): how many ranks RCCL
     joined, every rank's own stage times, how long the compute stream waited for each phase's messages (minimum and

@@ -506,7 +506,8 @@ int main(int argc, char **argv)
         }
         return 0;
     }
-    NCCL_OK(ncclCommInitRank(&R.comm, comm_world, id, comm_rank));
+    const bool no_comm = comm_world == 1 && !loopback && std::getenv("PSAMD_RING_NO_RCCL") != nullptr;      // (A/B: a world of one without a communicator)
+    if (!no_comm) NCCL_OK(ncclCommInitRank(&R.comm, comm_world, id, comm_rank));
     g_comm = R.comm;
     if (comm_rank == 0 && !id_file.empty()) std::remove(id_file.c_str());      // every rank has joined: the file has served
 
@@ -712,8 +713,8 @@ int main(int argc, char **argv)
         elapsed = (double)red[1] * 1e-9;
         int64_t gl = 0, gc = 0;
         const int grc = psamd_get_graph_stats(c0, &gl, &gc);
-        int rccl_ranks = 0;
-        NCCL_OK(ncclCommCount(R.comm, &rccl_ranks));
+        int rccl_ranks = R.comm ? 0 : 1;
+        if (R.comm) NCCL_OK(ncclCommCount(R.comm, &rccl_ranks));
         if (rank == 0 || loopback) {
             static const char *names[PSAMD_NUM_TIMERS] = {"hist", "scan", "scatter", "sort_cells", "pairs", "apply", "lifecycle", "init_iframe", "collide"};
             auto timers = [&](const double *v, double div) {
@@ -767,7 +768,7 @@ int main(int argc, char **argv)
         (void)hipFree(d_red);
         for (Slab &s : R.local) psamd_destroy(s.ctx);
         g_comm = nullptr;
-        ncclCommDestroy(R.comm);
+        if (R.comm) ncclCommDestroy(R.comm);
         return 0;
     }
 
@@ -822,7 +823,7 @@ int main(int argc, char **argv)
     }
     for (Slab &s : R.local) psamd_destroy(s.ctx);
     g_comm = nullptr;
-    ncclCommDestroy(R.comm);
+    if (R.comm) ncclCommDestroy(R.comm);
     (void)hipStreamDestroy(R.compute);
     if (R.transfer != R.compute) (void)hipStreamDestroy(R.transfer);
     return rc;

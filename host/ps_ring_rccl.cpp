@@ -110,6 +110,7 @@ struct Ring {
     bool loopback = false, overlap_interior = false;
     int side = 0;                       // 0: every RCCL call on the compute stream (default); 1: what has compute to travel beside goes on the transfer stream; 2: everything does (round 4)
     ncclComm_t comm = nullptr;
+    bool compute_owned = true;          // (false: the compute stream is the first context's own)
     hipStream_t compute = nullptr, transfer = nullptr;      // (transfer == compute without --no-side-stream's opposite)
     hipEvent_t ev_built = nullptr, ev_halo = nullptr, ev_paired = nullptr, ev_force = nullptr, ev_applied = nullptr, ev_xfer = nullptr;
     std::vector<Slab> local;            // the slabs this process holds (one per process in a real run; all of them in loopback mode, where every peer is comm rank 0)
@@ -541,6 +542,22 @@ int main(int argc, char **argv)
             }
         }
         PS_OK(ctx, psamd_fill_particles(ctx, n, xyz.data(), nullptr, nullptr, age.data(), fert.data(), nullptr, nullptr));
+        if (R.local.empty()) {
+            // Which stream the stage kernels (and, by default, the RCCL calls) run on: the first context's OWN stream.  Measured
+            // (profiles/r5_ab_host.txt): with a stream this program created itself -- before the contexts (PSAMD_RING_STREAM=0,
+            // what it did until late in round 5) or after the first one (2) -- a one-rank step takes 0.8-1.2 % longer, all of it
+            // inside the force pass's own time; on the context's own stream the C++ host is as fast as the Python host.  Eight
+            // slabs in one process: no difference.  The cause is not known (same flags, same kernels, same arguments).
+            const char *e = std::getenv("PSAMD_RING_STREAM");
+            const int mode = e ? std::atoi(e) : 1;
+            if (mode == 1 || mode == 2) {
+                const bool shared = R.transfer == R.compute;
+                (void)hipStreamDestroy(R.compute);
+                if (mode == 1) { void *st = nullptr; PS_OK(ctx, psamd_get_stream(ctx, &st)); R.compute = (hipStream_t)st; R.compute_owned = false; }
+                else HIP_OK(hipStreamCreateWithFlags(&R.compute, hipStreamNonBlocking));
+                if (shared) R.transfer = R.compute;
+            }
+        }
         PS_OK(ctx, psamd_set_stream(ctx, (void *)R.compute));
         PS_OK(ctx, psamd_set_graphs(ctx, graphs ? 1 : 0));
         if (bench) PS_OK(ctx, psamd_set_tdata_mirror(ctx, 0));      // (this host never fetches the reference's T_DATA buffer)
@@ -766,7 +783,7 @@ int main(int argc, char **argv)
         }
         if (barrier()) return bail();
         (void)hipFree(d_red);
-        for (Slab &s : R.local) psamd_destroy(s.ctx);
+        for (size_t i = R.local.size(); i-- > 0;) psamd_destroy(R.local[i].ctx);      // (the first context last: the others enqueue on its stream)
         g_comm = nullptr;
         if (R.comm) ncclCommDestroy(R.comm);
         return 0;
@@ -821,10 +838,10 @@ int main(int argc, char **argv)
         rc = bad ? 1 : 0;
         psamd_destroy(one);
     }
-    for (Slab &s : R.local) psamd_destroy(s.ctx);
+    for (size_t i = R.local.size(); i-- > 0;) psamd_destroy(R.local[i].ctx);      // (the first context last: the others enqueue on its stream)
     g_comm = nullptr;
     if (R.comm) ncclCommDestroy(R.comm);
-    (void)hipStreamDestroy(R.compute);
     if (R.transfer != R.compute) (void)hipStreamDestroy(R.transfer);
+    if (R.compute_owned) (void)hipStreamDestroy(R.compute);
     return rc;
 }

@@ -346,6 +346,8 @@ int psamd_slab_msg_upload(psamd_ctx *ctx, int which, const void *host, int64_t b
 /* Enqueue all further work on the caller's HIP stream (e.g. the one RCCL orders
  * against) instead of the context's own.  NULL restores the context's stream. */
 int psamd_set_stream(psamd_ctx *ctx, void *hip_stream);
+/* the HIP stream the context enqueues on now (its own unless psamd_set_stream gave it another) */
+int psamd_get_stream(psamd_ctx *ctx, void **hip_stream_out);
 
 /* One submission per stage sequence: with graphs on, the kernels a stage call enqueues (psamd_slab_build / _pairs /
  * _apply / _finish up to its read-back; psamd_step: init_iframe .. the queue replay) are captured into a hipGraph the

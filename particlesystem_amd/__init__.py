@@ -151,6 +151,7 @@ ABI = [
     ("psamd_snapshot_save", C.c_int, [_vp]),
     ("psamd_snapshot_restore", C.c_int, [_vp]),
     ("psamd_set_stream", C.c_int, [_vp, _vp]),
+    ("psamd_get_stream", C.c_int, [_vp, C.POINTER(C.c_void_p)]),
     ("psamd_slab_plan_describe", C.c_int, [C.POINTER(Config), C.POINTER(SlabPlan)]),
     ("psamd_get_slab_plan", C.c_int, [_vp, C.POINTER(SlabPlan)]),
     ("psamd_slab_buffers_get", C.c_int, [_vp, C.POINTER(SlabBuffers)]),

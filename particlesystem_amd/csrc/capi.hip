@@ -1818,6 +1818,13 @@ int psamd_set_stream(psamd_ctx *c, void *hip_stream)
     return PSAMD_OK;
 }
 
+int psamd_get_stream(psamd_ctx *c, void **out)
+{
+    if (!c || !out) return PSAMD_ERR_INVALID_ARG;
+    *out = (void *)c->stream;
+    return PSAMD_OK;
+}
+
 int psamd_debug_wave_trace(psamd_ctx *c, uint64_t *out, int64_t n_words)
 {
     if (!c || !out) return PSAMD_ERR_INVALID_ARG;

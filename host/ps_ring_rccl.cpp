@@ -550,11 +550,12 @@ int main(int argc, char **argv)
             // slabs in one process: no difference.  The cause is not known (same flags, same kernels, same arguments).
             const char *e = std::getenv("PSAMD_RING_STREAM");
             const int mode = e ? std::atoi(e) : 1;
-            if (mode == 1 || mode == 2) {
+            if (mode >= 1 && mode <= 4) {
                 const bool shared = R.transfer == R.compute;
                 (void)hipStreamDestroy(R.compute);
                 if (mode == 1) { void *st = nullptr; PS_OK(ctx, psamd_get_stream(ctx, &st)); R.compute = (hipStream_t)st; R.compute_owned = false; }
-                else HIP_OK(hipStreamCreateWithFlags(&R.compute, hipStreamNonBlocking));
+                else if (mode == 2) HIP_OK(hipStreamCreateWithFlags(&R.compute, hipStreamNonBlocking));
+                else { int lo = 0, hi = 0; HIP_OK(hipDeviceGetStreamPriorityRange(&lo, &hi)); HIP_OK(hipStreamCreateWithPriority(&R.compute, hipStreamNonBlocking, mode == 3 ? hi : lo)); }      // (3: highest priority, 4: lowest)
                 if (shared) R.transfer = R.compute;
             }
         }

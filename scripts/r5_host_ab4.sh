@@ -10,7 +10,7 @@ for l in sys.stdin:
         d = json.loads(l); k = d['kernel_us_median']
         print('   ms_per_step %.4f  pairs %.1f' % (1e3 * d['elapsed_s'] / d['steps'], k['pairs']))" >> $out; }
 for rep in 1 2; do
-for m in 0 1 2; do one "one rank, stream mode $m" PSAMD_RING_STREAM=$m timeout -k 10 120 $R; done
+for m in 0 1 3 4; do one "one rank, stream mode $m" PSAMD_RING_STREAM=$m timeout -k 10 120 $R; done
 done
-for m in 0 1 2; do one "eight slabs in loopback, stream mode $m" PSAMD_RING_STREAM=$m timeout -k 10 120 $L; done
+
 cat $out

@@ -237,7 +237,7 @@ struct alignas(128) DevCounters {
 constexpr int COUNTER_COPIES = 64;
 
 enum : int32_t {
-    ERR_CELL_TOO_BIG = 1,   // a cell holds more ids than the sort kernel can rank
+    ERR_CELL_TOO_BIG = 1,   // (not raised since round 5: k_sort_cells ranks a cell of any size, through global memory beyond its LDS room; the bit and its message stay for ABI stability)
     ERR_BAD_ID = 2,         // uploaded P_DATA_TYPE with id != slot
     ERR_OPS_OVERFLOW = 4,   // lifecycle op buffer too small
     ERR_BAD_POS = 16,       // uploaded live particle outside the box (or cell out of range)
